@@ -1,0 +1,178 @@
+/*
+ * rfuse.h -- C ABI of librfuse_hip.so: the MI355X (gfx950) kernels behind the refinement-inference hot path of
+ * RetrievalFuse.
+ *
+ * The reference (nihalsid/retrieval-fuse) is 100 % Python on PyTorch; it has NO FFI of its own.  Its boundary for
+ * this path is the Python class surface in model/__init__.py:6-61.  This header is therefore the build-defined
+ * native boundary underneath the drop-in Python classes in retrieval-fuse_amd/model/: every entry point below names
+ * the reference code whose arithmetic it replaces (file:line under /root/reference).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All tensor pointers are DEVICE pointers to contiguous
+ *     float32 (unless said otherwise) in the reference's own layouts: activations NCDHW, conv weights OIDHW,
+ *     Linear weights [out][in].
+ *   - No allocation, no global state, stream-ordered on `stream` (a hipStream_t passed as void*).  Scratch is
+ *     caller-provided (`ws`, sized by the matching *_ws_bytes function).
+ *   - Return 0 on success; <0 on error (RF_E_*).  rf_last_error() gives a thread-local message.
+ *   - Volumes are cubic with power-of-two edge (1..128), as every shipped config of the reference is.
+ */
+#ifndef RFUSE_H
+#define RFUSE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_OK 0
+#define RF_E_INVALID (-1)      /* bad argument (null pointer, non power-of-two edge, ...) */
+#define RF_E_UNSUPPORTED (-2)  /* shape outside what the kernels implement */
+#define RF_E_LAUNCH (-3)       /* HIP reported a launch error */
+#define RF_E_WORKSPACE (-4)    /* caller-provided scratch too small */
+
+int rf_abi_version(void);
+const char* rf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ U-Net primitives */
+
+/* Re-lay a 3x3x3 conv weight OIDHW [cout][cin][27] as the MFMA B-operand image [27][cin4][cout16]
+ * (cin4 = cin rounded up to 4, cout16 = cout rounded up to 16, zero filled).  One-off per weight update.
+ * Replaces nothing arithmetic; feeds rf_conv3d_k3_gn_relu.  Weights: model/unet.py:15-16,53 (bias=False). */
+int rf_conv3_pack_weight(const float* w_oidhw, int cout, int cin, float* w_packed, void* stream);
+size_t rf_conv3_packed_floats(int cout, int cin);
+
+/* GroupNorm statistics of the conv INPUT folded into per-(sample, channel) scale/shift:
+ *   y = x * scale[n][c] + shift[n][c]  ==  GroupNorm(G, C, eps, affine)(x)         model/unet.py:54-66 ('g' before 'c')
+ * The input is the virtual tensor cat(src0[n][c0][edge^3], nearest_upsample_x2(src1[n][c1][(edge/2)^3])) along
+ * channels -- Decoder.forward's interpolate + concat, model/unet.py:297-308,354-360 -- with c0 or c1 possibly 0.
+ * groups collapses to 1 when (c0+c1) < groups (model/unet.py:62-63) -- done by the CALLER; here groups divides c0+c1.
+ * Biased variance, float64 accumulation.  scale/shift: [n][c0+c1]. */
+int rf_gn_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                const float* gamma, const float* beta, int groups, float eps,
+                float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+size_t rf_gn_stats_ws_bytes(int n, int groups);
+
+/* out[n][cout][edge^3] = ReLU( conv3d_k3_pad1( GN(cat(src0, up2(src1))) ) ), no bias.
+ * One SingleConv of order 'gcr' (model/unet.py:19-76,79-100) including the decoder's upsample+concat read
+ * (model/unet.py:297-308) when c1 > 0.  Zero padding applies to the NORMALISED tensor.  fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32), exact fp32 FMA chains.  w_packed from rf_conv3_pack_weight. */
+int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                         const float* scale, const float* shift, const float* w_packed, int cout,
+                         float* out, void* stream);
+
+/* Same contract on the plain VALU path (one thread per output); the kernels' own cross-check and the path for
+ * 1^3 volumes.  Takes the ORIGINAL OIDHW weight. */
+int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                const float* scale, const float* shift, const float* w_oidhw, int cout,
+                                float* out, void* stream);
+
+/* MaxPool3d(kernel 2, stride 2): Encoder.forward, model/unet.py:237,249-251.  x [n][c][edge^3] -> [n][c][(edge/2)^3] */
+int rf_maxpool3d_2(const float* x, int n, int c, int edge, float* out, void* stream);
+
+/* out[n][0][v] = (tanh(sum_c w[c] x[n][c][v] + b) + post_add) * post_mul
+ * Conv3d(nf,1,1)+Tanh of Superresolution08FinalDecoder (model/refinement.py:54-55); with post_add=1,
+ * post_mul=trunc/2 also network_pred_to_df (trainer/train_refinement.py:242-243). */
+int rf_conv1x1_tanh(const float* x, int n, int c, size_t voxels, const float* w, const float* b,
+                    float post_add, float post_mul, float* out, void* stream);
+
+/* Valid (no padding) strided Conv3d + bias + LeakyReLU(slope): the layers of the conv patch encoders
+ * (Patch08 model/retrieval.py:140-147, PCPatch48 :221-234, Patch32 :8-19; slope 0.2).  x [n][cin][s^3], w OIDHW
+ * [cout][cin][k^3], out [n][cout][so^3] with so = (s-k)/stride + 1.  Plain fp32 FMAs (direct form). */
+int rf_conv3d_valid_leaky(const float* x, int n, int cin, int s, const float* w, const float* bias, int cout, int k,
+                          int stride, float slope, float* out, void* stream);
+
+/* --------------------------------------------------------------------------------------------- fold / unfold */
+
+/* Unfold3D.forward (model/attention.py:186-188): x [b][c][s^3] -> rows [(b*r^3)][c][e^3], r = s/e, row = ((b*r+px)*r+py)*r+pz */
+int rf_unfold3d(const float* x, int b, int c, int s, int e, float* rows, void* stream);
+/* Fold3D.forward (model/attention.py:170-176): exact inverse of rf_unfold3d */
+int rf_fold3d(const float* rows, int b, int c, int s, int e, float* x, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ Linear/MLP */
+
+/* nn.Linear weight [nout][nin] -> MFMA B-operand image [nin4][nout16] (zero padded). */
+int rf_linear_pack_weight(const float* w, int nout, int nin, float* w_packed, void* stream);
+size_t rf_linear_packed_floats(int nout, int nin);
+
+#define RF_ACT_NONE 0
+#define RF_ACT_RELU 1
+#define RF_ACT_LEAKY 2
+/* y[rows][nout] = act(x[rows][nin] . W^T + bias); act = none | ReLU | LeakyReLU(slope).
+ * AttentionFeatureEncoder layers (model/attention.py:36-42, slope 0.01), Patch04 layers (model/retrieval.py:68-78),
+ * final_layer of the conv patch encoders (model/retrieval.py:149).  fp32 MFMA. */
+int rf_linear(const float* x, int rows, int nin, const float* w_packed, const float* bias, int nout,
+              int act, float slope, float* y, void* stream);
+
+/* x[rows][dim] /= max(||x||_2, eps) in place: F.normalize (util/retrieval.py:66, model/attention.py:92-93) */
+int rf_l2_normalize_rows(float* x, int rows, int dim, float eps, void* stream);
+
+/* -------------------------------------------------------------------------------------------------- attention */
+
+#define RF_ATTN_SOFTMAX 0      /* attn_retrieval_mode False: softmax(sharpness * scores), model/attention.py:105-107 */
+#define RF_ATTN_GUMBEL_HARD 1  /* attn_retrieval_mode True: gumbel_softmax(25*scores, tau=1, hard=True), :100-103 */
+/* AttentionBlock.forward after the theta/phi encoders (model/attention.py:92-112), normalize=True, g=o=Identity,
+ * blend_mode=True:
+ *   xf[b][f], pf[b][k][f] raw encoder outputs (f = 32), L2-normalised here (eps 1e-12);
+ *   scores[b][k] = <xf, pf[k]>; switch = relu(max_k scores); weights by mode (noise[b][k] = Gumbel samples, mode 1);
+ *   out[b][d] = x[b][d]*(1-switch) + (sum_k weights[k]*p[b][k][d])*switch,  d = c*e^3 values per row.
+ * Optional debug outputs (may be NULL): scores_out[b][k], weights_out[b][k]. */
+int rf_attn_fuse(const float* x, const float* p, const float* xf, const float* pf, const float* noise,
+                 int b, int k, int d, int f, int mode, float sharpness,
+                 float* out, float* scores_out, float* weights_out, void* stream);
+
+/* PatchedAttentionBlock's regroup (model/attention.py:148-152): folded retrieved features [bk][c][s^3] (bk = b*K)
+ * -> attention rows p[(b*r^3)][K][c][e^3].  src_layout 0 = NCDHW volumes; 1 = patch-major output of the retrieval
+ * backbone [(b*K*q^3)][c][t^3] (q = s/t patches per edge, the layout Fold3D(q,t,c) would consume,
+ * trainer/train_refinement.py:37,112) so the fold is never materialised. */
+int rf_attn_gather_retrieved(const float* src, int src_layout, int b, int k, int c, int s, int e, int t,
+                             float* p_rows, void* stream);
+
+/* ----------------------------------------------------------------------------------------- retrieval (online) */
+
+/* Query windows of the retrieval dataset: pad raw input chunk [b][s^3] by `ctx` with pad_value, cut (s/ps)^3 windows
+ * of edge ps+2ctx at stride ps (dataset/scene.py:61,152-160), normalise (x-mean)/std
+ * (dataset/patched_scene_dataset.py:127).  out [(b*(s/ps)^3)][w^3]. */
+int rf_query_windows(const float* raw, int b, int s, int ps, int ctx, float pad_value, float mean, float stddev,
+                     float* out, void* stream);
+
+/* Database embedding image for the scan: emb [n][dim] row-major -> blocked [ceil(n/64)][dim][64] (rows beyond n
+ * are filled with +inf-distance padding).  DB rows: util/retrieval.py:32,39-45 (columns 7..70). */
+int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float* packed, void* stream);
+size_t rf_db_packed_floats(int64_t n, int dim);
+
+/* Exact squared-L2 top-k2 of q[nq][dim] against one DB shard (packed image of `n` rows whose global row ids start
+ * at row_base): stands where the reference calls FLANN nn_index(feats, 2K) (util/retrieval.py:92).
+ * dist = sum_d (q_d - x_d)^2 in fp32, ascending, ties -> lower global row id.
+ * out_dist [nq][k2] float32, out_idx [nq][k2] int64 (global ids); missing candidates (n < k2): dist=+inf, idx=-1. */
+int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2,
+               float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
+size_t rf_l2_topk_ws_bytes(int nq, int64_t n, int k2);
+
+/* Merge `parts` candidate lists per query (e.g. the all-gathered per-shard top-k2): in_dist/in_idx [parts][nq][k2]
+ * -> out [nq][k2] ascending by (dist, idx).  New (the reference searches one index); defines the sharded-DB merge. */
+int rf_topk_merge(const float* in_dist, const int64_t* in_idx, int parts, int nq, int k2,
+                  float* out_dist, int64_t* out_idx, void* stream);
+
+/* flann_knn_worker's post-processing (util/retrieval.py:93-100): look up db_meta[idx] = (scene, x0,x1,y0,y1,z0,z1),
+ * stably move neighbours whose scene == query_scene[q] (>=0) to the back, keep the first K.
+ * db_meta [n_total][7] int32.  out_meta [nq][K][7] int32, out_dist [nq][K], out_idx [nq][K]. */
+int rf_demote_same_scene(const float* dist, const int64_t* idx, int nq, int k2, const int32_t* db_meta,
+                         const int32_t* query_scene, int K, int32_t* out_meta, float* out_dist, int64_t* out_idx,
+                         void* stream);
+
+/* create_retrieval_from_mapping (util/retrieval.py:145-164, no_overlap) fused with the retrieval normalisation
+ * (dataset/patched_scene_dataset.py:130-133) and Unfold3D(16,1) (trainer/train_refinement.py:34,112):
+ * for chunk c, neighbour k, slot p: copy db_volumes[scene][x0:x1,y0:y1,z0:z1] (16^3) * trunc_ratio, scene<0 -> trunc
+ * fill; then (v-mean)/std.  meta [chunks*64][K][7] (slot-major as the mapping).
+ * layout 0: out [chunks][K][64^3] composed volumes; layout 1: out [(chunks*K*64)][16^3] unfolded patch rows. */
+int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* meta, int chunks, int K,
+                      float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
+                      float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFUSE_H */

@@ -1,0 +1,296 @@
+"""Golden-vector generator -- runs ONLY in the build container, where /root/reference exists.
+
+Imports the reference's own ``model`` package (pure PyTorch) and, under ``sys.modules`` stubs for the
+dependencies this image lacks (pyflann, trimesh, marching_cubes, pyrender, torchmetrics, the un-vendored Chamfer
+submodule), its ``util.retrieval`` module; runs them on seeded synthetic inputs with seeded weights and writes
+small ``.npz`` fixtures to tests/golden/.  Fixtures hold DATA only (inputs' digests, expected outputs); no
+reference source travels.
+
+    python oracle/gen_golden.py            # regenerate everything
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+from unittest import mock
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path('/root/reference')
+OUT = REPO / 'tests' / 'golden'
+
+sys.path.insert(0, str(REPO / 'retrieval-fuse_amd'))
+from rfuse import configs as rf_configs            # noqa: E402  (numpy-only product helpers: configs + generators)
+from rfuse import synthetic                        # noqa: E402
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def sub(t, stride):
+    """spatial subsample of an NCDHW tensor"""
+    return t[..., ::stride, ::stride, ::stride].contiguous().numpy()
+
+
+def stats(t):
+    t64 = t.double()
+    return np.array([t64.sum().item(), t64.abs().sum().item(), (t64 * t64).sum().item()], dtype=np.float64)
+
+
+def import_reference_model():
+    # our product package also has a top-level ``model``; make sure the reference's wins in this process
+    for k in [k for k in sys.modules if k == 'model' or k.startswith('model.')]:
+        del sys.modules[k]
+    sys.path.insert(0, str(REF))
+    import model as ref_model
+    assert str(REF) in ref_model.__file__, ref_model.__file__
+    return ref_model
+
+
+def load_seeded(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synthetic.seeded_state_dict(shapes, seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    module.eval()
+    return sd
+
+
+def chunk_inputs(cfg, seed, batch, stress=False):
+    """x_in [B,1,S,S,S] normalised; retr [B,K,64,64,64] normalised (K other synthetic chunks per sample)."""
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    xs, rs = [], []
+    for b in range(batch):
+        if stress and cfg['task'] != 'surface_reconstruction':
+            s_in = cfg['dataset_train']['input_chunk_size']
+            raw_in = synthetic.uniform_stress_volume(seed * 100 + b, (s_in,) * 3, trunc_i)
+            raw_r = [synthetic.uniform_stress_volume(seed * 100 + 50 + b * 10 + k, (64,) * 3, trunc_t) for k in range(cfg['K'])]
+        else:
+            raw_in = synthetic.make_chunk(seed * 100 + b, cfg)['input_raw']
+            raw_r = [synthetic.make_chunk(seed * 100 + 50 + b * 10 + k, cfg)['target_raw'] for k in range(cfg['K'])]
+        xs.append(synthetic.normalise_input(cfg, raw_in)[None])
+        rs.append(np.stack([synthetic.normalise_target(cfg, r) for r in raw_r]))
+    return np.stack(xs).astype(np.float32), np.stack(rs).astype(np.float32)
+
+
+def gen_network_fixture(ref_model, name, cfg_name, seed, batch, stress=False):
+    cfg = rf_configs.get_config(cfg_name)
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    with mock.patch('builtins.print'):
+        unet = ref_model.get_unet_backbone(cfg)
+        dec = ref_model.get_decoder(cfg)
+        rb = ref_model.get_retrieval_backbone(cfg)
+        pab = ref_model.get_attention_block(cfg)
+    w_digest = sha(*[v for m, s in ((unet, 11), (dec, 12), (rb, 13), (pab, 14)) for v in load_seeded(m, seed * 1000 + s).values()])
+    from model.attention import Unfold3D, Fold3D
+    unfold_shape, fold_features = Unfold3D(16, 1), Fold3D(4, 8, rb.nf)
+
+    x_in, retr = chunk_inputs(cfg, seed, batch, stress)
+    K = cfg['K']
+    out = {'cfg_name': cfg_name, 'seed': seed, 'batch': batch, 'stress': int(stress), 'weights_sha': w_digest,
+           'inputs_sha': sha(x_in, retr), 'target_trunc': np.float32(trunc_t)}
+    with torch.no_grad():
+        xt, rt = torch.from_numpy(x_in), torch.from_numpy(retr)
+        x_back = unet(xt)                                                # trainer/train_refinement.py:109
+        retrievals = rt[:, :K].reshape(batch * K, 1, 64, 64, 64)         # :255-257
+        x_retr = fold_features(rb(unfold_shape(retrievals)))             # :112
+        noise_seed = seed * 7 + 1
+        min_margin = np.inf
+        if cfg['attn_retrieval_mode']:
+            # the Gumbel draw is the first RNG use inside the attention forward: reproduce it with the same seed
+            while True:
+                torch.manual_seed(noise_seed)
+                nrows = batch * cfg['attn_num_patch'] ** 3
+                noise = -torch.empty(nrows, K, memory_format=torch.legacy_contiguous_format).exponential_().log()
+                torch.manual_seed(noise_seed)
+                x_attn = pab(x_back, x_retr)                             # :115
+                # margin of the hard arg-max, from an independent evaluation of the logits
+                sys.path.insert(0, str(REPO))
+                from oracle import refpath
+                det = {}
+                sdp = {k: v for k, v in pab.state_dict().items()}
+                x_chk = refpath.patched_attention_block(x_back, x_retr, sdp, cfg, noise, det)
+                top2 = torch.topk(det['scores'] * 25 + noise, 2, dim=1).values
+                min_margin = float((top2[:, 0] - top2[:, 1]).min())
+                assert torch.equal(x_chk, x_attn), 'captured Gumbel noise does not reproduce the reference forward'
+                if min_margin > 1e-4:
+                    break
+                noise_seed += 1
+            out['gumbel_noise'] = noise.numpy()
+            out['noise_seed'] = noise_seed
+        else:
+            x_attn = pab(x_back, x_retr)
+        pred = dec(x_attn)                                               # :116
+        df = (pred + 1) * trunc_t / 2                                    # :242-243
+    out.update(
+        min_margin=min_margin,
+        x_back_sub=sub(x_back, 2), x_back_stats=stats(x_back),
+        x_retr_sub=sub(x_retr, 4), x_retr_stats=stats(x_retr),
+        x_attn_sub=sub(x_attn, 2), x_attn_stats=stats(x_attn),
+        pred_stats=stats(pred), df=df.numpy().astype(np.float32),
+    )
+    np.savez_compressed(OUT / (name + '.npz'), **out)
+    print(name, 'df', df.shape, 'margin', min_margin, 'x_back absmax', float(x_back.abs().max()), 'pred range', float(pred.min()), float(pred.max()))
+
+
+def gen_query_fixture(ref_model, cfg_name, seed):
+    """A11: query windows -> fenc_input -> L2 normalise (util/retrieval.py:66)."""
+    cfg = rf_configs.get_config(cfg_name)
+    trunc_i, _ = rf_configs.truncations(cfg)
+    fenc_input, _ = ref_model.get_retrieval_networks(cfg['retrieval_model'])
+    load_seeded(fenc_input, seed * 1000 + 21)
+    raw = synthetic.make_chunk(seed * 100, cfg)['input_raw']
+    sys.path.insert(0, str(REPO))
+    from oracle import refpath
+    windows = refpath.extract_query_windows(raw, cfg, trunc_i)
+    with torch.no_grad():
+        z = fenc_input(torch.from_numpy(windows))
+        lat = cfg['retrieval_model']['latent_dim']
+        emb = torch.nn.functional.normalize(z.permute((0, 2, 3, 4, 1)).reshape((-1, lat)), dim=1)
+    np.savez_compressed(OUT / ('query_%s.npz' % cfg_name), cfg_name=cfg_name, seed=seed, windows_sha=sha(windows),
+                        windows_shape=np.array(windows.shape), emb=emb.numpy())
+    print('query', cfg_name, windows.shape, emb.shape)
+
+
+# ------------------------------------------------------------------ reference util/retrieval.py under stubs
+
+class _ExactFLANN:
+    """Brute-force stand-in for pyflann.FLANN: the interface the reference touches (load_index / nn_index)."""
+
+    def load_index(self, path, pts):
+        self.pts = np.asarray(pts, dtype=np.float64)
+
+    def nn_index(self, q, n, checks=None):
+        q = np.asarray(q, dtype=np.float64)
+        d = ((q[:, None, :] - self.pts[None, :, :]) ** 2).sum(-1)
+        order = np.argsort(d, axis=1, kind='stable')[:, :n]
+        return order.astype(np.int32), np.take_along_axis(d, order, axis=1).astype(np.float32)
+
+
+def import_reference_util_retrieval():
+    stub_names = ['pyflann', 'trimesh', 'trimesh.sample', 'trimesh.voxel', 'trimesh.voxel.ops', 'marching_cubes', 'pyrender',
+                  'torchmetrics', 'torchmetrics.metric', 'external', 'external.ChamferDistancePytorch',
+                  'external.ChamferDistancePytorch.chamfer3D', 'PIL', 'PIL.Image']
+    for n in stub_names:
+        if n not in sys.modules:
+            try:
+                __import__(n)
+            except Exception:
+                sys.modules[n] = types.ModuleType(n)
+    sys.modules['pyflann'].FLANN = _ExactFLANN
+    sys.modules['pyflann'].__all__ = ['FLANN']
+    if not hasattr(sys.modules['torchmetrics.metric'], 'Metric'):
+        sys.modules['torchmetrics.metric'].Metric = type('Metric', (torch.nn.Module,), {})
+    if not hasattr(sys.modules['external.ChamferDistancePytorch.chamfer3D'], 'dist_chamfer_3D'):
+        sys.modules['external.ChamferDistancePytorch.chamfer3D'].dist_chamfer_3D = types.ModuleType('dist_chamfer_3D')
+    tm = sys.modules['trimesh']
+    for attr, val in (('sample', sys.modules['trimesh.sample']), ('voxel', sys.modules['trimesh.voxel'])):
+        if not hasattr(tm, attr):
+            setattr(tm, attr, val)
+    for k in [k for k in sys.modules if k == 'util' or k.startswith('util.') or k == 'dataset' or k.startswith('dataset.')]:
+        del sys.modules[k]
+    sys.path.insert(0, str(REF))
+    import util.retrieval as ref_ret
+    assert str(REF) in ref_ret.__file__
+    return ref_ret
+
+
+class _FakeDataset:
+    """The handful of attributes create_retrieval_from_mapping touches (util/retrieval.py:145-164)."""
+
+    def __init__(self, volumes, scene_names, target_trunc, lookup):
+        self.volumes, self.scene_names = volumes, scene_names
+        self.target_trunc = np.float32(target_trunc)
+        self.patch_from_scene_lookup = lookup
+        self.no_overlap = True
+
+    def get_scene_size(self, scene):
+        return [64, 64, 64]
+
+    def get_scene_target(self, scene):
+        return self.volumes[self.scene_names.index(scene)]
+
+    def unpad(self, *e):
+        # patch_context_target = 8 (config/base/retrieval_superresolution.yaml:12), dataset/patched_scene_dataset.py:103-107
+        if len(e) == 2:
+            return [e[0], e[1] - 16]
+        return self.unpad(e[0], e[1]) + self.unpad(e[2], e[3]) + self.unpad(e[4], e[5])
+
+
+def gen_retrieval_fixture(seed=5):
+    ref_ret = import_reference_util_retrieval()
+    from dataset.scene import SceneHandler
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    K = cfg['K']
+    n_patches = 64 * 12
+    db = synthetic.make_database(seed, cfg, n_patches)
+    scene_names = ['scene%03d' % i for i in range(db['n_scenes'])]
+    rng = np.random.default_rng(seed + 1)
+    # queries: scene 3 of the train split (present in the DB index -> demotion active), 64 patches;
+    # make some of them close to DB rows of their own scene so demotion really reorders
+    q_scene = 3
+    queries = rng.standard_normal((64, 64)).astype(np.float32)
+    own = np.where(db['meta'][:, 0] == q_scene)[0]
+    for i in range(0, 64, 2):
+        queries[i] = db['emb'][own[i]] + 0.05 * rng.standard_normal(64).astype(np.float32)
+    queries /= np.linalg.norm(queries, axis=1, keepdims=True)
+    queries = queries.astype(np.float32)
+    # patch names of the query chunk, padded extents with context 8 (dataset/scene.py:152-160,169-171)
+    ext = SceneHandler.get_extents_for_size([64, 64, 64], 16, 8, 16)
+    patch_names = [SceneHandler.get_name_from_extent(scene_names[q_scene], ext[i]) for i in range(ext.shape[0])]
+    database = np.concatenate([db['meta'].astype(np.float32), db['emb']], axis=1)
+    with tempfile.TemporaryDirectory() as td:
+        tree = Path(td)
+        np.save(tree / 'database', database)
+        (tree / 'index.json').write_text(json.dumps(scene_names))
+        (tree / 'params.json').write_text(json.dumps({'checks': 32}))
+        res_train, res_val = dict.fromkeys(patch_names), dict.fromkeys(patch_names)
+        with mock.patch('builtins.print'):
+            ref_ret.flann_knn_worker(res_train, K, tree, [scene_names[q_scene]] * 64, patch_names, queries, True)
+            ref_ret.flann_knn_worker(res_val, K, tree, [scene_names[q_scene]] * 64, patch_names, queries, False)
+        map_train = np.stack([res_train[n] for n in patch_names])       # [64,K,8]
+        map_val = np.stack([res_val[n] for n in patch_names])
+        # one sentinel hit so the idx<0 branch of compose is exercised
+        map_val_s = map_val.copy()
+        map_val_s[5, 1, :7] = database[-1, :7]
+        ds_train = _FakeDataset(db['volumes'], scene_names, trunc_t, {})
+        lookup = {scene_names[q_scene]: patch_names}
+        ds = _FakeDataset(db['volumes'], scene_names, trunc_t, lookup)
+        composed = {}
+        for tag, m in (('train', map_train), ('val', map_val_s)):
+            mp = {n: m[i] for i, n in enumerate(patch_names)}
+            composed[tag] = ref_ret.create_retrieval_from_mapping(scene_names[q_scene], mp, K, ds_train, ds, tree).numpy()
+    np.savez_compressed(OUT / 'retrieval_map_compose.npz', seed=seed, n_patches=n_patches, q_scene=q_scene,
+                        queries=queries, db_sha=sha(db['meta'], db['emb'], db['volumes']),
+                        map_train=map_train, map_val=map_val, map_val_sentinel=map_val_s,
+                        compose_train_sha=sha(composed['train']), compose_val_sha=sha(composed['val']),
+                        compose_train_sub=composed['train'][:, ::4, ::4, ::4], compose_val_sub=composed['val'][:, ::4, ::4, ::4],
+                        extents_64_16_8_16=ext, extents_8_2_1_2=SceneHandler.get_extents_for_size([8, 8, 8], 2, 1, 2))
+    print('retrieval fixture', map_train.shape, composed['train'].shape)
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_model = import_reference_model()
+    gen_network_fixture(ref_model, 'net_C1', 'C1', seed=1, batch=1)
+    gen_network_fixture(ref_model, 'net_C2_stress_b2', 'C2', seed=2, batch=2, stress=True)
+    gen_network_fixture(ref_model, 'net_C3', 'C3', seed=3, batch=1)
+    gen_network_fixture(ref_model, 'net_C4', 'C4', seed=4, batch=1)
+    gen_network_fixture(ref_model, 'net_C5', 'C5', seed=5, batch=1)
+    for c in ('C1', 'C4', 'C5'):
+        gen_query_fixture(ref_model, c, seed=6)
+    gen_retrieval_fixture()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,501 @@
+// 3D U-Net primitives for gfx950: GroupNorm statistics, 3x3x3 convolution as an fp32-MFMA implicit GEMM with the
+// GroupNorm apply, nearest-upsample + concat read and ReLU fused in, max-pool, and the final 1x1x1 conv + tanh.
+//
+// Reference arithmetic being replaced: model/unet.py:19-76 (SingleConv 'gcr'), :237 (MaxPool3d 2), :297-308 and
+// :354-360 (upsample + concat), model/refinement.py:54-55 (1x1x1 conv + tanh).
+//
+// Conv design (rf_conv3d_k3_gn_relu)
+//   GEMM view: M = output voxels, N = cout, K = cin*27.  One workgroup (4 waves) owns P = 512 output voxels -- an
+//   8^3 box of one sample, or 8 whole 4^3 samples, or 64 whole 2^3 samples -- and up to 64 output channels.
+//   K is walked in chunks of 4 input channels: the chunk's halo box (GroupNorm already applied, zero outside the
+//   volume, upsample/concat resolved) and its [27][4][cout] weight slab are staged in LDS; then for each of the 27
+//   taps one v_mfma_f32_16x16x4_f32 k-step multiplies 16 voxels x 4 channels by 4 channels x 16 couts.  A operands
+//   are im2col reads straight out of the halo box (lane -> (voxel = lane&15, channel = lane>>4)), so the tap offset
+//   is a compile-time LDS immediate; B operands are rows of the weight slab.  Each wave keeps MB x NB accumulator
+//   tiles (8 x 4 x 4 VGPRs) so one A read is reused by NB MFMAs and one B read by MB MFMAs.
+//   fp32-input MFMA is bit-for-bit an fp32 FMA chain in k order (CDNA4 guide), so this is exact fp32 arithmetic.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ weight pack
+__global__ void k_conv3_pack(const float* __restrict__ w, int cout, int cin, int cin4, int cout16, float* __restrict__ wp) {
+    const size_t total = (size_t)27 * cin4 * cout16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout16);
+        const int ci = (int)((i / cout16) % cin4);
+        const int tap = (int)(i / ((size_t)cout16 * cin4));
+        float v = 0.f;
+        if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * 27 + tap];
+        wp[i] = v;
+    }
+}
+
+extern "C" size_t rf_conv3_packed_floats(int cout, int cin) {
+    return (size_t)27 * rf_round_up(cin, 4) * rf_round_up(cout, 16);
+}
+
+extern "C" int rf_conv3_pack_weight(const float* w, int cout, int cin, float* wp, void* stream) {
+    RF_REQUIRE(w && wp && cout > 0 && cin > 0, RF_E_INVALID, "rf_conv3_pack_weight: bad arguments");
+    const size_t total = rf_conv3_packed_floats(cout, cin);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_conv3_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                       rf_round_up(cin, 4), rf_round_up(cout, 16), wp);
+    RF_CHECK_LAUNCH("rf_conv3_pack_weight");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- GroupNorm stats
+// pass 1: per (sample, group, slice) partial sum / sum of squares in float64; upsampled channels weigh 8x.
+__global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ src0, int c0, const float* __restrict__ src1, int c1,
+                                                    size_t vol0, size_t vol1, int groups, int cpg, int slices,
+                                                    double2* __restrict__ part) {
+    const int ng = blockIdx.x, s = blockIdx.y;
+    const int nn = ng / groups, g = ng % groups;
+    const int tid = threadIdx.x;
+    double sum = 0.0, sq = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = g * cpg + cc;
+        const float* base;
+        size_t len;
+        double wgt;
+        if (c < c0) { base = src0 + ((size_t)nn * c0 + c) * vol0; len = vol0; wgt = 1.0; }
+        else { base = src1 + ((size_t)nn * c1 + (c - c0)) * vol1; len = vol1; wgt = 8.0; }
+        double ls = 0.0, lq = 0.0;
+        if ((len & 3) == 0) {
+            const size_t len4 = len >> 2;
+            const size_t lo = len4 * s / slices, hi = len4 * (s + 1) / slices;
+            const float4* b4 = reinterpret_cast<const float4*>(base);
+            for (size_t i = lo + tid; i < hi; i += 256) {
+                const float4 v = b4[i];
+                ls += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                lq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+        } else {
+            const size_t lo = len * s / slices, hi = len * (s + 1) / slices;
+            for (size_t i = lo + tid; i < hi; i += 256) {
+                const float v = base[i];
+                ls += v;
+                lq += (double)v * v;
+            }
+        }
+        sum += wgt * ls;
+        sq += wgt * lq;
+    }
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    __shared__ double red[8];
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { red[wave * 2] = sum; red[wave * 2 + 1] = sq; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 4; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+        part[(size_t)ng * slices + s] = make_double2(a, b);
+    }
+}
+
+// pass 2: fixed-order reduction of the slices, then scale = gamma*rstd, shift = beta - mean*scale per (n, c)
+__global__ void k_gn_finalize(const double2* __restrict__ part, int n, int C, int groups, int cpg, int slices, double count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, double eps,
+                              float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C) return;
+    const int nn = i / C, c = i % C, g = c / cpg;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < slices; ++s) {
+        const double2 p = part[((size_t)nn * groups + g) * slices + s];
+        a += p.x;
+        b += p.y;
+    }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    const double sc = (double)gamma[c] * rstd;
+    scale[i] = (float)sc;
+    shift[i] = (float)((double)beta[c] - mean * sc);
+}
+
+static int gn_slices(size_t group_elems) {
+    size_t s = (group_elems + 16383) / 16384;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+extern "C" size_t rf_gn_stats_ws_bytes(int n, int groups) { return (size_t)n * groups * 64 * sizeof(double2); }
+
+extern "C" int rf_gn_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                           const float* gamma, const float* beta, int groups, float eps,
+                           float* scale, float* shift, void* ws, size_t ws_bytes, void* stream) {
+    const int C = c0 + c1;
+    RF_REQUIRE(n > 0 && C > 0 && groups > 0 && C % groups == 0, RF_E_INVALID, "rf_gn_stats: channels %d not divisible by groups %d", C, groups);
+    RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_gn_stats: edge %d must be a power of two <= 128", edge);
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && gamma && beta && scale && shift && ws, RF_E_INVALID, "rf_gn_stats: null pointer");
+    RF_REQUIRE(c1 == 0 || edge >= 2, RF_E_INVALID, "rf_gn_stats: upsampled source needs edge >= 2");
+    RF_REQUIRE(ws_bytes >= rf_gn_stats_ws_bytes(n, groups), RF_E_WORKSPACE, "rf_gn_stats: workspace too small");
+    const size_t vol0 = (size_t)edge * edge * edge, vol1 = vol0 / 8;
+    const int cpg = C / groups;
+    const int slices = gn_slices((size_t)cpg * vol0);
+    hipLaunchKernelGGL(k_gn_partial, dim3(n * groups, slices), dim3(256), 0, (hipStream_t)stream, src0, c0, src1, c1, vol0, vol1,
+                       groups, cpg, slices, (double2*)ws);
+    RF_CHECK_LAUNCH("rf_gn_stats(partial)");
+    hipLaunchKernelGGL(k_gn_finalize, dim3((n * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double2*)ws, n, C, groups, cpg,
+                       slices, (double)cpg * (double)vol0, gamma, beta, (double)eps, scale, shift);
+    RF_CHECK_LAUNCH("rf_gn_stats(finalize)");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- conv, MFMA
+struct ConvArgs {
+    const float* src0;
+    const float* src1;
+    const float* scale;
+    const float* shift;
+    const float* wp;
+    float* out;
+    int c0, c1, n, edge, cout, cin4, cout16;
+};
+
+template <int TZ, int TY, int TX, int SPW, int MB, int NB>
+struct ConvTile {
+    static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    static constexpr int CH = HZ * HY * HX;            // halo floats per channel
+    static constexpr int CC = 4;                        // input channels per K chunk (= MFMA k)
+    static constexpr int XS = SPW * CC * CH;            // floats of the staged input box
+    static constexpr int XS_PAD = (XS + 3) / 4 * 4;
+    static constexpr int NCO = NB * 16;                 // couts per workgroup
+    static constexpr int COS = NCO + ((NB % 2 == 0) ? 16 : 0);   // row stride: k and k+1 rows on opposite bank halves
+    static constexpr int WS = 27 * CC * COS;
+    static constexpr int P = SPW * TZ * TY * TX;
+    static constexpr size_t LDS_BYTES = (size_t)(XS_PAD + WS) * sizeof(float);
+    static_assert(P == 4 * MB * 16, "4 waves x MB x 16 voxels must cover the tile");
+    static_assert(SPW == 1 || TX < 8, "multi-sample tiles are for whole small volumes");
+};
+
+template <int TZ, int TY, int TX, int SPW, int MB, int NB>
+__global__ __launch_bounds__(256, (NB >= 4 ? 2 : 3)) void k_conv3_mfma(ConvArgs a) {
+    using T = ConvTile<TZ, TY, TX, SPW, MB, NB>;
+    constexpr int HY = T::HY, HX = T::HX, CH = T::CH, CC = T::CC, NCO = T::NCO, COS = T::COS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ws = smem + T::XS_PAD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int edge = a.edge, cin = a.c0 + a.c1;
+    const int half = edge >> 1;
+
+    // ---- which voxels does this workgroup own?
+    int n0, z0 = 0, y0 = 0, x0 = 0;
+    if (SPW == 1) {
+        const int tx = edge / TX, ty = edge / TY, tz = edge / TZ;
+        int t = blockIdx.x;
+        x0 = (t % tx) * TX; t /= tx;
+        y0 = (t % ty) * TY; t /= ty;
+        z0 = (t % tz) * TZ; t /= tz;
+        n0 = t;
+    } else {
+        n0 = blockIdx.x * SPW;
+    }
+    const int cob = blockIdx.y * NCO;
+
+    // ---- per-lane LDS read bases
+    int aoff[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wave * (MB * 16) + mb * 16 + (lane & 15);
+        const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ, s = m / (TX * TY * TZ);
+        aoff[mb] = s * (CC * CH) + (z * HY + y) * HX + x + (lane >> 4) * CH;
+    }
+    const int boff = (lane >> 4) * COS + (lane & 15);
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int cbase = 0; cbase < cin; cbase += CC) {
+        // ---- stage the input halo box: GroupNorm applied, zero outside the volume, upsample+concat resolved
+        for (int i = tid; i < T::XS; i += 256) {
+            const int hx = i % HX, hy = (i / HX) % HY, hz = (i / (HX * HY)) % T::HZ;
+            const int c = (i / CH) % CC, s = i / (CC * CH);
+            const int nn = n0 + s, ci = cbase + c;
+            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+            float v = 0.f;
+            if (nn < a.n && ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge) {
+                float r;
+                if (ci < a.c0) r = a.src0[(((size_t)nn * a.c0 + ci) * edge + z) * edge * edge + (size_t)y * edge + x];
+                else r = a.src1[(((size_t)nn * a.c1 + (ci - a.c0)) * half + (z >> 1)) * half * half + (size_t)(y >> 1) * half + (x >> 1)];
+                const size_t si = (size_t)nn * cin + ci;
+                v = r * a.scale[si] + a.shift[si];
+            }
+            xs[i] = v;
+        }
+        // ---- stage the weight slab [27][4][NCO] (float4 rows)
+        for (int i = tid; i < 27 * CC * (NCO / 4); i += 256) {
+            const int co4 = i % (NCO / 4), r = i / (NCO / 4);          // r = tap*4 + c
+            const int tap = r >> 2, c = r & 3;
+            const int co = cob + co4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.cout16) v = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.cin4 + cbase + c) * a.cout16 + co);
+            *reinterpret_cast<float4*>(ws + r * COS + co4 * 4) = v;
+        }
+        __syncthreads();
+
+        // ---- 27 k-steps of 4 channels
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int tap = (dz * 3 + dy) * 3 + dx;
+                    const int toff = (dz * HY + dy) * HX + dx;
+                    float av[MB], bv[NB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) av[mb] = xs[aoff[mb] + toff];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bv[nb] = ws[boff + tap * (CC * COS) + nb * 16];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+                }
+        __syncthreads();
+    }
+
+    // ---- epilogue: ReLU, float4 stores (a lane holds 4 consecutive voxels of one cout)
+    const size_t vol = (size_t)edge * edge * edge;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wave * (MB * 16) + mb * 16 + (lane >> 4) * 4;
+        const int s = m / (TX * TY * TZ);
+        const int nn = n0 + s;
+        size_t off;
+        if (TX >= 4) {
+            const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ;
+            off = ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x);
+        } else {
+            off = (size_t)(m % (TX * TY * TZ));       // tile == whole volume: voxel order is memory order
+        }
+        if (nn < a.n) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = cob + nb * 16 + (lane & 15);
+                if (co < a.cout) {
+                    f32x4 v = acc[mb][nb];
+                    float4 o = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+                    *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * vol + off) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int TZ, int TY, int TX, int SPW, int MB, int NB>
+static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
+    using T = ConvTile<TZ, TY, TX, SPW, MB, NB>;
+    auto kern = k_conv3_mfma<TZ, TY, TX, SPW, MB, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (T::LDS_BYTES > 65536) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+            if (e != hipSuccess) { rf_set_error("rf_conv3d_k3_gn_relu: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
+        }
+        attr_set = true;
+    }
+    unsigned gx;
+    if (SPW == 1) gx = (unsigned)a.n * (a.edge / TZ) * (a.edge / TY) * (a.edge / TX);
+    else gx = (unsigned)((a.n + SPW - 1) / SPW);
+    const unsigned gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), T::LDS_BYTES, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu");
+    return RF_OK;
+}
+
+template <int TZ, int TY, int TX, int SPW>
+static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
+    if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 1>(a, stream);
+    if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 2>(a, stream);
+    return launch_conv3<TZ, TY, TX, SPW, 8, 4>(a, stream);
+}
+
+static int conv_check(const char* who, const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
+                      const float* shift, const float* w, int cout, float* out) {
+    RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "%s: bad sizes", who);
+    RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "%s: edge %d must be a power of two <= 128", who, edge);
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w && out, RF_E_INVALID, "%s: null pointer", who);
+    RF_REQUIRE(c1 == 0 || edge >= 2, RF_E_INVALID, "%s: upsampled source needs edge >= 2", who);
+    return RF_OK;
+}
+
+extern "C" int rf_conv3d_k3_gn_relu_direct(const float*, int, const float*, int, int, int, const float*, const float*, const float*, int,
+                                           float*, void*);
+
+extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                    const float* scale, const float* shift, const float* w_packed, int cout,
+                                    float* out, void* stream) {
+    int rc = conv_check("rf_conv3d_k3_gn_relu", src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out);
+    if (rc) return rc;
+    RF_REQUIRE(edge >= 2, RF_E_UNSUPPORTED, "rf_conv3d_k3_gn_relu: 1^3 volumes take the direct path (rf_conv3d_k3_gn_relu_direct)");
+    ConvArgs a;
+    a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
+    a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
+    hipStream_t s = (hipStream_t)stream;
+    if (edge >= 8) return dispatch_nb<8, 8, 8, 1>(a, s);
+    if (edge == 4) return dispatch_nb<4, 4, 4, 8>(a, s);
+    return dispatch_nb<2, 2, 2, 64>(a, s);
+}
+
+// ----------------------------------------------------------------------------------------------- conv, direct
+// One thread per output element; plain fp32 FMAs in (ci, tap) order.  Cross-check path and the 1^3 path.
+__global__ __launch_bounds__(256) void k_conv3_direct(const float* __restrict__ src0, int c0, const float* __restrict__ src1, int c1, int n,
+                                                      int edge, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ w, int cout, float* __restrict__ out) {
+    const size_t vol = (size_t)edge * edge * edge;
+    const size_t total = (size_t)n * cout * vol;
+    const int cin = c0 + c1, half = edge >> 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % edge), y = (int)((i / edge) % edge), z = (int)((i / ((size_t)edge * edge)) % edge);
+        const int co = (int)((i / vol) % cout), nn = (int)(i / (vol * cout));
+        float acc = 0.f;
+        for (int ci = 0; ci < cin; ++ci) {
+            const float sc = scale[(size_t)nn * cin + ci], sh = shift[(size_t)nn * cin + ci];
+            const float* wk = w + ((size_t)co * cin + ci) * 27;
+            for (int dz = 0; dz < 3; ++dz) {
+                const int zz = z + dz - 1;
+                if ((unsigned)zz >= (unsigned)edge) continue;
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = y + dy - 1;
+                    if ((unsigned)yy >= (unsigned)edge) continue;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int xx = x + dx - 1;
+                        if ((unsigned)xx >= (unsigned)edge) continue;
+                        float r;
+                        if (ci < c0) r = src0[(((size_t)nn * c0 + ci) * edge + zz) * edge * edge + (size_t)yy * edge + xx];
+                        else r = src1[(((size_t)nn * c1 + (ci - c0)) * half + (zz >> 1)) * half * half + (size_t)(yy >> 1) * half + (xx >> 1)];
+                        acc = fmaf(r * sc + sh, wk[(dz * 3 + dy) * 3 + dx], acc);
+                    }
+                }
+            }
+        }
+        out[i] = fmaxf(acc, 0.f);
+    }
+}
+
+extern "C" int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                           const float* scale, const float* shift, const float* w_oidhw, int cout,
+                                           float* out, void* stream) {
+    int rc = conv_check("rf_conv3d_k3_gn_relu_direct", src0, c0, src1, c1, n, edge, scale, shift, w_oidhw, cout, out);
+    if (rc) return rc;
+    const size_t total = (size_t)n * cout * edge * edge * edge;
+    const size_t want = (total + 255) / 256;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(k_conv3_direct, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src0, c0, src1, c1, n, edge, scale, shift, w_oidhw,
+                       cout, out);
+    RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu_direct");
+    return RF_OK;
+}
+
+// --------------------------------------------------------------------------------------------------- max pool
+__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, size_t planes, int edge, float* __restrict__ out) {
+    const int h = edge >> 1;
+    const size_t ovol = (size_t)h * h * h, total = planes * ovol;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % h), oy = (int)((i / h) % h), oz = (int)((i / ((size_t)h * h)) % h);
+        const size_t p = i / ovol;
+        const float* b = x + p * (size_t)edge * edge * edge + ((size_t)(2 * oz) * edge + 2 * oy) * edge + 2 * ox;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const float2 v = *reinterpret_cast<const float2*>(b + ((size_t)dz * edge + dy) * edge);
+                m = fmaxf(m, fmaxf(v.x, v.y));
+            }
+        out[i] = m;
+    }
+}
+
+extern "C" int rf_maxpool3d_2(const float* x, int n, int c, int edge, float* out, void* stream) {
+    RF_REQUIRE(x && out && n > 0 && c > 0, RF_E_INVALID, "rf_maxpool3d_2: bad arguments");
+    RF_REQUIRE(rf_is_pow2(edge) && edge >= 2 && edge <= 128, RF_E_INVALID, "rf_maxpool3d_2: edge %d", edge);
+    const size_t total = (size_t)n * c * (edge / 2) * (edge / 2) * (edge / 2);
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_maxpool2, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n * c, edge, out);
+    RF_CHECK_LAUNCH("rf_maxpool3d_2");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ 1x1x1 conv + tanh
+__global__ __launch_bounds__(256) void k_conv1x1_tanh(const float* __restrict__ x, int n, int c, size_t vox, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float post_add, float post_mul, float* __restrict__ out) {
+    const size_t vox4 = vox >> 2, total = (size_t)n * vox4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t nn = i / vox4, v4 = i % vox4;
+        const float bias = b[0];
+        float4 acc = make_float4(bias, bias, bias, bias);
+        const float4* xp = reinterpret_cast<const float4*>(x + nn * c * vox) + v4;
+        for (int ci = 0; ci < c; ++ci) {
+            const float4 v = xp[(size_t)ci * vox4];
+            const float wc = w[ci];
+            acc.x = fmaf(v.x, wc, acc.x); acc.y = fmaf(v.y, wc, acc.y); acc.z = fmaf(v.z, wc, acc.z); acc.w = fmaf(v.w, wc, acc.w);
+        }
+        float4 o;
+        o.x = (tanhf(acc.x) + post_add) * post_mul; o.y = (tanhf(acc.y) + post_add) * post_mul;
+        o.z = (tanhf(acc.z) + post_add) * post_mul; o.w = (tanhf(acc.w) + post_add) * post_mul;
+        reinterpret_cast<float4*>(out + nn * vox)[v4] = o;
+    }
+}
+
+extern "C" int rf_conv1x1_tanh(const float* x, int n, int c, size_t voxels, const float* w, const float* b,
+                               float post_add, float post_mul, float* out, void* stream) {
+    RF_REQUIRE(x && w && b && out && n > 0 && c > 0 && voxels > 0, RF_E_INVALID, "rf_conv1x1_tanh: bad arguments");
+    RF_REQUIRE((voxels & 3) == 0, RF_E_UNSUPPORTED, "rf_conv1x1_tanh: voxel count must be a multiple of 4");
+    const size_t want = ((size_t)n * (voxels / 4) + 255) / 256;
+    hipLaunchKernelGGL(k_conv1x1_tanh, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, x, n, c, voxels, w, b,
+                       post_add, post_mul, out);
+    RF_CHECK_LAUNCH("rf_conv1x1_tanh");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------- valid strided conv + LeakyReLU
+// Direct form for the patch encoders (tiny batches of small windows).  One thread per output voxel and cout.
+__global__ __launch_bounds__(256) void k_conv3_valid(const float* __restrict__ x, int n, int cin, int s, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int cout, int k, int stride, float slope, int so,
+                                                     float* __restrict__ out) {
+    const size_t ovol = (size_t)so * so * so, total = (size_t)n * cout * ovol;
+    const size_t ivol = (size_t)s * s * s;
+    const int k3 = k * k * k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % so), oy = (int)((i / so) % so), oz = (int)((i / ((size_t)so * so)) % so);
+        const int co = (int)((i / ovol) % cout);
+        const size_t nn = i / (ovol * cout);
+        float acc = bias ? bias[co] : 0.f;
+        const float* xb = x + nn * cin * ivol + ((size_t)(oz * stride) * s + oy * stride) * s + ox * stride;
+        const float* wb = w + (size_t)co * cin * k3;
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* xc = xb + ci * ivol;
+            const float* wc = wb + ci * k3;
+            for (int dz = 0; dz < k; ++dz)
+                for (int dy = 0; dy < k; ++dy)
+                    for (int dx = 0; dx < k; ++dx)
+                        acc = fmaf(xc[((size_t)dz * s + dy) * s + dx], wc[(dz * k + dy) * k + dx], acc);
+        }
+        out[i] = acc > 0.f ? acc : acc * slope;
+    }
+}
+
+extern "C" int rf_conv3d_valid_leaky(const float* x, int n, int cin, int s, const float* w, const float* bias, int cout, int k,
+                                     int stride, float slope, float* out, void* stream) {
+    RF_REQUIRE(x && w && out && n > 0 && cin > 0 && cout > 0 && k > 0 && stride > 0 && s >= k, RF_E_INVALID, "rf_conv3d_valid_leaky: bad arguments");
+    const int so = (s - k) / stride + 1;
+    const size_t total = (size_t)n * cout * so * so * so;
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_conv3_valid, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, x, n, cin, s, w, bias,
+                       cout, k, stride, slope, so, out);
+    RF_CHECK_LAUNCH("rf_conv3d_valid_leaky");
+    return RF_OK;
+}

@@ -1,0 +1,199 @@
+"""Patch attention -- MI355X-native stand-ins for the reference's model/attention.py (same names, constructor
+arguments, ``state_dict`` keys incl. the unused-but-serialised sig_scale / sig_shift).  Inference only.
+
+  AttentionFeatureEncoder  = 4 x rf_linear (fp32 MFMA GEMM, LeakyReLU(0.01) fused)          reference :29-46
+  AttentionBlock.forward   = theta/phi encoders + rf_attn_fuse                               reference :84-113
+  PatchedAttentionBlock    = rf_unfold3d / rf_attn_gather_retrieved / AttentionBlock / rf_fold3d   reference :141-157
+  Fold3D / Unfold3D        = rf_fold3d / rf_unfold3d (pure index remaps)                     reference :160-188
+
+Gumbel-hard attention (``retrieval_mode=True``, ShapeNet configs) is stochastic in the reference
+(``gumbel_softmax`` draws noise inside forward, reference :101-102); here the noise is an explicit tensor: pass
+``gumbel_noise`` to forward, or leave it None to draw ``-log(Exponential(1))`` samples on the device.
+"""
+import math
+
+import torch
+from torch import nn
+
+from rfuse import ops
+
+
+class LinearParams(nn.Module):
+    """nn.Linear parameter holder (keys ``weight`` [out,in], ``bias`` [out]; default Linear initialisation)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features) if in_features > 0 else 0
+        nn.init.uniform_(self.bias, -bound, bound)
+        self._packed = ops.PackedWeight('linear')
+
+    def apply_to(self, x, act=ops.ACT_NONE, slope=0.0):
+        return ops.linear(x, self._packed.get(self.weight), self.bias, self.out_features, act, slope)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features}, out_features={self.out_features}'
+
+
+class ActivationMarker(nn.Module):
+    """Parameter-free place-holder that keeps Sequential / ModuleList indices aligned with the reference."""
+
+    def __init__(self, kind, slope=0.0):
+        super().__init__()
+        self.kind, self.slope = kind, slope
+
+    def extra_repr(self):
+        return f'{self.kind}, slope={self.slope}'
+
+
+class AttentionFeatureEncoder(nn.Module):
+    """Linear(n_in,128) LeakyReLU Linear(128,128) LeakyReLU Linear(128,128) LeakyReLU Linear(128,n_out); reference :29-46."""
+
+    def __init__(self, n_in, n_out, e):
+        super().__init__()
+        self.n_in = n_in * (e ** 3)
+        self.n_out = n_out
+        print("Attention Feature: ", self.n_in, "-->", self.n_out)
+        self.encoder = nn.ModuleList([
+            LinearParams(self.n_in, 128), ActivationMarker('leaky_relu', 0.01),
+            LinearParams(128, 128), ActivationMarker('leaky_relu', 0.01),
+            LinearParams(128, 128), ActivationMarker('leaky_relu', 0.01),
+            LinearParams(128, self.n_out),
+        ])
+
+    def forward(self, x):
+        ops._no_grad_only(x, self.encoder[0].weight)
+        x = x.reshape((x.shape[0], self.n_in))
+        for i in (0, 2, 4):
+            x = self.encoder[i].apply_to(x, ops.ACT_LEAKY, 0.01)
+        return self.encoder[6].apply_to(x)
+
+
+class AttentionBlock(nn.Module):
+    """reference model/attention.py:49-116.  Built for the configuration every shipped config uses: normalize=True,
+    no_output_mapping=True (g = o = Identity), blend=True; the switch is relu(max_k scores) regardless of use_switching
+    (reference :97-99)."""
+
+    def __init__(self, num_output_channels, patch_extent, K, normalize, use_switching, retrieval_mode, no_output_mapping, blend):
+        super().__init__()
+        if not (normalize and no_output_mapping and blend):
+            raise NotImplementedError('only normalize=True, no_output_mapping=True, blend=True is built (all shipped configs)')
+        self.cf_op = num_output_channels
+        self.cf_feat = 32
+        self.K = K
+        self.patch_extent = patch_extent
+        self.theta = AttentionFeatureEncoder(num_output_channels, self.cf_feat, patch_extent)
+        self.phi = AttentionFeatureEncoder(num_output_channels, self.cf_feat, patch_extent)
+        self.init_scale = 35
+        self.init_shift = -27
+        self.sig_scale = nn.Parameter(torch.ones(1) * self.init_scale)
+        self.sig_shift = nn.Parameter(torch.ones(1) * self.init_shift)
+        self.retrieval_mode = retrieval_mode
+        self.blend_mode = blend
+        self.use_switching = use_switching
+        self.normalize = normalize
+
+    @staticmethod
+    def sample_gumbel(rows, k, device):
+        """-log(Exponential(1)) samples, the draw torch's gumbel_softmax makes (reference :102)."""
+        return -torch.empty(rows, k, device=device, dtype=torch.float32).exponential_().log()
+
+    def get_features(self, x, p):
+        """x, p: [B,C,E,E,E] -> L2-normalised theta(x), phi(p) [B,32]; reference :72-82."""
+        b = x.shape[0]
+        x_feat = self.theta(x.contiguous()).reshape((b, -1))
+        p_feat = self.phi(p.contiguous()).reshape((b, -1))
+        return ops.l2_normalize_rows_(x_feat), ops.l2_normalize_rows_(p_feat)
+
+    def forward(self, x, p, gumbel_noise=None, debug=None):
+        """x: [B,C,E,E,E]; p: [B,K,C,E,E,E] -> [B,C,E,E,E]; reference :84-113."""
+        b, k, c, e = p.shape[0], p.shape[1], p.shape[2], p.shape[3]
+        if k != self.K:
+            raise ValueError(f'expected K={self.K} retrieved patches per row, got {k} (reference MaxPool1d(K) would window silently)')
+        x, p = x.contiguous(), p.contiguous()
+        x_feat = self.theta(x)
+        p_feat = self.phi(p.reshape(b * k, c, e, e, e))
+        if self.retrieval_mode:
+            if gumbel_noise is None:
+                gumbel_noise = self.sample_gumbel(b, k, x.device)
+            out = ops.attn_fuse(x, p, x_feat, p_feat, gumbel_noise.contiguous(), ops.ATTN_GUMBEL_HARD, 25.0, debug=debug is not None)
+        else:
+            sharpness = float((self.cf_feat * e * e * e) * 4)
+            out = ops.attn_fuse(x, p, x_feat, p_feat, None, ops.ATTN_SOFTMAX, sharpness, debug=debug is not None)
+        if debug is not None:
+            out, debug['scores'], debug['weights'] = out
+        return out
+
+    def get_regularization_losses(self):
+        return ((self.sig_scale - self.init_scale) ** 2 + (self.sig_shift - self.init_shift) ** 2) if self.use_switching else 0
+
+
+class PatchedAttentionBlock(nn.Module):
+    """reference model/attention.py:119-157."""
+
+    def __init__(self, nf, num_patch_x, patch_extent, num_nearest_neighbors, attention_block):
+        super().__init__()
+        self.num_patch_x = num_patch_x
+        self.patch_extent = patch_extent
+        self.num_nearest_neighbors = num_nearest_neighbors
+        self.nf = nf
+        self.attention_blocks_layer = attention_block
+        self.fold_3d = Fold3D(num_patch_x, patch_extent, self.nf)
+        self.unfold_3d = Unfold3D(patch_extent, self.nf)
+        self.unfold_3d_occ = Unfold3D(patch_extent, 1)
+
+    def get_features(self, x_predicted, x_target, occupancy):
+        """reference :132-139 -> (theta feats [N,32], phi feats [N,32], per-patch occupancy any() [N] bool)."""
+        x_predicted_feat_ = self.unfold_3d(x_predicted)
+        x_target_feat_ = self.unfold_3d(x_target)
+        occupancy_ = self.unfold_3d_occ(occupancy.to(torch.float32))
+        x_feat_flat, p_feat_flat = self.attention_blocks_layer.get_features(x_predicted_feat_, x_target_feat_)
+        occupancy_flat = occupancy_.reshape((x_predicted_feat_.shape[0], -1)).ne(0).any(dim=1)
+        return x_feat_flat, p_feat_flat, occupancy_flat
+
+    def forward(self, x_predicted, x_retrieved, gumbel_noise=None, debug=None):
+        """x_predicted [B,F,S,S,S]; x_retrieved [B*K,F,S,S,S] (folded volumes) -> [B,F,S,S,S]."""
+        b, s = x_predicted.shape[0], x_predicted.shape[-1]
+        x_rows = self.unfold_3d(x_predicted)
+        p_rows = ops.attn_gather_retrieved(x_retrieved.contiguous(), 0, b, self.num_nearest_neighbors, self.nf, s, self.patch_extent)
+        out_rows = self.attention_blocks_layer(x_rows, p_rows, gumbel_noise, debug)
+        return self.fold_3d(out_rows)
+
+    def forward_patch_major(self, x_predicted, retrieved_patch_features, patch_edge, gumbel_noise=None):
+        """Same as forward, but the retrieved features come straight from the retrieval backbone in its patch-major
+        layout [(B*K*q^3), F, t,t,t] (what Fold3D(q, t, F) would consume, trainer/train_refinement.py:37,112): the fold
+        is never materialised."""
+        b, s = x_predicted.shape[0], x_predicted.shape[-1]
+        x_rows = self.unfold_3d(x_predicted)
+        p_rows = ops.attn_gather_retrieved(retrieved_patch_features.contiguous(), 1, b, self.num_nearest_neighbors, self.nf, s,
+                                           self.patch_extent, patch_edge)
+        out_rows = self.attention_blocks_layer(x_rows, p_rows, gumbel_noise)
+        return self.fold_3d(out_rows)
+
+
+class Fold3D(nn.Module):
+    """rows [(B*R^3), nf, e,e,e] -> [B, nf, R*e, R*e, R*e]; exact inverse of Unfold3D (reference :160-176)."""
+
+    def __init__(self, num_patch_x, patch_extent, nf):
+        super().__init__()
+        self.nf = nf
+        self.num_patch_x = num_patch_x
+        self.patch_extent = patch_extent
+
+    def forward(self, x):
+        return ops.fold3d(x.contiguous(), self.num_patch_x, self.patch_extent, self.nf)
+
+
+class Unfold3D(nn.Module):
+    """[B, nf, S,S,S] -> non-overlapping patches [(B*R^3), nf, e,e,e], rows ordered (b,px,py,pz) (reference :179-188)."""
+
+    def __init__(self, patch_extent, nf):
+        super().__init__()
+        self.patch_extent = patch_extent
+        self.nf = nf
+
+    def forward(self, x):
+        return ops.unfold3d(x.contiguous(), self.patch_extent)

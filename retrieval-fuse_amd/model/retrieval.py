@@ -1,0 +1,143 @@
+"""Patch embedding networks -- MI355X-native stand-ins for the reference's model/retrieval.py.
+
+All 14 class names of the reference exist with the same constructor ``(nf, z_dim)``, the same ``state_dict`` keys
+(``layers.<even index>.{weight,bias}``, ``final_layer.{weight,bias}``) and the same output shape ``[B, z_dim, 1,1,1]``,
+so ``model.get_retrieval_networks`` (reference model/__init__.py:6-38) keeps working.  Architectures are kept as data
+(one table row per class, reference line numbers alongside) and executed by two generic forwards:
+
+  MLP family   (Patch04 :64-84, Patch05 :87-107, Patch04V2 :110-132): rf_linear (fp32 MFMA) with fused ReLU
+  conv family  (Patch08 :136-156, Patch12 :364-388, Patch16 :277-303, Patch24 :306-332, Patch24V2 :335-361,
+                Patch32 :4-28, PCPatch32 :187-213, PCPatch48 :217-243, PCPatch64 :247-273):
+                rf_conv3d_valid_leaky (valid strided conv + bias + LeakyReLU 0.2) then rf_linear for final_layer
+
+The two BatchNorm variants (PatchNorm08 :160-184, PatchNorm32 :31-61) construct and serialise identically but their
+forward is not built: no shipped config selects them.
+"""
+import torch
+from torch import nn
+
+from model.attention import LinearParams, ActivationMarker
+from model.unet import Conv3dParams
+from rfuse import ops
+
+
+class _MLPPatchEncoder(nn.Module):
+    WIDTHS = ()          # in units of nf, input first (absolute voxel count)
+
+    def __init__(self, nf, z_dim):
+        super().__init__()
+        dims = [self.WIDTHS[0]] + [nf * m for m in self.WIDTHS[1:]] + [z_dim]
+        layers = []
+        for i in range(len(dims) - 1):
+            layers.append(LinearParams(dims[i], dims[i + 1]))
+            if i < len(dims) - 2:
+                layers.append(ActivationMarker('relu'))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x):
+        ops._no_grad_only(x, self.layers[0].weight)
+        x = x.contiguous().reshape([x.shape[0], -1])
+        last = len(self.layers) - 1
+        for i in range(0, len(self.layers), 2):
+            x = self.layers[i].apply_to(x, ops.ACT_NONE if i == last else ops.ACT_RELU)
+        return x.reshape([x.shape[0], x.shape[1], 1, 1, 1])
+
+
+class Patch04(_MLPPatchEncoder):
+    WIDTHS = (4 ** 3, 4, 8, 16, 8)
+
+
+class Patch05(_MLPPatchEncoder):
+    WIDTHS = (5 ** 3, 4, 8, 16, 8)
+
+
+class Patch04V2(_MLPPatchEncoder):
+    WIDTHS = (4 ** 3, 4, 8, 16, 16, 8)
+
+
+class BatchNormParams(nn.Module):
+    """nn.BatchNorm3d state holder (weight, bias, running_mean, running_var, num_batches_tracked)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+
+class _ConvPatchEncoder(nn.Module):
+    # rows: (cin multiple of nf [0 = single input channel], cout multiple, kernel, stride)
+    SPEC = ()
+    BATCHNORM = False
+
+    def __init__(self, nf, z_dim):
+        super().__init__()
+        layers = []
+        for cin_m, cout_m, k, stride in self.SPEC:
+            layers.append(Conv3dParams(1 if cin_m == 0 else cin_m * nf, cout_m * nf, k, bias=True, stride=stride, padding=0))
+            if self.BATCHNORM:
+                layers.append(BatchNormParams(cout_m * nf))
+            layers.append(ActivationMarker('leaky_relu', 0.2))
+        self.layers = nn.ModuleList(layers)
+        self.final_layer = LinearParams(self.SPEC[-1][1] * nf, z_dim)
+
+    def forward(self, x):
+        if self.BATCHNORM:
+            raise NotImplementedError(f'{type(self).__name__}: BatchNorm patch encoders are not built (no shipped config selects them)')
+        ops._no_grad_only(x, self.final_layer.weight)
+        x = x.contiguous()
+        for layer in self.layers:
+            if isinstance(layer, Conv3dParams):
+                x = ops.conv3d_valid_leaky(x, layer.weight, layer.bias, layer.stride, 0.2)
+        if tuple(x.shape[2:]) != (1, 1, 1):
+            raise ValueError(f'{type(self).__name__}: input window does not reduce to 1^3 (got {tuple(x.shape[2:])})')
+        x = self.final_layer.apply_to(x.reshape(x.shape[0], x.shape[1]))
+        return x.reshape([x.shape[0], x.shape[1], 1, 1, 1])
+
+
+class Patch32(_ConvPatchEncoder):
+    SPEC = ((0, 1, 5, 1), (1, 2, 3, 1), (2, 4, 3, 2), (4, 8, 3, 1), (8, 8, 3, 2), (8, 8, 4, 1))
+
+
+class PatchNorm32(_ConvPatchEncoder):
+    SPEC = Patch32.SPEC
+    BATCHNORM = True
+
+
+class Patch08(_ConvPatchEncoder):
+    SPEC = ((0, 1, 3, 1), (1, 4, 3, 1), (4, 4, 3, 1), (4, 8, 2, 1))
+
+
+class PatchNorm08(_ConvPatchEncoder):
+    SPEC = Patch08.SPEC
+    BATCHNORM = True
+
+
+class PCPatch32(_ConvPatchEncoder):
+    SPEC = ((0, 1, 3, 1), (1, 2, 3, 1), (2, 4, 3, 2), (4, 4, 3, 1), (4, 8, 3, 2), (8, 8, 3, 1), (8, 8, 3, 1))
+
+
+class PCPatch48(_ConvPatchEncoder):
+    SPEC = ((0, 1, 5, 1), (1, 2, 3, 1), (2, 4, 3, 2), (4, 4, 3, 2), (4, 8, 3, 2), (8, 8, 3, 1), (8, 8, 2, 1))
+
+
+class PCPatch64(_ConvPatchEncoder):
+    SPEC = ((0, 1, 5, 1), (1, 2, 3, 1), (2, 4, 3, 2), (4, 4, 3, 2), (4, 8, 3, 2), (8, 8, 3, 1), (8, 8, 4, 1))
+
+
+class Patch16(_ConvPatchEncoder):
+    SPEC = ((0, 1, 3, 1), (1, 2, 3, 1), (2, 2, 3, 1), (2, 4, 3, 1), (4, 4, 3, 1), (4, 8, 3, 1), (8, 8, 4, 1))
+
+
+class Patch24(_ConvPatchEncoder):
+    SPEC = ((0, 1, 5, 1), (1, 2, 3, 1), (2, 2, 3, 2), (2, 4, 3, 1), (4, 8, 3, 1), (8, 8, 3, 1), (8, 8, 2, 1))
+
+
+class Patch24V2(_ConvPatchEncoder):
+    SPEC = ((0, 1, 3, 1), (1, 2, 3, 1), (2, 2, 3, 2), (2, 4, 3, 1), (4, 8, 3, 1), (8, 8, 3, 1), (8, 8, 3, 1))
+
+
+class Patch12(_ConvPatchEncoder):
+    SPEC = ((0, 1, 3, 1), (1, 2, 3, 1), (2, 4, 3, 1), (4, 4, 3, 1), (4, 8, 3, 1), (8, 8, 2, 1))

@@ -1,0 +1,206 @@
+"""3D U-Net building blocks -- MI355X-native stand-ins for the reference's model/unet.py.
+
+Same class names, constructor arguments and ``state_dict`` keys as the reference (model/unet.py:79-100 SingleConv,
+:103-144 DoubleConv, :147-159 StepDownDoubleConv, :210-253 Encoder, :256-322 Decoder/DecoderNoJoining, :392-537
+Abstract3DUNet/UNet3D), so reference checkpoints load unchanged.  The modules only HOLD parameters; ``forward`` runs
+the gfx950 kernels of librfuse_hip.so through ``rfuse.ops``:
+
+  SingleConv('gcr')  = rf_gn_stats  +  rf_conv3d_k3_gn_relu  (GroupNorm apply, upsample+concat read, ReLU fused in)
+  Encoder pooling    = rf_maxpool3d_2
+  Decoder upsample + concat: never materialised -- the conv reads (skip, low-res) as two sources.
+
+Only layer order 'gcr' with DoubleConv is implemented: it is the only path any shipped config reaches (SURVEY.md 2,
+row 1).  Inference only (no autograd); CPU tensors raise.
+"""
+import math
+
+import torch
+from torch import nn
+
+from rfuse import ops
+
+
+class GroupNormParams(nn.Module):
+    """weight/bias holder with nn.GroupNorm's names, init (ones / zeros) and the <groups collapse of model/unet.py:62-63."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        if num_channels < num_groups:
+            num_groups = 1
+        assert num_channels % num_groups == 0, \
+            f'Expected number of channels in input to be divisible by num_groups. num_channels={num_channels}, num_groups={num_groups}'
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+    def extra_repr(self):
+        return f'{self.num_groups}, {self.num_channels}, eps={self.eps}'
+
+
+class Conv3dParams(nn.Module):
+    """weight (and optional bias) holder with nn.Conv3d's names, shapes (OIDHW) and default initialisation."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias, stride=1, padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+        self._packed = ops.PackedWeight('conv3')
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size ** 3
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def packed(self):
+        return self._packed.get(self.weight)
+
+    def extra_repr(self):
+        return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
+
+
+class SingleConv(nn.Module):
+    """GroupNorm -> Conv3d(k3, p1, no bias) -> ReLU, order 'gcr' (reference model/unet.py:19-76,79-100)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order='gcr', num_groups=8, padding=1):
+        super().__init__()
+        if order != 'gcr' or kernel_size != 3 or padding != 1:
+            raise NotImplementedError(
+                "only layer order 'gcr' with 3x3x3 kernels and padding 1 is built (the only order the shipped configs use); got "
+                f"order={order!r} kernel_size={kernel_size} padding={padding}")
+        self.groupnorm = GroupNormParams(num_groups, in_channels)
+        self.conv = Conv3dParams(in_channels, out_channels, 3, bias=False, padding=1)
+
+    def forward(self, x, upsampled=None, _direct=False):
+        """x: full-resolution source [N,C0,S,S,S] or None; ``upsampled``: low-resolution source [N,C1,S/2,S/2,S/2] that the
+        reference would nearest-upsample and concatenate after x (model/unet.py:297-308)."""
+        ops._no_grad_only(x, upsampled, self.conv.weight)
+        gn = self.groupnorm
+        scale, shift = ops.gn_scale_shift(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
+        edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
+        if _direct or edge == 1:
+            return ops.conv3d_gn_relu(x, upsampled, scale, shift, None, self.conv.out_channels, direct_weight=self.conv.weight)
+        return ops.conv3d_gn_relu(x, upsampled, scale, shift, self.conv.packed(), self.conv.out_channels)
+
+
+class DoubleConv(nn.Module):
+    """Two SingleConvs; channel plan of reference model/unet.py:125-144."""
+
+    def __init__(self, in_channels, out_channels, encoder, kernel_size=3, order='gcr', num_groups=8):
+        super().__init__()
+        if encoder:
+            c1_in, c1_out = in_channels, max(out_channels // 2, in_channels)
+            c2_in, c2_out = c1_out, out_channels
+        else:
+            c1_in, c1_out = in_channels, out_channels
+            c2_in, c2_out = out_channels, out_channels
+        self.SingleConv1 = SingleConv(c1_in, c1_out, kernel_size, order, num_groups)
+        self.SingleConv2 = SingleConv(c2_in, c2_out, kernel_size, order, num_groups)
+
+    def forward(self, x, upsampled=None):
+        return self.SingleConv2(self.SingleConv1(x, upsampled))
+
+
+class StepDownDoubleConv(nn.Module):
+    """in -> (in+out)//2 -> out (reference model/unet.py:149-159)."""
+
+    def __init__(self, in_channels, out_channels, encoder, kernel_size=3, order='gcr', num_groups=8):
+        super().__init__()
+        self.encoder = encoder
+        mid = (in_channels + out_channels) // 2
+        self.SingleConv1 = SingleConv(in_channels, mid, kernel_size, order, num_groups)
+        self.SingleConv2 = SingleConv(mid, out_channels, kernel_size, order, num_groups)
+
+    def forward(self, x, upsampled=None):
+        return self.SingleConv2(self.SingleConv1(x, upsampled))
+
+
+class Encoder(nn.Module):
+    """optional MaxPool3d(2) then the basic module (reference model/unet.py:230-253)."""
+
+    def __init__(self, in_channels, out_channels, conv_kernel_size=3, apply_pooling=True, pool_kernel_size=(2, 2, 2),
+                 pool_type='max', basic_module=DoubleConv, conv_layer_order='gcr', num_groups=8):
+        super().__init__()
+        if apply_pooling and (pool_type != 'max' or tuple(pool_kernel_size) != (2, 2, 2)):
+            raise NotImplementedError('only MaxPool3d(2) is built')
+        self.apply_pooling = apply_pooling
+        self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
+                                         order=conv_layer_order, num_groups=num_groups)
+
+    def forward(self, x):
+        if self.apply_pooling:
+            x = ops.maxpool2(x)
+        return self.basic_module(x)
+
+
+class Decoder(nn.Module):
+    """nearest upsample to the skip's size + concat (skip first) + basic module (reference model/unet.py:273-308)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, scale_factor=(2, 2, 2), basic_module=DoubleConv,
+                 conv_layer_order='gcr', num_groups=8, mode='nearest'):
+        super().__init__()
+        if basic_module not in (DoubleConv, StepDownDoubleConv) or mode != 'nearest' or tuple(scale_factor) != (2, 2, 2):
+            raise NotImplementedError('only nearest x2 upsampling with concat joining is built')
+        self.basic_module = basic_module(in_channels, out_channels, encoder=False, kernel_size=kernel_size,
+                                         order=conv_layer_order, num_groups=num_groups)
+
+    def forward(self, encoder_features, x):
+        if encoder_features.shape[2] != 2 * x.shape[2]:
+            raise NotImplementedError('skip connection must be exactly twice the decoder input resolution')
+        return self.basic_module(encoder_features, x)
+
+
+class DecoderNoJoining(Decoder):
+    """x2 nearest upsample then the basic module, no skip (reference model/unet.py:311-322)."""
+
+    # noinspection PyMethodOverriding
+    def forward(self, x):
+        return self.basic_module(None, x)
+
+
+def number_of_features_per_level(init_channel_number, num_levels):
+    return [init_channel_number * 2 ** k for k in range(num_levels)]
+
+
+class UNet3D(nn.Module):
+    """Encoder/decoder wiring of reference Abstract3DUNet (model/unet.py:424-520) with DoubleConv, final_conv=False."""
+
+    def __init__(self, in_channels, out_channels, final_sigmoid=True, f_maps=64, layer_order='gcr', num_groups=8, num_levels=4,
+                 is_segmentation=True, remove_n_final_layers=0, final_conv=False, **kwargs):
+        super().__init__()
+        if final_conv or is_segmentation:
+            raise NotImplementedError('final_conv / segmentation heads are never instantiated by the refinement path')
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
+        encoders = []
+        for i, out_feature_num in enumerate(f_maps):
+            encoders.append(Encoder(in_channels if i == 0 else f_maps[i - 1], out_feature_num, apply_pooling=(i > 0),
+                                    basic_module=DoubleConv, conv_layer_order=layer_order, num_groups=num_groups))
+        self.encoders = nn.ModuleList(encoders)
+
+        reversed_f_maps = list(reversed(f_maps))
+        if remove_n_final_layers > 0:
+            reversed_f_maps = reversed_f_maps[:-remove_n_final_layers]
+        outs = list(reversed_f_maps)
+        outs[-1] = out_channels                                      # model/unet.py:453-455
+        decoders = []
+        for i in range(len(reversed_f_maps) - 1):
+            in_feature_num = reversed_f_maps[i] + reversed_f_maps[i + 1]
+            last_and_trimmed = i == (len(reversed_f_maps) - 2) and remove_n_final_layers > 0      # model/unet.py:465
+            decoders.append(Decoder(in_feature_num, outs[i + 1], basic_module=StepDownDoubleConv if last_and_trimmed else DoubleConv,
+                                    conv_layer_order=layer_order, num_groups=num_groups))
+        self.decoders = nn.ModuleList(decoders)
+
+    def forward(self, x):
+        feats = []
+        for encoder in self.encoders:
+            x = encoder(x)
+            feats.insert(0, x)
+        feats = feats[1:]                                            # model/unet.py:500-504
+        for decoder, skip in zip(self.decoders, feats):              # zip truncates, model/unet.py:507
+            x = decoder(skip, x)
+        return x

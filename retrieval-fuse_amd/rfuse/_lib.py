@@ -1,0 +1,77 @@
+"""ctypes binding of librfuse_hip.so (the C ABI declared in include/rfuse.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.  ``import torch`` must come
+first so that the HIP runtime the library binds to is the one PyTorch-ROCm already loaded (same SONAME).
+"""
+import ctypes
+import os
+from pathlib import Path
+
+import torch  # noqa: F401  (loads libamdhip64 before we dlopen)
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get('RFUSE_LIB', _HERE / 'librfuse_hip.so'))
+
+c_fp = ctypes.c_void_p     # device float*
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+c_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); one entry per symbol declared in include/rfuse.h
+SIGNATURES = {
+    'rf_abi_version': (c_i, []),
+    'rf_last_error': (ctypes.c_char_p, []),
+    'rf_conv3_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),
+    'rf_conv3_packed_floats': (c_sz, [c_i, c_i]),
+    'rf_gn_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_p, c_sz, c_p]),
+    'rf_gn_stats_ws_bytes': (c_sz, [c_i, c_i]),
+    'rf_conv3d_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_conv3d_k3_gn_relu_direct': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_maxpool3d_2': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_conv1x1_tanh': (c_i, [c_fp, c_i, c_i, c_sz, c_fp, c_fp, c_f, c_f, c_fp, c_p]),
+    'rf_conv3d_valid_leaky': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_unfold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_fold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_linear_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),
+    'rf_linear_packed_floats': (c_sz, [c_i, c_i]),
+    'rf_linear': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_l2_normalize_rows': (c_i, [c_fp, c_i, c_i, c_f, c_p]),
+    'rf_attn_fuse': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_p]),
+    'rf_attn_gather_retrieved': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_query_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_p]),
+    'rf_db_pack_embeddings': (c_i, [c_fp, c_i64, c_i, c_fp, c_p]),
+    'rf_db_packed_floats': (c_sz, [c_i64, c_i]),
+    'rf_l2_topk': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_p, c_p, c_sz, c_p]),
+    'rf_l2_topk_ws_bytes': (c_sz, [c_i, c_i64, c_i]),
+    'rf_topk_merge': (c_i, [c_fp, c_p, c_i, c_i, c_i, c_fp, c_p, c_p]),
+    'rf_demote_same_scene': (c_i, [c_fp, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_fp, c_p, c_p]),
+    'rf_gather_patches': (c_i, [c_fp, c_i64, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_fp, c_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once) and attach argument/return types.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            'librfuse_hip.so not found at %s -- build it with `python retrieval-fuse_amd/csrc/build.py` '
+            '(or __graft_entry__.build()).  There is no CPU fallback for the refinement hot path.' % LIB_PATH)
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rf_last_error()
+        raise RuntimeError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,303 @@
+"""Tensor-level wrappers over the C ABI (include/rfuse.h).  PyTorch is used for device memory and streams only:
+every function takes contiguous float32 CUDA(HIP) tensors, launches on ``torch.cuda.current_stream()`` and returns
+freshly allocated outputs.  Anything else (CPU tensors, other dtypes, missing library) raises -- no fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ATTN_SOFTMAX, ATTN_GUMBEL_HARD = 0, 1
+
+
+def _req(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s: expected a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s: the refinement hot path runs on the GPU only (got a %s tensor); there is no CPU fallback' % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError('%s: expected %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s: tensor must be contiguous' % name)
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            'rfuse kernels implement inference only; call under torch.no_grad() '
+            '(backward for the custom ops is the "next" row N4 of SURVEY.md section 8f)')
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    """Persistent per-(device, stream) scratch, grown on demand."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+class PackedWeight:
+    """Caches the MFMA operand image of a Parameter; re-packs when the parameter is modified, moved or replaced."""
+
+    def __init__(self, kind):
+        self.kind = kind        # 'conv3' | 'linear'
+        self._key = None
+        self._packed = None
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        if key != self._key:
+            self._packed = pack_conv3_weight(w) if self.kind == 'conv3' else pack_linear_weight(w)
+            self._key = key
+        return self._packed
+
+
+# ------------------------------------------------------------------------------------------------ U-Net primitives
+
+def pack_conv3_weight(w):
+    _req(w.detach(), 'conv weight')
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError('pack_conv3_weight: expected an OIDHW 3x3x3 weight, got %s' % (tuple(w.shape),))
+    lib = _lib.load()
+    out = torch.empty(lib.rf_conv3_packed_floats(cout, cin), dtype=torch.float32, device=w.device)
+    _lib.check(lib.rf_conv3_pack_weight(_p(w.detach()), cout, cin, _p(out), _stream()), 'rf_conv3_pack_weight')
+    return out
+
+
+def _src_dims(src0, src1):
+    n = (src0 if src0 is not None else src1).shape[0]
+    c0 = src0.shape[1] if src0 is not None else 0
+    c1 = src1.shape[1] if src1 is not None else 0
+    edge = src0.shape[2] if src0 is not None else 2 * src1.shape[2]
+    for t, e in ((src0, edge), (src1, edge // 2)):
+        if t is not None and (t.dim() != 5 or tuple(t.shape[2:]) != (e, e, e) or t.shape[0] != n):
+            raise ValueError('expected cubic NCDHW volumes with matching batch, got %s' % (tuple(t.shape),))
+    return n, c0, c1, edge
+
+
+def gn_scale_shift(src0, src1, gamma, beta, groups, eps=1e-5):
+    """GroupNorm of cat(src0, up2(src1)) folded to per-(n, c) scale/shift.  Either source may be None."""
+    for t, nm in ((src0, 'src0'), (src1, 'src1')):
+        if t is not None:
+            _req(t, nm)
+    _req(gamma.detach(), 'gamma'), _req(beta.detach(), 'beta')
+    n, c0, c1, edge = _src_dims(src0, src1)
+    c = c0 + c1
+    if c < groups:
+        groups = 1                                           # model/unet.py:62-63
+    dev = gamma.device
+    lib = _lib.load()
+    scale = torch.empty((n, c), dtype=torch.float32, device=dev)
+    shift = torch.empty((n, c), dtype=torch.float32, device=dev)
+    nbytes = lib.rf_gn_stats_ws_bytes(n, groups)
+    ws = _workspace(dev, nbytes)
+    _lib.check(lib.rf_gn_stats(_p(src0), c0, _p(src1), c1, n, edge, _p(gamma.detach()), _p(beta.detach()), groups, eps,
+                               _p(scale), _p(shift), _p(ws), ws.numel(), _stream()), 'rf_gn_stats')
+    return scale, shift
+
+
+def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None):
+    """ReLU(conv3(GN(cat(src0, up2(src1))))).  1^3 volumes (and ``direct_weight`` calls) use the direct kernel."""
+    n, c0, c1, edge = _src_dims(src0, src1)
+    dev = scale.device
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    if direct_weight is not None:
+        _lib.check(lib.rf_conv3d_k3_gn_relu_direct(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(direct_weight.detach()),
+                                                   cout, _p(out), _stream()), 'rf_conv3d_k3_gn_relu_direct')
+    else:
+        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
+                                            _stream()), 'rf_conv3d_k3_gn_relu')
+    return out
+
+
+def maxpool2(x):
+    _req(x, 'x')
+    n, c, edge = x.shape[0], x.shape[1], x.shape[2]
+    out = torch.empty((n, c, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_maxpool3d_2(_p(x), n, c, edge, _p(out), _stream()), 'rf_maxpool3d_2')
+    return out
+
+
+def conv1x1_tanh(x, w, b, post_add=0.0, post_mul=1.0):
+    _req(x, 'x'), _req(w.detach(), 'w'), _req(b.detach(), 'b')
+    if w.shape[0] != 1:
+        raise NotImplementedError('conv1x1_tanh: one output channel (Conv3d(nf,1,1), model/refinement.py:54)')
+    n, c = x.shape[0], x.shape[1]
+    vox = x[0, 0].numel()
+    out = torch.empty((n, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv1x1_tanh(_p(x), n, c, vox, _p(w.detach()), _p(b.detach()), post_add, post_mul, _p(out), _stream()),
+               'rf_conv1x1_tanh')
+    return out
+
+
+def conv3d_valid_leaky(x, w, bias, stride, slope):
+    _req(x, 'x'), _req(w.detach(), 'w')
+    n, cin, s = x.shape[0], x.shape[1], x.shape[2]
+    cout, k = w.shape[0], w.shape[2]
+    so = (s - k) // stride + 1
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky(_p(x), n, cin, s, _p(w.detach()), _p(bias.detach() if bias is not None else None), cout, k,
+                                                 stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky')
+    return out
+
+
+# --------------------------------------------------------------------------------------------------- fold / unfold
+
+def unfold3d(x, e):
+    _req(x, 'x')
+    b, c, s = x.shape[0], x.shape[1], x.shape[2]
+    r = s // e
+    rows = torch.empty((b * r * r * r, c, e, e, e), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_unfold3d(_p(x), b, c, s, e, _p(rows), _stream()), 'rf_unfold3d')
+    return rows
+
+
+def fold3d(rows, r, e, c):
+    _req(rows, 'rows')
+    s = r * e
+    total = rows.numel()
+    b = total // (c * s * s * s)
+    if b * c * s * s * s != total:
+        raise ValueError('fold3d: %d values do not tile [b,%d,%d^3]' % (total, c, s))
+    x = torch.empty((b, c, s, s, s), dtype=torch.float32, device=rows.device)
+    _lib.check(_lib.load().rf_fold3d(_p(rows), b, c, s, e, _p(x), _stream()), 'rf_fold3d')
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------ Linear/MLP
+
+def pack_linear_weight(w):
+    _req(w.detach(), 'linear weight')
+    nout, nin = w.shape
+    lib = _lib.load()
+    out = torch.empty(lib.rf_linear_packed_floats(nout, nin), dtype=torch.float32, device=w.device)
+    _lib.check(lib.rf_linear_pack_weight(_p(w.detach()), nout, nin, _p(out), _stream()), 'rf_linear_pack_weight')
+    return out
+
+
+def linear(x, w_packed, bias, nout, act=ACT_NONE, slope=0.0):
+    _req(x, 'x')
+    rows, nin = x.shape
+    y = torch.empty((rows, nout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_linear(_p(x), rows, nin, _p(w_packed), _p(bias.detach() if bias is not None else None), nout, act, slope,
+                                     _p(y), _stream()), 'rf_linear')
+    return y
+
+
+def l2_normalize_rows_(x, eps=1e-12):
+    _req(x, 'x')
+    _lib.check(_lib.load().rf_l2_normalize_rows(_p(x), x.shape[0], x.shape[1], eps, _stream()), 'rf_l2_normalize_rows')
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------- attention
+
+def attn_gather_retrieved(src, layout, b, k, c, s, e, t=0):
+    _req(src, 'src')
+    r = s // e
+    p = torch.empty((b * r * r * r, k, c, e, e, e), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().rf_attn_gather_retrieved(_p(src), layout, b, k, c, s, e, t, _p(p), _stream()), 'rf_attn_gather_retrieved')
+    return p
+
+
+def attn_fuse(x, p, xf, pf, noise, mode, sharpness, debug=False):
+    """x [b,d]-like, p [b,K,d]-like, xf [b,f], pf [b*K,f] (raw encoder outputs), noise [b,K] or None."""
+    _req(x, 'x'), _req(p, 'p'), _req(xf, 'xf'), _req(pf, 'pf')
+    if noise is not None:
+        _req(noise, 'noise')
+    b = x.shape[0]
+    k = p.shape[1]
+    d = x[0].numel()
+    f = xf.shape[1]
+    out = torch.empty_like(x)
+    sc = torch.empty((b, k), dtype=torch.float32, device=x.device) if debug else None
+    wt = torch.empty((b, k), dtype=torch.float32, device=x.device) if debug else None
+    _lib.check(_lib.load().rf_attn_fuse(_p(x), _p(p), _p(xf), _p(pf), _p(noise), b, k, d, f, mode, sharpness, _p(out), _p(sc), _p(wt),
+                                        _stream()), 'rf_attn_fuse')
+    return (out, sc, wt) if debug else out
+
+
+# ------------------------------------------------------------------------------------------------------- retrieval
+
+def query_windows(raw, ps, ctx, pad_value, mean, std):
+    _req(raw, 'raw')
+    b, s = raw.shape[0], raw.shape[-1]
+    npatch, w = s // ps, ps + 2 * ctx
+    out = torch.empty((b * npatch ** 3, 1, w, w, w), dtype=torch.float32, device=raw.device)
+    _lib.check(_lib.load().rf_query_windows(_p(raw), b, s, ps, ctx, pad_value, mean, std, _p(out), _stream()), 'rf_query_windows')
+    return out
+
+
+def db_pack_embeddings(emb):
+    _req(emb, 'emb')
+    n, dim = emb.shape
+    lib = _lib.load()
+    out = torch.empty(lib.rf_db_packed_floats(n, dim), dtype=torch.float32, device=emb.device)
+    _lib.check(lib.rf_db_pack_embeddings(_p(emb), n, dim, _p(out), _stream()), 'rf_db_pack_embeddings')
+    return out
+
+
+def l2_topk(q, db_packed, n, row_base, k2):
+    _req(q, 'q'), _req(db_packed, 'db_packed')
+    nq, dim = q.shape
+    lib = _lib.load()
+    dist = torch.empty((nq, k2), dtype=torch.float32, device=q.device)
+    idx = torch.empty((nq, k2), dtype=torch.int64, device=q.device)
+    nbytes = lib.rf_l2_topk_ws_bytes(nq, n, k2)
+    ws = _workspace(q.device, nbytes)
+    _lib.check(lib.rf_l2_topk(_p(q), nq, dim, _p(db_packed), n, row_base, k2, _p(dist), _p(idx), _p(ws), ws.numel(), _stream()), 'rf_l2_topk')
+    return dist, idx
+
+
+def topk_merge(dist_parts, idx_parts):
+    """[parts, nq, k2] candidate lists -> [nq, k2] best by (dist, idx)."""
+    _req(dist_parts, 'dist_parts'), _req(idx_parts, 'idx_parts', torch.int64)
+    parts, nq, k2 = dist_parts.shape
+    dist = torch.empty((nq, k2), dtype=torch.float32, device=dist_parts.device)
+    idx = torch.empty((nq, k2), dtype=torch.int64, device=dist_parts.device)
+    _lib.check(_lib.load().rf_topk_merge(_p(dist_parts), _p(idx_parts), parts, nq, k2, _p(dist), _p(idx), _stream()), 'rf_topk_merge')
+    return dist, idx
+
+
+def demote_same_scene(dist, idx, db_meta, query_scene, K):
+    _req(dist, 'dist'), _req(idx, 'idx', torch.int64), _req(db_meta, 'db_meta', torch.int32)
+    if query_scene is not None:
+        _req(query_scene, 'query_scene', torch.int32)
+    nq, k2 = dist.shape
+    dev = dist.device
+    out_meta = torch.empty((nq, K, 7), dtype=torch.int32, device=dev)
+    out_dist = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    out_idx = torch.empty((nq, K), dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().rf_demote_same_scene(_p(dist), _p(idx), nq, k2, _p(db_meta), _p(query_scene), K, _p(out_meta), _p(out_dist),
+                                                _p(out_idx), _stream()), 'rf_demote_same_scene')
+    return out_meta, out_dist, out_idx
+
+
+def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, std, layout):
+    _req(db_volumes, 'db_volumes'), _req(meta, 'meta', torch.int32)
+    dev = db_volumes.device
+    if layout == 1:
+        out = torch.empty((chunks * K * 64, 1, 16, 16, 16), dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty((chunks, K, 64, 64, 64), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().rf_gather_patches(_p(db_volumes), db_volumes.shape[0], _p(meta), chunks, K, trunc_fill, trunc_ratio, mean, std,
+                                             layout, _p(out), _stream()), 'rf_gather_patches')
+    return out
