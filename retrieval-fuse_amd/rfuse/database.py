@@ -1,0 +1,84 @@
+"""Patch database resident in HBM, and the (optionally sharded) exact top-k search over it.
+
+Row semantics follow the reference's ``database.npy`` (util/retrieval.py:32,39-45): per row
+``[scene_idx, x0,x1,y0,y1,z0,z1, emb_0..emb_63]`` plus a final sentinel row (scene -1, an all-trunc patch,
+util/retrieval.py:21-26,45).  On the device it is kept as structure-of-arrays:
+
+  emb_packed  float32 [ceil(n_local/64)][64 dims][64 rows]   this rank's shard of the embedding matrix (scan layout)
+  meta        int32   [N+1][7]                               replicated (28 B/row)
+  volumes     float32 [S][64][64][64]                        replicated scene chunks the 16^3 boxes point into
+
+Sharding: rank g scans rows [g*N/W, (g+1)*N/W) for ALL queries and the per-shard top-2K
+(dist, global row id) lists are exchanged with one all-gather and merged -- the only collective on the path.
+The voxel store is replicated (1 M patches = 15 625 chunks = 16.4 GB fp32, trivial against 288 GB), so no payload
+exchange is needed.
+"""
+import torch
+
+from . import ops
+
+
+def shard_bounds(n_rows, rank, world):
+    """Contiguous row range of ``rank``; the remainder goes to the low ranks."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allgather_merge(q_local, local_topk, merge, k2, group=None):
+    """The sharded search protocol, independent of how the local scan / merge are computed (so it runs on gloo/CPU
+    in tests with numpy callables and on RCCL with the HIP kernels):
+
+      1. all-gather the queries (every shard must see every query)
+      2. local_topk(all_queries) -> (dist [Q,k2] f32, idx [Q,k2] i64 global ids) over this rank's rows
+      3. all-gather the candidate lists -> [W,Q,k2]
+      4. merge(dist_parts, idx_parts) restricted to this rank's own queries -> ([q_local,k2], [q_local,k2])
+
+    All ranks must pass the same number of local queries (chunk batches are split evenly)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nq = q_local.shape[0]
+    q_all = torch.empty((world * nq,) + tuple(q_local.shape[1:]), dtype=q_local.dtype, device=q_local.device)
+    dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
+    d_loc, i_loc = local_topk(q_all)
+    d_all = torch.empty((world,) + tuple(d_loc.shape), dtype=d_loc.dtype, device=d_loc.device)
+    i_all = torch.empty((world,) + tuple(i_loc.shape), dtype=i_loc.dtype, device=i_loc.device)
+    dist.all_gather_into_tensor(d_all, d_loc.contiguous(), group=group)
+    dist.all_gather_into_tensor(i_all, i_loc.contiguous(), group=group)
+    mine = slice(rank * nq, (rank + 1) * nq)
+    return merge(d_all[:, mine].contiguous(), i_all[:, mine].contiguous())
+
+
+class PatchDatabase:
+    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None):
+        """emb [N+1,64] float32 (unit rows), meta [N+1,7] int32, volumes [S,64,64,64] float32 -- host or device tensors /
+        numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes."""
+        emb = torch.as_tensor(emb)
+        self.n_rows = emb.shape[0]
+        self.dim = emb.shape[1]
+        self.rank, self.world, self.group = rank, world, group
+        self.lo, self.hi = shard_bounds(self.n_rows, rank, world)
+        self.device = torch.device(device)
+        shard = emb[self.lo:self.hi].to(self.device, torch.float32).contiguous()
+        self.emb_packed = ops.db_pack_embeddings(shard)
+        self.meta = torch.as_tensor(meta).to(self.device, torch.int32).contiguous()
+        self.volumes = torch.as_tensor(volumes).to(self.device, torch.float32).contiguous()
+        self.n_scenes = self.volumes.shape[0]
+
+    def local_topk(self, q, k2):
+        """Exact squared-L2 top-k2 of q against this rank's shard, global row ids."""
+        return ops.l2_topk(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2)
+
+    def search(self, q, k2):
+        """Top-k2 over the whole database for this rank's queries.  One process: a single scan.  W processes:
+        all-gather(queries) -> shard scans -> all-gather(candidates) -> merge."""
+        if self.world == 1:
+            return self.local_topk(q, k2)
+        return allgather_merge(q, lambda qa: self.local_topk(qa, k2), ops.topk_merge, k2, self.group)
+
+    def retrieve(self, q, K, query_scene=None):
+        """flann_knn_worker semantics (util/retrieval.py:92-100): top-2K, same-scene demotion, keep K.
+        Returns (meta [Q,K,7] int32, dist [Q,K], idx [Q,K])."""
+        dist, idx = self.search(q, 2 * K)
+        return ops.demote_same_scene(dist, idx, self.meta, query_scene, K)

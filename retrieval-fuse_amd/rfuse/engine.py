@@ -1,0 +1,95 @@
+"""Online retrieve -> attend -> refine for batches of 64^3 chunks on one MI355X (one process per GPU).
+
+This is the build's own runner for the data flow of ``RefinementTrainingModule.forward_full``
+(reference trainer/train_refinement.py:108-116) + ``network_pred_to_df`` (:242-243), with the reference's OFFLINE
+retrieval (util/retrieval.py ``--mode map`` / ``--mode compose``, :222-248) done online on the device:
+
+   raw input chunk  --rf_query_windows-->  query windows --fenc_input + normalise-->  unit embeddings        (A11, A16)
+                    --rf_l2_topk (+ all-gather + rf_topk_merge when the DB is sharded)-->  top-2K             (A12)
+                    --rf_demote_same_scene-->  top-K (scene, box)                                             (A13)
+                    --rf_gather_patches-->  K*64 retrieved 16^3 patches per chunk, normalised, already in the
+                                           Unfold3D(16,1) row layout                                          (A15, A16, A4)
+   retrieval_backbone(patches) ; unet_backbone(normalised input)                                              (A3, A1)
+   patched attention over the patch-major features (no Fold3D materialised)                                   (A5-A7)
+   decoder -> tanh -> df = (pred+1) * trunc/2                                                                 (A9, A10)
+
+Everything numeric runs in librfuse_hip.so; this file only sequences launches and owns tensors.
+"""
+import contextlib
+import io
+
+import torch
+
+import model as rf_model
+from . import ops
+from .configs import truncations
+
+
+class RefinementEngine:
+    def __init__(self, config, device='cuda:0', database=None, quiet=True):
+        self.config = config
+        self.device = torch.device(device)
+        self.K = config['K']
+        self.input_trunc, self.target_trunc = truncations(config)
+        sink = io.StringIO() if quiet else None
+        with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
+            self.unet_backbone = rf_model.get_unet_backbone(config)
+            self.decoder = rf_model.get_decoder(config)
+            self.retrieval_backbone = rf_model.get_retrieval_backbone(config)
+            self.patched_attention_block = rf_model.get_attention_block(config)
+            self.fenc_input, _ = rf_model.get_retrieval_networks(config['retrieval_model'])
+        for m in self.modules().values():
+            m.to(self.device).eval()
+        self.database = database
+
+    def modules(self):
+        return {'unet_backbone': self.unet_backbone, 'decoder': self.decoder, 'retrieval_backbone': self.retrieval_backbone,
+                'patched_attention_block': self.patched_attention_block, 'fenc_input': self.fenc_input}
+
+    def load_state_dicts(self, sds):
+        for name, sd in sds.items():
+            self.modules()[name].load_state_dict(sd)
+
+    # ---------------------------------------------------------------------------------------------- stages
+    @torch.no_grad()
+    def embed_queries(self, input_raw):
+        """input_raw [B,S,S,S] un-normalised -> unit query embeddings [B*P, latent] (P = 64 windows per chunk)."""
+        g, d = self.config['query_geometry'], self.config['dataset_train']
+        pad = 0.0 if self.config['task'] == 'surface_reconstruction' else self.input_trunc
+        win = ops.query_windows(input_raw, g['patch_size_input'], g['patch_context_input'], pad, d['input_mean'], d['input_std'])
+        z = self.fenc_input(win)
+        return ops.l2_normalize_rows_(z.reshape(z.shape[0], z.shape[1]))
+
+    @torch.no_grad()
+    def retrieve(self, input_raw, query_scene=None):
+        """-> (patches [(B*K*64),1,16,16,16] normalised, meta [B*64,K,7])."""
+        d = self.config['dataset_train']
+        q = self.embed_queries(input_raw)
+        meta, _, _ = self.database.retrieve(q, self.K, query_scene)
+        patches = ops.gather_patches(self.database.volumes, meta, input_raw.shape[0], self.K, self.target_trunc, 1.0,
+                                     d['target_mean'], d['target_std'], layout=1)
+        return patches, meta
+
+    @torch.no_grad()
+    def normalise_input(self, input_raw):
+        """(x - mean) / std of the whole chunk = the window kernel with one window and no context."""
+        d = self.config['dataset_train']
+        s = input_raw.shape[-1]
+        return ops.query_windows(input_raw, s, 0, 0.0, d['input_mean'], d['input_std']).reshape(input_raw.shape[0], 1, s, s, s)
+
+    @torch.no_grad()
+    def refine_from_patches(self, x_in, patches, gumbel_noise=None, stages=None):
+        """x_in [B,1,S,S,S] normalised; patches [(B*K*64),1,16^3] normalised -> df [B,1,64,64,64]."""
+        x_back = self.unet_backbone(x_in)
+        feats = self.retrieval_backbone(patches)                                  # [(B*K*64), nf, 8,8,8], patch-major
+        x = self.patched_attention_block.forward_patch_major(x_back, feats, feats.shape[-1], gumbel_noise)
+        df = self.decoder.forward_df(x, self.target_trunc)
+        if stages is not None:
+            stages.update(x_back=x_back, retrieval_features=feats, x_attn=x, df=df)
+        return df
+
+    @torch.no_grad()
+    def refine(self, input_raw, query_scene=None, gumbel_noise=None):
+        """The whole online path for a batch of chunks: raw low-res input [B,S,S,S] -> refined TSDF [B,1,64,64,64]."""
+        patches, _ = self.retrieve(input_raw, query_scene)
+        return self.refine_from_patches(self.normalise_input(input_raw), patches, gumbel_noise)

@@ -1,0 +1,321 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (rfuse.ops -> librfuse_hip.so) against the oracle /
+plain fp32 PyTorch-CPU references of the same op.  Run with ``-m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import refpath
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    from rfuse import ops as _ops
+    return _ops
+
+
+def rnd(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).float()
+
+
+def close(got, ref, tol=2e-5, what=''):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    bound = tol * max(1.0, ref.abs().max().item())
+    assert err <= bound, f'{what}: max abs err {err:.3e} > {bound:.3e}'
+
+
+def ref_gcr(src0, src1, gamma, beta, groups, w):
+    parts = []
+    if src0 is not None:
+        parts.append(src0)
+    if src1 is not None:
+        parts.append(F.interpolate(src1, scale_factor=2, mode='nearest'))
+    x = torch.cat(parts, dim=1)
+    g = 1 if x.shape[1] < groups else groups
+    x = F.group_norm(x, g, gamma, beta, eps=1e-5)
+    return F.relu(F.conv3d(x, w, None, padding=1))
+
+
+CONV_CASES = [
+    # (n, c0, c1, edge, cout, groups)
+    (2, 1, 0, 8, 8, 8),        # first layer: cin=1 (< groups -> one group), cout < 16
+    (3, 8, 0, 8, 16, 8),
+    (1, 16, 0, 16, 32, 8),     # several 8^3 tiles per sample
+    (2, 32, 64, 8, 56, 8),     # decoder read: skip + upsampled, cout=56 (StepDown), groups straddle the two sources
+    (1, 0, 32, 16, 32, 8),     # DecoderNoJoining: upsampled source only
+    (9, 16, 0, 4, 32, 8),      # 4^3 volumes: 8 samples per workgroup, partial last workgroup
+    (5, 64, 128, 4, 64, 8),    # 4^3 decoder read
+    (70, 64, 0, 2, 128, 8),    # 2^3 volumes: 64 samples per workgroup, cout block 2
+    (3, 64, 128, 2, 64, 8),
+    (4, 64, 0, 1, 128, 8),     # 1^3 -> direct path
+    (1, 6, 0, 8, 12, 6),       # nf=12 family: cin not a multiple of 4
+    (1, 78, 0, 8, 12, 6),
+    (1, 16, 0, 32, 16, 8),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv3d_gn_relu(ops, case):
+    n, c0, c1, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xffff)
+    src0 = rnd(gen, n, c0, edge, edge, edge).relu_() if c0 else None          # inputs are post-ReLU in the network
+    src1 = rnd(gen, n, c1, edge // 2, edge // 2, edge // 2).relu_() if c1 else None
+    cin = c0 + c1
+    gamma, beta = 1 + 0.2 * rnd(gen, cin), 0.2 * rnd(gen, cin)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin))
+    ref = ref_gcr(src0, src1, gamma, beta, groups, w)
+    d0 = src0.to(DEV) if src0 is not None else None
+    d1 = src1.to(DEV) if src1 is not None else None
+    scale, shift = ops.gn_scale_shift(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
+    # GroupNorm folding itself
+    g = 1 if cin < groups else groups
+    xcat = torch.cat([t for t in (src0, F.interpolate(src1, scale_factor=2, mode='nearest') if src1 is not None else None) if t is not None], 1)
+    xg = xcat.double().reshape(n, g, -1)
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    cpg = cin // g
+    sc_ref = gamma.double()[None] * rstd.repeat_interleave(cpg, 1)
+    sh_ref = beta.double()[None] - mean.repeat_interleave(cpg, 1) * sc_ref
+    close(scale, sc_ref, 1e-6, 'gn scale')
+    close(shift, sh_ref, 1e-6, 'gn shift')
+    wd = w.to(DEV)
+    direct = ops.conv3d_gn_relu(d0, d1, scale, shift, None, cout, direct_weight=wd)
+    close(direct, ref, 2e-5, 'direct conv vs torch')
+    if edge >= 2:
+        mfma = ops.conv3d_gn_relu(d0, d1, scale, shift, ops.pack_conv3_weight(wd), cout)
+        close(mfma, ref, 2e-5, 'mfma conv vs torch')
+        close(mfma, direct, 2e-5, 'mfma conv vs direct conv')
+
+
+def test_conv_identity_weight_is_transpose_detecting(ops):
+    """centre-tap identity on an asymmetric ramp: catches swapped voxel axes / channel transposes exactly."""
+    n, c, edge = 1, 16, 8
+    x = torch.arange(n * c * edge ** 3, dtype=torch.float32).reshape(n, c, edge, edge, edge) / 100.0
+    w = torch.zeros(c, c, 3, 3, 3)
+    for i in range(c):
+        w[(i * 5) % c, i, 1, 1, 1] = 1.0                  # a channel permutation, not the identity
+    scale = torch.ones(n, c, device=DEV)
+    shift = torch.zeros(n, c, device=DEV)
+    out = ops.conv3d_gn_relu(x.to(DEV), None, scale, shift, ops.pack_conv3_weight(w.to(DEV)), c)
+    ref = F.conv3d(x, w, padding=1)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_maxpool_and_conv1x1_tanh(ops):
+    gen = torch.Generator().manual_seed(3)
+    x = rnd(gen, 3, 5, 8, 8, 8)
+    assert torch.equal(ops.maxpool2(x.to(DEV)).cpu(), F.max_pool3d(x, 2))
+    x = rnd(gen, 2, 16, 16, 16, 16)
+    w, b = rnd(gen, 1, 16, 1, 1, 1, scale=0.3), rnd(gen, 1)
+    ref = torch.tanh(F.conv3d(x, w, b))
+    close(ops.conv1x1_tanh(x.to(DEV), w.to(DEV), b.to(DEV)), ref, 1e-6, 'conv1x1+tanh')
+    close(ops.conv1x1_tanh(x.to(DEV), w.to(DEV), b.to(DEV), 1.0, 0.0625 / 2), (ref + 1) * 0.0625 / 2, 1e-6, 'df epilogue')
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 2), (1, 16, 32, 2), (4, 1, 64, 16), (2, 16, 32, 8)])
+def test_unfold_fold(ops, shape):
+    b, c, s, e = shape
+    x = torch.arange(b * c * s ** 3, dtype=torch.float32).reshape(b, c, s, s, s)
+    rows = ops.unfold3d(x.to(DEV), e)
+    assert torch.equal(rows.cpu(), refpath.unfold3d(x, e))
+    assert torch.equal(ops.fold3d(rows, s // e, e, c).cpu(), x)
+
+
+@pytest.mark.parametrize('case', [(4096, 128, 128, 2), (1000, 128, 32, 0), (64, 64, 128, 1), (130, 512, 256, 1), (64, 256, 64, 0),
+                                  (37, 96, 128, 2), (5, 7, 3, 0)])
+def test_linear(ops, case):
+    rows, nin, nout, act = case
+    gen = torch.Generator().manual_seed(rows + nin)
+    x, w, b = rnd(gen, rows, nin), rnd(gen, nout, nin, scale=1 / np.sqrt(nin)), rnd(gen, nout)
+    ref = F.linear(x, w, b)
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
+    got = ops.linear(x.to(DEV), ops.pack_linear_weight(w.to(DEV)), b.to(DEV), nout, act, 0.01)
+    close(got, ref, 1e-5, 'linear')
+    eye = torch.eye(nin)[:min(nin, nout)] if nout <= nin else None
+    if eye is not None:      # asymmetric, transpose-detecting: y = first rows of x
+        got = ops.linear(x.to(DEV), ops.pack_linear_weight(eye.contiguous().to(DEV)), None, eye.shape[0])
+        assert torch.equal(got.cpu(), x[:, :eye.shape[0]])
+
+
+def test_l2_normalize(ops):
+    gen = torch.Generator().manual_seed(5)
+    x = rnd(gen, 77, 64)
+    x[3] = 0
+    got = ops.l2_normalize_rows_(x.clone().to(DEV))
+    close(got, F.normalize(x, dim=1), 1e-6, 'normalize')
+
+
+@pytest.mark.parametrize('mode,K,c', [(0, 4, 16), (1, 4, 16), (0, 8, 16), (1, 4, 12)])
+def test_attention_block(ops, mode, K, c):
+    """AttentionBlock.forward through the HIP path vs the oracle restatement (model/attention.py:84-113)."""
+    import contextlib, io
+    from model.attention import AttentionBlock
+    gen = torch.Generator().manual_seed(11 + K + c + mode)
+    b, e = 600, 2
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = AttentionBlock(c, e, K, True, True, bool(mode), True, True)
+    sd = {k: rnd(gen, *v.shape, scale=0.15) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    blk.to(DEV)
+    x = rnd(gen, b, c, e, e, e).relu_()
+    p = rnd(gen, b, K, c, e, e, e).relu_()
+    p[:, 0] = x + 0.05 * rnd(gen, b, c, e, e, e)             # one close candidate -> sharp softmax with real mixing
+    noise = -torch.empty(b, K).exponential_(generator=gen).log() if mode else None
+    det = {}
+    with torch.no_grad():
+        ref = refpath.attention_block(x, p, {'a.' + k: v for k, v in sd.items()}, 'a', bool(mode), noise, det)
+        dbg = {}
+        got = blk(x.to(DEV), p.to(DEV), noise.to(DEV) if noise is not None else None, dbg)
+    close(dbg['scores'], det['scores'], 2e-6, 'scores')
+    if mode:
+        top2 = torch.topk(det['scores'] * 25 + noise, 2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-4              # rows whose hard arg-max cannot flip by rounding
+        assert safe.float().mean() > 0.99
+        close(got.cpu()[safe], ref[safe], 1e-5, 'gumbel-hard attention')
+        assert torch.equal(dbg['weights'].cpu()[safe].round(), det['weights'][safe].round())
+    else:
+        # sharpness 1024 amplifies score rounding: weights agree to ~1e-3 relative, outputs accordingly
+        close(dbg['weights'], det['weights'], 2e-3, 'softmax weights')
+        close(got, ref, 2e-3, 'softmax attention')
+
+
+def test_attn_gather_layouts(ops):
+    gen = torch.Generator().manual_seed(2)
+    b, K, c, s, e, t = 2, 4, 3, 16, 2, 8
+    vols = rnd(gen, b * K, c, s, s, s)
+    r = s // e
+    ref = refpath.unfold3d(vols, e).reshape(b, K, r, r, r, c, e, e, e).permute(0, 2, 3, 4, 1, 5, 6, 7, 8).reshape(-1, K, c, e, e, e)
+    got0 = ops.attn_gather_retrieved(vols.to(DEV), 0, b, K, c, s, e)
+    assert torch.equal(got0.cpu(), ref)
+    patch_major = refpath.unfold3d(vols, t)                   # what the retrieval backbone emits: [(b*K*q^3), c, t^3]
+    got1 = ops.attn_gather_retrieved(patch_major.to(DEV), 1, b, K, c, s, e, t)
+    assert torch.equal(got1.cpu(), ref)
+
+
+@pytest.mark.parametrize('cfg_name', ['C1', 'C4', 'C5'])
+def test_query_windows_bit_exact(ops, cfg_name):
+    from rfuse import configs, synthetic
+    cfg = configs.get_config(cfg_name)
+    trunc_i, _ = configs.truncations(cfg)
+    raws = np.stack([synthetic.make_chunk(50 + i, cfg)['input_raw'] for i in range(2)])
+    ref = np.concatenate([refpath.extract_query_windows(r, cfg, trunc_i) for r in raws])
+    g, d = cfg['query_geometry'], cfg['dataset_train']
+    pad = 0.0 if cfg['task'] == 'surface_reconstruction' else trunc_i
+    got = ops.query_windows(torch.from_numpy(raws).to(DEV), g['patch_size_input'], g['patch_context_input'], pad, d['input_mean'], d['input_std'])
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def check_topk(idx_got, dist_got, q, emb, k2, row_base=0):
+    """bit-exact indices vs the float64 oracle; where the float64 gap to the next neighbour is < 1e-6 either order is
+    allowed (SURVEY.md section 7 'hard parts')."""
+    idx_ref, dist_ref = refpath.knn_exact(q, emb, min(k2 + 1, emb.shape[0]))
+    idx_got = idx_got.cpu().numpy() - row_base
+    nq = q.shape[0]
+    n_valid = min(k2, emb.shape[0])
+    exact = 0
+    for i in range(nq):
+        for j in range(n_valid):
+            if idx_got[i, j] == idx_ref[i, j]:
+                exact += 1
+                continue
+            d_here = ((q[i].astype(np.float64) - emb[idx_got[i, j]].astype(np.float64)) ** 2).sum()
+            assert abs(d_here - dist_ref[i, j]) < 1e-6, f'query {i} rank {j}: got row {idx_got[i, j]} (d={d_here}), want {idx_ref[i, j]} (d={dist_ref[i, j]})'
+    np.testing.assert_allclose(dist_got.cpu().numpy()[:, :n_valid], dist_ref[:, :n_valid], rtol=1e-5, atol=1e-6)
+    return exact / (nq * n_valid)
+
+
+@pytest.mark.parametrize('n,nq,k2', [(1000, 64, 8), (50_001, 128, 8), (4097, 70, 16), (5, 3, 8), (64, 1, 8)])
+def test_l2_topk(ops, n, nq, k2):
+    rng = np.random.default_rng(n + nq)
+    emb = rng.standard_normal((n, 64)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, 64)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = emb[min(7, n - 1)]                                   # an exact hit (distance 0)
+    if n > 10:
+        emb[9] = emb[4]                                         # an exact tie: lower row id must win
+        q[1 % nq] = emb[4]
+    packed = ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV))
+    dist, idx = ops.l2_topk(torch.from_numpy(q).to(DEV), packed, n, 0, k2)
+    frac = check_topk(idx, dist, q, emb, k2)
+    assert frac > 0.999
+    if n < k2:
+        assert (idx.cpu()[:, n:] == -1).all() and torch.isinf(dist.cpu()[:, n:]).all()
+    if n > 10:
+        row = idx.cpu().numpy()[1 % nq]
+        assert row[0] == 4 and row[1] == 9
+
+
+def test_sharded_topk_merge_equals_single_scan(ops):
+    rng = np.random.default_rng(1)
+    n, nq, k2, shards = 10_000, 96, 8, 4
+    emb = rng.standard_normal((n, 64)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, 64)).astype(np.float32)
+    qd = torch.from_numpy(q).to(DEV)
+    full_d, full_i = ops.l2_topk(qd, ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV)), n, 0, k2)
+    from rfuse.database import shard_bounds
+    ds, is_ = [], []
+    for r in range(shards):
+        lo, hi = shard_bounds(n, r, shards)
+        d, i = ops.l2_topk(qd, ops.db_pack_embeddings(torch.from_numpy(emb[lo:hi]).to(DEV)), hi - lo, lo, k2)
+        ds.append(d), is_.append(i)
+    md, mi = ops.topk_merge(torch.stack(ds), torch.stack(is_))
+    assert torch.equal(mi, full_i) and torch.equal(md, full_d)
+
+
+def test_demote_and_gather_match_oracle(ops):
+    from rfuse import configs, synthetic
+    cfg = configs.get_config('C1')
+    _, trunc_t = configs.truncations(cfg)
+    K = cfg['K']
+    db = synthetic.make_database(5, cfg, 64 * 12)
+    rng = np.random.default_rng(8)
+    q = rng.standard_normal((128, 64)).astype(np.float32)
+    own = np.where(db['meta'][:, 0] == 3)[0]
+    for i in range(0, 64, 2):
+        q[i] = db['emb'][own[i]] + 0.05 * rng.standard_normal(64).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    qscene = np.concatenate([np.full(64, 3), np.full(64, -1)]).astype(np.int32)      # chunk 0 demotes, chunk 1 does not
+    idx, dist = refpath.knn_exact(q, db['emb'], 2 * K)
+    rows = refpath.mapping_rows(idx, dist, db['meta'])
+    ref_map = refpath.demote_same_scene(rows, qscene, K)
+    meta_d = torch.from_numpy(db['meta']).to(DEV)
+    m, d, i = ops.demote_same_scene(torch.from_numpy(dist.astype(np.float32)).to(DEV), torch.from_numpy(idx).to(DEV), meta_d,
+                                    torch.from_numpy(qscene).to(DEV), K)
+    np.testing.assert_array_equal(m.cpu().numpy(), ref_map[..., :7].astype(np.int32))
+    np.testing.assert_array_equal(d.cpu().numpy(), ref_map[..., 7])
+    # a sentinel hit exercises the trunc fill
+    m[5, 1] = torch.tensor([-1, 0, 16, 0, 16, 0, 16], dtype=torch.int32)
+    ref_map[5, 1, :7] = [-1, 0, 16, 0, 16, 0, 16]
+    dd = cfg['dataset_train']
+    vols = torch.from_numpy(db['volumes']).to(DEV)
+    composed = ops.gather_patches(vols, m, 2, K, trunc_t, 1.0, dd['target_mean'], dd['target_std'], layout=0).cpu().numpy()
+    rows16 = ops.gather_patches(vols, m, 2, K, trunc_t, 1.0, dd['target_mean'], dd['target_std'], layout=1).cpu()
+    for c in range(2):
+        ref = refpath.compose_retrieval(ref_map[c * 64:(c + 1) * 64], db['volumes'], K, trunc_t)
+        ref = ((ref - np.float32(dd['target_mean'])) / np.float32(dd['target_std'])).astype(np.float32)    # patched_scene_dataset.py:133
+        assert np.array_equal(composed[c], ref)
+    assert torch.equal(rows16, refpath.unfold3d(torch.from_numpy(composed).reshape(2 * K, 1, 64, 64, 64), 16))
+
+
+@pytest.mark.parametrize('spec', [(3, 1, 8, 16, 3, 1), (2, 4, 12, 8, 3, 2), (2, 3, 6, 5, 2, 1), (1, 1, 20, 6, 5, 1), (2, 8, 4, 8, 4, 1)])
+def test_conv3d_valid_leaky(ops, spec):
+    n, cin, s, cout, k, stride = spec
+    gen = torch.Generator().manual_seed(sum(spec))
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    ref = F.leaky_relu(F.conv3d(x, w, b, stride=stride), 0.2)
+    close(ops.conv3d_valid_leaky(x.to(DEV), w.to(DEV), b.to(DEV), stride, 0.2), ref, 1e-5, 'valid conv')
+
+
+def test_cpu_tensors_raise(ops):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.maxpool2(torch.zeros(1, 1, 2, 2, 2))

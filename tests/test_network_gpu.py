@@ -1,0 +1,143 @@
+"""GPU parity of the whole refinement path: the drop-in modules (model.*) and the online engine against the golden
+vectors captured from the reference (tests/golden/) and against the oracle.  Bar (BASELINE.json north_star):
+<= 1e-4 abs on the reconstructed TSDF ``df``; top-k indices exact (checked in test_kernels_gpu.py)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import refpath
+from rfuse import configs as rf_configs
+from rfuse import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+DF_TOL = 1e-4          # abs, on reconstructed TSDF values (north_star)
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    return torch.device(DEV)
+
+
+def build_modules(cfg):
+    import model
+    with contextlib.redirect_stdout(io.StringIO()):
+        return {'unet_backbone': model.get_unet_backbone(cfg), 'decoder': model.get_decoder(cfg),
+                'retrieval_backbone': model.get_retrieval_backbone(cfg), 'patched_attention_block': model.get_attention_block(cfg)}
+
+
+def maxerr(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.mark.parametrize('name', ['net_C1', 'net_C2_stress_b2', 'net_C3', 'net_C4', 'net_C5'])
+def test_modules_match_reference_golden(gpu, name):
+    """forward_full wiring with the drop-in classes exactly as the reference trainer uses them
+    (trainer/train_refinement.py:108-116): Unfold3D(16,1) -> retrieval_backbone -> Fold3D(4,8,nf) -> attention -> decoder."""
+    from model.attention import Unfold3D, Fold3D
+    fix = helpers.load_fixture(name)
+    cfg0 = rf_configs.get_config(str(fix['cfg_name']))
+    mods = build_modules(cfg0)
+    shapes = {k: {n: tuple(v.shape) for n, v in m.state_dict().items()} for k, m in mods.items()}
+    cfg, x_in, retr, sds = helpers.fixture_problem(fix, shapes)
+    for k, m in mods.items():
+        m.load_state_dict(sds[k])
+        m.to(gpu).eval()
+    K, B = cfg['K'], x_in.shape[0]
+    trunc_t = float(fix['target_trunc'])
+    noise = torch.from_numpy(fix['gumbel_noise']).to(gpu) if 'gumbel_noise' in fix else None
+    with torch.no_grad():
+        x_back = mods['unet_backbone'](torch.from_numpy(x_in).to(gpu))
+        retrievals = torch.from_numpy(retr).to(gpu)[:, :K].reshape(B * K, 1, 64, 64, 64)
+        feats = mods['retrieval_backbone'](Unfold3D(16, 1)(retrievals))
+        x_retr = Fold3D(4, 8, cfg['nf'])(feats)
+        x_attn = mods['patched_attention_block'](x_back, x_retr, noise)
+        pred = mods['decoder'](x_attn)
+        df = (pred + 1) * trunc_t / 2
+        # the fused route: patch-major attention input + df epilogue
+        x_attn2 = mods['patched_attention_block'].forward_patch_major(x_back, feats, 8, noise)
+        df2 = mods['decoder'].forward_df(x_attn2, trunc_t)
+    e_back = maxerr(x_back[..., ::2, ::2, ::2].cpu(), fix['x_back_sub'])
+    e_retr = maxerr(x_retr[..., ::4, ::4, ::4].cpu(), fix['x_retr_sub'])
+    e_attn = maxerr(x_attn[..., ::2, ::2, ::2].cpu(), fix['x_attn_sub'])
+    e_df = maxerr(df.cpu(), fix['df'])
+    print(f'{name}: x_back {e_back:.2e}  x_retr {e_retr:.2e}  x_attn {e_attn:.2e}  df {e_df:.2e}  (trunc {trunc_t})')
+    assert e_back <= 5e-5 * max(1.0, float(np.abs(fix['x_back_sub']).max()))
+    assert e_retr <= 5e-5 * max(1.0, float(np.abs(fix['x_retr_sub']).max()))
+    assert torch.equal(x_attn, x_attn2) and torch.equal(df, df2), 'patch-major route must equal the folded route bit for bit'
+    assert e_df <= DF_TOL, f'df max abs err {e_df:.3e}'
+    # tanh output itself, relative to its range (tight check for large-trunc datasets)
+    assert e_df / (trunc_t / 2) <= 1e-3
+
+
+@pytest.mark.parametrize('cfg_name', ['C1', 'C4', 'C5'])
+def test_query_encoder_matches_reference_golden(gpu, cfg_name):
+    import model
+    fix = helpers.load_fixture('query_' + cfg_name)
+    cfg = rf_configs.get_config(cfg_name)
+    trunc_i, _ = rf_configs.truncations(cfg)
+    raw = synthetic.make_chunk(int(fix['seed']) * 100, cfg)['input_raw']
+    fenc_input, _ = model.get_retrieval_networks(cfg['retrieval_model'])
+    shapes = {k: tuple(v.shape) for k, v in fenc_input.state_dict().items()}
+    fenc_input.load_state_dict(helpers.seeded_sd(shapes, int(fix['seed']) * 1000 + helpers.SD_OFFSETS['fenc_input']))
+    from rfuse.engine import RefinementEngine
+    eng = RefinementEngine(cfg, gpu)
+    eng.fenc_input.load_state_dict(fenc_input.state_dict())
+    emb = eng.embed_queries(torch.from_numpy(raw[None]).to(gpu))
+    assert maxerr(emb.cpu(), fix['emb']) <= 2e-6
+
+
+def test_engine_online_path_matches_oracle(gpu):
+    """retrieve (embed -> exact kNN -> demotion -> gather) + attend + refine, end to end, vs the oracle doing the same
+    with float64 kNN and the reference's compose semantics."""
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C3')                      # softmax attention: deterministic
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    K, B = cfg['K'], 2
+    db = synthetic.make_database(21, cfg, 64 * 40)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {}
+    for name, m in eng.modules().items():
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sds[name] = helpers.seeded_sd(shapes, 900 + len(name))
+    eng.load_state_dicts(sds)
+    raws = np.stack([synthetic.make_chunk(300 + b, cfg)['input_raw'] for b in range(B)])
+    qscene = np.concatenate([np.full(64, 2), np.full(64, -1)]).astype(np.int32)
+    df = eng.refine(torch.from_numpy(raws).to(gpu), torch.from_numpy(qscene).to(gpu)).cpu().numpy()
+
+    # ---- oracle
+    with torch.no_grad():
+        q = torch.cat([refpath.embed_queries(refpath.extract_query_windows(r, cfg, trunc_i), sds['fenc_input'], cfg) for r in raws]).numpy()
+    idx, dist = refpath.knn_exact(q, db['emb'], 2 * K)
+    mapping = refpath.demote_same_scene(refpath.mapping_rows(idx, dist, db['meta']), qscene, K)
+    d = cfg['dataset_train']
+    retr = np.stack([refpath.compose_retrieval(mapping[b * 64:(b + 1) * 64], db['volumes'], K, trunc_t) for b in range(B)])
+    retr = ((retr - np.float32(d['target_mean'])) / np.float32(d['target_std'])).astype(np.float32)
+    x_in = np.stack([synthetic.normalise_input(cfg, r)[None] for r in raws])
+    with torch.no_grad():
+        df_ref = refpath.forward_full(sds, cfg, torch.from_numpy(x_in), torch.from_numpy(retr), trunc_t).numpy()
+    # the engine's retrieval must pick the same database rows (exact kNN), then the fields agree to tolerance
+    patches, meta = eng.retrieve(torch.from_numpy(raws).to(gpu), torch.from_numpy(qscene).to(gpu))
+    np.testing.assert_array_equal(meta.cpu().numpy(), mapping[..., :7].astype(np.int32))
+    assert maxerr(df, df_ref) <= DF_TOL
+
+
+def test_state_dict_roundtrip_and_repack(gpu):
+    """load_state_dict after a forward must invalidate the packed-weight cache."""
+    cfg = rf_configs.get_config('C1')
+    mods = build_modules(cfg)
+    dec = mods['decoder'].to(gpu).eval()
+    x = torch.rand(1, 16, 32, 32, 32, device=gpu)
+    with torch.no_grad():
+        a = dec(x)
+        sd = {k: v * 0.5 if 'conv.weight' in k else v for k, v in dec.state_dict().items()}
+        dec.load_state_dict(sd)
+        b = dec(x)
+    assert not torch.equal(a, b)
