@@ -1,0 +1,74 @@
+"""Dev tool (GPU box): teacher-forced attention / decoder stage errors against the oracle for a golden fixture."""
+import contextlib, io, sys
+from pathlib import Path
+import numpy as np, torch
+REPO = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(REPO), str(REPO / 'retrieval-fuse_amd'), str(REPO / 'tests')]
+import helpers
+from oracle import refpath
+from rfuse import configs as rf_configs
+import model
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'net_C3'
+fix = helpers.load_fixture(name)
+cfg0 = rf_configs.get_config(str(fix['cfg_name']))
+with contextlib.redirect_stdout(io.StringIO()):
+    mods = {'unet_backbone': model.get_unet_backbone(cfg0), 'decoder': model.get_decoder(cfg0),
+            'retrieval_backbone': model.get_retrieval_backbone(cfg0), 'patched_attention_block': model.get_attention_block(cfg0)}
+shapes = {k: {n: tuple(v.shape) for n, v in m.state_dict().items()} for k, m in mods.items()}
+cfg, x_in, retr, sds = helpers.fixture_problem(fix, shapes)
+dev = torch.device('cuda:0')
+for k, m in mods.items():
+    m.load_state_dict(sds[k]); m.to(dev).eval()
+noise = torch.from_numpy(fix['gumbel_noise']) if 'gumbel_noise' in fix else None
+st, det = {}, {}
+torch.set_num_threads(16)
+with torch.no_grad():
+    refpath.forward_full(sds, cfg, torch.from_numpy(x_in), torch.from_numpy(retr), float(fix['target_trunc']), noise, st)
+    refpath.patched_attention_block(st['x_back'], st['x_retrieval'], sds['patched_attention_block'], cfg, noise, det)
+    dbg = {}
+    pab = mods['patched_attention_block']
+    xa = pab(st['x_back'].to(dev), st['x_retrieval'].to(dev), noise.to(dev) if noise is not None else None, dbg)
+    print('teacher-forced attention: scores err %.3e  weights err %.3e  x_attn err %.3e' % (
+        (dbg['scores'].cpu() - det['scores']).abs().max(), (dbg['weights'].cpu() - det['weights']).abs().max(), (xa.cpu() - st['x_attn']).abs().max()))
+    sw = det['switch'].squeeze(1)
+    print('switch stats: min %.4f max %.4f; rows with mixed weights (max w < 0.999): %d of %d' % (sw.min(), sw.max(), (det['weights'].max(1).values < 0.999).sum(), sw.numel()))
+    # feature-level errors of the theta/phi encoders
+    e = cfg['attn_patch_extent'] // 2
+    xr = refpath.unfold3d(st['x_back'], e)
+    tf_ref = refpath.attention_feature_encoder(xr, sds['patched_attention_block'], 'attention_blocks_layer.theta')
+    tf_got = pab.attention_blocks_layer.theta(xr.to(dev))
+    tf64 = refpath.attention_feature_encoder(xr.double(), {k: v.double() for k, v in sds['patched_attention_block'].items()}, 'attention_blocks_layer.theta')
+    print('theta MLP: hip-vs-torch %.3e  torch-vs-f64 %.3e  hip-vs-f64 %.3e  |feat|max %.3f' % ((tf_got.cpu() - tf_ref).abs().max(), (tf_ref.double() - tf64).abs().max(), (tf_got.cpu().double() - tf64).abs().max(), tf_ref.abs().max()))
+    df_tf = mods['decoder'].forward_df(st['x_attn'].to(dev), float(fix['target_trunc']))
+    print('teacher-forced decoder: df err %.3e' % (df_tf.cpu() - st['df']).abs().max())
+    # chained
+    xb = mods['unet_backbone'](torch.from_numpy(x_in).to(dev))
+    print('chained x_back err %.3e' % (xb.cpu() - st['x_back']).abs().max())
+    xa2 = pab(xb, st['x_retrieval'].to(dev), noise.to(dev) if noise is not None else None)
+    print('attention with hip x_back + oracle x_retr: x_attn err %.3e' % (xa2.cpu() - st['x_attn']).abs().max())
+    err = (xa2.cpu() - st['x_attn']).abs()
+    print('   frac elements > 1e-3: %.5f' % (err > 1e-3).float().mean())
+with torch.no_grad():
+    from model.attention import Unfold3D, Fold3D
+    K, B = cfg['K'], x_in.shape[0]
+    retrievals = torch.from_numpy(retr).to(dev)[:, :K].reshape(B * K, 1, 64, 64, 64)
+    feats = mods['retrieval_backbone'](Unfold3D(16, 1)(retrievals))
+    xr_hip = Fold3D(4, 8, cfg['nf'])(feats)
+    e = (xr_hip.cpu() - st['x_retrieval']).abs()
+    print('chained x_retr err max %.3e  mean %.3e  |ref|max %.2f' % (e.max(), e.mean(), st['x_retrieval'].abs().max()))
+    dbg2 = {}
+    xa3 = pab(st['x_back'].to(dev), xr_hip, noise.to(dev) if noise is not None else None, dbg2)
+    print('attention with oracle x_back + hip x_retr: scores err %.3e weights err %.3e x_attn err %.3e' % (
+        (dbg2['scores'].cpu() - det['scores']).abs().max(), (dbg2['weights'].cpu() - det['weights']).abs().max(), (xa3.cpu() - st['x_attn']).abs().max()))
+    xa4 = pab(xb, xr_hip, noise.to(dev) if noise is not None else None)
+    ea = (xa4.cpu() - st['x_attn']).abs()
+    print('full hip chain x_attn err max %.3e, frac>1e-3 %.6f' % (ea.max(), (ea > 1e-3).float().mean()))
+    df4 = mods['decoder'].forward_df(xa4, float(fix['target_trunc']))
+    ed = (df4.cpu() - st['df']).abs()
+    print('full hip chain df err max %.3e  p99.9 %.3e  frac>1e-4 %.6f' % (ed.max(), torch.quantile(ed.flatten()[:1000000], 0.999), (ed > 1e-4).float().mean()))
+    # where is the worst row?
+    wr = (dbg2['weights'].cpu() - det['weights']).abs().max(1).values
+    i = int(wr.argmax())
+    print('worst row', i, 'ref scores', det['scores'][i].tolist(), 'hip scores', dbg2['scores'][i].tolist())
+    print('   ref weights', det['weights'][i].tolist(), 'hip', dbg2['weights'][i].tolist())
