@@ -323,3 +323,13 @@ def compose_retrieval(mapping, db_volumes, K, target_trunc, trunc_ratio=1.0):
             # float32 tensor * python float, as torch does it at :162
             out[k, xx:xx + 16, yy:yy + 16, zz:zz + 16] = (torch.from_numpy(np.ascontiguousarray(src)) * float(trunc_ratio)).numpy()
     return out
+
+
+def knn_cdist_f32(queries, db_emb, n_neighbors):
+    """fp32 multi-threaded exact kNN (torch.cdist + topk) -- the CPU-baseline kNN named in BASELINE.md section 3.
+    Used ONLY for timing the CPU baseline in bench.py; parity checks use knn_exact (float64)."""
+    q = torch.as_tensor(queries, dtype=torch.float32)
+    d = torch.as_tensor(db_emb, dtype=torch.float32)
+    dist = torch.cdist(q, d) ** 2
+    vals, idx = torch.topk(dist, n_neighbors, dim=1, largest=False, sorted=True)
+    return idx.numpy(), vals.numpy()

@@ -52,15 +52,23 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ sr
     const int nn = ng / groups, g = ng % groups;
     const int tid = threadIdx.x;
     double sum = 0.0, sq = 0.0;
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = g * cpg + cc;
+    // the group's channels are contiguous in memory within each source: at most two segments (src0 part, src1 part)
+    const int ca = g * cpg, cb = ca + cpg;
+    for (int seg = 0; seg < 2; ++seg) {
         const float* base;
         size_t len;
         double wgt;
-        if (c < c0) { base = src0 + ((size_t)nn * c0 + c) * vol0; len = vol0; wgt = 1.0; }
-        else { base = src1 + ((size_t)nn * c1 + (c - c0)) * vol1; len = vol1; wgt = 8.0; }
+        if (seg == 0) {
+            const int hi_c = cb < c0 ? cb : c0;
+            if (ca >= hi_c) continue;
+            base = src0 + ((size_t)nn * c0 + ca) * vol0; len = (size_t)(hi_c - ca) * vol0; wgt = 1.0;
+        } else {
+            const int lo_c = ca > c0 ? ca : c0;
+            if (lo_c >= cb) continue;
+            base = src1 + ((size_t)nn * c1 + (lo_c - c0)) * vol1; len = (size_t)(cb - lo_c) * vol1; wgt = 8.0;
+        }
         double ls = 0.0, lq = 0.0;
-        if ((len & 3) == 0) {
+        if ((len & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
             const size_t len4 = len >> 2;
             const size_t lo = len4 * s / slices, hi = len4 * (s + 1) / slices;
             const float4* b4 = reinterpret_cast<const float4*>(base);
@@ -173,7 +181,7 @@ struct ConvTile {
 };
 
 template <int TZ, int TY, int TX, int SPW, int MB, int NB>
-__global__ __launch_bounds__(256, (NB >= 4 ? 2 : 3)) void k_conv3_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256, (MB * NB >= 32 ? 2 : (MB * NB >= 16 ? 3 : 4))) void k_conv3_mfma(ConvArgs a) {
     using T = ConvTile<TZ, TY, TX, SPW, MB, NB>;
     constexpr int HY = T::HY, HX = T::HX, CH = T::CH, CC = T::CC, NCO = T::NCO, COS = T::COS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -216,20 +224,60 @@ __global__ __launch_bounds__(256, (NB >= 4 ? 2 : 3)) void k_conv3_mfma(ConvArgs 
 
     for (int cbase = 0; cbase < cin; cbase += CC) {
         // ---- stage the input halo box: GroupNorm applied, zero outside the volume, upsample+concat resolved
-        for (int i = tid; i < T::XS; i += 256) {
-            const int hx = i % HX, hy = (i / HX) % HY, hz = (i / (HX * HY)) % T::HZ;
-            const int c = (i / CH) % CC, s = i / (CC * CH);
+        // One thread per halo ROW (HX = TX + 2 floats): the TX interior voxels come in with vector loads, the two
+        // x-halo voxels with (conditional) scalar loads; rows outside the volume are written as zeros without loads.
+        constexpr int ROWS = SPW * CC * T::HZ * HY;
+        for (int r = tid; r < ROWS; r += 256) {
+            const int hy = r % HY, hz = (r / HY) % T::HZ, c = (r / (HY * T::HZ)) % CC, s = r / (HY * T::HZ * CC);
             const int nn = n0 + s, ci = cbase + c;
-            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-            float v = 0.f;
-            if (nn < a.n && ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge) {
-                float r;
-                if (ci < a.c0) r = a.src0[(((size_t)nn * a.c0 + ci) * edge + z) * edge * edge + (size_t)y * edge + x];
-                else r = a.src1[(((size_t)nn * a.c1 + (ci - a.c0)) * half + (z >> 1)) * half * half + (size_t)(y >> 1) * half + (x >> 1)];
+            const int z = z0 + hz - 1, y = y0 + hy - 1;
+            float v[HX];
+#pragma unroll
+            for (int j = 0; j < HX; ++j) v[j] = 0.f;
+            if (nn < a.n && ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge) {
                 const size_t si = (size_t)nn * cin + ci;
-                v = r * a.scale[si] + a.shift[si];
+                const float sc = a.scale[si], sh = a.shift[si];
+                const bool has_l = x0 > 0, has_r = x0 + TX < edge;
+                if (ci < a.c0) {
+                    const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
+                    if (TX >= 4) {
+#pragma unroll
+                        for (int q = 0; q < TX / 4; ++q) {
+                            const float4 t = reinterpret_cast<const float4*>(row)[q];
+                            v[1 + 4 * q] = t.x; v[2 + 4 * q] = t.y; v[3 + 4 * q] = t.z; v[4 + 4 * q] = t.w;
+                        }
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(row);
+                        v[1] = t.x; v[2] = t.y;
+                    }
+                    if (has_l) v[0] = row[-1];
+                    if (has_r) v[HX - 1] = row[TX];
+                } else {
+                    // nearest x2 upsample: voxel x reads low-res x>>1, so the interior is TX/2 low-res values, each used twice
+                    const float* row = a.src1 + ((((size_t)nn * a.c1 + (ci - a.c0)) * half + (z >> 1)) * half + (y >> 1)) * half + (x0 >> 1);
+                    float lo[TX / 2 > 0 ? TX / 2 : 1];
+                    if (TX == 8) {
+                        const float4 t = *reinterpret_cast<const float4*>(row);
+                        lo[0] = t.x; lo[1] = t.y; lo[2] = t.z; lo[3] = t.w;
+                    } else if (TX == 4) {
+                        const float2 t = *reinterpret_cast<const float2*>(row);
+                        lo[0] = t.x; lo[1] = t.y;
+                    } else {
+                        lo[0] = row[0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) v[1 + j] = lo[j >> 1];
+                    if (has_l) v[0] = row[-1];
+                    if (has_r) v[HX - 1] = row[TX / 2];
+                }
+#pragma unroll
+                for (int j = 1; j <= TX; ++j) v[j] = v[j] * sc + sh;
+                v[0] = has_l ? v[0] * sc + sh : 0.f;
+                v[HX - 1] = has_r ? v[HX - 1] * sc + sh : 0.f;
             }
-            xs[i] = v;
+            float* dst = xs + (s * CC + c) * CH + (hz * HY + hy) * HX;
+#pragma unroll
+            for (int j = 0; j < HX; ++j) dst[j] = v[j];
         }
         // ---- stage the weight slab [27][4][NCO] (float4 rows)
         for (int i = tid; i < 27 * CC * (NCO / 4); i += 256) {
@@ -316,9 +364,10 @@ static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
 
 template <int TZ, int TY, int TX, int SPW>
 static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
-    if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 1>(a, stream);
-    if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 2>(a, stream);
-    return launch_conv3<TZ, TY, TX, SPW, 8, 4>(a, stream);
+    constexpr int MB = SPW * TZ * TY * TX / 64;
+    if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, MB, 1>(a, stream);
+    if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, MB, 2>(a, stream);
+    return launch_conv3<TZ, TY, TX, SPW, MB, 4>(a, stream);
 }
 
 static int conv_check(const char* who, const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
@@ -344,9 +393,13 @@ extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1
     a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
     a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
     hipStream_t s = (hipStream_t)stream;
-    if (edge >= 8) return dispatch_nb<8, 8, 8, 1>(a, s);
-    if (edge == 4) return dispatch_nb<4, 4, 4, 8>(a, s);
-    return dispatch_nb<2, 2, 2, 64>(a, s);
+    // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
+    const long long vox = (long long)n * edge * edge * edge;
+    const long long wgs512 = (vox + 511) / 512 * ((a.cout16 + 63) / 64);
+    const bool small = wgs512 < 1024;
+    if (edge >= 8) return small ? dispatch_nb<4, 4, 8, 1>(a, s) : dispatch_nb<8, 8, 8, 1>(a, s);
+    if (edge == 4) return small ? dispatch_nb<4, 4, 4, 2>(a, s) : dispatch_nb<4, 4, 4, 8>(a, s);
+    return small ? dispatch_nb<2, 2, 2, 16>(a, s) : dispatch_nb<2, 2, 2, 64>(a, s);
 }
 
 // ----------------------------------------------------------------------------------------------- conv, direct

@@ -41,6 +41,7 @@ class RefinementEngine:
         for m in self.modules().values():
             m.to(self.device).eval()
         self.database = database
+        self._side_stream = None
 
     def modules(self):
         return {'unet_backbone': self.unet_backbone, 'decoder': self.decoder, 'retrieval_backbone': self.retrieval_backbone,
@@ -77,11 +78,30 @@ class RefinementEngine:
         s = input_raw.shape[-1]
         return ops.query_windows(input_raw, s, 0, 0.0, d['input_mean'], d['input_std']).reshape(input_raw.shape[0], 1, s, s, s)
 
+    def _fork_backbone(self, x_in):
+        """Launch the U-Net backbone on a second HIP stream: it depends only on the input chunk, is made of small
+        launches (1^3..32^3 volumes of a few chunks) that cannot fill 256 CUs, and so runs in the shadow of the
+        retrieval path (top-k scan, patch gather, retrieval backbone) on the main stream."""
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            x_back = self.unet_backbone(x_in)
+        x_in.record_stream(side)
+        x_back.record_stream(main)
+        return x_back, side
+
     @torch.no_grad()
     def refine_from_patches(self, x_in, patches, gumbel_noise=None, stages=None):
         """x_in [B,1,S,S,S] normalised; patches [(B*K*64),1,16^3] normalised -> df [B,1,64,64,64]."""
-        x_back = self.unet_backbone(x_in)
+        x_back, side = self._fork_backbone(x_in)
         feats = self.retrieval_backbone(patches)                                  # [(B*K*64), nf, 8,8,8], patch-major
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return self._attend_and_decode(x_back, feats, gumbel_noise, stages)
+
+    def _attend_and_decode(self, x_back, feats, gumbel_noise, stages=None):
         x = self.patched_attention_block.forward_patch_major(x_back, feats, feats.shape[-1], gumbel_noise)
         df = self.decoder.forward_df(x, self.target_trunc)
         if stages is not None:
@@ -91,5 +111,8 @@ class RefinementEngine:
     @torch.no_grad()
     def refine(self, input_raw, query_scene=None, gumbel_noise=None):
         """The whole online path for a batch of chunks: raw low-res input [B,S,S,S] -> refined TSDF [B,1,64,64,64]."""
+        x_back, side = self._fork_backbone(self.normalise_input(input_raw))
         patches, _ = self.retrieve(input_raw, query_scene)
-        return self.refine_from_patches(self.normalise_input(input_raw), patches, gumbel_noise)
+        feats = self.retrieval_backbone(patches)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return self._attend_and_decode(x_back, feats, gumbel_noise)

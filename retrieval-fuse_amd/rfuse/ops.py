@@ -113,12 +113,25 @@ def gn_scale_shift(src0, src1, gamma, beta, groups, eps=1e-5):
     return scale, shift
 
 
+# bench.py hook: time selected conv launches with HIP events recorded on the launch stream
+conv_event_filter = None        # callable(cin, cout, edge, n) -> bool
+conv_events = []                # [(start_event, end_event, flops)]
+
+
 def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None):
     """ReLU(conv3(GN(cat(src0, up2(src1))))).  1^3 volumes (and ``direct_weight`` calls) use the direct kernel."""
     n, c0, c1, edge = _src_dims(src0, src1)
     dev = scale.device
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev)
     lib = _lib.load()
+    if conv_event_filter is not None and direct_weight is None and conv_event_filter(c0 + c1, cout, edge, n):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
+                                            _stream()), 'rf_conv3d_k3_gn_relu')
+        ev1.record()
+        conv_events.append((ev0, ev1, 2.0 * 27 * (c0 + c1) * cout * edge ** 3 * n))
+        return out
     if direct_weight is not None:
         _lib.check(lib.rf_conv3d_k3_gn_relu_direct(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(direct_weight.detach()),
                                                    cout, _p(out), _stream()), 'rf_conv3d_k3_gn_relu_direct')
