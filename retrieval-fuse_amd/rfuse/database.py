@@ -42,10 +42,12 @@ def allgather_merge(q_local, local_topk, merge, k2, group=None):
     q_all = torch.empty((world * nq,) + tuple(q_local.shape[1:]), dtype=q_local.dtype, device=q_local.device)
     dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
     d_loc, i_loc = local_topk(q_all)
-    d_all = torch.empty((world,) + tuple(d_loc.shape), dtype=d_loc.dtype, device=d_loc.device)
-    i_all = torch.empty((world,) + tuple(i_loc.shape), dtype=i_loc.dtype, device=i_loc.device)
-    dist.all_gather_into_tensor(d_all, d_loc.contiguous(), group=group)
-    dist.all_gather_into_tensor(i_all, i_loc.contiguous(), group=group)
+    nq_all, k2_ = d_loc.shape
+    d_flat = torch.empty((world * nq_all, k2_), dtype=d_loc.dtype, device=d_loc.device)      # rank-major concatenation
+    i_flat = torch.empty((world * nq_all, k2_), dtype=i_loc.dtype, device=i_loc.device)
+    dist.all_gather_into_tensor(d_flat, d_loc.contiguous(), group=group)
+    dist.all_gather_into_tensor(i_flat, i_loc.contiguous(), group=group)
+    d_all, i_all = d_flat.view(world, nq_all, k2_), i_flat.view(world, nq_all, k2_)
     mine = slice(rank * nq, (rank + 1) * nq)
     return merge(d_all[:, mine].contiguous(), i_all[:, mine].contiguous())
 
