@@ -4,7 +4,7 @@
 // Reference arithmetic being replaced: model/unet.py:19-76 (SingleConv 'gcr'), :237 (MaxPool3d 2), :297-308 and
 // :354-360 (upsample + concat), model/refinement.py:54-55 (1x1x1 conv + tanh).
 //
-// Conv design (rf_conv3d_k3_gn_relu)
+// The MFMA convolution itself lives in conv3d_mfma.hip.  Original design notes (rf_conv3d_k3_gn_relu)
 //   GEMM view: M = output voxels, N = cout, K = cin*27.  One workgroup (4 waves) owns P = 512 output voxels -- an
 //   8^3 box of one sample, or 8 whole 4^3 samples, or 64 whole 2^3 samples -- and up to 64 output channels.
 //   K is walked in chunks of 4 input channels: the chunk's halo box (GroupNorm already applied, zero outside the
@@ -15,6 +15,7 @@
 //   tiles (8 x 4 x 4 VGPRs) so one A read is reused by NB MFMAs and one B read by MB MFMAs.
 //   fp32-input MFMA is bit-for-bit an fp32 FMA chain in k order (CDNA4 guide), so this is exact fp32 arithmetic.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------ weight pack
 __global__ void k_conv3_pack(const float* __restrict__ w, int cout, int cin, int cin4, int cout16, float* __restrict__ wp) {
@@ -153,223 +154,6 @@ extern "C" int rf_gn_stats(const float* src0, int c0, const float* src1, int c1,
     return RF_OK;
 }
 
-// ------------------------------------------------------------------------------------------------- conv, MFMA
-struct ConvArgs {
-    const float* src0;
-    const float* src1;
-    const float* scale;
-    const float* shift;
-    const float* wp;
-    float* out;
-    int c0, c1, n, edge, cout, cin4, cout16;
-};
-
-template <int TZ, int TY, int TX, int SPW, int MB, int NB>
-struct ConvTile {
-    static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
-    static constexpr int CH = HZ * HY * HX;            // halo floats per channel
-    static constexpr int CC = 4;                        // input channels per K chunk (= MFMA k)
-    static constexpr int XS = SPW * CC * CH;            // floats of the staged input box
-    static constexpr int XS_PAD = (XS + 3) / 4 * 4;
-    static constexpr int NCO = NB * 16;                 // couts per workgroup
-    static constexpr int COS = NCO + ((NB % 2 == 0) ? 16 : 0);   // row stride: k and k+1 rows on opposite bank halves
-    static constexpr int WS = 27 * CC * COS;
-    static constexpr int P = SPW * TZ * TY * TX;
-    static constexpr size_t LDS_BYTES = (size_t)(XS_PAD + WS) * sizeof(float);
-    static_assert(P == 4 * MB * 16, "4 waves x MB x 16 voxels must cover the tile");
-    static_assert(SPW == 1 || TX < 8, "multi-sample tiles are for whole small volumes");
-};
-
-template <int TZ, int TY, int TX, int SPW, int MB, int NB>
-__global__ __launch_bounds__(256, (MB * NB >= 32 ? 2 : (MB * NB >= 16 ? 3 : 4))) void k_conv3_mfma(ConvArgs a) {
-    using T = ConvTile<TZ, TY, TX, SPW, MB, NB>;
-    constexpr int HY = T::HY, HX = T::HX, CH = T::CH, CC = T::CC, NCO = T::NCO, COS = T::COS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;
-    float* ws = smem + T::XS_PAD;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int edge = a.edge, cin = a.c0 + a.c1;
-    const int half = edge >> 1;
-
-    // ---- which voxels does this workgroup own?
-    int n0, z0 = 0, y0 = 0, x0 = 0;
-    if (SPW == 1) {
-        const int tx = edge / TX, ty = edge / TY, tz = edge / TZ;
-        int t = blockIdx.x;
-        x0 = (t % tx) * TX; t /= tx;
-        y0 = (t % ty) * TY; t /= ty;
-        z0 = (t % tz) * TZ; t /= tz;
-        n0 = t;
-    } else {
-        n0 = blockIdx.x * SPW;
-    }
-    const int cob = blockIdx.y * NCO;
-
-    // ---- per-lane LDS read bases
-    int aoff[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int m = wave * (MB * 16) + mb * 16 + (lane & 15);
-        const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ, s = m / (TX * TY * TZ);
-        aoff[mb] = s * (CC * CH) + (z * HY + y) * HX + x + (lane >> 4) * CH;
-    }
-    const int boff = (lane >> 4) * COS + (lane & 15);
-
-    f32x4 acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int cbase = 0; cbase < cin; cbase += CC) {
-        // ---- stage the input halo box: GroupNorm applied, zero outside the volume, upsample+concat resolved
-        // One thread per halo ROW (HX = TX + 2 floats): the TX interior voxels come in with vector loads, the two
-        // x-halo voxels with (conditional) scalar loads; rows outside the volume are written as zeros without loads.
-        constexpr int ROWS = SPW * CC * T::HZ * HY;
-        for (int r = tid; r < ROWS; r += 256) {
-            const int hy = r % HY, hz = (r / HY) % T::HZ, c = (r / (HY * T::HZ)) % CC, s = r / (HY * T::HZ * CC);
-            const int nn = n0 + s, ci = cbase + c;
-            const int z = z0 + hz - 1, y = y0 + hy - 1;
-            float v[HX];
-#pragma unroll
-            for (int j = 0; j < HX; ++j) v[j] = 0.f;
-            if (nn < a.n && ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge) {
-                const size_t si = (size_t)nn * cin + ci;
-                const float sc = a.scale[si], sh = a.shift[si];
-                const bool has_l = x0 > 0, has_r = x0 + TX < edge;
-                if (ci < a.c0) {
-                    const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
-                    if (TX >= 4) {
-#pragma unroll
-                        for (int q = 0; q < TX / 4; ++q) {
-                            const float4 t = reinterpret_cast<const float4*>(row)[q];
-                            v[1 + 4 * q] = t.x; v[2 + 4 * q] = t.y; v[3 + 4 * q] = t.z; v[4 + 4 * q] = t.w;
-                        }
-                    } else {
-                        const float2 t = *reinterpret_cast<const float2*>(row);
-                        v[1] = t.x; v[2] = t.y;
-                    }
-                    if (has_l) v[0] = row[-1];
-                    if (has_r) v[HX - 1] = row[TX];
-                } else {
-                    // nearest x2 upsample: voxel x reads low-res x>>1, so the interior is TX/2 low-res values, each used twice
-                    const float* row = a.src1 + ((((size_t)nn * a.c1 + (ci - a.c0)) * half + (z >> 1)) * half + (y >> 1)) * half + (x0 >> 1);
-                    float lo[TX / 2 > 0 ? TX / 2 : 1];
-                    if (TX == 8) {
-                        const float4 t = *reinterpret_cast<const float4*>(row);
-                        lo[0] = t.x; lo[1] = t.y; lo[2] = t.z; lo[3] = t.w;
-                    } else if (TX == 4) {
-                        const float2 t = *reinterpret_cast<const float2*>(row);
-                        lo[0] = t.x; lo[1] = t.y;
-                    } else {
-                        lo[0] = row[0];
-                    }
-#pragma unroll
-                    for (int j = 0; j < TX; ++j) v[1 + j] = lo[j >> 1];
-                    if (has_l) v[0] = row[-1];
-                    if (has_r) v[HX - 1] = row[TX / 2];
-                }
-#pragma unroll
-                for (int j = 1; j <= TX; ++j) v[j] = v[j] * sc + sh;
-                v[0] = has_l ? v[0] * sc + sh : 0.f;
-                v[HX - 1] = has_r ? v[HX - 1] * sc + sh : 0.f;
-            }
-            float* dst = xs + (s * CC + c) * CH + (hz * HY + hy) * HX;
-#pragma unroll
-            for (int j = 0; j < HX; ++j) dst[j] = v[j];
-        }
-        // ---- stage the weight slab [27][4][NCO] (float4 rows)
-        for (int i = tid; i < 27 * CC * (NCO / 4); i += 256) {
-            const int co4 = i % (NCO / 4), r = i / (NCO / 4);          // r = tap*4 + c
-            const int tap = r >> 2, c = r & 3;
-            const int co = cob + co4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < a.cout16) v = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.cin4 + cbase + c) * a.cout16 + co);
-            *reinterpret_cast<float4*>(ws + r * COS + co4 * 4) = v;
-        }
-        __syncthreads();
-
-        // ---- 27 k-steps of 4 channels
-#pragma unroll
-        for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int tap = (dz * 3 + dy) * 3 + dx;
-                    const int toff = (dz * HY + dy) * HX + dx;
-                    float av[MB], bv[NB];
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) av[mb] = xs[aoff[mb] + toff];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bv[nb] = ws[boff + tap * (CC * COS) + nb * 16];
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
-                }
-        __syncthreads();
-    }
-
-    // ---- epilogue: ReLU, float4 stores (a lane holds 4 consecutive voxels of one cout)
-    const size_t vol = (size_t)edge * edge * edge;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int m = wave * (MB * 16) + mb * 16 + (lane >> 4) * 4;
-        const int s = m / (TX * TY * TZ);
-        const int nn = n0 + s;
-        size_t off;
-        if (TX >= 4) {
-            const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ;
-            off = ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x);
-        } else {
-            off = (size_t)(m % (TX * TY * TZ));       // tile == whole volume: voxel order is memory order
-        }
-        if (nn < a.n) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int co = cob + nb * 16 + (lane & 15);
-                if (co < a.cout) {
-                    f32x4 v = acc[mb][nb];
-                    float4 o = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-                    *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * vol + off) = o;
-                }
-            }
-        }
-    }
-}
-
-template <int TZ, int TY, int TX, int SPW, int MB, int NB>
-static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
-    using T = ConvTile<TZ, TY, TX, SPW, MB, NB>;
-    auto kern = k_conv3_mfma<TZ, TY, TX, SPW, MB, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (T::LDS_BYTES > 65536) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-            if (e != hipSuccess) { rf_set_error("rf_conv3d_k3_gn_relu: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
-        }
-        attr_set = true;
-    }
-    unsigned gx;
-    if (SPW == 1) gx = (unsigned)a.n * (a.edge / TZ) * (a.edge / TY) * (a.edge / TX);
-    else gx = (unsigned)((a.n + SPW - 1) / SPW);
-    const unsigned gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), T::LDS_BYTES, stream, a);
-    RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu");
-    return RF_OK;
-}
-
-template <int TZ, int TY, int TX, int SPW>
-static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
-    constexpr int MB = SPW * TZ * TY * TX / 64;
-    if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, MB, 1>(a, stream);
-    if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, MB, 2>(a, stream);
-    return launch_conv3<TZ, TY, TX, SPW, MB, 4>(a, stream);
-}
-
 static int conv_check(const char* who, const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
                       const float* shift, const float* w, int cout, float* out) {
     RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "%s: bad sizes", who);
@@ -377,29 +161,6 @@ static int conv_check(const char* who, const float* src0, int c0, const float* s
     RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w && out, RF_E_INVALID, "%s: null pointer", who);
     RF_REQUIRE(c1 == 0 || edge >= 2, RF_E_INVALID, "%s: upsampled source needs edge >= 2", who);
     return RF_OK;
-}
-
-extern "C" int rf_conv3d_k3_gn_relu_direct(const float*, int, const float*, int, int, int, const float*, const float*, const float*, int,
-                                           float*, void*);
-
-extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                    const float* scale, const float* shift, const float* w_packed, int cout,
-                                    float* out, void* stream) {
-    int rc = conv_check("rf_conv3d_k3_gn_relu", src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out);
-    if (rc) return rc;
-    RF_REQUIRE(edge >= 2, RF_E_UNSUPPORTED, "rf_conv3d_k3_gn_relu: 1^3 volumes take the direct path (rf_conv3d_k3_gn_relu_direct)");
-    ConvArgs a;
-    a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
-    a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
-    a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
-    hipStream_t s = (hipStream_t)stream;
-    // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
-    const long long vox = (long long)n * edge * edge * edge;
-    const long long wgs512 = (vox + 511) / 512 * ((a.cout16 + 63) / 64);
-    const bool small = wgs512 < 1024;
-    if (edge >= 8) return small ? dispatch_nb<4, 4, 8, 1>(a, s) : dispatch_nb<8, 8, 8, 1>(a, s);
-    if (edge == 4) return small ? dispatch_nb<4, 4, 4, 2>(a, s) : dispatch_nb<4, 4, 4, 8>(a, s);
-    return small ? dispatch_nb<2, 2, 2, 16>(a, s) : dispatch_nb<2, 2, 2, 64>(a, s);
 }
 
 // ----------------------------------------------------------------------------------------------- conv, direct

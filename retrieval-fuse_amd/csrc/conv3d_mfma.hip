@@ -1,0 +1,422 @@
+// rf_conv3d_k3_gn_relu: 3x3x3 convolution (pad 1, no bias) as an fp32-MFMA implicit GEMM for gfx950 with the
+// GroupNorm apply, the decoder's nearest-upsample + concat read and the ReLU fused in.
+// Reference arithmetic: model/unet.py:19-76 (SingleConv 'gcr'), :297-308 and :354-360 (upsample + concat).
+//
+// GEMM view: M = output voxels, N = cout, K = cin*27.  A workgroup of NW waves owns P = NW*MB*16 output voxels --
+// a box of one sample, or several whole small volumes -- and up to NB*16 output channels.  K is walked in chunks of
+// 4 input channels (= the k of v_mfma_f32_16x16x4_f32).  Per chunk:
+//
+//   weights  [27 taps][4 ch][NB*16 cout] slab of the packed weight image  --LDS-DMA (global_load_lds, 16 B/lane)-->
+//            LDS, DOUBLE buffered: the slab of chunk c+1 streams in while chunk c is being multiplied; no VGPRs.
+//            The image is stored with odd k-rows rotated by 16 floats (done on the SOURCE address, the DMA destination
+//            is lane-linear) so the k / k+1 halves of a B read hit different banks.
+//   input    halo box [4 ch][TZ+2][TY+2][TX+2] of the chunk: one thread per halo row; the row's global loads for
+//            chunk c+1 are issued BEFORE the MFMA loop of chunk c into registers and committed to LDS after it with
+//            GroupNorm (x*scale+shift) applied, zeros outside the volume, upsample/concat resolved.
+//   compute  27 taps: A operands are im2col reads straight out of the halo box (lane -> voxel lane&15, channel lane>>4;
+//            the tap offset is a compile-time LDS immediate), B operands rows of the slab; MB x NB accumulator tiles
+//            per wave.  fp32-input MFMA == fp32 FMA chain in k order, so this is exact fp32 arithmetic.
+//
+// Tile choice (measured): 8 waves x MB=4 (512 voxels) keeps accumulators at 64 VGPRs so two workgroups =
+// 4 waves/SIMD stay resident -- the MFMA loop of the earlier 4-wave x MB=8 tile (128 accumulator VGPRs, 2 waves/SIMD)
+// was only 78 % busy on its own.  Small problems take 4 waves x MB=2 (128 voxels) to fill the chip.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(1))) const void* rf_gptr;
+typedef __attribute__((address_space(3))) void* rf_lptr;
+
+struct ConvArgs {
+    const float* src0;
+    const float* src1;
+    const float* scale;
+    const float* shift;
+    const float* wp;
+    float* out;
+    int c0, c1, n, edge, cout, cin4, cout16;
+    int ablate;        // dev knob (RFUSE_CONV_ABLATE): 1 = stage only the first chunk, 2 = skip the MFMA loop
+};
+
+template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB>
+struct ConvTile {
+    static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    static constexpr int CH = HZ * HY * HX;            // halo floats per channel
+    static constexpr int CC = 4;                        // input channels per K chunk (= MFMA k)
+    static constexpr int XS = SPW * CC * CH;            // floats of the staged input box
+    static constexpr int XS_PAD = (XS + 3) / 4 * 4;
+    static constexpr int NCO = NB * 16;                 // couts per workgroup
+    static constexpr int WSLAB = 27 * CC * NCO;         // floats of one weight slab (unpadded: the DMA image is linear)
+    static constexpr int WSLAB_PAD = (WSLAB + 255) / 256 * 256;   // whole 1-KiB DMA pieces
+    static constexpr int NT = NW * 64;
+    static constexpr int P = SPW * TZ * TY * TX;
+    static constexpr size_t LDS_BYTES = (size_t)(XS_PAD + 2 * WSLAB_PAD) * sizeof(float);
+    static_assert(P == NW * MB * 16, "NW waves x MB x 16 voxels must cover the tile");
+    static_assert(SPW == 1 || TX < 8, "multi-sample tiles are for whole small volumes");
+};
+
+// PFX: prefetch the next chunk's input rows through registers under the MFMA loop (costs RPT*(TX+4) VGPRs)
+template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, bool PFX>
+__global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
+    using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB>;
+    constexpr int HY = T::HY, HX = T::HX, CH = T::CH, CC = T::CC, NCO = T::NCO, NT = T::NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* wsb = smem + T::XS_PAD;                       // two slabs of WSLAB_PAD floats
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int edge = a.edge, cin = a.c0 + a.c1;
+    const int half = edge >> 1;
+
+    // ---- which voxels does this workgroup own?
+    int n0, z0 = 0, y0 = 0, x0 = 0;
+    if (SPW == 1) {
+        const int tx = edge / TX, ty = edge / TY, tz = edge / TZ;
+        int t = blockIdx.x;
+        x0 = (t % tx) * TX; t /= tx;
+        y0 = (t % ty) * TY; t /= ty;
+        z0 = (t % tz) * TZ; t /= tz;
+        n0 = t;
+    } else {
+        n0 = blockIdx.x * SPW;
+    }
+    const int cob = blockIdx.y * NCO;
+
+    // ---- per-lane LDS read offsets
+    int aoff[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wave * (MB * 16) + mb * 16 + (lane & 15);
+        const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ, s = m / (TX * TY * TZ);
+        aoff[mb] = s * (CC * CH) + (z * HY + y) * HX + x + (lane >> 4) * CH;
+    }
+    // slab row r = tap*4 + k holds cout column col at float (col + ROT*(r&1)) % NCO: rows k and k+1 on different banks
+    constexpr int ROT = NCO >= 32 ? 16 : 0;
+    int boff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        boff[nb] = (lane >> 4) * NCO + ((nb * 16 + (lane & 15) + ROT * ((lane >> 4) & 1)) % NCO);
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- weight slab of one chunk -> LDS by DMA: piece q (1 KiB = 64 lanes x 16 B) is issued by wave q % NW
+    constexpr int WF4 = T::WSLAB / 4;                      // float4s in a slab
+    constexpr int NPIECE = (WF4 + 63) / 64;
+    auto dma_weights = [&](int cbase, int buf, int lane) {
+        float* dst = wsb + buf * T::WSLAB_PAD;
+#pragma unroll
+        for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+            const int q = wave + i * NW;                   // wave-uniform
+            if (q < NPIECE) {
+                int idx = q * 64 + lane;                   // float4 index inside the slab (LDS image is linear in idx)
+                if (idx >= WF4) idx = WF4 - 1;             // tail lanes of the last piece: harmless duplicate into the pad
+                const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
+                const int col = (slot + NCO - ROT * (r & 1)) % NCO;      // logical cout column stored at this slot
+                int co = cob + col;
+                if (co >= a.cout16) co = col % a.cout16;   // cout block wider than the packed image: any valid column (masked at store)
+                const float* src = a.wp + ((size_t)(r >> 2) * a.cin4 + cbase + (r & 3)) * a.cout16 + co;
+                __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- input halo rows: one thread per row (HX = TX + 2 floats), register-staged
+    constexpr int ROWS = SPW * CC * T::HZ * HY;
+    constexpr int RPT = (ROWS + NT - 1) / NT;
+    float xraw[RPT][TX + 2];       // [left halo | TX interior (or TX/2 low-res values) | right halo]
+    float xsc[RPT], xsh[RPT];
+    const bool has_l = x0 > 0, has_r = x0 + TX < edge;
+
+    auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
+        hy = r % HY; hz = (r / HY) % T::HZ; c = (r / (HY * T::HZ)) % CC; s = r / (HY * T::HZ * CC);
+        nn = n0 + s; ci = cbase + c; z = z0 + hz - 1; y = y0 + hy - 1;
+        return r < ROWS && nn < a.n && ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge;
+    };
+
+    auto issue_rows = [&](int cbase, int tid) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            int s, c, hz, hy, nn, ci, z, y;
+            if (row_coords(tid + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
+                const size_t si = (size_t)nn * cin + ci;
+                xsc[i] = a.scale[si];
+                xsh[i] = a.shift[si];
+                if (ci < a.c0) {
+                    const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
+                    if (TX >= 4) {
+#pragma unroll
+                        for (int q = 0; q < TX / 4; ++q) {
+                            const float4 t = reinterpret_cast<const float4*>(row)[q];
+                            xraw[i][1 + 4 * q] = t.x; xraw[i][2 + 4 * q] = t.y; xraw[i][3 + 4 * q] = t.z; xraw[i][4 + 4 * q] = t.w;
+                        }
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(row);
+                        xraw[i][1] = t.x; xraw[i][2] = t.y;
+                    }
+                    if (has_l) xraw[i][0] = row[-1];
+                    if (has_r) xraw[i][TX + 1] = row[TX];
+                } else {
+                    // nearest x2 upsample: voxel x reads low-res x>>1 -> TX/2 low-res values, expanded at commit time
+                    const float* row = a.src1 + ((((size_t)nn * a.c1 + (ci - a.c0)) * half + (z >> 1)) * half + (y >> 1)) * half + (x0 >> 1);
+                    if (TX == 8) {
+                        const float4 t = *reinterpret_cast<const float4*>(row);
+                        xraw[i][1] = t.x; xraw[i][2] = t.y; xraw[i][3] = t.z; xraw[i][4] = t.w;
+                    } else if (TX == 4) {
+                        const float2 t = *reinterpret_cast<const float2*>(row);
+                        xraw[i][1] = t.x; xraw[i][2] = t.y;
+                    } else {
+                        xraw[i][1] = row[0];
+                    }
+                    if (has_l) xraw[i][0] = row[-1];
+                    if (has_r) xraw[i][TX + 1] = row[TX / 2];
+                }
+            }
+        }
+    };
+
+    auto commit_rows = [&](int cbase, int tid) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * NT;
+            int s, c, hz, hy, nn, ci, z, y;
+            const bool ok = row_coords(r, cbase, s, c, hz, hy, nn, ci, z, y);
+            if (r < ROWS) {
+                float v[TX + 2];
+                if (ok) {
+                    const float sc = xsc[i], sh = xsh[i];
+                    if (ci < a.c0) {
+#pragma unroll
+                        for (int j = 1; j <= TX; ++j) v[j] = xraw[i][j] * sc + sh;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TX; ++j) v[1 + j] = xraw[i][1 + (j >> 1)] * sc + sh;
+                    }
+                    v[0] = has_l ? xraw[i][0] * sc + sh : 0.f;
+                    v[TX + 1] = has_r ? xraw[i][TX + 1] * sc + sh : 0.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TX + 2; ++j) v[j] = 0.f;
+                }
+                float* dst = xs + (s * CC + c) * CH + (hz * HY + hy) * HX;
+#pragma unroll
+                for (int j = 0; j < TX + 2; ++j) dst[j] = v[j];
+            }
+        }
+    };
+
+    // ---- prologue: chunk 0
+    dma_weights(0, 0, lane);
+    issue_rows(0, tid);
+    commit_rows(0, tid);
+    __syncthreads();                                       // also drains the DMA (vmcnt(0) before the barrier)
+
+    int buf = 0;
+    for (int cbase = 0; cbase < cin; cbase += CC) {
+        const bool more = cbase + CC < cin && a.ablate != 1;
+        // opaque copy of the thread id: keeps the compiler from hoisting the per-row index math (lane-constant across
+        // chunks) out of the K loop, where it would sit in -- and spill from -- registers the MFMA loop needs
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        if (more) {
+            if (PFX) issue_rows(cbase + CC, tid_o);        // global loads fly under the MFMA loop ...
+            dma_weights(cbase + CC, buf ^ 1, tid_o & 63);  // ... and so does the next weight slab
+        }
+        if (a.ablate != 2) {
+            const float* ws = wsb + buf * T::WSLAB_PAD;
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int tap = (dz * 3 + dy) * 3 + dx;
+                        const int toff = (dz * HY + dy) * HX + dx;
+                        float av[MB], bv[NB];
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) av[mb] = xs[aoff[mb] + toff];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[nb] = ws[boff[nb] + tap * (CC * NCO)];
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+                    }
+        }
+        __syncthreads();                                   // everyone is done reading xs / ws[buf]; loads + DMA have landed
+        if (more) {
+            int tid_c = tid;
+            asm volatile("" : "+v"(tid_c));
+            if (!PFX) issue_rows(cbase + CC, tid_c);
+            commit_rows(cbase + CC, tid_c);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: ReLU, float4 stores (a lane holds 4 consecutive voxels of one cout)
+    const size_t vol = (size_t)edge * edge * edge;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wave * (MB * 16) + mb * 16 + (lane >> 4) * 4;
+        const int s = m / (TX * TY * TZ);
+        const int nn = n0 + s;
+        size_t off;
+        if (TX >= 4) {
+            const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ;
+            off = ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x);
+        } else {
+            off = (size_t)(m % (TX * TY * TZ));       // tile == whole volume: voxel order is memory order
+        }
+        if (nn < a.n) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = cob + nb * 16 + (lane & 15);
+                if (co < a.cout) {
+                    f32x4 v = acc[mb][nb];
+                    float4 o = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+                    *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * vol + off) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, bool PFX = true>
+static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
+    using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB>;
+    auto kern = k_conv3_mfma<TZ, TY, TX, SPW, NW, MB, NB, WPS, PFX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (T::LDS_BYTES > 65536) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+            if (e != hipSuccess) { rf_set_error("rf_conv3d_k3_gn_relu: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
+        }
+        attr_set = true;
+    }
+    unsigned gx;
+    if (SPW == 1) gx = (unsigned)a.n * (a.edge / TZ) * (a.edge / TY) * (a.edge / TX);
+    else gx = (unsigned)((a.n + SPW - 1) / SPW);
+    const unsigned gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(T::NT), T::LDS_BYTES, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu");
+    return RF_OK;
+}
+
+// big: 8 waves x MB 4 = 512 voxels (two workgroups = 4 waves/SIMD per CU); small: 4 waves x MB 2 = 128 voxels
+template <int TZ, int TY, int TX, int SPW, bool BIG>
+static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
+    if constexpr (BIG) {
+        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4>(a, stream);
+        if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 2, 4>(a, stream);
+        return launch_conv3<TZ, TY, TX, SPW, 8, 4, 4, 4>(a, stream);
+    } else {
+        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 4, 2, 1, 4>(a, stream);
+        if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 4, 2, 2, 4>(a, stream);
+        return launch_conv3<TZ, TY, TX, SPW, 4, 2, 4, 4>(a, stream);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- cin == 1 layers
+// First conv of every U-Net (1 -> nf/2 channels, model/unet.py:128-132): K = 27 only, so the MFMA form would waste 3/4 of
+// its k and half of its n.  It is HBM-bound (reads 4 B, writes 4*COUT B per voxel): plain VALU, one voxel per thread
+// and all COUT channels in registers, halo tile and the [27][COUT] weights in LDS (weight reads are LDS broadcasts).
+template <int TZ, int TY, int TX, int COUT>
+__global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
+    // one thread per (y, x) column of the tile, TZ voxels deep: each weight read (an LDS broadcast) feeds TZ voxels and
+    // each input read feeds up to 3 of them, so LDS traffic per voxel is ~3x lower than a voxel-per-thread form
+    constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+    static_assert(TY * TX == 256, "one thread per (y,x) column");
+    __shared__ float xs[HZ * HY * HX];
+    __shared__ __attribute__((aligned(16))) float wl[27 * 8];          // [tap][8] (COUT <= 8, zero padded)
+    const int tid = threadIdx.x, edge = a.edge;
+    const int tx = edge / TX, ty = edge / TY, tz = edge / TZ;
+    int t = blockIdx.x;
+    const int x0 = (t % tx) * TX; t /= tx;
+    const int y0 = (t % ty) * TY; t /= ty;
+    const int z0 = (t % tz) * TZ; t /= tz;
+    const int nn = t;
+    for (int i = tid; i < 27 * 8; i += 256) wl[i] = (i % 8) < COUT ? a.wp[(size_t)(i / 8) * a.cin4 * a.cout16 + (i % 8)] : 0.f;   // packed [tap][ci=0][co]
+    const float sc = a.scale[nn], sh = a.shift[nn];
+    const float* src = a.src0 + (size_t)nn * edge * edge * edge;
+    for (int i = tid; i < HZ * HY * HX; i += 256) {
+        const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+        float v = 0.f;
+        if ((unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge)
+            v = src[((size_t)z * edge + y) * edge + x] * sc + sh;
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int x = tid % TX, y = tid / TX;
+    float acc[TZ][COUT];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[z][co] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float col[HZ];
+#pragma unroll
+            for (int hz = 0; hz < HZ; ++hz) col[hz] = xs[(hz * HY + (y + dy)) * HX + x + dx];
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int z = 0; z < TZ; ++z)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[z][co] = fmaf(col[z + dz], wv[co], acc[z][co]);
+            }
+        }
+    const size_t vol = (size_t)edge * edge * edge;
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) {
+        float* o = a.out + (size_t)nn * COUT * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) o[co * vol] = fmaxf(acc[z][co], 0.f);
+    }
+}
+
+template <int COUT>
+static int launch_cin1(const ConvArgs& a, hipStream_t stream) {      // edge >= 16
+    const unsigned g = (unsigned)a.n * (a.edge / 4) * (a.edge / 16) * (a.edge / 16);
+    hipLaunchKernelGGL((k_conv3_cin1<4, 16, 16, COUT>), dim3(g), dim3(256), 0, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu(cin1)");
+    return RF_OK;
+}
+
+extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                    const float* scale, const float* shift, const float* w_packed, int cout,
+                                    float* out, void* stream) {
+    RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "rf_conv3d_k3_gn_relu: bad sizes");
+    RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_conv3d_k3_gn_relu: edge %d must be a power of two <= 128", edge);
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w_packed && out, RF_E_INVALID, "rf_conv3d_k3_gn_relu: null pointer");
+    RF_REQUIRE(edge >= 2, RF_E_UNSUPPORTED, "rf_conv3d_k3_gn_relu: 1^3 volumes take the direct path (rf_conv3d_k3_gn_relu_direct)");
+    ConvArgs a;
+    a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
+    a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
+    static const int abl = getenv("RFUSE_CONV_ABLATE") ? atoi(getenv("RFUSE_CONV_ABLATE")) : 0;
+    a.ablate = abl;
+    hipStream_t s = (hipStream_t)stream;
+    if (c0 == 1 && c1 == 0 && edge >= 16) {
+        if (cout == 8) return launch_cin1<8>(a, s);
+        if (cout == 6) return launch_cin1<6>(a, s);
+    }
+    // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
+    static const int force_tile = getenv("RFUSE_CONV_TILE") ? atoi(getenv("RFUSE_CONV_TILE")) : 0;   // dev knob: 1 = small, 2 = big
+    const long long vox = (long long)n * edge * edge * edge;
+    const long long wgs512 = (vox + 511) / 512 * ((a.cout16 + 63) / 64);
+    const bool big = force_tile == 1 ? false : (force_tile == 2 ? true : wgs512 >= 1024);
+    if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, true>(a, s) : dispatch_nb<4, 4, 8, 1, false>(a, s);
+    if (edge == 4) return big ? dispatch_nb<4, 4, 4, 8, true>(a, s) : dispatch_nb<4, 4, 4, 2, false>(a, s);
+    return big ? dispatch_nb<2, 2, 2, 64, true>(a, s) : dispatch_nb<2, 2, 2, 16, false>(a, s);
+}
