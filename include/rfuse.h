@@ -63,6 +63,19 @@ int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, i
                          const float* scale, const float* shift, const float* w_packed, int cout,
                          float* out, void* stream);
 
+/* Same convolution, additionally emitting the GroupNorm statistics of its (ReLU'd) output for the NEXT layer:
+ * stats [n][cout][tiles] pairs of float64 (sum, sum of squares) per workgroup tile, tiles = rf_conv3d_stats_tiles(...)
+ * (0 = this shape takes a path without fused statistics).  Deterministic (fixed reduction order, no atomics). */
+int rf_conv3d_k3_gn_relu_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                               const float* scale, const float* shift, const float* w_packed, int cout,
+                               float* out, double* stats, void* stream);
+int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout);
+
+/* rf_gn_stats's result from producer-side statistics instead of re-reading the tensors: stats0 [n][c0][tiles0],
+ * stats1 [n][c1][tiles1] (the low-res source; its sums count 8x).  edge = full resolution.  model/unet.py:54-66. */
+int rf_gn_from_stats(const double* stats0, int c0, int tiles0, const double* stats1, int c1, int tiles1, int n, int edge,
+                     const float* gamma, const float* beta, int groups, float eps, float* scale, float* shift, void* stream);
+
 /* Same contract on the plain VALU path (one thread per output); the kernels' own cross-check and the path for
  * 1^3 volumes.  Takes the ORIGINAL OIDHW weight. */
 int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const float* src1, int c1, int n, int edge,
@@ -71,6 +84,9 @@ int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const float* src1, in
 
 /* MaxPool3d(kernel 2, stride 2): Encoder.forward, model/unet.py:237,249-251.  x [n][c][edge^3] -> [n][c][(edge/2)^3] */
 int rf_maxpool3d_2(const float* x, int n, int c, int edge, float* out, void* stream);
+/* ... also emitting stats [n*c][rf_maxpool_stats_tiles(edge)] (sum, sum of squares) of the pooled output */
+int rf_maxpool3d_2_stats(const float* x, int n, int c, int edge, float* out, double* stats, void* stream);
+int rf_maxpool_stats_tiles(int edge);
 
 /* out[n][0][v] = (tanh(sum_c w[c] x[n][c][v] + b) + post_add) * post_mul
  * Conv3d(nf,1,1)+Tanh of Superresolution08FinalDecoder (model/refinement.py:54-55); with post_add=1,

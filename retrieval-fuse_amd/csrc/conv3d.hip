@@ -214,13 +214,27 @@ extern "C" int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const floa
 }
 
 // --------------------------------------------------------------------------------------------------- max pool
-__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, size_t planes, int edge, float* __restrict__ out) {
+// One workgroup per (plane = sample*channel, chunk of up to 2048 outputs); optionally emits the chunk's (sum, sum of
+// squares) so the next GroupNorm never re-reads the pooled tensor.
+#define RF_POOL_CHUNK 2048
+// one WAVE per (plane, chunk): no LDS, no block barrier; 4 units per workgroup
+__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, size_t units, int edge, int chunks, float* __restrict__ out,
+                                                  double2* __restrict__ stats) {
     const int h = edge >> 1;
-    const size_t ovol = (size_t)h * h * h, total = planes * ovol;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % h), oy = (int)((i / h) % h), oz = (int)((i / ((size_t)h * h)) % h);
-        const size_t p = i / ovol;
-        const float* b = x + p * (size_t)edge * edge * edge + ((size_t)(2 * oz) * edge + 2 * oy) * edge + 2 * ox;
+    const size_t ovol = (size_t)h * h * h;
+    const size_t unit = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= units) return;
+    const int lane = threadIdx.x & 63;
+    const size_t plane = unit / chunks;
+    const int chunk = (int)(unit % chunks);
+    const float* src = x + plane * (size_t)edge * edge * edge;
+    float* dst = out + plane * ovol;
+    const size_t lo = (size_t)chunk * RF_POOL_CHUNK;
+    const size_t hi = lo + RF_POOL_CHUNK < ovol ? lo + RF_POOL_CHUNK : ovol;
+    double sm = 0.0, sq = 0.0;
+    for (size_t i = lo + lane; i < hi; i += 64) {
+        const int ox = (int)(i % h), oy = (int)((i / h) % h), oz = (int)(i / ((size_t)h * h));
+        const float* b = src + ((size_t)(2 * oz) * edge + 2 * oy) * edge + 2 * ox;
         float m = -INFINITY;
 #pragma unroll
         for (int dz = 0; dz < 2; ++dz)
@@ -229,17 +243,98 @@ __global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, s
                 const float2 v = *reinterpret_cast<const float2*>(b + ((size_t)dz * edge + dy) * edge);
                 m = fmaxf(m, fmaxf(v.x, v.y));
             }
-        out[i] = m;
+        dst[i] = m;
+        sm += (double)m;
+        sq += (double)m * m;
+    }
+    if (stats) {
+        sm = wave_sum(sm);
+        sq = wave_sum(sq);
+        if (lane == 0) stats[unit] = make_double2(sm, sq);
     }
 }
 
-extern "C" int rf_maxpool3d_2(const float* x, int n, int c, int edge, float* out, void* stream) {
+extern "C" int rf_maxpool_stats_tiles(int edge) {
+    const size_t ovol = (size_t)(edge / 2) * (edge / 2) * (edge / 2);
+    return (int)((ovol + RF_POOL_CHUNK - 1) / RF_POOL_CHUNK);
+}
+
+static int maxpool_impl(const float* x, int n, int c, int edge, float* out, double* stats, void* stream) {
     RF_REQUIRE(x && out && n > 0 && c > 0, RF_E_INVALID, "rf_maxpool3d_2: bad arguments");
     RF_REQUIRE(rf_is_pow2(edge) && edge >= 2 && edge <= 128, RF_E_INVALID, "rf_maxpool3d_2: edge %d", edge);
-    const size_t total = (size_t)n * c * (edge / 2) * (edge / 2) * (edge / 2);
-    const size_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_maxpool2, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n * c, edge, out);
+    const int chunks = rf_maxpool_stats_tiles(edge);
+    const size_t units = (size_t)n * c * chunks;
+    hipLaunchKernelGGL(k_maxpool2, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, units, edge, chunks, out,
+                       reinterpret_cast<double2*>(stats));
     RF_CHECK_LAUNCH("rf_maxpool3d_2");
+    return RF_OK;
+}
+
+extern "C" int rf_maxpool3d_2(const float* x, int n, int c, int edge, float* out, void* stream) {
+    return maxpool_impl(x, n, c, edge, out, nullptr, stream);
+}
+
+extern "C" int rf_maxpool3d_2_stats(const float* x, int n, int c, int edge, float* out, double* stats, void* stream) {
+    RF_REQUIRE(stats, RF_E_INVALID, "rf_maxpool3d_2_stats: null stats buffer");
+    return maxpool_impl(x, n, c, edge, out, stats, stream);
+}
+
+// ------------------------------------------------------------------------------- GroupNorm from fused statistics
+// scale/shift of GroupNorm(cat(src0, up2(src1))) from per-(sample, channel, tile) partial sums emitted by the producers
+// of src0 / src1 (rf_conv3d_k3_gn_relu_stats, rf_maxpool3d_2_stats).  One wave per (sample, group); fixed summation order.
+__global__ __launch_bounds__(256) void k_gn_from_stats(const double2* __restrict__ st0, int c0, int t0, const double2* __restrict__ st1, int c1,
+                                                       int t1, int units, int groups, int cpg, double count, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, double eps, float* __restrict__ scale,
+                                                       float* __restrict__ shift) {
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= units) return;
+    const int nn = unit / groups, g = unit % groups, lane = threadIdx.x & 63;
+    const int C = c0 + c1, ca = g * cpg, cb = ca + cpg;
+    double sm = 0.0, sq = 0.0;
+    {   // src0 channels of the group: contiguous run of (channels x tiles) entries
+        const int hi_c = cb < c0 ? cb : c0;
+        if (ca < hi_c) {
+            const double2* p = st0 + ((size_t)nn * c0 + ca) * t0;
+            const int len = (hi_c - ca) * t0;
+            for (int i = lane; i < len; i += 64) { sm += p[i].x; sq += p[i].y; }
+        }
+    }
+    {   // src1 (upsampled) channels: every low-res voxel is seen 8 times
+        const int lo_c = ca > c0 ? ca : c0;
+        if (lo_c < cb) {
+            const double2* p = st1 + ((size_t)nn * c1 + (lo_c - c0)) * t1;
+            const int len = (cb - lo_c) * t1;
+            double a = 0.0, b = 0.0;
+            for (int i = lane; i < len; i += 64) { a += p[i].x; b += p[i].y; }
+            sm += 8.0 * a;
+            sq += 8.0 * b;
+        }
+    }
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    const double mean = sm / count;
+    double var = sq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + eps);
+    for (int c = ca + lane; c < cb; c += 64) {
+        const double sc = (double)gamma[c] * rstd;
+        scale[(size_t)nn * C + c] = (float)sc;
+        shift[(size_t)nn * C + c] = (float)((double)beta[c] - mean * sc);
+    }
+}
+
+extern "C" int rf_gn_from_stats(const double* stats0, int c0, int tiles0, const double* stats1, int c1, int tiles1, int n, int edge,
+                                const float* gamma, const float* beta, int groups, float eps, float* scale, float* shift, void* stream) {
+    const int C = c0 + c1;
+    RF_REQUIRE(n > 0 && C > 0 && groups > 0 && C % groups == 0, RF_E_INVALID, "rf_gn_from_stats: channels %d not divisible by groups %d", C, groups);
+    RF_REQUIRE((c0 == 0 || (stats0 && tiles0 > 0)) && (c1 == 0 || (stats1 && tiles1 > 0)) && gamma && beta && scale && shift, RF_E_INVALID,
+               "rf_gn_from_stats: null pointer / zero tiles");
+    RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_gn_from_stats: edge %d", edge);
+    const int cpg = C / groups;
+    hipLaunchKernelGGL(k_gn_from_stats, dim3((n * groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(stats0), c0, tiles0,
+                       reinterpret_cast<const double2*>(stats1), c1, tiles1, n * groups, groups, cpg, (double)cpg * edge * edge * edge, gamma, beta, (double)eps,
+                       scale, shift);
+    RF_CHECK_LAUNCH("rf_gn_from_stats");
     return RF_OK;
 }
 

@@ -35,6 +35,8 @@ struct ConvArgs {
     float* out;
     int c0, c1, n, edge, cout, cin4, cout16;
     int ablate;        // dev knob (RFUSE_CONV_ABLATE): 1 = stage only the first chunk, 2 = skip the MFMA loop
+    double2* stats;    // optional [n][cout][stats_tiles] (sum, sum of squares) of the ReLU'd output, per workgroup tile
+    int stats_tiles;
 };
 
 template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB>
@@ -284,6 +286,74 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
             }
         }
     }
+
+    // ---- optional: GroupNorm statistics of the output for the NEXT layer, per (sample, cout), this workgroup's tile.
+    // Fixed reduction order (registers -> lane groups -> waves through LDS), float64: deterministic, no atomics.
+    if (a.stats) {
+        constexpr int VOL = TZ * TY * TX;                       // voxels of one sample inside the tile
+        constexpr int WV = MB * 16;                             // voxels per wave
+        constexpr int SLOTS = VOL >= WV ? 1 : WV / VOL;         // sample slots per wave (2^3 volumes: several samples per wave)
+        static_assert(VOL >= WV || VOL == 8, "sub-wave samples are 2^3 volumes");
+        static_assert((size_t)NW * SLOTS * NCO * 2 * sizeof(double) <= T::LDS_BYTES, "stats scratch must fit the tile's LDS");
+        double* red = reinterpret_cast<double*>(smem);          // [NW][SLOTS][NCO][2]; the K loop ended on a barrier
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (SLOTS == 1) {
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = (double)fmaxf(acc[mb][nb][r], 0.f);
+                        sm += v; sq += v * v;
+                    }
+                sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+                sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                if (lane < 16) {
+                    red[((size_t)wave * NCO + nb * 16 + lane) * 2] = sm;
+                    red[((size_t)wave * NCO + nb * 16 + lane) * 2 + 1] = sq;
+                }
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    double sm = 0.0, sq = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = (double)fmaxf(acc[mb][nb][r], 0.f);
+                        sm += v; sq += v * v;
+                    }
+                    sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);      // lanes {0..31}: sample 2mb, {32..63}: 2mb+1
+                    if ((lane & 16) == 0) {
+                        const int slot = mb * 2 + (lane >> 5);
+                        red[(((size_t)wave * SLOTS + slot) * NCO + nb * 16 + (lane & 15)) * 2] = sm;
+                        red[(((size_t)wave * SLOTS + slot) * NCO + nb * 16 + (lane & 15)) * 2 + 1] = sq;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int tile = SPW == 1 ? (int)(blockIdx.x % ((edge / TZ) * (edge / TY) * (edge / TX))) : 0;
+        for (int idx = tid; idx < SPW * NCO; idx += NT) {
+            const int sidx = idx / NCO, col = idx % NCO;
+            const int co = cob + col, nn = n0 + sidx;
+            if (co < a.cout && nn < a.n) {
+                double sm = 0.0, sq = 0.0;
+                if (SLOTS == 1) {
+                    constexpr int WPSMP = VOL / WV;             // waves per sample
+#pragma unroll
+                    for (int w = 0; w < WPSMP; ++w) {
+                        sm += red[((size_t)(sidx * WPSMP + w) * NCO + col) * 2];
+                        sq += red[((size_t)(sidx * WPSMP + w) * NCO + col) * 2 + 1];
+                    }
+                } else {
+                    const int w = (sidx * VOL) / WV, slot = ((sidx * VOL) % WV) / VOL;
+                    sm = red[(((size_t)w * SLOTS + slot) * NCO + col) * 2];
+                    sq = red[(((size_t)w * SLOTS + slot) * NCO + col) * 2 + 1];
+                }
+                a.stats[((size_t)nn * a.cout + co) * a.stats_tiles + tile] = make_double2(sm, sq);
+            }
+        }
+    }
 }
 
 template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, bool PFX = true>
@@ -383,6 +453,28 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) o[co * vol] = fmaxf(acc[z][co], 0.f);
     }
+    if (a.stats) {
+        __shared__ double red[4 * 8 * 2];
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            double sm = 0.0, sq = 0.0;
+#pragma unroll
+            for (int z = 0; z < TZ; ++z) {
+                const double v = (double)fmaxf(acc[z][co], 0.f);
+                sm += v; sq += v * v;
+            }
+            sm = wave_sum(sm); sq = wave_sum(sq);
+            if (lane == 0) { red[(wave * 8 + co) * 2] = sm; red[(wave * 8 + co) * 2 + 1] = sq; }
+        }
+        __syncthreads();
+        if (tid < COUT) {
+            double sm = 0.0, sq = 0.0;
+            for (int w = 0; w < 4; ++w) { sm += red[(w * 8 + tid) * 2]; sq += red[(w * 8 + tid) * 2 + 1]; }
+            const int tile = (int)(blockIdx.x % (tx * ty * tz));
+            a.stats[((size_t)nn * COUT + tid) * a.stats_tiles + tile] = make_double2(sm, sq);
+        }
+    }
 }
 
 template <int COUT>
@@ -393,9 +485,25 @@ static int launch_cin1(const ConvArgs& a, hipStream_t stream) {      // edge >= 
     return RF_OK;
 }
 
-extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                    const float* scale, const float* shift, const float* w_packed, int cout,
-                                    float* out, void* stream) {
+// which tiling will rf_conv3d_k3_gn_relu use, and how many stats tiles per sample does that give?
+static bool conv_use_cin1(int c0, int c1, int edge, int cout) { return c0 == 1 && c1 == 0 && edge >= 16 && (cout == 8 || cout == 6); }
+static bool conv_use_big(int n, int edge, int cout16) {
+    static const int force_tile = getenv("RFUSE_CONV_TILE") ? atoi(getenv("RFUSE_CONV_TILE")) : 0;   // dev knob: 1 = small, 2 = big
+    const long long vox = (long long)n * edge * edge * edge;
+    const long long wgs512 = (vox + 511) / 512 * ((cout16 + 63) / 64);
+    return force_tile == 1 ? false : (force_tile == 2 ? true : wgs512 >= 1024);
+}
+
+extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) {
+    if (edge < 2) return 0;                                    // direct path: no fused statistics
+    if (conv_use_cin1(c0, c1, edge, cout)) return (edge / 4) * (edge / 16) * (edge / 16);
+    if (edge <= 4) return 1;                                   // whole-volume tiles
+    return conv_use_big(n, edge, rf_round_up(cout, 16)) ? (edge / 8) * (edge / 8) * (edge / 8) : (edge / 4) * (edge / 4) * (edge / 8);
+}
+
+static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                       const float* scale, const float* shift, const float* w_packed, int cout,
+                       float* out, double* stats, void* stream) {
     RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "rf_conv3d_k3_gn_relu: bad sizes");
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_conv3d_k3_gn_relu: edge %d must be a power of two <= 128", edge);
     RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w_packed && out, RF_E_INVALID, "rf_conv3d_k3_gn_relu: null pointer");
@@ -406,17 +514,26 @@ extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1
     a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
     static const int abl = getenv("RFUSE_CONV_ABLATE") ? atoi(getenv("RFUSE_CONV_ABLATE")) : 0;
     a.ablate = abl;
+    a.stats = reinterpret_cast<double2*>(stats);
+    a.stats_tiles = stats ? rf_conv3d_stats_tiles(c0, c1, n, edge, cout) : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (c0 == 1 && c1 == 0 && edge >= 16) {
-        if (cout == 8) return launch_cin1<8>(a, s);
-        if (cout == 6) return launch_cin1<6>(a, s);
-    }
+    if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
-    static const int force_tile = getenv("RFUSE_CONV_TILE") ? atoi(getenv("RFUSE_CONV_TILE")) : 0;   // dev knob: 1 = small, 2 = big
-    const long long vox = (long long)n * edge * edge * edge;
-    const long long wgs512 = (vox + 511) / 512 * ((a.cout16 + 63) / 64);
-    const bool big = force_tile == 1 ? false : (force_tile == 2 ? true : wgs512 >= 1024);
+    const bool big = conv_use_big(n, edge, a.cout16);
     if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, true>(a, s) : dispatch_nb<4, 4, 8, 1, false>(a, s);
     if (edge == 4) return big ? dispatch_nb<4, 4, 4, 8, true>(a, s) : dispatch_nb<4, 4, 4, 2, false>(a, s);
     return big ? dispatch_nb<2, 2, 2, 64, true>(a, s) : dispatch_nb<2, 2, 2, 16, false>(a, s);
+}
+
+extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                    const float* scale, const float* shift, const float* w_packed, int cout,
+                                    float* out, void* stream) {
+    return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, nullptr, stream);
+}
+
+extern "C" int rf_conv3d_k3_gn_relu_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                          const float* scale, const float* shift, const float* w_packed, int cout,
+                                          float* out, double* stats, void* stream) {
+    RF_REQUIRE(stats, RF_E_INVALID, "rf_conv3d_k3_gn_relu_stats: null stats buffer");
+    return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, stats, stream);
 }

@@ -13,7 +13,7 @@
 //   accumulates sum (q_d - x_d)^2 in fp32, compares against the list's current k-th best and only on a hit takes the
 //   (rare) cooperative insertion path.  Candidates are 64-bit keys (dist_bits << 32 | global_row): for non-negative
 //   floats the IEEE bit pattern is monotone, so one unsigned compare orders by (distance, row id) -- ties go to the
-//   lower row id, deterministically.  Every (slice, wave) writes its own sorted list; a bitonic merge kernel reduces
+//   lower row id, deterministically.  Every (slice, query) gets one sorted list; a bitonic merge kernel reduces
 //   them per query.  The same merge serves the RCCL all-gathered per-shard lists.
 #include "common.h"
 
@@ -86,25 +86,44 @@ __device__ __forceinline__ void list_insert(u64& e, int lane, u64 cand) {
     if (lane < K2) e = lane < pos ? e : (lane == pos ? cand : up);
 }
 
+// ascending bitonic sort of one key per lane across the wave (64 keys, 21 compare-exchange steps on the crossbar)
+__device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u64 other = __shfl_xor(key, j, 64);
+            const bool asc = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const u64 mn = key < other ? key : other, mx = key < other ? other : key;
+            key = (lower == asc) ? mn : mx;
+        }
+    }
+    return key;
+}
+
+// One workgroup = (DB slice, tile of RF_TQ queries); its 4 waves SPLIT THE QUERIES (RF_QW each) and every wave walks all
+// 64-row blocks of the slice, so there is exactly one candidate list per (slice, query).  A wave's lists live in
+// registers (list j: entry i in lane i of e[j]).  The first block initialises a list with a wave-wide sort; afterwards a
+// row enters only if it beats the list's current worst (ballot), which becomes rare quickly (~K2/b hits for block b).
+#define RF_QW (RF_TQ / 4)
 template <int K2>
 __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, int nq, const float* __restrict__ db, long long n,
                                                  unsigned row_base, int blocks_per_slice, u64* __restrict__ parts) {
-    // lists[wave][query-in-tile][K2]
-    __shared__ u64 lists[4 * RF_TQ * K2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = blockIdx.x, q0 = blockIdx.y * RF_TQ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x, q0 = blockIdx.y * RF_TQ + wave * RF_QW;
     const long long nblk = (n + 63) / 64;
-    u64* mine = lists + (size_t)wave * RF_TQ * K2;
-    for (int i = lane; i < RF_TQ * K2; i += 64) mine[i] = RF_KEY_NONE;
-    __syncthreads();
-
     const long long blk_lo = (long long)slice * blocks_per_slice;
     long long blk_hi = blk_lo + blocks_per_slice;
     if (blk_hi > nblk) blk_hi = nblk;
-    const int nq_tile = (nq - q0) < RF_TQ ? (nq - q0) : RF_TQ;
 
-    for (long long blk = blk_lo + wave; blk < blk_hi; blk += 4) {
-        // this lane's DB row: 64 coalesced loads, one per dim
+    u64 e[RF_QW];
+#pragma unroll
+    for (int j = 0; j < RF_QW; ++j) e[j] = RF_KEY_NONE;
+
+    for (long long blk = blk_lo; blk < blk_hi; ++blk) {
+        // this lane's DB row: 64 coalesced loads, one per dim (the 4 waves read the same block: L1/L2 hits)
         float x[RF_DIM];
         const float* bp = db + (size_t)blk * RF_DIM * 64 + lane;
 #pragma unroll
@@ -112,39 +131,45 @@ __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, in
         const long long row = blk * 64 + lane;
         const bool valid = row < n;
         const unsigned grow = row_base + (unsigned)row;
+        const bool first = blk == blk_lo;
 
-        for (int qi = 0; qi < nq_tile; ++qi) {
-            const float* qp = q + (size_t)(q0 + qi) * RF_DIM;     // wave-uniform address -> scalar loads
-            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int d = 0; d < RF_DIM; d += 2) {
-                const float t0 = qp[d] - x[d], t1 = qp[d + 1] - x[d + 1];
-                a0 = fmaf(t0, t0, a0);
-                a1 = fmaf(t1, t1, a1);
-            }
-            const float dist = a0 + a1;
-            const u64 key = valid ? make_key(dist, grow) : RF_KEY_NONE;
-            const u64 worst = mine[qi * K2 + (K2 - 1)];           // broadcast LDS read
-            unsigned long long hits = __ballot(key < worst);
-            if (hits) {
-                u64 e = lane < K2 ? mine[qi * K2 + lane] : RF_KEY_NONE;
-                while (hits) {
-                    const int src = __ffsll((long long)hits) - 1;
-                    hits &= hits - 1;
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(key & 0xffffffffu), src);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(key >> 32), src);
-                    list_insert<K2>(e, lane, ((u64)hi << 32) | lo);
+        for (int j = 0; j < RF_QW; ++j) {
+            const int qi = q0 + j;
+            if (qi < nq) {                                           // wave-uniform
+                const float* qp = q + (size_t)qi * RF_DIM;           // wave-uniform address -> scalar loads
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int d = 0; d < RF_DIM; d += 2) {
+                    const float t0 = qp[d] - x[d], t1 = qp[d + 1] - x[d + 1];
+                    a0 = fmaf(t0, t0, a0);
+                    a1 = fmaf(t1, t1, a1);
                 }
-                if (lane < K2) mine[qi * K2 + lane] = e;
+                const u64 key = valid ? make_key(a0 + a1, grow) : RF_KEY_NONE;
+                if (first) {
+                    const u64 sorted = wave_sort64(key, lane);
+                    e[j] = lane < K2 ? sorted : RF_KEY_NONE;
+                } else {
+                    const unsigned wlo = __builtin_amdgcn_readlane((unsigned)(e[j] & 0xffffffffu), K2 - 1);
+                    const unsigned whi = __builtin_amdgcn_readlane((unsigned)(e[j] >> 32), K2 - 1);
+                    const u64 worst = ((u64)whi << 32) | wlo;
+                    unsigned long long hits = __ballot(key < worst);
+                    while (hits) {
+                        const int src = __ffsll((long long)hits) - 1;
+                        hits &= hits - 1;
+                        const unsigned lo = __builtin_amdgcn_readlane((unsigned)(key & 0xffffffffu), src);
+                        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(key >> 32), src);
+                        list_insert<K2>(e[j], lane, ((u64)hi << 32) | lo);
+                    }
+                }
             }
         }
     }
-    __syncthreads();
-    // every (slice, wave) publishes its lists: parts[(slice*4 + wave)][q][K2]
-    const int nparts_q = nq;
-    for (int i = tid; i < 4 * RF_TQ * K2; i += 256) {
-        const int w = i / (RF_TQ * K2), rem = i % (RF_TQ * K2), qi = rem / K2, j = rem % K2;
-        if (qi < nq_tile) parts[((size_t)(slice * 4 + w) * nparts_q + (q0 + qi)) * K2 + j] = lists[i];
+    // publish: parts[slice][q][K2]
+#pragma unroll
+    for (int j = 0; j < RF_QW; ++j) {
+        const int qi = q0 + j;
+        if (qi < nq && lane < K2) parts[((size_t)slice * nq + qi) * K2 + lane] = e[j];
     }
 }
 
@@ -182,10 +207,10 @@ __global__ __launch_bounds__(256) void k_merge_keys(const u64* __restrict__ part
 }
 
 static int pick_slices(long long nblk, int qtiles) {
-    // enough workgroups to fill 256 CUs a few times over, but at most 32 slices (128 lists per query to merge)
+    // enough workgroups to fill 256 CUs a few times over, at most 64 slices (= lists per query to merge)
     long long s = (1024 + qtiles - 1) / qtiles;
-    if (s > 32) s = 32;
-    if (s > (nblk + 3) / 4) s = (nblk + 3) / 4;
+    if (s > 64) s = 64;
+    if (s > (nblk + 3) / 4) s = (nblk + 3) / 4;                     // at least 4 blocks per list
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -193,7 +218,7 @@ static int pick_slices(long long nblk, int qtiles) {
 extern "C" size_t rf_l2_topk_ws_bytes(int nq, int64_t n, int k2) {
     (void)n;
     const int k2p = k2 <= 8 ? 8 : 16;
-    return (size_t)32 * 4 * (size_t)nq * k2p * sizeof(u64);
+    return (size_t)64 * (size_t)nq * k2p * sizeof(u64);           // one K2-wide list per (slice <= 64, query)
 }
 
 static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2, float* out_dist, int64_t* out_idx, hipStream_t s, const char* who) {
@@ -223,8 +248,8 @@ extern "C" int rf_l2_topk(const float* q, int nq, int dim, const float* db_packe
     if (k2p == 8) hipLaunchKernelGGL(k_l2_topk<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, db_packed, (long long)n, (unsigned)row_base, bps, parts);
     else hipLaunchKernelGGL(k_l2_topk<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, db_packed, (long long)n, (unsigned)row_base, bps, parts);
     RF_CHECK_LAUNCH("rf_l2_topk(scan)");
-    // merge the slices*4 lists (each k2p wide) and emit the first k2
-    return launch_merge(parts, slices * 4, nq, k2p, k2, out_dist, out_idx, s, "rf_l2_topk(merge)");
+    // merge the per-slice lists (each k2p wide) and emit the first k2
+    return launch_merge(parts, slices, nq, k2p, k2, out_dist, out_idx, s, "rf_l2_topk(merge)");
 }
 
 // merge from (dist, idx) arrays: the all-gathered per-shard results

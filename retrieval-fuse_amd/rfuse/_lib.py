@@ -28,6 +28,11 @@ SIGNATURES = {
     'rf_gn_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_p, c_sz, c_p]),
     'rf_gn_stats_ws_bytes': (c_sz, [c_i, c_i]),
     'rf_conv3d_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_conv3d_k3_gn_relu_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p, c_p]),
+    'rf_conv3d_stats_tiles': (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    'rf_gn_from_stats': (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_p]),
+    'rf_maxpool3d_2_stats': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_p]),
+    'rf_maxpool_stats_tiles': (c_i, [c_i]),
     'rf_conv3d_k3_gn_relu_direct': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
     'rf_maxpool3d_2': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_conv1x1_tanh': (c_i, [c_fp, c_i, c_i, c_sz, c_fp, c_fp, c_f, c_f, c_fp, c_p]),

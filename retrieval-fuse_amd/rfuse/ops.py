@@ -106,11 +106,40 @@ def gn_scale_shift(src0, src1, gamma, beta, groups, eps=1e-5):
     lib = _lib.load()
     scale = torch.empty((n, c), dtype=torch.float32, device=dev)
     shift = torch.empty((n, c), dtype=torch.float32, device=dev)
+    st0, st1 = _fresh_stats(src0), _fresh_stats(src1)
+    if USE_FUSED_STATS and (src0 is None or st0 is not None) and (src1 is None or st1 is not None):
+        # the producers (conv / max-pool epilogues) already emitted per-tile sums: no re-read of the activations
+        _lib.check(lib.rf_gn_from_stats(_p(st0[0]) if st0 else _p(None), c0, st0[1] if st0 else 0,
+                                        _p(st1[0]) if st1 else _p(None), c1, st1[1] if st1 else 0, n, edge,
+                                        _p(gamma.detach()), _p(beta.detach()), groups, eps, _p(scale), _p(shift), _stream()), 'rf_gn_from_stats')
+        return scale, shift
     nbytes = lib.rf_gn_stats_ws_bytes(n, groups)
     ws = _workspace(dev, nbytes)
     _lib.check(lib.rf_gn_stats(_p(src0), c0, _p(src1), c1, n, edge, _p(gamma.detach()), _p(beta.detach()), groups, eps,
                                _p(scale), _p(shift), _p(ws), ws.numel(), _stream()), 'rf_gn_stats')
     return scale, shift
+
+
+USE_FUSED_STATS = True          # producers attach (stats, tiles, version) to their outputs as ``tensor._rf_stats``
+
+
+def _fresh_stats(t):
+    """Producer-side statistics of ``t`` if they are attached and ``t`` has not been modified in place since."""
+    st = getattr(t, '_rf_stats', None) if t is not None else None
+    return st if st is not None and st[2] == t._version else None
+
+
+def _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out):
+    """MFMA conv launch; emits the output's GroupNorm statistics for the next layer when the tiling supports it."""
+    tiles = lib.rf_conv3d_stats_tiles(c0, c1, n, edge, cout) if USE_FUSED_STATS else 0
+    if tiles > 0:
+        stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=out.device)
+        _lib.check(lib.rf_conv3d_k3_gn_relu_stats(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
+                                                  _p(stats), _stream()), 'rf_conv3d_k3_gn_relu_stats')
+        out._rf_stats = (stats, tiles, out._version)
+    else:
+        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
+                                            _stream()), 'rf_conv3d_k3_gn_relu')
 
 
 # bench.py hook: time selected conv launches with HIP events recorded on the launch stream
@@ -127,8 +156,7 @@ def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None)
     if conv_event_filter is not None and direct_weight is None and conv_event_filter(c0 + c1, cout, edge, n):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
-                                            _stream()), 'rf_conv3d_k3_gn_relu')
+        _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out)
         ev1.record()
         conv_events.append((ev0, ev1, 2.0 * 27 * (c0 + c1) * cout * edge ** 3 * n))
         return out
@@ -136,8 +164,7 @@ def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None)
         _lib.check(lib.rf_conv3d_k3_gn_relu_direct(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(direct_weight.detach()),
                                                    cout, _p(out), _stream()), 'rf_conv3d_k3_gn_relu_direct')
     else:
-        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
-                                            _stream()), 'rf_conv3d_k3_gn_relu')
+        _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out)
     return out
 
 
@@ -145,7 +172,14 @@ def maxpool2(x):
     _req(x, 'x')
     n, c, edge = x.shape[0], x.shape[1], x.shape[2]
     out = torch.empty((n, c, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rf_maxpool3d_2(_p(x), n, c, edge, _p(out), _stream()), 'rf_maxpool3d_2')
+    lib = _lib.load()
+    if USE_FUSED_STATS:
+        tiles = lib.rf_maxpool_stats_tiles(edge)
+        stats = torch.empty((n, c, tiles, 2), dtype=torch.float64, device=x.device)
+        _lib.check(lib.rf_maxpool3d_2_stats(_p(x), n, c, edge, _p(out), _p(stats), _stream()), 'rf_maxpool3d_2_stats')
+        out._rf_stats = (stats, tiles, out._version)
+    else:
+        _lib.check(lib.rf_maxpool3d_2(_p(x), n, c, edge, _p(out), _stream()), 'rf_maxpool3d_2')
     return out
 
 

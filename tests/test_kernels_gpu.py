@@ -319,3 +319,39 @@ def test_conv3d_valid_leaky(ops, spec):
 def test_cpu_tensors_raise(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.maxpool2(torch.zeros(1, 1, 2, 2, 2))
+
+
+@pytest.mark.parametrize('case', [(3, 8, 16, 16, 8), (70, 16, 2, 64, 8), (9, 16, 4, 32, 8), (2, 1, 16, 8, 8), (2, 16, 32, 16, 8), (5, 12, 8, 24, 6)])
+def test_fused_groupnorm_statistics_match_recomputed(ops, case):
+    """conv / max-pool epilogue statistics (rf_conv3d_k3_gn_relu_stats, rf_maxpool3d_2_stats -> rf_gn_from_stats) give the
+    same scale/shift as re-reading the tensors (rf_gn_stats), incl. the skip+upsample two-source case."""
+    n, cin, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = rnd(gen, n, cin, edge, edge, edge).relu_().to(DEV)
+    gamma, beta = (1 + 0.2 * rnd(gen, cin)).to(DEV), (0.2 * rnd(gen, cin)).to(DEV)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin)).to(DEV)
+    sc, sh = ops.gn_scale_shift(x, None, gamma, beta, groups)
+    y = ops.conv3d_gn_relu(x, None, sc, sh, ops.pack_conv3_weight(w), cout)
+    assert getattr(y, '_rf_stats', None) is not None, 'conv did not emit statistics'
+    g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+    fused = ops.gn_scale_shift(y, None, g2, b2, groups)
+    plain = ops.gn_scale_shift(y.clone(), None, g2, b2, groups)            # clone(): no attached statistics -> re-read path
+    close(fused[0], plain[0], 1e-6, 'scale from fused stats')
+    close(fused[1], plain[1], 1e-6, 'shift from fused stats')
+    if edge >= 4:
+        pooled = ops.maxpool2(y)
+        g3, b3 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+        f2 = ops.gn_scale_shift(pooled, None, g3, b3, groups)
+        p2 = ops.gn_scale_shift(pooled.clone(), None, g3, b3, groups)
+        close(f2[0], p2[0], 1e-6, 'scale from pooled stats')
+        close(f2[1], p2[1], 1e-6, 'shift from pooled stats')
+        # decoder read: skip = y (full res), upsampled = a conv output at half resolution
+        z = ops.conv3d_gn_relu(pooled, None, f2[0], f2[1], ops.pack_conv3_weight(rnd(gen, 2 * cout, cout, 3, 3, 3, scale=0.1).to(DEV)), 2 * cout)
+        g4, b4 = (1 + 0.2 * rnd(gen, 3 * cout)).to(DEV), (0.2 * rnd(gen, 3 * cout)).to(DEV)
+        f3 = ops.gn_scale_shift(y, z, g4, b4, groups)
+        p3 = ops.gn_scale_shift(y.clone(), z.clone(), g4, b4, groups)
+        close(f3[0], p3[0], 1e-6, 'scale, two sources')
+        close(f3[1], p3[1], 1e-6, 'shift, two sources')
+    y.mul_(2.0)                                                            # in-place edit invalidates the attached statistics
+    stale = ops.gn_scale_shift(y, None, g2, b2, groups)
+    close(stale[0], ops.gn_scale_shift(y.clone(), None, g2, b2, groups)[0], 1e-6, 'stale stats must not be used')
