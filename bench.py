@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='64^3 chunks per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='64^3 chunks per GPU per step')
     ap.add_argument('--config', default='C2')
     ap.add_argument('--db', type=int, default=0, help='database patches (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -173,6 +173,12 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / elapsed
+        # HBM traffic of the dominant kernel: PMC-measured (separate rocprofv3 --pmc passes, FETCH_SIZE x2 gfx950 correction
+        # + WRITE_SIZE, committed under profiles/), scaled per patch to this launch; None when no summary is committed
+        traffic = None
+        pmc_file = REPO / 'profiles' / 'r01_dominant_kernel.json'
+        if pmc_file.exists() and args.config in ('C1', 'C2', 'C3'):
+            traffic = json.loads(pmc_file.read_text())['traffic_bytes_per_patch'] * B * K * 64
         out = {
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -181,9 +187,10 @@ def main():
                                    'random-init weights' % (args.config, cfg['dataset_train']['dataset_name'], K, n_patches, 2 * K),
                        'chunks_per_gpu_per_step': B, 'db_patches': n_patches,
                        'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + RCCL all-gather of top-2K' % (world, world)},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_conv3_mfma<8,8,8,1,8,4> (retrieval backbone %d->%d @8^3, %d patches)' % (dom_cin, dom_cout, B * K * 64),
+            'roofline': {'bound': 'mfma', 'kernel': 'k_conv3_mfma<8^3 tile, 8 waves, MB4, NB4> (retrieval backbone %d->%d @8^3, %d patches)' % (dom_cin, dom_cout, B * K * 64),
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': None, 'launch_ms': kern_ms, 'flops_per_launch': kern_flops},
+                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms, 'flops_per_launch': kern_flops,
+                         'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * 512 * (dom_cin + dom_cout)},
         }
         if world == 1 and not args.no_cpu_baseline:
             state = {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}
