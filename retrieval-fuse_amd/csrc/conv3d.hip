@@ -282,13 +282,17 @@ extern "C" int rf_maxpool3d_2_stats(const float* x, int n, int c, int edge, floa
 // ------------------------------------------------------------------------------- GroupNorm from fused statistics
 // scale/shift of GroupNorm(cat(src0, up2(src1))) from per-(sample, channel, tile) partial sums emitted by the producers
 // of src0 / src1 (rf_conv3d_k3_gn_relu_stats, rf_maxpool3d_2_stats).  One wave per (sample, group); fixed summation order.
+// LPU = lanes per (sample, group) unit: 64 (one wave per unit) when a group spans many stats entries (big volumes, many
+// tiles), 1 (one thread per unit) when it spans a handful (thousands of small samples) -- same fixed summation order.
+template <int LPU>
 __global__ __launch_bounds__(256) void k_gn_from_stats(const double2* __restrict__ st0, int c0, int t0, const double2* __restrict__ st1, int c1,
                                                        int t1, int units, int groups, int cpg, double count, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, double eps, float* __restrict__ scale,
                                                        float* __restrict__ shift) {
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gtid = blockIdx.x * 256 + threadIdx.x;
+    const int unit = gtid / LPU, lane = gtid % LPU;
     if (unit >= units) return;
-    const int nn = unit / groups, g = unit % groups, lane = threadIdx.x & 63;
+    const int nn = unit / groups, g = unit % groups;
     const int C = c0 + c1, ca = g * cpg, cb = ca + cpg;
     double sm = 0.0, sq = 0.0;
     {   // src0 channels of the group: contiguous run of (channels x tiles) entries
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void k_gn_from_stats(const double2* __restrict
         if (ca < hi_c) {
             const double2* p = st0 + ((size_t)nn * c0 + ca) * t0;
             const int len = (hi_c - ca) * t0;
-            for (int i = lane; i < len; i += 64) { sm += p[i].x; sq += p[i].y; }
+            for (int i = lane; i < len; i += LPU) { sm += p[i].x; sq += p[i].y; }
         }
     }
     {   // src1 (upsampled) channels: every low-res voxel is seen 8 times
@@ -305,18 +309,20 @@ __global__ __launch_bounds__(256) void k_gn_from_stats(const double2* __restrict
             const double2* p = st1 + ((size_t)nn * c1 + (lo_c - c0)) * t1;
             const int len = (cb - lo_c) * t1;
             double a = 0.0, b = 0.0;
-            for (int i = lane; i < len; i += 64) { a += p[i].x; b += p[i].y; }
+            for (int i = lane; i < len; i += LPU) { a += p[i].x; b += p[i].y; }
             sm += 8.0 * a;
             sq += 8.0 * b;
         }
     }
-    sm = wave_sum(sm);
-    sq = wave_sum(sq);
+    if (LPU == 64) {
+        sm = wave_sum(sm);
+        sq = wave_sum(sq);
+    }
     const double mean = sm / count;
     double var = sq / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + eps);
-    for (int c = ca + lane; c < cb; c += 64) {
+    for (int c = ca + lane; c < cb; c += LPU) {
         const double sc = (double)gamma[c] * rstd;
         scale[(size_t)nn * C + c] = (float)sc;
         shift[(size_t)nn * C + c] = (float)((double)beta[c] - mean * sc);
@@ -331,9 +337,16 @@ extern "C" int rf_gn_from_stats(const double* stats0, int c0, int tiles0, const 
                "rf_gn_from_stats: null pointer / zero tiles");
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_gn_from_stats: edge %d", edge);
     const int cpg = C / groups;
-    hipLaunchKernelGGL(k_gn_from_stats, dim3((n * groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(stats0), c0, tiles0,
-                       reinterpret_cast<const double2*>(stats1), c1, tiles1, n * groups, groups, cpg, (double)cpg * edge * edge * edge, gamma, beta, (double)eps,
-                       scale, shift);
+    const int units = n * groups;
+    const long long entries = (long long)cpg * (tiles0 > tiles1 ? tiles0 : tiles1);     // stats entries one unit sums (upper bound)
+    if (entries <= 128 && units >= 1024)
+        hipLaunchKernelGGL(k_gn_from_stats<1>, dim3((units + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(stats0), c0,
+                           tiles0, reinterpret_cast<const double2*>(stats1), c1, tiles1, units, groups, cpg, (double)cpg * edge * edge * edge, gamma,
+                           beta, (double)eps, scale, shift);
+    else
+        hipLaunchKernelGGL(k_gn_from_stats<64>, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(stats0), c0,
+                           tiles0, reinterpret_cast<const double2*>(stats1), c1, tiles1, units, groups, cpg, (double)cpg * edge * edge * edge, gamma,
+                           beta, (double)eps, scale, shift);
     RF_CHECK_LAUNCH("rf_gn_from_stats");
     return RF_OK;
 }

@@ -41,7 +41,7 @@ class RefinementEngine:
         for m in self.modules().values():
             m.to(self.device).eval()
         self.database = database
-        self._side_stream = None
+        self._side_streams = {}          # one helper stream per caller stream (several batches may be in flight)
 
     def modules(self):
         return {'unet_backbone': self.unet_backbone, 'decoder': self.decoder, 'retrieval_backbone': self.retrieval_backbone,
@@ -83,9 +83,9 @@ class RefinementEngine:
         launches (1^3..32^3 volumes of a few chunks) that cannot fill 256 CUs, and so runs in the shadow of the
         retrieval path (top-k scan, patch gather, retrieval backbone) on the main stream."""
         main = torch.cuda.current_stream(self.device)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(self.device)
-        side = self._side_stream
+        side = self._side_streams.get(main.cuda_stream)
+        if side is None:
+            side = self._side_streams[main.cuda_stream] = torch.cuda.Stream(self.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             x_back = self.unet_backbone(x_in)
