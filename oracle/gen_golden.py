@@ -289,7 +289,36 @@ def main():
     gen_network_fixture(ref_model, 'net_C5', 'C5', seed=5, batch=1)
     for c in ('C1', 'C4', 'C5'):
         gen_query_fixture(ref_model, c, seed=6)
+    for c in ('C1', 'C5'):
+        gen_dbrow_fixture(ref_model, c)
     gen_retrieval_fixture()
+
+
+
+# ---------------------------------------------------------------------------------- "next" row N1: database build
+def gen_dbrow_fixture(ref_model, cfg_name='C1', seed=8):
+    """DB-side rows as create_dictionary builds them (util/retrieval.py:29-45): 32^3 target windows (16 + 8 context, padded
+    with trunc, dataset/scene.py:71,94) normalised (dataset/patched_scene_dataset.py:128) -> fenc_target -> L2 normalise;
+    plus the 'zero patch' row: an all-ONES 32^3 patch fed un-normalised (util/retrieval.py:21-26)."""
+    cfg = rf_configs.get_config(cfg_name)
+    _, trunc_t = rf_configs.truncations(cfg)
+    _, fenc_target = ref_model.get_retrieval_networks(cfg['retrieval_model'])
+    load_seeded(fenc_target, seed * 1000 + 22)
+    raw = synthetic.make_chunk(seed * 100, cfg)['target_raw']
+    g = cfg['query_geometry']
+    ps, pc = g['patch_size_target'], g['patch_context_target']
+    padded = np.pad(raw, pc, mode='constant', constant_values=trunc_t)
+    w = ps + 2 * pc
+    wins = np.stack([padded[x:x + w, y:y + w, z:z + w] for x in range(0, 64, ps) for y in range(0, 64, ps) for z in range(0, 64, ps)])[:, None]
+    wins = synthetic.normalise_target(cfg, wins)
+    lat = cfg['retrieval_model']['latent_dim']
+    with torch.no_grad():
+        emb = torch.nn.functional.normalize(fenc_target(torch.from_numpy(wins)).permute((0, 2, 3, 4, 1)).reshape((-1, lat)), dim=1).numpy()
+        ones = torch.from_numpy(np.ones([w] * 3, dtype=np.float32)).unsqueeze(0).unsqueeze(0)
+        zero_emb = torch.nn.functional.normalize(fenc_target(ones).permute((0, 2, 3, 4, 1)).reshape((-1, lat)), dim=1).numpy()
+    zero_row = np.hstack([np.array([-1], dtype=np.float32)[:, np.newaxis]] + [np.array([0], dtype=np.float32)[:, np.newaxis], np.array([ps], dtype=np.float32)[:, np.newaxis]] * 3 + [zero_emb])
+    np.savez_compressed(OUT / ('dbrow_%s.npz' % cfg_name), cfg_name=cfg_name, seed=seed, windows_sha=sha(wins), emb=emb, zero_row=zero_row)
+    print('dbrow', cfg_name, wins.shape, emb.shape, zero_row.shape)
 
 
 if __name__ == '__main__':

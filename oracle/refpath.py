@@ -252,6 +252,7 @@ _CONV_ENCODER_STRIDES = {
     (3, 3, 3, 2): (1, 1, 1, 1),                 # Patch08      model/retrieval.py:140-147
     (5, 3, 3, 3, 3, 3, 2): (1, 1, 2, 2, 2, 1, 1),   # PCPatch48    model/retrieval.py:221-234
     (5, 3, 3, 3, 3, 4): (1, 1, 2, 1, 2, 1),     # Patch32      model/retrieval.py:8-19
+    (3, 3, 3, 3, 3, 3, 3): (1, 1, 2, 1, 1, 1, 1),   # Patch24V2    model/retrieval.py:339-352
 }
 
 
@@ -333,3 +334,31 @@ def knn_cdist_f32(queries, db_emb, n_neighbors):
     dist = torch.cdist(q, d) ** 2
     vals, idx = torch.topk(dist, n_neighbors, dim=1, largest=False, sorted=True)
     return idx.numpy(), vals.numpy()
+
+
+# ------------------------------------------------------------------------------- database build ("next" row N1)
+
+def database_rows(volumes, sd_target, config, target_trunc):
+    """create_dictionary + get_zero_patch_entry restated (util/retrieval.py:21-45): [S*64 + 1, 7 + latent] float32 rows.
+    volumes [S,64,64,64] raw target chunks; windows = patch_size_target + 2*context, padded with target_trunc
+    (dataset/scene.py:71,94), normalised (dataset/patched_scene_dataset.py:128); boxes stored un-padded (:41-44)."""
+    g, d = config['query_geometry'], config['dataset_train']
+    ps, pc = g['patch_size_target'], g['patch_context_target']
+    w = ps + 2 * pc
+    rows = []
+    for s, vol in enumerate(volumes):
+        padded = np.pad(np.asarray(vol, dtype=np.float32), pc, mode='constant', constant_values=target_trunc)
+        wins, boxes = [], []
+        for x in range(0, 64, ps):
+            for y in range(0, 64, ps):
+                for z in range(0, 64, ps):
+                    wins.append(padded[x:x + w, y:y + w, z:z + w])
+                    boxes.append([s, x, x + ps, y, y + ps, z, z + ps])
+        wins = ((np.stack(wins)[:, None] - np.float32(d['target_mean'])) / np.float32(d['target_std'])).astype(np.float32)
+        with torch.no_grad():
+            emb = F.normalize(conv_patch_embed(torch.from_numpy(wins), sd_target), dim=1).numpy()
+        rows.append(np.concatenate([np.asarray(boxes, dtype=np.float32), emb], axis=1))
+    with torch.no_grad():
+        zero = F.normalize(conv_patch_embed(torch.ones(1, 1, w, w, w), sd_target), dim=1).numpy()
+    rows.append(np.concatenate([np.array([[-1, 0, ps, 0, ps, 0, ps]], dtype=np.float32), zero], axis=1))
+    return np.concatenate(rows).astype(np.float32)

@@ -52,7 +52,58 @@ def allgather_merge(q_local, local_topk, merge, k2, group=None):
     return merge(d_all[:, mine].contiguous(), i_all[:, mine].contiguous())
 
 
+@torch.no_grad()
+def build_database_rows(config, fenc_target, volumes, device, patch_mask=None, chunks_per_batch=8):
+    """``create_dictionary`` on the device (reference util/retrieval.py:29-45).
+
+    volumes [S,64,64,64] raw (un-normalised) target chunks.  For every chunk the 64 target windows
+    (patch_size_target + 2*context, padded with the truncation value, dataset/scene.py:71,94; stride = patch size) are
+    cut and normalised by rf_query_windows, embedded by ``fenc_target`` (valid-conv patch encoder, HIP kernels) and
+    L2-normalised; rows get the UN-padded boxes (util/retrieval.py:41-44).  The last row is the reference's "zero patch"
+    sentinel: scene -1, box (0,ps)^3, embedding of an all-ones un-normalised window (util/retrieval.py:21-26,45).
+    ``patch_mask`` [S,64] bool keeps a subset (the dataset's occupancy filter lives outside the hot path).
+    Returns (emb [N+1,latent] float32, meta [N+1,7] int32) on ``device``."""
+    from .configs import truncations
+    from .synthetic import patch_boxes_64
+    g, d = config['query_geometry'], config['dataset_train']
+    ps, ctx = g['patch_size_target'], g['patch_context_target']
+    if ps != 16:
+        raise NotImplementedError('the database rows assume 16^3 target patches (every shipped config)')
+    _, trunc_t = truncations(config)
+    device = torch.device(device)
+    fenc_target = fenc_target.to(device).eval()
+    vols = torch.as_tensor(volumes)
+    n_scenes = vols.shape[0]
+    embs = []
+    for s0 in range(0, n_scenes, chunks_per_batch):
+        raw = vols[s0:s0 + chunks_per_batch].to(device, torch.float32).contiguous()
+        win = ops.query_windows(raw, ps, ctx, trunc_t, d['target_mean'], d['target_std'])
+        z = fenc_target(win)
+        embs.append(ops.l2_normalize_rows_(z.reshape(z.shape[0], z.shape[1])))
+    w = ps + 2 * ctx
+    ones = torch.ones((1, 1, w, w, w), dtype=torch.float32, device=device)
+    z = fenc_target(ones)
+    embs.append(ops.l2_normalize_rows_(z.reshape(1, -1)))
+    emb = torch.cat(embs)
+    boxes = torch.from_numpy(patch_boxes_64())
+    scene_idx = torch.arange(n_scenes, dtype=torch.int32).repeat_interleave(64)[:, None]
+    meta = torch.cat([scene_idx, boxes.repeat(n_scenes, 1)], dim=1)
+    if patch_mask is not None:
+        keep = torch.as_tensor(patch_mask).reshape(-1).bool()
+        meta = meta[keep]
+        emb = torch.cat([emb[:-1][keep.to(device)], emb[-1:]])
+    sentinel = torch.tensor([[-1, 0, ps, 0, ps, 0, ps]], dtype=torch.int32)
+    meta = torch.cat([meta, sentinel]).to(device)
+    return emb.contiguous(), meta.contiguous()
+
+
 class PatchDatabase:
+    @classmethod
+    def build(cls, config, fenc_target, volumes, device, rank=0, world=1, group=None, patch_mask=None):
+        """Database straight from scene chunks: embeddings computed on the device (see build_database_rows)."""
+        emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
+        return cls(emb, meta, volumes, device, rank, world, group)
+
     def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None):
         """emb [N+1,64] float32 (unit rows), meta [N+1,7] int32, volumes [S,64,64,64] float32 -- host or device tensors /
         numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes."""

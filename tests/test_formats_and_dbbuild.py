@@ -1,0 +1,93 @@
+"""'Next' rows N1 (database build) and N2 (on-disk formats) of SURVEY.md section 8f."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import refpath
+from rfuse import configs as rf_configs
+from rfuse import formats, synthetic
+
+
+def _target_sd(cfg, seed):
+    import model
+    _, fenc_target = model.get_retrieval_networks(cfg['retrieval_model'])
+    shapes = {k: tuple(v.shape) for k, v in fenc_target.state_dict().items()}
+    return fenc_target, helpers.seeded_sd(shapes, seed * 1000 + 22)
+
+
+@pytest.mark.parametrize('cfg_name', ['C1', 'C5'])
+def test_oracle_database_rows_match_reference(cfg_name):
+    """oracle restatement of create_dictionary / get_zero_patch_entry vs embeddings captured from the reference's fenc_target"""
+    fix = helpers.load_fixture('dbrow_' + cfg_name)
+    cfg = rf_configs.get_config(cfg_name)
+    _, trunc_t = rf_configs.truncations(cfg)
+    _, sd = _target_sd(cfg, int(fix['seed']))
+    raw = synthetic.make_chunk(int(fix['seed']) * 100, cfg)['target_raw']
+    rows = refpath.database_rows(raw[None], sd, cfg, trunc_t)
+    assert rows.shape == (65, 71)
+    assert np.abs(rows[:64, 7:] - fix['emb']).max() <= 1e-6
+    assert np.abs(rows[64] - fix['zero_row'][0]).max() <= 1e-6
+    np.testing.assert_array_equal(rows[:64, 1:7].astype(np.int32), synthetic.patch_boxes_64())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg_name', ['C1', 'C5'])
+def test_device_database_build_matches_reference(cfg_name):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    from rfuse.database import build_database_rows
+    fix = helpers.load_fixture('dbrow_' + cfg_name)
+    cfg = rf_configs.get_config(cfg_name)
+    fenc_target, sd = _target_sd(cfg, int(fix['seed']))
+    fenc_target.load_state_dict(sd)
+    raws = np.stack([synthetic.make_chunk(int(fix['seed']) * 100 + i, cfg)['target_raw'] for i in range(3)])
+    emb, meta = build_database_rows(cfg, fenc_target, raws, 'cuda:0', chunks_per_batch=2)
+    emb, meta = emb.cpu().numpy(), meta.cpu().numpy()
+    assert emb.shape == (3 * 64 + 1, 64) and meta.shape == (3 * 64 + 1, 7)
+    assert np.abs(emb[:64] - fix['emb']).max() <= 2e-6
+    assert np.abs(emb[-1] - fix['zero_row'][0, 7:]).max() <= 2e-6
+    np.testing.assert_array_equal(meta[-1], fix['zero_row'][0, :7].astype(np.int32))
+    np.testing.assert_array_equal(meta[64:128, 0], np.full(64, 1))
+    np.testing.assert_array_equal(meta[:64, 1:], synthetic.patch_boxes_64())
+    # subset build (occupancy filter stand-in)
+    mask = np.zeros((3, 64), dtype=bool)
+    mask[1, ::2] = True
+    emb2, meta2 = build_database_rows(cfg, fenc_target, raws, 'cuda:0', patch_mask=mask)
+    assert emb2.shape[0] == 33 and (meta2[:-1, 0].cpu().numpy() == 1).all()
+    np.testing.assert_array_equal(emb2[:-1].cpu().numpy(), emb[64:128][::2])
+
+
+def test_patch_names_and_database_files_roundtrip(tmp_path):
+    fix = helpers.load_fixture('retrieval_map_compose')
+    names = formats.chunk_patch_names('sceneA')
+    assert len(names) == 64 and names[0] == 'sceneA--0000_0032_0000_0032_0000_0032' and names[-1] == 'sceneA--0048_0080_0048_0080_0048_0080'
+    # the reference's own extent enumeration (captured from SceneHandler.get_extents_for_size) gives the same names
+    ref_names = [formats.patch_name('sceneA', e) for e in fix['extents_64_16_8_16']]
+    assert names == ref_names
+    assert formats.parse_patch_name(names[5]) == ('sceneA', [0, 32, 16, 48, 16, 48])
+    db = synthetic.make_database(3, rf_configs.get_config('C1'), 200, with_volumes=False)
+    formats.save_database(tmp_path, db['meta'], db['emb'], ['s%d' % i for i in range(db['n_scenes'])])
+    arr = np.load(tmp_path / 'database.npy')
+    assert arr.shape == (201, 71) and arr.dtype == np.float32 and arr[-1, 0] == -1
+    meta, emb, index = formats.load_database(tmp_path)
+    np.testing.assert_array_equal(meta, db['meta'])
+    np.testing.assert_array_equal(emb, db['emb'])
+    assert index[2] == 's2'
+
+
+def test_mapping_and_compose_files_match_reference_layout(tmp_path):
+    fix = helpers.load_fixture('retrieval_map_compose')
+    ref_map = fix['map_train']                                   # [64,K,8] as flann_knn_worker produced it
+    names = formats.chunk_patch_names('scene003')
+    mapping = formats.mapping_to_dict(names, ref_map[..., :7].astype(np.int32), ref_map[..., 7])
+    assert mapping[names[7]].shape == (ref_map.shape[1], 8) and mapping[names[7]].dtype == np.float32
+    np.testing.assert_array_equal(mapping[names[7]], ref_map[7])
+    formats.save_mapping(tmp_path / 'map_train.npy', mapping)
+    back = formats.load_mapping(tmp_path / 'map_train.npy')
+    meta, dist = formats.dict_to_mapping(back, names)
+    np.testing.assert_array_equal(meta, ref_map[..., :7].astype(np.int32))
+    np.testing.assert_array_equal(dist, ref_map[..., 7])
+    vols = np.random.default_rng(0).random((4, 64, 64, 64)).astype(np.float32)
+    formats.save_compose(tmp_path, 'scene003', vols)
+    np.testing.assert_array_equal(formats.load_compose(tmp_path, 'scene003'), vols)
