@@ -91,3 +91,23 @@ def test_mapping_and_compose_files_match_reference_layout(tmp_path):
     vols = np.random.default_rng(0).random((4, 64, 64, 64)).astype(np.float32)
     formats.save_compose(tmp_path, 'scene003', vols)
     np.testing.assert_array_equal(formats.load_compose(tmp_path, 'scene003'), vols)
+
+
+def test_combine_chunks_semantics():
+    """N3: chunk names carry the position (dataset/patched_scene_dataset.py:153-174); later chunks overwrite, gaps keep trunc."""
+    from rfuse import scene
+    rng = np.random.default_rng(1)
+    names = ['houseA__room1__0_0_0', 'houseA__room1__64_0_0', 'houseA__room1__64_64_128', 'houseB__room2__0_0_0']
+    vols = [rng.random((64, 64, 64)).astype(np.float32) for _ in names]
+    out = scene.combine_chunks(names, vols, '3DFront', trunc_val=0.1625)
+    assert set(out) == {'houseA__room1', 'houseB__room2'}
+    a = out['houseA__room1']
+    assert a.shape == (128, 128, 192)
+    np.testing.assert_array_equal(a[:64, :64, :64], vols[0])
+    np.testing.assert_array_equal(a[64:128, 64:128, 128:192], vols[2])
+    assert (a[:64, 64:, :] == 0.1625).all()
+    # low-res inputs: positions divided by the scale factor (combine_inputs, :176-177)
+    lo = scene.combine_chunks(names[:2], [v[::8, ::8, ::8] for v in vols[:2]], 'Matterport3D16', scale_factor=8, chunk_size=8, trunc_val=1.0)
+    assert lo['houseA__room1'].shape == (16, 8, 8)
+    one = scene.combine_chunks(['02691156__abc'], [vols[0]], 'ShapeNetV2')
+    np.testing.assert_array_equal(one['02691156__abc'], vols[0])
