@@ -188,6 +188,11 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
                       float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
                       float* out, void* stream);
 
+/* out[m][width] = src[idx[m]][width] (width % 4 == 0): row gather used to fetch cached, query-independent retrieval
+ * backbone features of database patches (an optional serving mode; the reference recomputes them,
+ * trainer/train_refinement.py:112). */
+int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t m, int width, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

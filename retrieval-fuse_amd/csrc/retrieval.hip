@@ -384,3 +384,21 @@ extern "C" int rf_gather_patches(const float* db_volumes, int64_t n_scenes, cons
     RF_CHECK_LAUNCH("rf_gather_patches");
     return RF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------- row gather
+// out[m][:] = src[idx[m]][:] for rows of `width` floats (width % 4 == 0): fetches cached per-database-patch retrieval
+// features (query independent, see rfuse/database.py:build_feature_cache).  One workgroup per output row.
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, long long n_src, const long long* __restrict__ idx,
+                                                     int width4, float* __restrict__ out) {
+    const long long r = idx[blockIdx.x];
+    const float4* s4 = reinterpret_cast<const float4*>(src) + (size_t)(r < 0 || r >= n_src ? 0 : r) * width4;
+    float4* o4 = reinterpret_cast<float4*>(out) + (size_t)blockIdx.x * width4;
+    for (int i = threadIdx.x; i < width4; i += 256) o4[i] = s4[i];
+}
+
+extern "C" int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t m, int width, float* out, void* stream) {
+    RF_REQUIRE(src && idx && out && n_src > 0 && m > 0 && width > 0 && (width & 3) == 0, RF_E_INVALID, "rf_gather_rows: bad arguments");
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, src, (long long)n_src, (const long long*)idx, width / 4, out);
+    RF_CHECK_LAUNCH("rf_gather_rows");
+    return RF_OK;
+}

@@ -118,6 +118,34 @@ class PatchDatabase:
         self.meta = torch.as_tensor(meta).to(self.device, torch.int32).contiguous()
         self.volumes = torch.as_tensor(volumes).to(self.device, torch.float32).contiguous()
         self.n_scenes = self.volumes.shape[0]
+        self.feature_cache = None        # see build_feature_cache
+
+    @torch.no_grad()
+    def build_feature_cache(self, retrieval_backbone, config, rows_per_batch=4096):
+        """OPTIONAL serving mode.  The retrieval backbone's output for a database patch does not depend on the query
+        (GroupNorm is per sample, patches are processed independently, trainer/train_refinement.py:112), so it can be
+        computed once per database row and kept in HBM: [N+1, nf, 8,8,8] fp32 = 32 KB/row (50 k rows 1.6 GB, 1 M rows
+        32 GB of 288 GB).  ``RefinementEngine.refine(use_feature_cache=True)`` then replaces the whole retrieval backbone
+        (76 of 87 GFLOP per chunk) by a row gather.  This skips work: bench.py reports it separately, never as `value`."""
+        from .configs import truncations
+        d = config['dataset_train']
+        _, trunc_t = truncations(config)
+        n = self.n_rows
+        feats = None
+        for lo in range(0, n, rows_per_batch):
+            hi = min(lo + rows_per_batch, n)
+            m = self.meta[lo:hi]
+            pad = (-m.shape[0]) % 64
+            if pad:
+                m = torch.cat([m, self.meta[-1:].expand(pad, 7)])
+            patches = ops.gather_patches(self.volumes, m.reshape(-1, 1, 7).contiguous(), m.shape[0] // 64, 1, trunc_t, 1.0,
+                                         d['target_mean'], d['target_std'], layout=1)
+            f = retrieval_backbone(patches)[:hi - lo]
+            if feats is None:
+                feats = torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=self.device)
+            feats[lo:hi] = f
+        self.feature_cache = feats
+        return feats
 
     def local_topk(self, q, k2):
         """Exact squared-L2 top-k2 of q against this rank's shard, global row ids."""

@@ -338,6 +338,15 @@ def demote_same_scene(dist, idx, db_meta, query_scene, K):
     return out_meta, out_dist, out_idx
 
 
+def gather_rows(src, idx):
+    """out[m] = src[idx[m]] for a row-major float32 ``src`` [R, ...] and int64 ``idx`` [M]."""
+    _req(src, 'src'), _req(idx, 'idx', torch.int64)
+    width = src[0].numel()
+    out = torch.empty((idx.numel(),) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().rf_gather_rows(_p(src), src.shape[0], _p(idx), idx.numel(), width, _p(out), _stream()), 'rf_gather_rows')
+    return out
+
+
 def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, std, layout):
     _req(db_volumes, 'db_volumes'), _req(meta, 'meta', torch.int32)
     dev = db_volumes.device

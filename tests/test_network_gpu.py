@@ -149,3 +149,26 @@ def test_state_dict_roundtrip_and_repack(gpu):
         dec.load_state_dict(sd)
         b = dec(x)
     assert not torch.equal(a, b)
+
+
+def test_feature_cache_mode_matches_full_path(gpu):
+    """optional serving mode: cached retrieval-backbone features per database row == recomputing them per query"""
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C3')
+    db = synthetic.make_database(33, cfg, 64 * 6 + 10)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {}
+    for name, m in eng.modules().items():
+        sds[name] = helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 400 + len(name))
+    eng.load_state_dicts(sds)
+    # make the sentinel row a likely hit for one query chunk: query == sentinel embedding direction is random, so force it
+    raws = np.stack([synthetic.make_chunk(700 + b, cfg)['input_raw'] for b in range(2)])
+    x = torch.from_numpy(raws).to(gpu)
+    full = eng.refine(x)
+    with pytest.raises(RuntimeError, match='build_feature_cache'):
+        eng.refine(x, use_feature_cache=True)
+    cache = eng.database.build_feature_cache(eng.retrieval_backbone, cfg, rows_per_batch=128)
+    assert tuple(cache.shape) == (64 * 6 + 11, cfg['nf'], 8, 8, 8)
+    cached = eng.refine(x, use_feature_cache=True)
+    assert maxerr(cached.cpu(), full.cpu()) <= 1e-5
