@@ -39,11 +39,12 @@ struct ConvArgs {
     int stats_tiles;
 };
 
-template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB>
+template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int CC_>
 struct ConvTile {
     static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
     static constexpr int CH = HZ * HY * HX;            // halo floats per channel
-    static constexpr int CC = 4;                        // input channels per K chunk (= MFMA k)
+    static constexpr int CC = CC_;                      // input channels per K chunk: 4 (one MFMA k-step per tap) or 8 (two)
+    static_assert(CC_ == 4 || CC_ == 8, "K chunk is one or two MFMA k-steps deep");
     static constexpr int XS = SPW * CC * CH;            // floats of the staged input box
     static constexpr int XS_PAD = (XS + 3) / 4 * 4;
     static constexpr int NCO = NB * 16;                 // couts per workgroup
@@ -57,9 +58,9 @@ struct ConvTile {
 };
 
 // PFX: prefetch the next chunk's input rows through registers under the MFMA loop (costs RPT*(TX+4) VGPRs)
-template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, bool PFX>
+template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, bool PFX, int CCT>
 __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
-    using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB>;
+    using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB, CCT>;
     constexpr int HY = T::HY, HX = T::HX, CH = T::CH, CC = T::CC, NCO = T::NCO, NT = T::NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
                 const int col = (slot + NCO - ROT * (r & 1)) % NCO;      // logical cout column stored at this slot
                 int co = cob + col;
                 if (co >= a.cout16) co = col % a.cout16;   // cout block wider than the packed image: any valid column (masked at store)
-                const float* src = a.wp + ((size_t)(r >> 2) * a.cin4 + cbase + (r & 3)) * a.cout16 + co;
+                int ci = cbase + r % CC;                  // slab row r = tap*CC + channel
+                if (ci >= a.cin4) ci = a.cin4 - 1;         // chunk reaches past the packed image (cin4 % CC != 0): the matching input rows are zero
+                const float* src = a.wp + ((size_t)(r / CC) * a.cin4 + ci) * a.cout16 + co;
                 __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
             }
         }
@@ -229,25 +232,31 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
         }
         if (a.ablate != 2) {
             const float* ws = wsb + buf * T::WSLAB_PAD;
+            // operand reads of tap t+1 are issued before the MFMAs of tap t (explicit double buffering: left to itself
+            // hipcc emits read -> s_waitcnt lgkmcnt(0) -> MFMAs per tap pair and exposes the whole LDS latency)
+            constexpr int KS = CC / 4;                         // MFMA k-steps per tap
+            float av[2][MB], bv[2][NB];
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz)
+            for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff[mb]];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+            for (int nb = 0; nb < NB; ++nb) bv[0][nb] = ws[boff[nb]];
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int tap = (dz * 3 + dy) * 3 + dx;
-                        const int toff = (dz * HY + dy) * HX + dx;
-                        float av[MB], bv[NB];
+            for (int st = 0; st < 27 * KS; ++st) {             // step = (tap, k-step)
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < 27 * KS) {
+                    const int t1 = (st + 1) / KS, k1 = (st + 1) % KS;
+                    const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 + k1 * 4 * CH;
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) av[mb] = xs[aoff[mb] + toff];
+                    for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xs[aoff[mb] + toff];
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) bv[nb] = ws[boff[nb] + tap * (CC * NCO)];
+                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + (t1 * CC + k1 * 4) * NCO];
+                }
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
-                    }
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+            }
         }
         __syncthreads();                                   // everyone is done reading xs / ws[buf]; loads + DMA have landed
         if (more) {
@@ -356,10 +365,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     }
 }
 
-template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, bool PFX = true>
+template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, int CCT = 4>
 static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
-    using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB>;
-    auto kern = k_conv3_mfma<TZ, TY, TX, SPW, NW, MB, NB, WPS, PFX>;
+    using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB, CCT>;
+    auto kern = k_conv3_mfma<TZ, TY, TX, SPW, NW, MB, NB, WPS, true, CCT>;
     static bool attr_set = false;
     if (!attr_set) {
         if (T::LDS_BYTES > 65536) {
@@ -381,7 +390,11 @@ static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
 template <int TZ, int TY, int TX, int SPW, bool BIG>
 static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
     if constexpr (BIG) {
-        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4>(a, stream);
+        // 16-cout layers: an 8-channel chunk (216 instead of 108 MFMAs per wave between barriers) measured 3-7 % SLOWER than
+        // the 4-channel chunk on every such layer (tools/conv_bench.py), so it stays off; RFUSE_CONV_CC8=1 re-enables it
+        static const bool cc8 = getenv("RFUSE_CONV_CC8") && getenv("RFUSE_CONV_CC8")[0] == '1';
+        if (a.cout16 <= 16) return (cc8 && (a.c0 + a.c1) % 8 == 0) ? launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4, 8>(a, stream)
+                                                           : launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4>(a, stream);
         if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 2, 4>(a, stream);
         return launch_conv3<TZ, TY, TX, SPW, 8, 4, 4, 4>(a, stream);
     } else {
@@ -497,7 +510,7 @@ static bool conv_use_big(int n, int edge, int cout16) {
 extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) {
     if (edge < 2) return 0;                                    // direct path: no fused statistics
     if (conv_use_cin1(c0, c1, edge, cout)) return (edge / 4) * (edge / 16) * (edge / 16);
-    if (edge <= 4) return 1;                                   // whole-volume tiles
+    if (edge <= 4) return 1;                                   // whole-volume tiles (always the 128-voxel form)
     return conv_use_big(n, edge, rf_round_up(cout, 16)) ? (edge / 8) * (edge / 8) * (edge / 8) : (edge / 4) * (edge / 4) * (edge / 8);
 }
 
@@ -521,8 +534,10 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
     const bool big = conv_use_big(n, edge, a.cout16);
     if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, true>(a, s) : dispatch_nb<4, 4, 8, 1, false>(a, s);
-    if (edge == 4) return big ? dispatch_nb<4, 4, 4, 8, true>(a, s) : dispatch_nb<4, 4, 4, 2, false>(a, s);
-    return big ? dispatch_nb<2, 2, 2, 64, true>(a, s) : dispatch_nb<2, 2, 2, 16, false>(a, s);
+    // 4^3 / 2^3 volumes: always the 128-voxel tiles (2 / 16 whole samples per workgroup); the 512-voxel multi-sample forms
+    // need 5-16 halo rows per thread in registers, spill, and measured slower
+    if (edge == 4) return dispatch_nb<4, 4, 4, 2, false>(a, s);
+    return dispatch_nb<2, 2, 2, 16, false>(a, s);
 }
 
 extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
