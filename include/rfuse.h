@@ -100,6 +100,13 @@ int rf_conv1x1_tanh(const float* x, int n, int c, size_t voxels, const float* w,
 int rf_conv3d_valid_leaky(const float* x, int n, int cin, int s, const float* w, const float* bias, int cout, int k,
                           int stride, float slope, float* out, void* stream);
 
+/* The same layer on the matrix cores (fp32 MFMA implicit GEMM, K index = tap*cin + ci, operands gathered from cache, no
+ * LDS): w_packed = rf_convv_pack_weight image [k^3*cin -> 4][cout -> 16].  Used by the conv patch encoders. */
+int rf_conv3d_valid_leaky_mfma(const float* x, int n, int cin, int s, const float* w_packed, const float* bias, int cout, int k,
+                               int stride, float slope, float* out, void* stream);
+int rf_convv_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream);
+size_t rf_convv_packed_floats(int cout, int cin, int k);
+
 /* --------------------------------------------------------------------------------------------- fold / unfold */
 
 /* Unfold3D.forward (model/attention.py:186-188): x [b][c][s^3] -> rows [(b*r^3)][c][e^3], r = s/e, row = ((b*r+px)*r+py)*r+pz */

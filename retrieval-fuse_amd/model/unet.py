@@ -47,7 +47,7 @@ class Conv3dParams(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
-        self._packed = ops.PackedWeight('conv3')
+        self._packed = ops.PackedWeight('conv3' if (kernel_size == 3 and padding == 1) else 'convv')
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))

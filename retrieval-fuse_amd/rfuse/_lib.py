@@ -37,6 +37,9 @@ SIGNATURES = {
     'rf_maxpool3d_2': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_conv1x1_tanh': (c_i, [c_fp, c_i, c_i, c_sz, c_fp, c_fp, c_f, c_f, c_fp, c_p]),
     'rf_conv3d_valid_leaky': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_conv3d_valid_leaky_mfma': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_convv_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_convv_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_unfold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_fold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_linear_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),

@@ -63,7 +63,7 @@ class PackedWeight:
     def get(self, w):
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
         if key != self._key:
-            self._packed = pack_conv3_weight(w) if self.kind == 'conv3' else pack_linear_weight(w)
+            self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight}[self.kind](w)
             self._key = key
         return self._packed
 
@@ -192,6 +192,26 @@ def conv1x1_tanh(x, w, b, post_add=0.0, post_mul=1.0):
     out = torch.empty((n, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().rf_conv1x1_tanh(_p(x), n, c, vox, _p(w.detach()), _p(b.detach()), post_add, post_mul, _p(out), _stream()),
                'rf_conv1x1_tanh')
+    return out
+
+
+def pack_convv_weight(w):
+    _req(w.detach(), 'conv weight')
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    lib = _lib.load()
+    out = torch.empty(lib.rf_convv_packed_floats(cout, cin, k), dtype=torch.float32, device=w.device)
+    _lib.check(lib.rf_convv_pack_weight(_p(w.detach()), cout, cin, k, _p(out), _stream()), 'rf_convv_pack_weight')
+    return out
+
+
+def conv3d_valid_leaky_mfma(x, w_packed, bias, cout, k, stride, slope):
+    """valid strided conv + bias + LeakyReLU on the matrix cores (w_packed from pack_convv_weight)."""
+    _req(x, 'x')
+    n, cin, s = x.shape[0], x.shape[1], x.shape[2]
+    so = (s - k) // stride + 1
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_mfma(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
+                                                      stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_mfma')
     return out
 
 

@@ -316,6 +316,18 @@ def test_conv3d_valid_leaky(ops, spec):
     close(ops.conv3d_valid_leaky(x.to(DEV), w.to(DEV), b.to(DEV), stride, 0.2), ref, 1e-5, 'valid conv')
 
 
+@pytest.mark.parametrize('spec', [(3, 1, 8, 16, 3, 1), (2, 4, 12, 8, 3, 2), (2, 3, 6, 5, 2, 1), (1, 1, 20, 6, 5, 1), (2, 8, 4, 8, 4, 1), (2, 12, 13, 24, 3, 1),
+                                  (3, 24, 11, 48, 3, 2), (5, 96, 2, 96, 2, 1), (1, 1, 48, 12, 5, 1)])
+def test_conv3d_valid_leaky_mfma(ops, spec):
+    """matrix-core form of the patch encoders' layers vs torch (odd edges, strides, cin = 1, cout not a multiple of 16)"""
+    n, cin, s, cout, k, stride = spec
+    gen = torch.Generator().manual_seed(sum(spec) + 1)
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    ref = F.leaky_relu(F.conv3d(x, w, b, stride=stride), 0.2)
+    got = ops.conv3d_valid_leaky_mfma(x.to(DEV), ops.pack_convv_weight(w.to(DEV)), b.to(DEV), cout, k, stride, 0.2)
+    close(got, ref, 1e-5, 'valid conv (mfma)')
+
+
 def test_cpu_tensors_raise(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.maxpool2(torch.zeros(1, 1, 2, 2, 2))
