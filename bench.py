@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--config', default='C2')
     ap.add_argument('--db', type=int, default=0, help='database patches (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--feature-cache', action='store_true', help='also time the optional cached-retrieval-features serving mode (reported separately)')
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
     return ap.parse_args()
 
@@ -192,7 +193,7 @@ def main():
                          'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms, 'flops_per_launch': kern_flops,
                          'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * 512 * (dom_cin + dom_cout)},
         }
-        if world == 1 and n_patches <= 200_000:
+        if args.feature_cache and world == 1 and n_patches <= 200_000:
             # Reported separately, NEVER as `value`: optional serving mode that fetches per-database-row retrieval-backbone
             # features (query independent) from a 32 KB/row HBM cache instead of recomputing them (skips 87 % of the FLOPs).
             database.build_feature_cache(eng.retrieval_backbone, cfg)

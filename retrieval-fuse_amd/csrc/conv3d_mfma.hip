@@ -39,6 +39,14 @@ struct ConvArgs {
     int stats_tiles;
 };
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id, each XCD with its own L2.  Tiles that split a sample
+// (8-voxel = 32-byte row pieces of 64..512-byte rows) would then share every cache line across XCDs: partial-line writes
+// that no L2 can merge and 128-byte fills for 32 bytes of use.  Remap so that XCD k walks a contiguous range of tiles.
+__device__ __forceinline__ unsigned rf_xcd_contiguous(unsigned b, unsigned g) {
+    const unsigned per = g >> 3, rem = g & 7u, k = b & 7u;
+    return k * per + (k < rem ? k : rem) + (b >> 3);
+}
+
 template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int CC_>
 struct ConvTile {
     static constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
@@ -73,9 +81,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
 
     // ---- which voxels does this workgroup own?
     int n0, z0 = 0, y0 = 0, x0 = 0;
+    const unsigned lblock = (SPW == 1 && gridDim.y == 1) ? rf_xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     if (SPW == 1) {
         const int tx = edge / TX, ty = edge / TY, tz = edge / TZ;
-        int t = blockIdx.x;
+        int t = (int)lblock;
         x0 = (t % tx) * TX; t /= tx;
         y0 = (t % ty) * TY; t /= ty;
         z0 = (t % tz) * TZ; t /= tz;
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
             }
         }
         __syncthreads();
-        const int tile = SPW == 1 ? (int)(blockIdx.x % ((edge / TZ) * (edge / TY) * (edge / TX))) : 0;
+        const int tile = SPW == 1 ? (int)(lblock % ((edge / TZ) * (edge / TY) * (edge / TX))) : 0;
         for (int idx = tid; idx < SPW * NCO; idx += NT) {
             const int sidx = idx / NCO, col = idx % NCO;
             const int co = cob + col, nn = n0 + sidx;
@@ -387,9 +396,14 @@ static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
 }
 
 // big: 8 waves x MB 4 = 512 voxels (two workgroups = 4 waves/SIMD per CU); small: 4 waves x MB 2 = 128 voxels
-template <int TZ, int TY, int TX, int SPW, bool BIG>
+enum { TILE_SMALL = 0, TILE_BIG = 1, TILE_MID = 2 };
+template <int TZ, int TY, int TX, int SPW, int MODE>
 static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
-    if constexpr (BIG) {
+    if constexpr (MODE == TILE_MID) {                     // 8 waves x MB 2: 256 voxels = 4 / 32 whole 4^3 / 2^3 samples
+        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 2, 1, 4>(a, stream);
+        if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 2, 2, 4>(a, stream);
+        return launch_conv3<TZ, TY, TX, SPW, 8, 2, 4, 4>(a, stream);
+    } else if constexpr (MODE == TILE_BIG) {
         // 16-cout layers: an 8-channel chunk (216 instead of 108 MFMAs per wave between barriers) measured 3-7 % SLOWER than
         // the 4-channel chunk on every such layer (tools/conv_bench.py), so it stays off; RFUSE_CONV_CC8=1 re-enables it
         static const bool cc8 = getenv("RFUSE_CONV_CC8") && getenv("RFUSE_CONV_CC8")[0] == '1';
@@ -418,7 +432,8 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float wl[27 * 8];          // [tap][8] (COUT <= 8, zero padded)
     const int tid = threadIdx.x, edge = a.edge;
     const int tx = edge / TX, ty = edge / TY, tz = edge / TZ;
-    int t = blockIdx.x;
+    const unsigned lblock = rf_xcd_contiguous(blockIdx.x, gridDim.x);
+    int t = (int)lblock;
     const int x0 = (t % tx) * TX; t /= tx;
     const int y0 = (t % ty) * TY; t /= ty;
     const int z0 = (t % tz) * TZ; t /= tz;
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
         if (tid < COUT) {
             double sm = 0.0, sq = 0.0;
             for (int w = 0; w < 4; ++w) { sm += red[(w * 8 + tid) * 2]; sq += red[(w * 8 + tid) * 2 + 1]; }
-            const int tile = (int)(blockIdx.x % (tx * ty * tz));
+            const int tile = (int)(lblock % (tx * ty * tz));
             a.stats[((size_t)nn * COUT + tid) * a.stats_tiles + tile] = make_double2(sm, sq);
         }
     }
@@ -533,11 +548,13 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
     const bool big = conv_use_big(n, edge, a.cout16);
-    if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, true>(a, s) : dispatch_nb<4, 4, 8, 1, false>(a, s);
+    if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, TILE_BIG>(a, s) : dispatch_nb<4, 4, 8, 1, TILE_SMALL>(a, s);
     // 4^3 / 2^3 volumes: always the 128-voxel tiles (2 / 16 whole samples per workgroup); the 512-voxel multi-sample forms
     // need 5-16 halo rows per thread in registers, spill, and measured slower
-    if (edge == 4) return dispatch_nb<4, 4, 4, 2, false>(a, s);
-    return dispatch_nb<2, 2, 2, 16, false>(a, s);
+    static const int mid = getenv("RFUSE_CONV_MID") ? atoi(getenv("RFUSE_CONV_MID")) : 1;          // dev knob: 0 = never, 2 = also 2^3
+    const bool use_mid = mid >= 1;
+    if (edge == 4) return use_mid && n >= 4096 ? dispatch_nb<4, 4, 4, 4, TILE_MID>(a, s) : dispatch_nb<4, 4, 4, 2, TILE_SMALL>(a, s);
+    return mid == 2 && n >= 8192 ? dispatch_nb<2, 2, 2, 32, TILE_MID>(a, s) : dispatch_nb<2, 2, 2, 16, TILE_SMALL>(a, s);
 }
 
 extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
