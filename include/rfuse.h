@@ -153,6 +153,29 @@ int rf_attn_fuse(const float* x, const float* p, const float* xf, const float* p
 int rf_attn_gather_retrieved(const float* src, int src_layout, int b, int k, int c, int s, int e, int t,
                              float* p_rows, void* stream);
 
+/* Volume-domain route of PatchedAttentionBlock.forward (model/attention.py:141-157) for attention patch extent e = 2,
+ * hidden width 128, feature width 32 (every shipped config): the unfolded rows are never materialised.
+ *
+ * rf_attn_mlp_pack: the 4 Linear layers of one AttentionFeatureEncoder (model/attention.py:36-42; w1 [128][n_in],
+ *   w2, w3 [128][128], w4 [32][128], nn.Linear layout) -> one MFMA operand image of rf_attn_mlp_packed_floats(n_in) floats.
+ * rf_attn_mlp_rows:   out[rows][32] = encoder(x[rows][n_in])                       (LeakyReLU 0.01 between layers)
+ * rf_attn_mlp_volume: the same encoder applied to every 2^3 attention patch of b*kv feature volumes read in place:
+ *   src = [(b*kv*q^3)][c][t^3] patch-major (q = s/t; t == s: plain NCDHW volumes [b*kv][c][s^3]), row feature order
+ *   (c, e0, e1, e2) as Unfold3D gives; out[((bb*r^3 + prow)*kv + k)][32], r = s/2, prow = (p0*r + p1)*r + p2.
+ * rf_attn_weights: per row: L2-normalise xf[rows][f], pf[rows][k][f]; scores; switch = relu(max_k scores); weights by
+ *   mode (as rf_attn_fuse) -> weights[rows][k], switches[rows], optional scores_out[rows][k].
+ * rf_attn_blend: out[b][c][s^3] = x*(1-switch[row]) + (sum_k weights[row][k]*retrieved_k)*switch[row], row = the
+ *   attention patch of the voxel; `retrieved` in the same patch-major / volume layout as rf_attn_mlp_volume's src.   */
+size_t rf_attn_mlp_packed_floats(int n_in);
+int rf_attn_mlp_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                     const float* w4, const float* b4, int n_in, float* packed, void* stream);
+int rf_attn_mlp_rows(const float* x, int rows, int n_in, const float* packed, float* out, void* stream);
+int rf_attn_mlp_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, float* out, void* stream);
+int rf_attn_weights(const float* xf, const float* pf, const float* noise, int rows, int k, int f, int mode, float sharpness,
+                    float* weights, float* switches, float* scores_out, void* stream);
+int rf_attn_blend(const float* x, const float* retrieved, int b, int k, int c, int s, int t, const float* weights,
+                  const float* switches, float* out, void* stream);
+
 /* ----------------------------------------------------------------------------------------- retrieval (online) */
 
 /* Query windows of the retrieval dataset: pad raw input chunk [b][s^3] by `ctx` with pad_value, cut (s/ps)^3 windows

@@ -8,6 +8,10 @@
 // the kernel is HBM-bound (reads (1+K)*(d+f) floats, writes d floats per row).
 #include "common.h"
 
+// torch evaluates these expressions op by op (every product and sum rounded).  This file is built with
+// -ffp-contract=off (csrc/build.py): hipcc's default -ffp-contract=fast fuses a*b+c in the backend, where neither
+// __fmul_rn/__fadd_rn nor `#pragma clang fp contract(off)` reach.  Explicit fmaf() stays an FMA.
+
 // rows[((b*r+p0)*r+p1)*r+p2][c][e0][e1][e2] = x[b][c][p0*e+e0][p1*e+e1][p2*e+e2]
 __global__ __launch_bounds__(256) void k_unfold3d(const float* __restrict__ x, int b, int c, int s, int e, float* __restrict__ rows) {
     const int r = s / e;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void k_attn_fuse(const float* __restrict__ x, 
             for (int k = 0; k < RF_MAX_K; ++k)
                 if (k < K) ws = fmaf(w[k], p[((size_t)row * K + k) * d + j], ws);
             const float xr = x[(size_t)row * d + j];
-            out[(size_t)row * d + j] = xr * (1.f - sw) + ws * sw;
+            out[(size_t)row * d + j] = __fadd_rn(__fmul_rn(xr, 1.f - sw), __fmul_rn(ws, sw));     // torch: x*(1-s) + p*s, no contraction
         }
     }
 }

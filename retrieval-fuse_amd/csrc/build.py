@@ -8,8 +8,11 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 OUT = HERE.parent / 'rfuse' / 'librfuse_hip.so'
-SOURCES = ['capi.hip', 'conv3d.hip', 'conv3d_mfma.hip', 'conv_valid_mfma.hip', 'linear.hip', 'attention.hip', 'retrieval.hip']
+SOURCES = ['capi.hip', 'conv3d.hip', 'conv3d_mfma.hip', 'conv_valid_mfma.hip', 'linear.hip', 'attention.hip', 'attention_fused.hip', 'retrieval.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# the attention / gather-normalise kernels restate torch expressions op by op: no a*b+c fusion across operations (explicit fmaf() stays an FMA).
+# hipcc's default -ffp-contract=fast fuses in the backend, where neither __fmul_rn nor `#pragma clang fp contract(off)` reach.
+EXTRA_FLAGS = {'attention.hip': ['-ffp-contract=off'], 'attention_fused.hip': ['-ffp-contract=off'], 'retrieval.hip': ['-ffp-contract=off']}
 
 
 def _stale(obj, deps):
@@ -24,8 +27,8 @@ def build(force=False, verbose=False):
 
     def compile_one(src):
         obj = objdir / (src.replace('.hip', '.o'))
-        if force or _stale(obj, [HERE / src] + headers):
-            cmd = [hipcc] + FLAGS + ['-c', str(HERE / src), '-o', str(obj)]
+        if force or _stale(obj, [HERE / src, HERE / 'build.py'] + headers):
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', str(HERE / src), '-o', str(obj)]
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True)

@@ -63,10 +63,20 @@ class AttentionFeatureEncoder(nn.Module):
             LinearParams(128, 128), ActivationMarker('leaky_relu', 0.01),
             LinearParams(128, self.n_out),
         ])
+        self._fused = ops.PackedAttnMLP()
+
+    def fusable(self):
+        """True when the 4 layers fit the fused MFMA kernel (rf_attn_mlp_*): n_in a multiple of 16 up to 128, 32 outputs."""
+        return ops.USE_FUSED_ATTN_MLP and self.n_in % 16 == 0 and 16 <= self.n_in <= 128 and self.n_out == 32
+
+    def packed_fused(self):
+        return self._fused.get([self.encoder[i] for i in (0, 2, 4, 6)])
 
     def forward(self, x):
         ops._no_grad_only(x, self.encoder[0].weight)
         x = x.reshape((x.shape[0], self.n_in))
+        if self.fusable():
+            return ops.attn_mlp_rows(x.contiguous(), self.packed_fused())
         for i in (0, 2, 4):
             x = self.encoder[i].apply_to(x, ops.ACT_LEAKY, 0.01)
         return self.encoder[6].apply_to(x)
@@ -127,6 +137,30 @@ class AttentionBlock(nn.Module):
             out, debug['scores'], debug['weights'] = out
         return out
 
+    def volume_route_ok(self):
+        """The volume-domain kernels (rf_attn_mlp_volume / rf_attn_weights / rf_attn_blend) cover attention patch extent 2."""
+        return self.patch_extent == 2 and self.cf_op % 2 == 0 and self.theta.fusable() and self.phi.fusable()
+
+    def forward_volumes(self, x_predicted, retrieved, patch_edge, gumbel_noise=None, debug=None):
+        """Same result as unfold -> forward -> fold, computed in the folded layout: x_predicted [B,C,S,S,S]; ``retrieved`` the
+        features of the B*K retrieved volumes, patch-major with patch edge ``patch_edge`` (== S: plain NCDHW volumes)."""
+        ops._no_grad_only(x_predicted, retrieved, self.theta.encoder[0].weight)
+        b, c, s = x_predicted.shape[0], x_predicted.shape[1], x_predicted.shape[2]
+        x_predicted, retrieved = x_predicted.contiguous(), retrieved.contiguous()
+        x_feat = ops.attn_mlp_volume(x_predicted, b, 1, c, s, s, self.theta.packed_fused())
+        p_feat = ops.attn_mlp_volume(retrieved, b, self.K, c, s, patch_edge, self.phi.packed_fused())
+        rows = x_feat.shape[0]
+        if self.retrieval_mode:
+            if gumbel_noise is None:
+                gumbel_noise = self.sample_gumbel(rows, self.K, x_predicted.device)
+            res = ops.attn_weights(x_feat, p_feat, gumbel_noise.contiguous(), self.K, ops.ATTN_GUMBEL_HARD, 25.0, debug=debug is not None)
+        else:
+            sharpness = float((self.cf_feat * self.patch_extent ** 3) * 4)
+            res = ops.attn_weights(x_feat, p_feat, None, self.K, ops.ATTN_SOFTMAX, sharpness, debug=debug is not None)
+        if debug is not None:
+            debug['scores'], debug['weights'] = res[2], res[0]
+        return ops.attn_blend(x_predicted, retrieved, self.K, patch_edge, res[0], res[1])
+
     def get_regularization_losses(self):
         return ((self.sig_scale - self.init_scale) ** 2 + (self.sig_shift - self.init_shift) ** 2) if self.use_switching else 0
 
@@ -157,6 +191,8 @@ class PatchedAttentionBlock(nn.Module):
     def forward(self, x_predicted, x_retrieved, gumbel_noise=None, debug=None):
         """x_predicted [B,F,S,S,S]; x_retrieved [B*K,F,S,S,S] (folded volumes) -> [B,F,S,S,S]."""
         b, s = x_predicted.shape[0], x_predicted.shape[-1]
+        if self.attention_blocks_layer.volume_route_ok():
+            return self.attention_blocks_layer.forward_volumes(x_predicted, x_retrieved, s, gumbel_noise, debug)
         x_rows = self.unfold_3d(x_predicted)
         p_rows = ops.attn_gather_retrieved(x_retrieved.contiguous(), 0, b, self.num_nearest_neighbors, self.nf, s, self.patch_extent)
         out_rows = self.attention_blocks_layer(x_rows, p_rows, gumbel_noise, debug)
@@ -167,6 +203,8 @@ class PatchedAttentionBlock(nn.Module):
         layout [(B*K*q^3), F, t,t,t] (what Fold3D(q, t, F) would consume, trainer/train_refinement.py:37,112): the fold
         is never materialised."""
         b, s = x_predicted.shape[0], x_predicted.shape[-1]
+        if self.attention_blocks_layer.volume_route_ok():
+            return self.attention_blocks_layer.forward_volumes(x_predicted, retrieved_patch_features, patch_edge, gumbel_noise)
         x_rows = self.unfold_3d(x_predicted)
         p_rows = ops.attn_gather_retrieved(retrieved_patch_features.contiguous(), 1, b, self.num_nearest_neighbors, self.nf, s,
                                            self.patch_extent, patch_edge)

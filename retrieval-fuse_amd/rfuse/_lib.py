@@ -48,6 +48,12 @@ SIGNATURES = {
     'rf_l2_normalize_rows': (c_i, [c_fp, c_i, c_i, c_f, c_p]),
     'rf_attn_fuse': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_p]),
     'rf_attn_gather_retrieved': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_attn_mlp_packed_floats': (c_sz, [c_i]),
+    'rf_attn_mlp_pack': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_attn_mlp_rows': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_p]),
+    'rf_attn_mlp_volume': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_p]),
+    'rf_attn_weights': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_p]),
+    'rf_attn_blend': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
     'rf_query_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_p]),
     'rf_db_pack_embeddings': (c_i, [c_fp, c_i64, c_i, c_fp, c_p]),
     'rf_db_packed_floats': (c_sz, [c_i64, c_i]),

@@ -302,6 +302,82 @@ def attn_fuse(x, p, xf, pf, noise, mode, sharpness, debug=False):
     return (out, sc, wt) if debug else out
 
 
+USE_FUSED_ATTN_MLP = True       # False: per-layer rf_linear + the row-domain attention kernels (kept for cross-checks)
+
+
+class PackedAttnMLP:
+    """MFMA operand image of one AttentionFeatureEncoder (4 Linear layers); re-packed when any parameter changes."""
+
+    def __init__(self):
+        self._key = None
+        self._packed = None
+
+    def get(self, layers):
+        params = [t for l in layers for t in (l.weight, l.bias)]
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.device) for t in params)
+        if key != self._key:
+            for t in params:
+                _req(t.detach(), 'attention MLP parameter')
+            n_in = layers[0].weight.shape[1]
+            shapes = [tuple(l.weight.shape) for l in layers]
+            if shapes != [(128, n_in), (128, 128), (128, 128), (32, 128)] or n_in % 16 or not 16 <= n_in <= 128:
+                raise ValueError('fused attention MLP needs Linear(n_in,128) x (128,128) x (128,128) x (128,32) with n_in a multiple of 16 <= 128, '
+                                 'got %s' % (shapes,))
+            lib = _lib.load()
+            out = torch.empty(lib.rf_attn_mlp_packed_floats(n_in), dtype=torch.float32, device=params[0].device)
+            _lib.check(lib.rf_attn_mlp_pack(*[_p(t.detach()) for t in params], n_in, _p(out), _stream()), 'rf_attn_mlp_pack')
+            self._packed, self._key = out, key
+        return self._packed
+
+
+def attn_mlp_rows(x, packed):
+    """x [rows, n_in] -> [rows, 32] through the fused 4-layer encoder."""
+    _req(x, 'x')
+    rows, n_in = x.shape
+    out = torch.empty((rows, 32), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_attn_mlp_rows(_p(x), rows, n_in, _p(packed), _p(out), _stream()), 'rf_attn_mlp_rows')
+    return out
+
+
+def attn_mlp_volume(src, b, kv, c, s, t, packed):
+    """Encoder over every 2^3 attention patch of b*kv feature volumes (patch-major [(b*kv*q^3), c, t,t,t], or NCDHW when t == s)
+    -> [(b*r^3*kv), 32], rows ordered (b, prow, k)."""
+    _req(src, 'src')
+    if src.numel() != b * kv * c * s * s * s:
+        raise ValueError('attn_mlp_volume: %d values are not %d volumes of [%d,%d^3]' % (src.numel(), b * kv, c, s))
+    r = s // 2
+    out = torch.empty((b * r * r * r * kv, 32), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().rf_attn_mlp_volume(_p(src), b, kv, c, s, t, _p(packed), _p(out), _stream()), 'rf_attn_mlp_volume')
+    return out
+
+
+def attn_weights(xf, pf, noise, k, mode, sharpness, debug=False):
+    """xf [rows,f], pf [rows*k,f] raw encoder outputs -> (weights [rows,k], switches [rows][, scores [rows,k]])."""
+    _req(xf, 'xf'), _req(pf, 'pf')
+    if noise is not None:
+        _req(noise, 'noise')
+    rows, f = xf.shape
+    if pf.shape[0] != rows * k:
+        raise ValueError('attn_weights: %d phi rows for %d theta rows and K=%d' % (pf.shape[0], rows, k))
+    w = torch.empty((rows, k), dtype=torch.float32, device=xf.device)
+    sw = torch.empty((rows,), dtype=torch.float32, device=xf.device)
+    sc = torch.empty((rows, k), dtype=torch.float32, device=xf.device) if debug else None
+    _lib.check(_lib.load().rf_attn_weights(_p(xf), _p(pf), _p(noise), rows, k, f, mode, sharpness, _p(w), _p(sw), _p(sc), _stream()),
+               'rf_attn_weights')
+    return (w, sw, sc) if debug else (w, sw)
+
+
+def attn_blend(x, retrieved, k, t, weights, switches):
+    """x [b,c,s,s,s]; retrieved features of b*k volumes (patch-major with patch edge t, or NCDHW when t == s) -> [b,c,s,s,s]."""
+    _req(x, 'x'), _req(retrieved, 'retrieved'), _req(weights, 'weights'), _req(switches, 'switches')
+    b, c, s = x.shape[0], x.shape[1], x.shape[2]
+    if retrieved.numel() != b * k * c * s * s * s:
+        raise ValueError('attn_blend: retrieved features do not match %d x %d volumes' % (b, k))
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().rf_attn_blend(_p(x), _p(retrieved), b, k, c, s, t, _p(weights), _p(switches), _p(out), _stream()), 'rf_attn_blend')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------- retrieval
 
 def query_windows(raw, ps, ctx, pad_value, mean, std):

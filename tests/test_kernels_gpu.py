@@ -200,6 +200,107 @@ def test_attn_gather_layouts(ops):
     assert torch.equal(got1.cpu(), ref)
 
 
+def _seeded_encoder(gen, n_in_channels, e, scale=0.15):
+    import contextlib, io
+    from model.attention import AttentionFeatureEncoder
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = AttentionFeatureEncoder(n_in_channels, 32, e)
+    sd = {k: rnd(gen, *v.shape, scale=scale) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    return enc.to(DEV), sd
+
+
+@pytest.mark.parametrize('rows,c', [(1000, 16), (16, 12), (5000, 12), (1, 2), (257, 16)])
+def test_attn_mlp_rows_matches_float64(ops, rows, c):
+    """Fused 4-layer AttentionFeatureEncoder (rf_attn_mlp_rows) vs float64 (model/attention.py:36-46)."""
+    gen = torch.Generator().manual_seed(rows + c)
+    enc, sd = _seeded_encoder(gen, c, 2)
+    assert enc.fusable()
+    x = rnd(gen, rows, c * 8)
+    h = x.double()
+    for i in (0, 2, 4, 6):
+        h = h @ sd['encoder.%d.weight' % i].double().t() + sd['encoder.%d.bias' % i].double()
+        if i < 6:
+            h = F.leaky_relu(h, 0.01)
+    with torch.no_grad():
+        got = enc(x.to(DEV))
+        ops.USE_FUSED_ATTN_MLP = False
+        try:
+            layered = enc(x.to(DEV))
+        finally:
+            ops.USE_FUSED_ATTN_MLP = True
+    close(got, h.float(), 2e-6, 'fused MLP')
+    close(got, layered, 2e-6, 'fused vs per-layer rf_linear')
+
+
+@pytest.mark.parametrize('b,kv,c,s,t', [(2, 1, 16, 32, 32), (2, 4, 16, 32, 8), (1, 8, 12, 32, 8), (3, 2, 4, 8, 4), (1, 1, 2, 4, 2)])
+def test_attn_mlp_volume_equals_rows_on_unfolded(ops, b, kv, c, s, t):
+    """Reading the 2^3 attention patches in place (NCDHW or patch-major) == the same encoder on the materialised rows, bit for bit."""
+    gen = torch.Generator().manual_seed(b * 7 + kv + c + s + t)
+    enc, _ = _seeded_encoder(gen, c, 2)
+    vols = rnd(gen, b * kv, c, s, s, s)
+    r3 = (s // 2) ** 3
+    rows = refpath.unfold3d(vols, 2).reshape(b, kv, r3, c * 8).permute(0, 2, 1, 3).reshape(-1, c * 8).contiguous()
+    src = vols if t == s else refpath.unfold3d(vols, t)
+    with torch.no_grad():
+        want = ops.attn_mlp_rows(rows.to(DEV), enc.packed_fused())
+        got = ops.attn_mlp_volume(src.to(DEV), b, kv, c, s, t, enc.packed_fused())
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('mode,K,c,s,t', [(1, 4, 16, 32, 8), (0, 4, 16, 32, 8), (0, 8, 16, 32, 32), (1, 4, 12, 16, 8), (0, 3, 2, 4, 2)])
+def test_attn_weights_and_blend_equal_row_domain_kernels(ops, mode, K, c, s, t):
+    """rf_attn_weights + rf_attn_blend (folded layout) == unfold -> regroup -> rf_attn_fuse -> fold on the same features, bit for bit."""
+    gen = torch.Generator().manual_seed(mode + K + c + s + t)
+    b, e = 2, 2
+    r = s // e
+    rows = b * r ** 3
+    x = rnd(gen, b, c, s, s, s).relu_()
+    vols = rnd(gen, b * K, c, s, s, s).relu_()
+    xf, pf = rnd(gen, rows, 32), rnd(gen, rows * K, 32)
+    pf[::K] = xf + 0.02 * rnd(gen, rows, 32)                 # candidate 0 close to the query: switch > 0, real mixing
+    noise = (-torch.empty(rows, K).exponential_(generator=gen).log()).to(DEV) if mode else None
+    sharp = 25.0 if mode else 1024.0
+    src = (vols if t == s else refpath.unfold3d(vols, t)).to(DEV)
+    xd, xfd, pfd = x.to(DEV), xf.to(DEV), pf.to(DEV)
+    w, sw, sc = ops.attn_weights(xfd, pfd, noise, K, mode, sharp, debug=True)
+    got = ops.attn_blend(xd, src, K, t, w, sw)
+    x_rows = ops.unfold3d(xd, e)
+    p_rows = ops.attn_gather_retrieved(src, 0 if t == s else 1, b, K, c, s, e, t)
+    out_rows, sc_old, w_old = ops.attn_fuse(x_rows, p_rows, xfd, pfd, noise, mode, sharp, debug=True)
+    want = ops.fold3d(out_rows, r, e, c)
+    assert torch.equal(sc, sc_old) and torch.equal(w, w_old)
+    assert (sw > 0).float().mean() > 0.5
+    assert torch.equal(got, want)
+
+
+def test_patched_attention_volume_route_vs_row_route(ops):
+    """PatchedAttentionBlock.forward_patch_major: volume-domain route vs the materialised-rows route (softmax mode)."""
+    import contextlib, io
+    from model.attention import AttentionBlock, PatchedAttentionBlock
+    gen = torch.Generator().manual_seed(77)
+    b, K, c, s, t = 2, 4, 16, 32, 8
+    with contextlib.redirect_stdout(io.StringIO()):
+        pab = PatchedAttentionBlock(c, 16, 2, K, AttentionBlock(c, 2, K, True, True, False, True, True))
+    pab.load_state_dict({k: rnd(gen, *v.shape, scale=0.15) for k, v in pab.state_dict().items()})
+    pab.to(DEV)
+    x = rnd(gen, b, c, s, s, s).relu_()
+    vols = rnd(gen, b * K, c, s, s, s).relu_()
+    vols[::K] = x + 0.05 * rnd(gen, b, c, s, s, s)
+    feats = refpath.unfold3d(vols, t).to(DEV)
+    with torch.no_grad():
+        assert pab.attention_blocks_layer.volume_route_ok()
+        got = pab.forward_patch_major(x.to(DEV), feats, t)
+        ops.USE_FUSED_ATTN_MLP = False
+        try:
+            assert not pab.attention_blocks_layer.volume_route_ok()
+            want = pab.forward_patch_major(x.to(DEV), feats, t)
+        finally:
+            ops.USE_FUSED_ATTN_MLP = True
+    close(got, want, 2e-3, 'volume route vs row route')     # sharpness 1024 amplifies the rounding of the two MLP forms
+
+
 @pytest.mark.parametrize('cfg_name', ['C1', 'C4', 'C5'])
 def test_query_windows_bit_exact(ops, cfg_name):
     from rfuse import configs, synthetic
