@@ -1,0 +1,561 @@
+// rf_conv3d_up_k3_gn_relu: the DECODER form of SingleConv 'gcr' (reference model/unet.py:19-76 with the nearest x2
+// upsample + concat of :297-308 / :354-360) for gfx950 -- same result as rf_conv3d_k3_gn_relu on (skip, low-res) sources,
+// with the upsampled channels convolved in LOW resolution.
+//
+// A 3x3x3 convolution over a nearest-x2-upsampled volume reads, per axis, only TWO distinct low-res voxels:
+//     output x even (phase 0): taps x-1 | x, x+1  ->  low-res X-1 (weight w0)      and X   (w1 + w2),  X = x >> 1
+//     output x odd  (phase 1): taps x-1, x | x+1  ->  low-res X   (weight w0 + w1) and X+1 (w2)
+// so for each of the 8 output parities (pz,py,px) the 27 taps collapse to 2x2x2 taps with pre-summed weights: 8/27 of
+// the multiply-adds and a (T/2+2)^3 instead of a (T+2)^3 halo for those channels.  Zero padding commutes (the upsampled
+// border is padded with zeros exactly where the low-res border is), GroupNorm is per (sample, channel) and commutes too.
+// The retrieval backbone's decoders spend 2/3 of their channels on the upsampled source (192->64 @4^3: 128 of 192,
+// 96->56 @8^3: 64 of 96), the final decoder's first conv all of them.
+//
+// Work split: all voxels of one MFMA m-block must share their B operand, i.e. their parity.  A workgroup of 8 waves owns
+// a T^3 box (T = 8: one box of a sample; T = 4: four whole 4^3 samples); WAVE w OWNS PARITY w = (pz,py,px): its MB
+// m-blocks are the (T/2)^3 lattice of that parity.  K loop:
+//   A) skip channels (c0): 4-channel chunks, 27 taps on the full-res halo box, weight slab [27][4][NB*16] shared by the
+//      8 waves through LDS (LDS-DMA, double buffered) -- the scheme of conv3d_mfma.hip.
+//   B) upsampled channels (c1): 8-channel chunks, 8 taps on the low-res halo box (double buffered in LDS); every wave
+//      needs its own parity's weights [8 taps][8 ch][NB*16], read once per workgroup: they go global -> registers
+//      directly (one tap ahead), not through LDS.
+// Epilogue: accumulators -> LDS tile [16 cout][box] -> ReLU -> contiguous float4 rows to HBM (the parity split would
+// otherwise leave every lane with stride-2 scalars), GroupNorm statistics of the output for the next layer as in
+// conv3d_mfma.hip (float64, fixed order, per workgroup tile).
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(1))) const void* rf_gptr;
+typedef __attribute__((address_space(3))) void* rf_lptr;
+
+// ---------------------------------------------------------------------------------------------------- weight image
+// [27][c0_4][cout16] (skip channels, as rf_conv3_pack_weight)  ++  [c1_8/8][8 parities][8 taps][8 ch][cout16]
+static inline size_t up_c0_floats(int cout, int c0) { return (size_t)27 * rf_round_up(c0, 4) * rf_round_up(cout, 16); }
+
+extern "C" size_t rf_conv3_up_packed_floats(int cout, int c0, int c1) {
+    return up_c0_floats(cout, c0) + (size_t)rf_round_up(c1, 8) * 64 * rf_round_up(cout, 16);
+}
+
+__global__ void k_conv3_up_pack(const float* __restrict__ w, int cout, int c0, int c1, int c0_4, int c1_8, int cout16, float* __restrict__ wp) {
+    const int cin = c0 + c1;
+    const size_t n0 = (size_t)27 * c0_4 * cout16, total = n0 + (size_t)c1_8 * 64 * cout16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < n0) {
+            const int co = (int)(i % cout16), ci = (int)((i / cout16) % c0_4), tap = (int)(i / ((size_t)cout16 * c0_4));
+            if (co < cout && ci < c0) v = w[((size_t)co * cin + ci) * 27 + tap];
+        } else {
+            const size_t q = i - n0;
+            const int co = (int)(q % cout16), k8 = (int)((q / cout16) % 8), tap = (int)((q / ((size_t)cout16 * 8)) % 8);
+            const int ph = (int)((q / ((size_t)cout16 * 64)) % 8), chunk = (int)(q / ((size_t)cout16 * 512));
+            const int ci = chunk * 8 + k8;
+            if (co < cout && ci < c1) {
+                // per axis: parity 0: low-res tap 0 <- {0}, tap 1 <- {1,2};  parity 1: tap 0 <- {0,1}, tap 1 <- {2}
+                const int pz = ph >> 2, py = (ph >> 1) & 1, px = ph & 1, tz = tap >> 2, ty = (tap >> 1) & 1, tx = tap & 1;
+                const int z_lo = tz == 0 ? 0 : (pz ? 2 : 1), z_hi = tz == 0 ? (pz ? 1 : 0) : 2;
+                const int y_lo = ty == 0 ? 0 : (py ? 2 : 1), y_hi = ty == 0 ? (py ? 1 : 0) : 2;
+                const int x_lo = tx == 0 ? 0 : (px ? 2 : 1), x_hi = tx == 0 ? (px ? 1 : 0) : 2;
+                const float* wk = w + ((size_t)co * cin + c0 + ci) * 27;
+                double s = 0.0;                                  // summed in float64, rounded once
+                for (int dz = z_lo; dz <= z_hi; ++dz)
+                    for (int dy = y_lo; dy <= y_hi; ++dy)
+                        for (int dx = x_lo; dx <= x_hi; ++dx) s += (double)wk[(dz * 3 + dy) * 3 + dx];
+                v = (float)s;
+            }
+        }
+        wp[i] = v;
+    }
+}
+
+extern "C" int rf_conv3_up_pack_weight(const float* w_oidhw, int cout, int c0, int c1, float* w_packed, void* stream) {
+    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && c0 >= 0 && c1 > 0, RF_E_INVALID, "rf_conv3_up_pack_weight: bad arguments");
+    const size_t total = rf_conv3_up_packed_floats(cout, c0, c1);
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_conv3_up_pack, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, c0, c1,
+                       rf_round_up(c0, 4), rf_round_up(c1, 8), rf_round_up(cout, 16), w_packed);
+    RF_CHECK_LAUNCH("rf_conv3_up_pack_weight");
+    return RF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------- kernel
+struct UpArgs {
+    const float* src0;
+    const float* src1;
+    const float* scale;
+    const float* shift;
+    const float* wp;
+    float* out;
+    int c0, c1, n, edge, cout, c0_4, c1_8, cout16;
+    double2* stats;    // optional [n][cout][stats_tiles]
+    int stats_tiles;
+};
+
+__device__ __forceinline__ unsigned up_xcd_contiguous(unsigned b, unsigned g) {      // see conv3d_mfma.hip
+    const unsigned per = g >> 3, rem = g & 7u, k = b & 7u;
+    return k * per + (k < rem ? k : rem) + (b >> 3);
+}
+
+template <int TE, int SPW, int MB, int NB>
+struct UpTile {
+    static constexpr int NW = 8, NT = 512;
+    static constexpr int L = TE / 2, LH = L + 2, HE = TE + 2;
+    static constexpr int CH0 = HE * HE * HE, CH1 = LH * LH * LH;
+    static constexpr int XS0 = SPW * 4 * CH0;                          // full-res halo box of a 4-channel chunk
+    static constexpr int XS1 = SPW * 8 * CH1;                          // low-res halo box of an 8-channel chunk (x2 buffers)
+    static constexpr int XS = ((XS0 > 2 * XS1 ? XS0 : 2 * XS1) + 3) / 4 * 4;
+    static constexpr int NCO = NB * 16;
+    static constexpr int WSLAB = 27 * 4 * NCO;
+    static constexpr int WSLAB_PAD = (WSLAB + 255) / 256 * 256;
+    static constexpr int P = SPW * TE * TE * TE;
+    static constexpr int EPI = 16 * (P + 1);                           // epilogue tile [16 cout][P + 1]
+    static constexpr int MAIN = XS + 2 * WSLAB_PAD;
+    static constexpr size_t LDS_BYTES = (size_t)(MAIN > EPI ? MAIN : EPI) * sizeof(float);
+    static_assert(P == NW * MB * 16, "8 waves x MB x 16 voxels must cover the box");
+    static_assert(SPW * L * L * L == MB * 16, "one parity lattice per wave");
+    static_assert((TE == 8 && SPW == 1) || (TE == 4 && SPW == 4), "built tiles: one 8^3 box, or four whole 4^3 samples");
+};
+
+template <int TE, int SPW, int MB, int NB>
+__global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
+    using T = UpTile<TE, SPW, MB, NB>;
+    constexpr int L = T::L, LH = T::LH, HE = T::HE, CH0 = T::CH0, CH1 = T::CH1, NCO = T::NCO, NT = T::NT, P = T::P;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* wsb = smem + T::XS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;     // this wave's output parity
+    const int edge = a.edge, half = edge >> 1, cin = a.c0 + a.c1;
+
+    // ---- which box?
+    int n0, z0 = 0, y0 = 0, x0 = 0, tile = 0;
+    if (SPW == 1) {
+        const unsigned lb = gridDim.y == 1 ? up_xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+        const int tpe = edge / TE;
+        int t = (int)lb;
+        tile = t % (tpe * tpe * tpe);
+        x0 = (t % tpe) * TE; t /= tpe;
+        y0 = (t % tpe) * TE; t /= tpe;
+        z0 = (t % tpe) * TE; t /= tpe;
+        n0 = t;
+    } else {
+        n0 = blockIdx.x * SPW;
+    }
+    const int cob = blockIdx.y * NCO;
+
+    constexpr int ROT = NCO >= 32 ? 16 : 0;                             // slab bank rotation, as conv3d_mfma.hip
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ================================================================================= A) skip channels, 27 taps
+    if (a.c0 > 0) {
+        // per-lane LDS offsets of the operands: voxel v = mb*16 + li of this wave's parity lattice, channel kq.  Derived
+        // from an opaque copy of the lane id so that they only live inside this phase of the kernel.
+        int lane_a = lane;
+        asm volatile("" : "+v"(lane_a));
+        const int kq_a = lane_a >> 4, li_a = lane_a & 15;
+        int aoff0[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int v = mb * 16 + li_a;
+            const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
+            aoff0[mb] = (s * 4 + kq_a) * CH0 + ((2 * Z + pz) * HE + (2 * Y + py)) * HE + (2 * X + px);
+        }
+        int boff[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) boff[nb] = kq_a * NCO + ((nb * 16 + li_a + ROT * (kq_a & 1)) % NCO);
+        constexpr int WF4 = T::WSLAB / 4, NPIECE = (WF4 + 63) / 64;
+        auto dma_weights = [&](int cbase, int buf, int lane_) {
+            float* dst = wsb + buf * T::WSLAB_PAD;
+#pragma unroll
+            for (int i = 0; i < (NPIECE + 7) / 8; ++i) {
+                const int q = wave + i * 8;
+                if (q < NPIECE) {
+                    int idx = q * 64 + lane_;
+                    if (idx >= WF4) idx = WF4 - 1;
+                    const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
+                    const int col = (slot + NCO - ROT * (r & 1)) % NCO;
+                    int co = cob + col;
+                    if (co >= a.cout16) co = col % a.cout16;
+                    int ci = cbase + r % 4;
+                    if (ci >= a.c0_4) ci = a.c0_4 - 1;
+                    const float* src = a.wp + ((size_t)(r / 4) * a.c0_4 + ci) * a.cout16 + co;
+                    __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+                }
+            }
+        };
+        constexpr int ROWS = SPW * 4 * HE * HE;
+        constexpr int RPT = (ROWS + NT - 1) / NT;
+        float xraw[RPT][TE + 2];
+        float xsc[RPT], xsh[RPT];
+        const bool has_l = x0 > 0, has_r = x0 + TE < edge;
+        auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
+            hy = r % HE; hz = (r / HE) % HE; c = (r / (HE * HE)) % 4; s = r / (HE * HE * 4);
+            nn = n0 + s; ci = cbase + c; z = z0 + hz - 1; y = y0 + hy - 1;
+            return r < ROWS && nn < a.n && ci < a.c0 && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge;
+        };
+        auto issue_rows = [&](int cbase, int tid_) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                int s, c, hz, hy, nn, ci, z, y;
+                if (row_coords(tid_ + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
+                    const size_t si = (size_t)nn * cin + ci;
+                    xsc[i] = a.scale[si];
+                    xsh[i] = a.shift[si];
+                    const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
+#pragma unroll
+                    for (int q = 0; q < TE / 4; ++q) {
+                        const float4 t = reinterpret_cast<const float4*>(row)[q];
+                        xraw[i][1 + 4 * q] = t.x; xraw[i][2 + 4 * q] = t.y; xraw[i][3 + 4 * q] = t.z; xraw[i][4 + 4 * q] = t.w;
+                    }
+                    if (has_l) xraw[i][0] = row[-1];
+                    if (has_r) xraw[i][TE + 1] = row[TE];
+                }
+            }
+        };
+        auto commit_rows = [&](int cbase, int tid_) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = tid_ + i * NT;
+                int s, c, hz, hy, nn, ci, z, y;
+                const bool ok = row_coords(r, cbase, s, c, hz, hy, nn, ci, z, y);
+                if (r < ROWS) {
+                    float v[TE + 2];
+                    if (ok) {
+                        const float sc = xsc[i], sh = xsh[i];
+#pragma unroll
+                        for (int j = 1; j <= TE; ++j) v[j] = xraw[i][j] * sc + sh;
+                        v[0] = has_l ? xraw[i][0] * sc + sh : 0.f;
+                        v[TE + 1] = has_r ? xraw[i][TE + 1] * sc + sh : 0.f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TE + 2; ++j) v[j] = 0.f;
+                    }
+                    float* dst = xs + (s * 4 + c) * CH0 + (hz * HE + hy) * HE;
+#pragma unroll
+                    for (int j = 0; j < TE + 2; ++j) dst[j] = v[j];
+                }
+            }
+        };
+
+        dma_weights(0, 0, lane);
+        issue_rows(0, tid);
+        commit_rows(0, tid);
+        __syncthreads();
+        int buf = 0;
+        for (int cbase = 0; cbase < a.c0; cbase += 4) {
+            const bool more = cbase + 4 < a.c0;
+            int tid_o = tid;                                            // opaque: keeps the row index math inside the loop
+            asm volatile("" : "+v"(tid_o));
+            if (more) {
+                issue_rows(cbase + 4, tid_o);
+                dma_weights(cbase + 4, buf ^ 1, tid_o & 63);
+            }
+            {
+                const float* ws = wsb + buf * T::WSLAB_PAD;
+                float av[2][MB], bv[2][NB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff0[mb]];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bv[0][nb] = ws[boff[nb]];
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const int cur = t & 1, nxt = cur ^ 1;
+                    if (t + 1 < 27) {
+                        const int t1 = t + 1;
+                        const int toff = ((t1 / 9) * HE + (t1 / 3) % 3) * HE + t1 % 3;
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xs[aoff0[mb] + toff];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + t1 * 4 * NCO];
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (more) {
+                int tid_c = tid;
+                asm volatile("" : "+v"(tid_c));
+                commit_rows(cbase + 4, tid_c);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ========================================================================== B) upsampled channels, 8 low-res taps
+    {
+        constexpr int ROWS = SPW * 8 * LH * LH;                         // rows of LH floats
+        constexpr int RPT = (ROWS + NT - 1) / NT;
+        float xraw[RPT][LH];
+        float xsc[RPT], xsh[RPT];
+        const int Z0 = z0 >> 1, Y0 = y0 >> 1, X0 = x0 >> 1;
+        const bool has_l = X0 > 0, has_r = X0 + L < half;
+        auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
+            hy = r % LH; hz = (r / LH) % LH; c = (r / (LH * LH)) % 8; s = r / (LH * LH * 8);
+            nn = n0 + s; ci = cbase + c; z = Z0 + hz - 1; y = Y0 + hy - 1;
+            return r < ROWS && nn < a.n && ci < a.c1 && (unsigned)z < (unsigned)half && (unsigned)y < (unsigned)half;
+        };
+        auto issue_rows = [&](int cbase, int tid_) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                int s, c, hz, hy, nn, ci, z, y;
+                if (row_coords(tid_ + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
+                    const size_t si = (size_t)nn * cin + a.c0 + ci;
+                    xsc[i] = a.scale[si];
+                    xsh[i] = a.shift[si];
+                    const float* row = a.src1 + ((((size_t)nn * a.c1 + ci) * half + z) * half + y) * half + X0;
+                    if (L == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(row);
+                        xraw[i][1] = t.x; xraw[i][2] = t.y; xraw[i][3] = t.z; xraw[i][4] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(row);
+                        xraw[i][1] = t.x; xraw[i][2] = t.y;
+                    }
+                    if (has_l) xraw[i][0] = row[-1];
+                    if (has_r) xraw[i][L + 1] = row[L];
+                }
+            }
+        };
+        auto commit_rows = [&](int cbase, int tid_, float* dstbuf) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = tid_ + i * NT;
+                int s, c, hz, hy, nn, ci, z, y;
+                const bool ok = row_coords(r, cbase, s, c, hz, hy, nn, ci, z, y);
+                if (r < ROWS) {
+                    float v[LH];
+                    if (ok) {
+                        const float sc = xsc[i], sh = xsh[i];
+#pragma unroll
+                        for (int j = 1; j <= L; ++j) v[j] = xraw[i][j] * sc + sh;
+                        v[0] = has_l ? xraw[i][0] * sc + sh : 0.f;
+                        v[L + 1] = has_r ? xraw[i][L + 1] * sc + sh : 0.f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < LH; ++j) v[j] = 0.f;
+                    }
+                    float* dst = dstbuf + (s * 8 + c) * CH1 + (hz * LH + hy) * LH;
+#pragma unroll
+                    for (int j = 0; j < LH; ++j) dst[j] = v[j];
+                }
+            }
+        };
+
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));
+        const int kq = lane_b >> 4, li = lane_b & 15;
+        int aoff1[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int v = mb * 16 + li;
+            const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
+            aoff1[mb] = (s * 8 + kq) * CH1 + ((Z + pz) * LH + (Y + py)) * LH + (X + px);
+        }
+        // this wave's weights: [chunk][parity = wave][tap][k8][cout16]; step st = tap*2 + kstep advances 4 rows of cout16
+        int colv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            int co = cob + nb * 16 + li;
+            if (co >= a.cout16) co = a.cout16 - 1;                      // block wider than the image: masked at the store
+            colv[nb] = co;
+        }
+        const float* wq = a.wp + (size_t)27 * a.c0_4 * a.cout16 + ((size_t)wave * 64 + kq) * a.cout16;
+        const size_t chunk_stride = (size_t)512 * a.cout16, step_stride = (size_t)4 * a.cout16;
+        const int nchunk = a.c1_8 >> 3;
+
+        float bv[2][NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[0][nb] = wq[colv[nb]];      // chunk 0, step 0
+        issue_rows(0, tid);
+        commit_rows(0, tid, xs);
+        __syncthreads();
+        int buf = 0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const bool more = ch + 1 < nchunk;
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            if (more) issue_rows((ch + 1) * 8, tid_o);
+            const float* xb = xs + buf * T::XS1;
+            const float* wc = wq + (size_t)ch * chunk_stride;
+            float av[2][MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[0][mb] = xb[aoff1[mb]];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {                           // step = (tap, k-step)
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < 16) {
+                    const int t1 = (st + 1) >> 1, k1 = (st + 1) & 1;
+                    const int toff = ((t1 >> 2) * LH + ((t1 >> 1) & 1)) * LH + (t1 & 1) + k1 * 4 * CH1;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xb[aoff1[mb] + toff];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = wc[(size_t)(st + 1) * step_stride + colv[nb]];
+                } else if (more) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = wc[chunk_stride + colv[nb]];     // step 0 of the next chunk
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+            }
+            if (more) {
+                int tid_c = tid;
+                asm volatile("" : "+v"(tid_c));
+                commit_rows((ch + 1) * 8, tid_c, xs + (buf ^ 1) * T::XS1);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ===================================================================================================== epilogue
+    // accumulators -> LDS [16 cout][P + 1] in memory order of the box -> ReLU'd float4 rows; statistics on the way
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int kq = lane_e >> 4, li = lane_e & 15;
+    float* eb = smem;
+    double* red = reinterpret_cast<double*>(smem);                       // [8 waves][SPW][16 cout][2], used after the stores
+    const size_t vol = (size_t)edge * edge * edge;
+    constexpr int TE3 = TE * TE * TE;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = mb * 16 + kq * 4 + r;                      // D rows of this lane: voxels 4*kq + r of the m-block
+                const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
+                const int lin = s * TE3 + ((2 * Z + pz) * TE + (2 * Y + py)) * TE + (2 * X + px);
+                eb[li * (P + 1) + lin] = fmaxf(acc[mb][nb][r], 0.f);
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < 16 * (P / 4); q += NT) {
+            const int col = q / (P / 4), lin = (q % (P / 4)) * 4;
+            const int co = cob + nb * 16 + col;
+            const int s = lin / TE3, rem = lin % TE3;
+            const int nn = n0 + s;
+            if (co < a.cout && nn < a.n) {
+                const float* e = eb + col * (P + 1) + lin;
+                const float4 o = make_float4(e[0], e[1], e[2], e[3]);
+                const int x = rem % TE, y = (rem / TE) % TE, z = rem / (TE * TE);
+                *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x)) = o;
+            }
+        }
+        __syncthreads();
+
+        if (a.stats) {
+            // per (sample, cout) sum / sum of squares of the ReLU'd tile: registers -> lane groups -> waves (fixed order)
+            if (SPW == 1) {
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = (double)fmaxf(acc[mb][nb][r], 0.f);
+                        sm += v; sq += v * v;
+                    }
+                sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+                sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+                if (lane < 16) { red[(wave * 16 + lane) * 2] = sm; red[(wave * 16 + lane) * 2 + 1] = sq; }
+            } else {
+                // T = 4, four samples: voxel v = mb*16 + 4*kq + r belongs to sample v / 8 = 2*mb + (kq >> 1)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    double sm = 0.0, sq = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = (double)fmaxf(acc[mb][nb][r], 0.f);
+                        sm += v; sq += v * v;
+                    }
+                    sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);        // kq pairs {0,1} and {2,3}
+                    if ((lane & 16) == 0) {
+                        const int s = 2 * mb + (kq >> 1);
+                        red[((wave * SPW + s) * 16 + li) * 2] = sm;
+                        red[((wave * SPW + s) * 16 + li) * 2 + 1] = sq;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < SPW * 16) {
+                const int s = tid / 16, col = tid % 16;
+                const int co = cob + nb * 16 + col, nn = n0 + s;
+                if (co < a.cout && nn < a.n) {
+                    double sm = 0.0, sq = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        sm += red[((w * SPW + s) * 16 + col) * 2];
+                        sq += red[((w * SPW + s) * 16 + col) * 2 + 1];
+                    }
+                    a.stats[((size_t)nn * a.cout + co) * a.stats_tiles + tile] = make_double2(sm, sq);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int TE, int SPW, int MB, int NB>
+static int launch_up(const UpArgs& a, hipStream_t stream) {
+    using T = UpTile<TE, SPW, MB, NB>;
+    auto kern = k_conv3_up<TE, SPW, MB, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (T::LDS_BYTES > 65536) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+            if (e != hipSuccess) { rf_set_error("rf_conv3d_up_k3_gn_relu: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
+        }
+        attr_set = true;
+    }
+    const unsigned gx = SPW == 1 ? (unsigned)a.n * (a.edge / TE) * (a.edge / TE) * (a.edge / TE) : (unsigned)((a.n + SPW - 1) / SPW);
+    const unsigned gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(T::NT), T::LDS_BYTES, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_up_k3_gn_relu");
+    return RF_OK;
+}
+
+template <int TE, int SPW, int MB>
+static int dispatch_up(const UpArgs& a, hipStream_t stream) {
+    if (a.cout16 <= 16) return launch_up<TE, SPW, MB, 1>(a, stream);
+    if (a.cout16 <= 32) return launch_up<TE, SPW, MB, 2>(a, stream);
+    return launch_up<TE, SPW, MB, 4>(a, stream);
+}
+
+// Shapes the parity-split kernel takes: a low-res source, edge 4 (four samples per workgroup) or a multiple of 8, and
+// enough boxes to give the 256 CUs work (small launches stay on rf_conv3d_k3_gn_relu's 128-voxel tiles).
+extern "C" int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout) {
+    static const int off = getenv("RFUSE_CONV_UP") ? atoi(getenv("RFUSE_CONV_UP")) == 0 : 0;       // dev knob: RFUSE_CONV_UP=0 disables
+    if (off || c1 <= 0 || c0 < 0 || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 4 || edge > 128) return 0;
+    const long long gy = (rf_round_up(cout, 16) + 63) / 64;
+    const long long boxes = edge == 4 ? (n + 3) / 4 : (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
+    return boxes * gy >= 256;
+}
+
+extern "C" int rf_conv3d_up_stats_tiles(int edge) { return edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8); }
+
+extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
+                                       const float* shift, const float* w_packed, int cout, float* out, double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_up_supported(c0, c1, n, edge, cout) || (c1 > 0 && c0 >= 0 && n > 0 && cout > 0 && rf_is_pow2(edge) && edge >= 4 && edge <= 128),
+               RF_E_UNSUPPORTED, "rf_conv3d_up_k3_gn_relu: needs a low-res source and a power-of-two edge in 4..128 (got c1=%d edge=%d)", c1, edge);
+    RF_REQUIRE((c0 == 0 || src0) && src1 && scale && shift && w_packed && out, RF_E_INVALID, "rf_conv3d_up_k3_gn_relu: null pointer");
+    UpArgs a;
+    a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
+    a.c0_4 = rf_round_up(c0, 4); a.c1_8 = rf_round_up(c1, 8); a.cout16 = rf_round_up(cout, 16);
+    a.stats = reinterpret_cast<double2*>(stats);
+    a.stats_tiles = stats ? rf_conv3d_up_stats_tiles(edge) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    return edge == 4 ? dispatch_up<4, 4, 2>(a, s) : dispatch_up<8, 1, 4>(a, s);
+}

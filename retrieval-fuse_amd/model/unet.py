@@ -48,6 +48,7 @@ class Conv3dParams(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
         self._packed = ops.PackedWeight('conv3' if (kernel_size == 3 and padding == 1) else 'convv')
+        self._packed_up = ops.PackedWeight('conv3up')
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -58,6 +59,10 @@ class Conv3dParams(nn.Module):
 
     def packed(self):
         return self._packed.get(self.weight)
+
+    def packed_up(self, c0):
+        """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""
+        return self._packed_up.get(self.weight, c0)
 
     def extra_repr(self):
         return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
@@ -84,6 +89,9 @@ class SingleConv(nn.Module):
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
         if _direct or edge == 1:
             return ops.conv3d_gn_relu(x, upsampled, scale, shift, None, self.conv.out_channels, direct_weight=self.conv.weight)
+        if ops.conv_up_supported(x, upsampled, self.conv.out_channels):
+            c0 = x.shape[1] if x is not None else 0
+            return ops.conv3d_up_gn_relu(x, upsampled, scale, shift, self.conv.packed_up(c0), self.conv.out_channels)
         return ops.conv3d_gn_relu(x, upsampled, scale, shift, self.conv.packed(), self.conv.out_channels)
 
 

@@ -60,10 +60,11 @@ class PackedWeight:
         self._key = None
         self._packed = None
 
-    def get(self, w):
-        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+    def get(self, w, *extra):
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
-            self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight}[self.kind](w)
+            self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
+                            'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
             self._key = key
         return self._packed
 
@@ -165,6 +166,52 @@ def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None)
                                                    cout, _p(out), _stream()), 'rf_conv3d_k3_gn_relu_direct')
     else:
         _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out)
+    return out
+
+
+def pack_conv3_up_weight(w, c0):
+    """Weight image of the decoder-form conv: the first c0 input channels are the skip source, the rest the upsampled one."""
+    _req(w.detach(), 'conv weight')
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3, 3) or not 0 <= c0 < cin:
+        raise ValueError('pack_conv3_up_weight: expected an OIDHW 3x3x3 weight and 0 <= c0 < cin, got %s, c0=%d' % (tuple(w.shape), c0))
+    lib = _lib.load()
+    out = torch.empty(lib.rf_conv3_up_packed_floats(cout, c0, cin - c0), dtype=torch.float32, device=w.device)
+    _lib.check(lib.rf_conv3_up_pack_weight(_p(w.detach()), cout, c0, cin - c0, _p(out), _stream()), 'rf_conv3_up_pack_weight')
+    return out
+
+
+def conv_up_supported(src0, src1, cout):
+    """True when the parity-split decoder kernel (rf_conv3d_up_k3_gn_relu) takes this (skip, low-res) pair."""
+    if src1 is None or not USE_CONV_UP:
+        return False
+    n, c0, c1, edge = _src_dims(src0, src1)
+    return bool(_lib.load().rf_conv3d_up_supported(c0, c1, n, edge, cout))
+
+
+USE_CONV_UP = True              # False: decoder convs run the generic kernel on the (virtually) upsampled source
+
+
+def conv3d_up_gn_relu(src0, src1, scale, shift, w_up_packed, cout):
+    """ReLU(conv3(GN(cat(src0, up2(src1))))) with the upsampled channels convolved in low resolution."""
+    n, c0, c1, edge = _src_dims(src0, src1)
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=scale.device)
+    lib = _lib.load()
+    stats = None
+    if USE_FUSED_STATS:
+        tiles = lib.rf_conv3d_up_stats_tiles(edge)
+        stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=out.device)
+    timed = conv_event_filter is not None and conv_event_filter(c0 + c1, cout, edge, n)
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.rf_conv3d_up_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_up_packed), cout, _p(out),
+                                           _p(stats), _stream()), 'rf_conv3d_up_k3_gn_relu')
+    if timed:
+        ev1.record()
+        conv_events.append((ev0, ev1, 2.0 * (27 * c0 + 8 * c1) * cout * edge ** 3 * n))      # multiply-adds actually executed
+    if stats is not None:
+        out._rf_stats = (stats, tiles, out._version)
     return out
 
 

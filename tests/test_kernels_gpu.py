@@ -95,6 +95,52 @@ def test_conv3d_gn_relu(ops, case):
         close(mfma, direct, 2e-5, 'mfma conv vs direct conv')
 
 
+UP_CASES = [
+    # (n, c0, c1, edge, cout, groups): shapes rf_conv3d_up_supported accepts (>= 256 boxes)
+    (256, 32, 64, 8, 56, 8),    # retrieval backbone dec1 (dominant layer), cout 56 -> NB 4 with a half-empty block
+    (300, 0, 16, 8, 16, 8),     # DecoderNoJoining: no skip source
+    (1027, 64, 128, 4, 64, 8),  # 4^3 decoder read, four samples per workgroup, ragged last workgroup
+    (2, 0, 16, 64, 16, 8),      # final decoder: 8^3 boxes of a 64^3 volume (halo crosses box borders)
+    (40, 6, 12, 16, 12, 6),     # nf = 12 family: c0 % 4 != 0, c1 % 8 != 0
+    (300, 8, 8, 8, 72, 8),      # cout16 = 80: two cout blocks
+    (260, 4, 8, 8, 24, 4),      # NB = 2
+    (1100, 16, 8, 4, 24, 8),
+]
+
+
+@pytest.mark.parametrize('case', UP_CASES)
+def test_conv3d_up_parity_split_decoder_kernel(ops, case):
+    """rf_conv3d_up_k3_gn_relu (upsampled channels convolved in low resolution, pre-summed taps) vs float64 torch on the
+    materialised upsample + concat (model/unet.py:297-308, 19-76) and vs the generic kernel; fused statistics too."""
+    n, c0, c1, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case))
+    src0 = rnd(gen, n, c0, edge, edge, edge).relu_() if c0 else None
+    src1 = rnd(gen, n, c1, edge // 2, edge // 2, edge // 2).relu_()
+    cin = c0 + c1
+    gamma, beta = 1 + 0.2 * rnd(gen, cin), 0.2 * rnd(gen, cin)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin))
+    d0 = src0.to(DEV) if src0 is not None else None
+    d1 = src1.to(DEV)
+    assert ops.conv_up_supported(d0, d1, cout)
+    scale, shift = ops.gn_scale_shift(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
+    wd = w.to(DEV)
+    got = ops.conv3d_up_gn_relu(d0, d1, scale, shift, ops.pack_conv3_up_weight(wd, c0), cout)
+    generic = ops.conv3d_gn_relu(d0, d1, scale, shift, ops.pack_conv3_weight(wd), cout)
+    close(got, generic, 1e-5, 'parity-split vs generic kernel')
+    sub = slice(0, min(n, 24))                                 # float64 reference on a slice (CPU time)
+    sub_tail = slice(max(0, n - 5), n)
+    for sl in (sub, sub_tail):
+        ref = ref_gcr(src0[sl].double() if c0 else None, src1[sl].double(), gamma.double(), beta.double(), groups, w.double())
+        close(got[sl], ref.float(), 1e-5, 'parity-split vs float64 torch')
+    g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+    g = groups if cout % groups == 0 else 1
+    assert getattr(got, '_rf_stats', None) is not None
+    fused = ops.gn_scale_shift(got, None, g2, b2, g)
+    plain = ops.gn_scale_shift(got.clone(), None, g2, b2, g)
+    close(fused[0], plain[0], 1e-6, 'scale from fused stats')
+    close(fused[1], plain[1], 1e-6, 'shift from fused stats')
+
+
 def test_conv_identity_weight_is_transpose_detecting(ops):
     """centre-tap identity on an asymmetric ramp: catches swapped voxel axes / channel transposes exactly."""
     n, c, edge = 1, 16, 8
