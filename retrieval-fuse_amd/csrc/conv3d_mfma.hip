@@ -252,6 +252,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
 #pragma unroll
             for (int st = 0; st < 27 * KS; ++st) {             // step = (tap, k-step)
                 const int cur = st & 1, nxt = cur ^ 1;
+                // keep the operand reads of later taps out of this step: left alone, hipcc pairs reads of neighbouring taps
+                // into ds_read2 far ahead of their use (long live ranges: +30..50 VGPRs, spills in the parity-split kernel)
+                asm volatile("" ::: "memory");
                 if (st + 1 < 27 * KS) {
                     const int t1 = (st + 1) / KS, k1 = (st + 1) % KS;
                     const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 + k1 * 4 * CH;

@@ -108,8 +108,11 @@ struct UpTile {
     static constexpr int WSLAB_PAD = (WSLAB + 255) / 256 * 256;
     static constexpr int P = SPW * TE * TE * TE;
     static constexpr int EPI = 16 * (P + 1);                           // epilogue tile [16 cout][P + 1]
-    static constexpr int MAIN = XS + 2 * WSLAB_PAD;
-    static constexpr size_t LDS_BYTES = (size_t)(MAIN > EPI ? MAIN : EPI) * sizeof(float);
+    static constexpr int MAIN = XS + 2 * WSLAB_PAD;                     // phase A: halo box + two shared weight slabs
+    static constexpr int MAINB = 2 * XS1 + NW * 2 * 16 * NCO;          // phase B: two low-res boxes + per-wave quarter slabs x2
+    static constexpr int LDS_FLOATS = MAIN > MAINB ? (MAIN > EPI ? MAIN : EPI) : (MAINB > EPI ? MAINB : EPI);
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+    static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
     static_assert(P == NW * MB * 16, "8 waves x MB x 16 voxels must cover the box");
     static_assert(SPW * L * L * L == MB * 16, "one parity lattice per wave");
     static_assert((TE == 8 && SPW == 1) || (TE == 4 && SPW == 4), "built tiles: one 8^3 box, or four whole 4^3 samples");
@@ -266,6 +269,9 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
                     const int cur = t & 1, nxt = cur ^ 1;
+                    // keep the operand reads of later taps out of this step: left alone, hipcc pairs reads of neighbouring
+                    // taps into ds_read2 far ahead of their use and then spills them (and an accumulator) to scratch
+                    asm volatile("" ::: "memory");
                     if (t + 1 < 27) {
                         const int t1 = t + 1;
                         const int toff = ((t1 / 9) * HE + (t1 / 3) % 3) * HE + t1 % 3;
@@ -361,54 +367,75 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
             aoff1[mb] = (s * 8 + kq) * CH1 + ((Z + pz) * LH + (Y + py)) * LH + (X + px);
         }
-        // this wave's weights: [chunk][parity = wave][tap][k8][cout16]; step st = tap*2 + kstep advances 4 rows of cout16
-        int colv[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            int co = cob + nb * 16 + li;
-            if (co >= a.cout16) co = a.cout16 - 1;                      // block wider than the image: masked at the store
-            colv[nb] = co;
-        }
-        const float* wq = a.wp + (size_t)27 * a.c0_4 * a.cout16 + ((size_t)wave * 64 + kq) * a.cout16;
-        const size_t chunk_stride = (size_t)512 * a.cout16, step_stride = (size_t)4 * a.cout16;
+        // This wave's weights: image rows [chunk][parity = wave][tap][k8] of cout16 floats.  They stream through a
+        // wave-private, double-buffered LDS slab one QUARTER chunk (2 taps x 8 channels = 16 rows x NCO) at a time by DMA:
+        // no VGPRs, and -- unlike register prefetches -- no s_waitcnt vmcnt inside the MFMA steps (vmcnt retires in order,
+        // so a register prefetch waited on every step would also wait for the slow halo-row loads issued before it).
+        // Slab row r = (tap&1)*8 + k8 holds cout column col at float (col + 16*(r&3)) % NCO: the 4 k rows of a B read sit
+        // on different banks.
+        constexpr int QF = 16 * NCO;                                    // floats per quarter slab
+        constexpr int QP = QF / 256;                                    // 1-KiB DMA pieces per quarter
+        float* wslab = smem + 2 * T::XS1 + wave * (2 * QF);
+        const float* wimg = a.wp + (size_t)27 * a.c0_4 * a.cout16 + (size_t)wave * 64 * a.cout16;
         const int nchunk = a.c1_8 >> 3;
-
-        float bv[2][NB];
+        auto dma_quarter = [&](int Q, int lane_) {                      // Q = chunk*4 + quarter
+            float* dst = wslab + (Q & 1) * QF;
+            const float* src = wimg + ((size_t)(Q >> 2) * 512 + (size_t)(Q & 3) * 16) * a.cout16;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[0][nb] = wq[colv[nb]];      // chunk 0, step 0
+            for (int p = 0; p < QP; ++p) {
+                const int idx = p * 64 + lane_;                         // float4 index inside the slab
+                const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
+                const int col = (slot + NCO - (16 * (r & 3)) % NCO) % NCO;
+                int co = cob + col;
+                if (co >= a.cout16) co = col % a.cout16;                // block wider than the image: masked at the store
+                __builtin_amdgcn_global_load_lds((rf_gptr)(src + (size_t)r * a.cout16 + co), (rf_lptr)(dst + p * 256), 16, 0, 0);
+            }
+        };
+        int boff1[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) boff1[nb] = kq * NCO + ((nb * 16 + li + 16 * kq) % NCO);
+
+        dma_quarter(0, lane_b);
         issue_rows(0, tid);
         commit_rows(0, tid, xs);
-        __syncthreads();
+        __syncthreads();                                                // rows of chunk 0 and quarter 0 have landed
         int buf = 0;
         for (int ch = 0; ch < nchunk; ++ch) {
             const bool more = ch + 1 < nchunk;
-            int tid_o = tid;
-            asm volatile("" : "+v"(tid_o));
-            if (more) issue_rows((ch + 1) * 8, tid_o);
             const float* xb = xs + buf * T::XS1;
-            const float* wc = wq + (size_t)ch * chunk_stride;
-            float av[2][MB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[0][mb] = xb[aoff1[mb]];
+            for (int q = 0; q < 4; ++q) {
+                int lane_o = lane, tid_o = tid;                         // opaque: index math stays inside the loop
+                asm volatile("" : "+v"(lane_o), "+v"(tid_o));
+                // quarter Q = 4*ch + q landed?  (wave-private slab: only this wave's own DMA, no barrier)
+                // (also for Q = 0: a wave without halo rows to load has nothing else that would make it wait for its DMA)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (q < 3 || more) dma_quarter(ch * 4 + q + 1, lane_o); // into the buffer quarter Q-1 was read from
+                if (q == 0 && more) issue_rows((ch + 1) * 8, tid_o);    // a whole quarter of MFMAs to land before the next wait
+                const float* ws = wslab + (q & 1) * QF;
+                float av[2][MB], bv[2][NB];
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {                           // step = (tap, k-step)
-                const int cur = st & 1, nxt = cur ^ 1;
-                if (st + 1 < 16) {
-                    const int t1 = (st + 1) >> 1, k1 = (st + 1) & 1;
-                    const int toff = ((t1 >> 2) * LH + ((t1 >> 1) & 1)) * LH + (t1 & 1) + k1 * 4 * CH1;
+                for (int mb = 0; mb < MB; ++mb) av[0][mb] = xb[aoff1[mb] + (((2 * q) >> 2) * LH + (((2 * q) >> 1) & 1)) * LH];
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xb[aoff1[mb] + toff];
+                for (int nb = 0; nb < NB; ++nb) bv[0][nb] = ws[boff1[nb]];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = wc[(size_t)(st + 1) * step_stride + colv[nb]];
-                } else if (more) {
+                for (int st = 0; st < 4; ++st) {                        // step = (tap 2q + st/2, k-step st&1)
+                    const int cur = st & 1, nxt = cur ^ 1;
+                    asm volatile("" ::: "memory");
+                    if (st + 1 < 4) {
+                        const int t1 = 2 * q + ((st + 1) >> 1), k1 = (st + 1) & 1;
+                        const int toff = ((t1 >> 2) * LH + ((t1 >> 1) & 1)) * LH + (t1 & 1) + k1 * 4 * CH1;
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = wc[chunk_stride + colv[nb]];     // step 0 of the next chunk
+                        for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xb[aoff1[mb] + toff];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff1[nb] + (st + 1) * 4 * NCO];
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
                 }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
             }
             if (more) {
                 int tid_c = tid;
