@@ -140,6 +140,7 @@ def main():
     raw_dev = torch.from_numpy(raws).to(device)
 
     # dominant kernel: the 96->56 (nf=16) first conv of the retrieval backbone's last decoder, n = B*K*64 patches of 8^3
+    # (32 skip channels at 8^3 + 64 channels upsampled from 4^3: the parity-split kernel rf_conv3d_up_k3_gn_relu)
     nf = cfg['nf']
     dom_cin, dom_cout = 6 * nf, (6 * nf + nf) // 2
     ops.conv_event_filter = lambda cin, cout, edge, n: cin == dom_cin and cout == dom_cout and edge == 8 and n == B * K * 64
@@ -188,10 +189,15 @@ def main():
                                    'random-init weights' % (args.config, cfg['dataset_train']['dataset_name'], K, n_patches, 2 * K),
                        'chunks_per_gpu_per_step': B, 'db_patches': n_patches,
                        'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + RCCL all-gather of top-2K' % (world, world)},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_conv3_mfma<8^3 tile, 8 waves, MB4, NB4> (retrieval backbone %d->%d @8^3, %d patches)' % (dom_cin, dom_cout, B * K * 64),
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4> (retrieval backbone decoder conv %d+%d->%d @8^3: '
+                                   '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, %d patches)'
+                                   % (2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms, 'flops_per_launch': kern_flops,
-                         'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * 512 * (dom_cin + dom_cout)},
+                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms,
+                         'flops_per_launch': kern_flops,          # multiply-adds the kernel executes: 2*(27*c0 + 8*c1)*cout per voxel
+                         'direct_form_flops_per_launch': 2.0 * 27 * dom_cin * dom_cout * 512 * B * K * 64,
+                         'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * (2 * nf * 512 + 4 * nf * 64 + dom_cout * 512)},
         }
         if args.feature_cache and world == 1 and n_patches <= 200_000:
             # Reported separately, NEVER as `value`: optional serving mode that fetches per-database-row retrieval-backbone
