@@ -7,6 +7,7 @@
 // far too small and block-diagonal for MFMA; they run as wave-shuffle reductions, one wave per attention row, and
 // the kernel is HBM-bound (reads (1+K)*(d+f) floats, writes d floats per row).
 #include "common.h"
+#include "attn_row.h"
 
 // torch evaluates these expressions op by op (every product and sum rounded).  This file is built with
 // -ffp-contract=off (csrc/build.py): hipcc's default -ffp-contract=fast fuses a*b+c in the backend, where neither
@@ -105,7 +106,6 @@ extern "C" int rf_attn_gather_retrieved(const float* src, int src_layout, int b,
 }
 
 // ------------------------------------------------------------------------------------------------- fused attention
-#define RF_MAX_K 16
 
 __global__ __launch_bounds__(256) void k_attn_fuse(const float* __restrict__ x, const float* __restrict__ p, const float* __restrict__ xf,
                                                    const float* __restrict__ pf, const float* __restrict__ noise, int rows, int K, int d, int f,
@@ -113,82 +113,10 @@ __global__ __launch_bounds__(256) void k_attn_fuse(const float* __restrict__ x, 
                                                    float* __restrict__ weights_out) {
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
-        // ---- theta features, L2 normalised (F.normalize: v / max(||v||, 1e-12))
-        float xv[2];                                         // f <= 128
-        float n2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = lane + j * 64;
-            xv[j] = idx < f ? xf[(size_t)row * f + idx] : 0.f;
-            n2 += xv[j] * xv[j];
-        }
-        n2 = wave_sum(n2);
-        const float xden = fmaxf(sqrtf(n2), 1e-12f);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) xv[j] = xv[j] / xden;
-
-        // ---- scores against the K phi features
-        float sc[RF_MAX_K];
-        float smax = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < RF_MAX_K; ++k) {
-            if (k < K) {
-                float pv[2], pn2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int idx = lane + j * 64;
-                    pv[j] = idx < f ? pf[((size_t)row * K + k) * f + idx] : 0.f;
-                    pn2 += pv[j] * pv[j];
-                }
-                pn2 = wave_sum(pn2);
-                const float pden = fmaxf(sqrtf(pn2), 1e-12f);
-                float dot = 0.f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) dot += xv[j] * (pv[j] / pden);
-                dot = wave_sum(dot);
-                sc[k] = dot;
-                smax = fmaxf(smax, dot);
-            } else {
-                sc[k] = -INFINITY;
-            }
-        }
-        const float sw = fmaxf(smax, 0.f);                    // relu(max_k scores), model/attention.py:99
-
-        // ---- weights
-        float w[RF_MAX_K];
-        if (mode == RF_ATTN_SOFTMAX) {
-            // softmax(sharpness * scores): z = sharpness*s rounded first (no FMA contraction), then exp(z - zmax) as torch does
-            const float zmax = __fmul_rn(sharpness, smax);
-            float den = 0.f;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                w[k] = k < K ? expf(__fsub_rn(__fmul_rn(sharpness, sc[k]), zmax)) : 0.f;
-                den += w[k];
-            }
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) w[k] = w[k] / den;
-        } else {
-            // gumbel_softmax(logits = 25*scores, tau = 1, hard = True): y_hard - y_soft + y_soft
-            float lg[RF_MAX_K], lmax = -INFINITY;
-            int arg = 0;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                lg[k] = k < K ? __fadd_rn(__fmul_rn(sc[k], 25.f), noise[(size_t)row * K + k]) : -INFINITY;
-                if (lg[k] > lmax) { lmax = lg[k]; arg = k; }
-            }
-            float den = 0.f;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                w[k] = k < K ? expf(lg[k] - lmax) : 0.f;
-                den += w[k];
-            }
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                const float ys = w[k] / den;
-                const float yh = (k == arg) ? 1.f : 0.f;
-                w[k] = (yh - ys) + ys;
-            }
-        }
+        // ---- scores, switch, weights: every lane evaluates the row redundantly (uniform loads) with the arithmetic shared
+        // with the volume-domain route (rf_attn_row_weights), so the two routes agree bit for bit
+        float sc[RF_MAX_K], w[RF_MAX_K], sw;
+        rf_attn_row_weights(xf + (size_t)row * f, pf + (size_t)row * K * f, noise ? noise + (size_t)row * K : nullptr, K, f, mode, sharpness, sc, w, sw);
         if (lane < K) {
             // static indexing only (runtime-indexed register arrays go to scratch)
             float sv = 0.f, wv = 0.f;

@@ -17,6 +17,7 @@
 // 16*kb + 4*g + r makes that exactly register r of the previous D: the weight image is packed in the matching order
 // ([kb][ib][lane][r] = W[16*ib + (lane&15)][16*kb + 4*(lane>>4) + r]) and the activations are consumed where they are.
 #include "common.h"
+#include "attn_row.h"
 
 // The scalar arithmetic here restates torch expressions op by op (every product and sum rounded).  This file is built
 // with -ffp-contract=off (csrc/build.py): hipcc's default -ffp-contract=fast fuses a*b+c in the backend, where neither
@@ -261,94 +262,22 @@ extern "C" int rf_attn_mlp_volume(const float* src, int b, int kv, int c, int s,
 }
 
 // ------------------------------------------------------------------------------------------------ weights per row
-#define RF_MAX_K 16
-
-// same arithmetic, in the same order, as the first half of k_attn_fuse (attention.hip): one wave per row
+// one THREAD per attention row (a row is 32 + K*32 floats of features: nothing to share across lanes); the arithmetic is
+// rf_attn_row_weights, shared with k_attn_fuse
 __global__ __launch_bounds__(256) void k_attn_weights(const float* __restrict__ xf, const float* __restrict__ pf, const float* __restrict__ noise,
                                                       int rows, int K, int f, int mode, float sharpness, float* __restrict__ w_out,
                                                       float* __restrict__ sw_out, float* __restrict__ scores_out) {
-    const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
-        float xv[2];
-        float n2 = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int idx = lane + jj * 64;
-            xv[jj] = idx < f ? xf[(size_t)row * f + idx] : 0.f;
-            n2 += xv[jj] * xv[jj];
-        }
-        n2 = wave_sum(n2);
-        const float xden = fmaxf(sqrtf(n2), 1e-12f);
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) xv[jj] = xv[jj] / xden;
-
-        float sc[RF_MAX_K];
-        float smax = -INFINITY;
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        float sc[RF_MAX_K], w[RF_MAX_K], sw;
+        rf_attn_row_weights(xf + (size_t)row * f, pf + (size_t)row * K * f, noise ? noise + (size_t)row * K : nullptr, K, f, mode, sharpness, sc, w, sw);
 #pragma unroll
         for (int k = 0; k < RF_MAX_K; ++k) {
             if (k < K) {
-                float pv[2], pn2 = 0.f;
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int idx = lane + jj * 64;
-                    pv[jj] = idx < f ? pf[((size_t)row * K + k) * f + idx] : 0.f;
-                    pn2 += pv[jj] * pv[jj];
-                }
-                pn2 = wave_sum(pn2);
-                const float pden = fmaxf(sqrtf(pn2), 1e-12f);
-                float dot = 0.f;
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) dot += xv[jj] * (pv[jj] / pden);
-                dot = wave_sum(dot);
-                sc[k] = dot;
-                smax = fmaxf(smax, dot);
-            } else {
-                sc[k] = -INFINITY;
+                w_out[(size_t)row * K + k] = w[k];
+                if (scores_out) scores_out[(size_t)row * K + k] = sc[k];
             }
         }
-        const float sw = fmaxf(smax, 0.f);                    // relu(max_k scores), model/attention.py:99
-
-        float w[RF_MAX_K];
-        if (mode == RF_ATTN_SOFTMAX) {
-            const float zmax = __fmul_rn(sharpness, smax);
-            float den = 0.f;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                w[k] = k < K ? expf(__fsub_rn(__fmul_rn(sharpness, sc[k]), zmax)) : 0.f;
-                den += w[k];
-            }
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) w[k] = w[k] / den;
-        } else {
-            float lg[RF_MAX_K], lmax = -INFINITY;
-            int arg = 0;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                lg[k] = k < K ? __fadd_rn(__fmul_rn(sc[k], 25.f), noise[(size_t)row * K + k]) : -INFINITY;
-                if (lg[k] > lmax) { lmax = lg[k]; arg = k; }
-            }
-            float den = 0.f;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                w[k] = k < K ? expf(lg[k] - lmax) : 0.f;
-                den += w[k];
-            }
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k) {
-                const float ys = w[k] / den;
-                const float yh = (k == arg) ? 1.f : 0.f;
-                w[k] = (yh - ys) + ys;
-            }
-        }
-        if (lane < K) {
-            float sv = 0.f, wv = 0.f;
-#pragma unroll
-            for (int k = 0; k < RF_MAX_K; ++k)
-                if (k == lane) { sv = sc[k]; wv = w[k]; }
-            w_out[(size_t)row * K + lane] = wv;
-            if (scores_out) scores_out[(size_t)row * K + lane] = sv;
-        }
-        if (lane == 0) sw_out[row] = sw;
+        sw_out[row] = sw;
     }
 }
 
@@ -358,7 +287,7 @@ extern "C" int rf_attn_weights(const float* xf, const float* pf, const float* no
     RF_REQUIRE(k >= 1 && k <= RF_MAX_K, RF_E_UNSUPPORTED, "rf_attn_weights: K=%d outside 1..%d", k, RF_MAX_K);
     RF_REQUIRE(f >= 1 && f <= 128, RF_E_UNSUPPORTED, "rf_attn_weights: feature width %d outside 1..128", f);
     RF_REQUIRE(mode == RF_ATTN_SOFTMAX || (mode == RF_ATTN_GUMBEL_HARD && noise), RF_E_INVALID, "rf_attn_weights: Gumbel-hard mode needs the noise tensor");
-    const int want = (rows + 3) / 4;
+    const int want = (rows + 255) / 256;
     hipLaunchKernelGGL(k_attn_weights, dim3(want < 8192 ? want : 8192), dim3(256), 0, (hipStream_t)stream, xf, pf, noise, rows, k, f, mode, sharpness,
                        weights, switches, scores_out);
     RF_CHECK_LAUNCH("rf_attn_weights");

@@ -23,7 +23,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objdir = HERE / 'build'
     objdir.mkdir(exist_ok=True)
-    headers = [HERE / 'common.h', HERE.parents[1] / 'include' / 'rfuse.h']
+    headers = [HERE / 'common.h', HERE / 'attn_row.h', HERE.parents[1] / 'include' / 'rfuse.h']
 
     def compile_one(src):
         obj = objdir / (src.replace('.hip', '.o'))
