@@ -107,6 +107,16 @@ int rf_conv3d_valid_leaky_mfma(const float* x, int n, int cin, int s, const floa
 int rf_convv_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream);
 size_t rf_convv_packed_floats(int cout, int cin, int k);
 
+/* rf_conv3d_k3_gn_relu with the encoder's MaxPool3d(2) (model/unet.py:230-253) fused into the epilogue: additionally
+ * writes pool_out [n][cout][(edge/2)^3] = maxpool2(out) and, when pool_stats is non-NULL, its (sum, sum of squares)
+ * [n][cout][rf_conv3d_stats_tiles(...)][2] for rf_gn_from_stats.  out == NULL: only the pooled tensor is written (an
+ * encoder level whose full-resolution output nobody reads: UNet3D with remove_n_final_layers, model/unet.py:500-507);
+ * stats must then be NULL.  Only shapes with rf_conv3d_pool_supported(...) == 1 (the 8^3-box tiling). */
+int rf_conv3d_pool_supported(int c0, int c1, int n, int edge, int cout);
+int rf_conv3d_k3_gn_relu_pool(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                              const float* scale, const float* shift, const float* w_packed, int cout,
+                              float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
+
 /* Decoder form of rf_conv3d_k3_gn_relu (model/unet.py:297-308: nearest x2 upsample of the low-res source, concat after
  * the skip source, then SingleConv 'gcr'): same inputs and result, but the c1 upsampled channels are convolved in LOW
  * resolution -- per output parity the 27 taps collapse to 2x2x2 taps with pre-summed weights (8/27 of the multiply-adds

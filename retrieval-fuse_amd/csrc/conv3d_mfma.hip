@@ -37,6 +37,29 @@ struct ConvArgs {
     int ablate;        // dev knob (RFUSE_CONV_ABLATE): 1 = stage only the first chunk, 2 = skip the MFMA loop
     double2* stats;    // optional [n][cout][stats_tiles] (sum, sum of squares) of the ReLU'd output, per workgroup tile
     int stats_tiles;
+    // fused MaxPool3d(2) of the output (8^3 boxes only): pool_out [n][cout][(edge/2)^3] and its statistics
+    // [n][cout][stats_tiles]; pool_mode 0 = off, 1 = write both, 2 = pooled only (`out` is not written: an encoder level
+    // whose full-resolution output nobody reads, model/unet.py:500-507 with remove_n_final_layers)
+    float* pool_out;
+    double2* pool_stats;
+    int pool_mode;
+};
+
+// Voxel order inside the 8^3 box of the 8-wave x MB 4 tile: m = wave*64 + mb*16 + i -> (z, y, x) such that one lane's
+// accumulators (mb = 0..3, rows r = 0..3 of its lane group) hold whole 2x2x2 pooling cells up to one lane exchange:
+//   x = i & 7, y = 4*(wave & 1) + 2*(mb >> 1) + (i >> 3), z = 2*(wave >> 1) + (mb & 1)
+// (z pairs in mb, x pairs in r, y pairs in lanes l / l^32).  Other tiles keep the plain row-major order.
+template <int TZ, int TY, int TX, int NW, int MB>
+struct BoxOrder {
+    static constexpr bool POOLABLE = TZ == 8 && TY == 8 && TX == 8 && NW == 8 && MB == 4;
+    __device__ static __forceinline__ void voxel(int wave, int mb, int i, int& s, int& z, int& y, int& x) {
+        if (POOLABLE) {
+            s = 0; x = i & 7; y = 4 * (wave & 1) + 2 * (mb >> 1) + (i >> 3); z = 2 * (wave >> 1) + (mb & 1);
+        } else {
+            const int m = wave * (MB * 16) + mb * 16 + i;
+            x = m % TX; y = (m / TX) % TY; z = (m / (TX * TY)) % TZ; s = m / (TX * TY * TZ);
+        }
+    }
 };
 
 // Workgroups are handed to the 8 XCDs round-robin by linear id, each XCD with its own L2.  Tiles that split a sample
@@ -98,8 +121,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     int aoff[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-        const int m = wave * (MB * 16) + mb * 16 + (lane & 15);
-        const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ, s = m / (TX * TY * TZ);
+        int s, z, y, x;
+        BoxOrder<TZ, TY, TX, NW, MB>::voxel(wave, mb, lane & 15, s, z, y, x);
         aoff[mb] = s * (CC * CH) + (z * HY + y) * HX + x + (lane >> 4) * CH;
     }
     // slab row r = tap*4 + k holds cout column col at float (col + ROT*(r&1)) % NCO: rows k and k+1 on different banks
@@ -285,17 +308,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     const size_t vol = (size_t)edge * edge * edge;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-        const int m = wave * (MB * 16) + mb * 16 + (lane >> 4) * 4;
-        const int s = m / (TX * TY * TZ);
+        int s, z, y, x;
+        BoxOrder<TZ, TY, TX, NW, MB>::voxel(wave, mb, (lane >> 4) * 4, s, z, y, x);
         const int nn = n0 + s;
         size_t off;
         if (TX >= 4) {
-            const int x = m % TX, y = (m / TX) % TY, z = (m / (TX * TY)) % TZ;
             off = ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x);
         } else {
-            off = (size_t)(m % (TX * TY * TZ));       // tile == whole volume: voxel order is memory order
+            off = (size_t)((wave * (MB * 16) + mb * 16 + (lane >> 4) * 4) % (TX * TY * TZ));   // tile == whole volume: voxel order is memory order
         }
-        if (nn < a.n) {
+        if (nn < a.n && a.pool_mode != 2) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int co = cob + nb * 16 + (lane & 15);
@@ -372,6 +394,64 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
                     sq = red[(((size_t)w * SLOTS + slot) * NCO + col) * 2 + 1];
                 }
                 a.stats[((size_t)nn * a.cout + co) * a.stats_tiles + tile] = make_double2(sm, sq);
+            }
+        }
+    }
+
+    // ---- optional: fused MaxPool3d(2) of the ReLU'd box and the pooled tensor's GroupNorm statistics (8^3 boxes).  A lane's
+    // accumulators hold the z pair (mb, mb+1) and the x pairs (r) of its pooling cells; the y pair sits in lane ^ 32.
+    if constexpr (BoxOrder<TZ, TY, TX, NW, MB>::POOLABLE) {
+        if (a.pool_mode) {
+            const int hedge = edge >> 1, kq = lane >> 4;
+            const size_t pvol = (size_t)hedge * hedge * hedge;
+            double* red = reinterpret_cast<double*>(smem);      // [NW][NCO][2]
+            if (a.stats) __syncthreads();                       // the statistics block above may still be reading `red`
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int co = cob + nb * 16 + (lane & 15);
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int yh = 0; yh < 2; ++yh) {
+                    const f32x4 u = acc[2 * yh][nb], v = acc[2 * yh + 1][nb];
+                    float p0 = fmaxf(fmaxf(u[0], u[1]), fmaxf(v[0], v[1]));
+                    float p1 = fmaxf(fmaxf(u[2], u[3]), fmaxf(v[2], v[3]));
+                    p0 = fmaxf(p0, __shfl_xor(p0, 32, 64));
+                    p1 = fmaxf(p1, __shfl_xor(p1, 32, 64));
+                    p0 = fmaxf(p0, 0.f);                        // max and ReLU commute
+                    p1 = fmaxf(p1, 0.f);
+                    if (kq < 2) {
+                        sm += (double)p0 + (double)p1;
+                        sq += (double)p0 * (double)p0 + (double)p1 * (double)p1;
+                        if (co < a.cout) {
+                            const int pz = (z0 >> 1) + (wave >> 1), py = (y0 >> 1) + 2 * (wave & 1) + yh, px = (x0 >> 1) + 2 * kq;
+                            *reinterpret_cast<float2*>(a.pool_out + ((size_t)n0 * a.cout + co) * pvol + ((size_t)pz * hedge + py) * hedge + px) =
+                                make_float2(p0, p1);
+                        }
+                    }
+                }
+                if (a.pool_stats) {
+                    sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);       // the two x halves (lane groups 0 and 1)
+                    if (lane < 16) {
+                        red[((size_t)wave * NCO + nb * 16 + lane) * 2] = sm;
+                        red[((size_t)wave * NCO + nb * 16 + lane) * 2 + 1] = sq;
+                    }
+                }
+            }
+            if (a.pool_stats) {
+                __syncthreads();
+                const int tile = (int)(lblock % ((edge / TZ) * (edge / TY) * (edge / TX)));
+                for (int col = tid; col < NCO; col += NT) {
+                    const int co = cob + col;
+                    if (co < a.cout) {
+                        double sm = 0.0, sq = 0.0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            sm += red[((size_t)w * NCO + col) * 2];
+                            sq += red[((size_t)w * NCO + col) * 2 + 1];
+                        }
+                        a.pool_stats[((size_t)n0 * a.cout + co) * a.stats_tiles + tile] = make_double2(sm, sq);
+                    }
+                }
             }
         }
     }
@@ -534,10 +614,11 @@ extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) 
 
 static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                        const float* scale, const float* shift, const float* w_packed, int cout,
-                       float* out, double* stats, void* stream) {
+                       float* out, double* stats, void* stream, float* pool_out = nullptr, double* pool_stats = nullptr, int pool_mode = 0) {
     RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "rf_conv3d_k3_gn_relu: bad sizes");
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_conv3d_k3_gn_relu: edge %d must be a power of two <= 128", edge);
-    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w_packed && out, RF_E_INVALID, "rf_conv3d_k3_gn_relu: null pointer");
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w_packed && (out || pool_mode == 2), RF_E_INVALID,
+               "rf_conv3d_k3_gn_relu: null pointer");
     RF_REQUIRE(edge >= 2, RF_E_UNSUPPORTED, "rf_conv3d_k3_gn_relu: 1^3 volumes take the direct path (rf_conv3d_k3_gn_relu_direct)");
     ConvArgs a;
     a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
@@ -546,7 +627,8 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     static const int abl = getenv("RFUSE_CONV_ABLATE") ? atoi(getenv("RFUSE_CONV_ABLATE")) : 0;
     a.ablate = abl;
     a.stats = reinterpret_cast<double2*>(stats);
-    a.stats_tiles = stats ? rf_conv3d_stats_tiles(c0, c1, n, edge, cout) : 0;
+    a.stats_tiles = (stats || pool_stats) ? rf_conv3d_stats_tiles(c0, c1, n, edge, cout) : 0;
+    a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats); a.pool_mode = pool_mode;
     hipStream_t s = (hipStream_t)stream;
     if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
@@ -564,6 +646,21 @@ extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1
                                     const float* scale, const float* shift, const float* w_packed, int cout,
                                     float* out, void* stream) {
     return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, nullptr, stream);
+}
+
+// fused MaxPool3d(2): only the 8^3-box tiling (edge >= 8, enough boxes, not the cin == 1 kernel) holds whole pooling cells
+extern "C" int rf_conv3d_pool_supported(int c0, int c1, int n, int edge, int cout) {
+    return edge >= 8 && rf_is_pow2(edge) && edge <= 128 && !conv_use_cin1(c0, c1, edge, cout) && conv_use_big(n, edge, rf_round_up(cout, 16));
+}
+
+extern "C" int rf_conv3d_k3_gn_relu_pool(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                         const float* scale, const float* shift, const float* w_packed, int cout,
+                                         float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
+    RF_REQUIRE(pool_out, RF_E_INVALID, "rf_conv3d_k3_gn_relu_pool: null pooled output");
+    RF_REQUIRE(rf_conv3d_pool_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_k3_gn_relu_pool: shape not on the 8^3-box tiling (ask rf_conv3d_pool_supported)");
+    RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_k3_gn_relu_pool: statistics of an output that is not written");
+    return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, stats, stream, pool_out, pool_stats, out ? 1 : 2);
 }
 
 extern "C" int rf_conv3d_k3_gn_relu_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,

@@ -80,19 +80,28 @@ class SingleConv(nn.Module):
         self.groupnorm = GroupNormParams(num_groups, in_channels)
         self.conv = Conv3dParams(in_channels, out_channels, 3, bias=False, padding=1)
 
-    def forward(self, x, upsampled=None, _direct=False):
+    def forward(self, x, upsampled=None, _direct=False, pool=None):
         """x: full-resolution source [N,C0,S,S,S] or None; ``upsampled``: low-resolution source [N,C1,S/2,S/2,S/2] that the
-        reference would nearest-upsample and concatenate after x (model/unet.py:297-308)."""
+        reference would nearest-upsample and concatenate after x (model/unet.py:297-308).
+
+        ``pool``: None -> returns the output; 'also' / 'only' -> returns (output, MaxPool3d(2)(output)) with the pooling
+        fused into the conv epilogue where the tiling allows ('only': the caller never reads the full-resolution output, which
+        is then not written at all and returned as None)."""
         ops._no_grad_only(x, upsampled, self.conv.weight)
         gn = self.groupnorm
+        cout = self.conv.out_channels
         scale, shift = ops.gn_scale_shift(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
+        if pool is not None and upsampled is None and not _direct and edge >= 8 and ops.conv_pool_supported(x, None, cout):
+            return ops.conv3d_gn_relu_pool(x, None, scale, shift, self.conv.packed(), cout, keep_full=(pool == 'also'))
         if _direct or edge == 1:
-            return ops.conv3d_gn_relu(x, upsampled, scale, shift, None, self.conv.out_channels, direct_weight=self.conv.weight)
-        if ops.conv_up_supported(x, upsampled, self.conv.out_channels):
+            out = ops.conv3d_gn_relu(x, upsampled, scale, shift, None, cout, direct_weight=self.conv.weight)
+        elif ops.conv_up_supported(x, upsampled, cout):
             c0 = x.shape[1] if x is not None else 0
-            return ops.conv3d_up_gn_relu(x, upsampled, scale, shift, self.conv.packed_up(c0), self.conv.out_channels)
-        return ops.conv3d_gn_relu(x, upsampled, scale, shift, self.conv.packed(), self.conv.out_channels)
+            out = ops.conv3d_up_gn_relu(x, upsampled, scale, shift, self.conv.packed_up(c0), cout)
+        else:
+            out = ops.conv3d_gn_relu(x, upsampled, scale, shift, self.conv.packed(), cout)
+        return out if pool is None else (out, ops.maxpool2(out))
 
 
 class DoubleConv(nn.Module):
@@ -109,8 +118,8 @@ class DoubleConv(nn.Module):
         self.SingleConv1 = SingleConv(c1_in, c1_out, kernel_size, order, num_groups)
         self.SingleConv2 = SingleConv(c2_in, c2_out, kernel_size, order, num_groups)
 
-    def forward(self, x, upsampled=None):
-        return self.SingleConv2(self.SingleConv1(x, upsampled))
+    def forward(self, x, upsampled=None, pool=None):
+        return self.SingleConv2(self.SingleConv1(x, upsampled), pool=pool)
 
 
 class StepDownDoubleConv(nn.Module):
@@ -139,10 +148,11 @@ class Encoder(nn.Module):
         self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
                                          order=conv_layer_order, num_groups=num_groups)
 
-    def forward(self, x):
+    def forward(self, x, prepooled=None, pool=None):
+        """``prepooled``: MaxPool3d(2)(x) when the producer already emitted it (fused epilogue); ``pool``: see SingleConv.forward."""
         if self.apply_pooling:
-            x = ops.maxpool2(x)
-        return self.basic_module(x)
+            x = prepooled if prepooled is not None else ops.maxpool2(x)
+        return self.basic_module(x, pool=pool) if pool is not None else self.basic_module(x)
 
 
 class Decoder(nn.Module):
@@ -205,8 +215,17 @@ class UNet3D(nn.Module):
 
     def forward(self, x):
         feats = []
-        for encoder in self.encoders:
-            x = encoder(x)
+        n_enc, n_dec = len(self.encoders), len(self.decoders)
+        pooled = None
+        for i, encoder in enumerate(self.encoders):
+            # Who reads this level's full-resolution output?  The next level reads MaxPool3d(2) of it; a decoder reads it as
+            # a skip only for levels n_enc-1-n_dec .. n_enc-2 (model/unet.py:500-507: the list is cut and zip() truncates, so
+            # with remove_n_final_layers the finest levels are never joined).  Unread outputs are not even written.
+            if i == n_enc - 1:
+                x, pooled = encoder(x, prepooled=pooled), None
+            else:
+                is_skip = i >= n_enc - 1 - n_dec
+                x, pooled = encoder(x, prepooled=pooled, pool='also' if is_skip else 'only')
             feats.insert(0, x)
         feats = feats[1:]                                            # model/unet.py:500-504
         for decoder, skip in zip(self.decoders, feats):              # zip truncates, model/unet.py:507

@@ -169,6 +169,39 @@ def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None)
     return out
 
 
+USE_FUSED_POOL = True           # False: encoders always run the stand-alone max-pool kernel
+
+
+def conv_pool_supported(src0, src1, cout):
+    """True when rf_conv3d_k3_gn_relu_pool (MaxPool3d(2) fused into the conv epilogue) takes this shape."""
+    if not USE_FUSED_POOL:
+        return False
+    n, c0, c1, edge = _src_dims(src0, src1)
+    return bool(_lib.load().rf_conv3d_pool_supported(c0, c1, n, edge, cout))
+
+
+def conv3d_gn_relu_pool(src0, src1, scale, shift, w_packed, cout, keep_full=True):
+    """(ReLU(conv3(GN(x))) or None, its MaxPool3d(2)); with keep_full=False the full-resolution tensor is never written."""
+    n, c0, c1, edge = _src_dims(src0, src1)
+    dev = scale.device
+    lib = _lib.load()
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if keep_full else None
+    pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev)
+    stats = pstats = None
+    if USE_FUSED_STATS:
+        tiles = lib.rf_conv3d_stats_tiles(c0, c1, n, edge, cout)
+        pstats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev)
+        if keep_full:
+            stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev)
+    _lib.check(lib.rf_conv3d_k3_gn_relu_pool(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out), _p(stats),
+                                             _p(pooled), _p(pstats), _stream()), 'rf_conv3d_k3_gn_relu_pool')
+    if stats is not None:
+        out._rf_stats = (stats, tiles, out._version)
+    if pstats is not None:
+        pooled._rf_stats = (pstats, tiles, pooled._version)
+    return out, pooled
+
+
 def pack_conv3_up_weight(w, c0):
     """Weight image of the decoder-form conv: the first c0 input channels are the skip source, the rest the upsampled one."""
     _req(w.detach(), 'conv weight')

@@ -141,6 +141,34 @@ def test_conv3d_up_parity_split_decoder_kernel(ops, case):
     close(fused[1], plain[1], 1e-6, 'shift from fused stats')
 
 
+@pytest.mark.parametrize('case', [(300, 8, 16, 16, 8), (1100, 16, 8, 32, 8), (2, 16, 64, 16, 8), (130, 6, 16, 12, 6), (520, 16, 8, 72, 8)])
+def test_conv_with_fused_maxpool_epilogue(ops, case):
+    """rf_conv3d_k3_gn_relu_pool == conv followed by the stand-alone MaxPool3d(2) kernel, bit for bit, with and without the
+    full-resolution output; the pooled tensor's fused statistics give the same GroupNorm fold as re-reading it."""
+    n, cin, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = rnd(gen, n, cin, edge, edge, edge).relu_().to(DEV)
+    gamma, beta = (1 + 0.2 * rnd(gen, cin)).to(DEV), (0.2 * rnd(gen, cin)).to(DEV)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin)).to(DEV)
+    sc, sh = ops.gn_scale_shift(x, None, gamma, beta, groups)
+    wp = ops.pack_conv3_weight(w)
+    assert ops.conv_pool_supported(x, None, cout)
+    plain = ops.conv3d_gn_relu(x, None, sc, sh, wp, cout)
+    want_pool = ops.maxpool2(plain)
+    full, pooled = ops.conv3d_gn_relu_pool(x, None, sc, sh, wp, cout, keep_full=True)
+    assert torch.equal(full, plain) and torch.equal(pooled, want_pool)
+    none, pooled_only = ops.conv3d_gn_relu_pool(x, None, sc, sh, wp, cout, keep_full=False)
+    assert none is None and torch.equal(pooled_only, want_pool)
+    g = groups if cout % groups == 0 else 1
+    g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+    for t in (pooled, pooled_only, full):
+        assert getattr(t, '_rf_stats', None) is not None
+        fused = ops.gn_scale_shift(t, None, g2, b2, g)
+        reread = ops.gn_scale_shift(t.clone(), None, g2, b2, g)
+        close(fused[0], reread[0], 1e-6, 'scale from fused stats')
+        close(fused[1], reread[1], 1e-6, 'shift from fused stats')
+
+
 def test_conv_identity_weight_is_transpose_detecting(ops):
     """centre-tap identity on an asymmetric ramp: catches swapped voxel axes / channel transposes exactly."""
     n, c, edge = 1, 16, 8
