@@ -98,7 +98,7 @@ def cpu_baseline(cfg, eng_state, db_host, raws, target_s=15.0, n_chunks=0):
         if best_t is None or t1 < best_t:
             best_t, best_threads = t1, threads
     torch.set_num_threads(best_threads)
-    n = n_chunks or int(max(4, min(64, round(target_s / max(best_t, 1e-3)))))
+    n = n_chunks or int(max(4, min(160, round(target_s / max(best_t, 1e-3)))))
     t0 = time.perf_counter()
     for i in range(n):
         one_chunk(raws[i % len(raws)])
