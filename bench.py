@@ -25,6 +25,10 @@ for p in (str(REPO), str(REPO / 'retrieval-fuse_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# The engine runs the U-Net backbone on a second HIP stream next to the retrieval path.  ROCm maps streams onto
+# GPU_MAX_HW_QUEUES (default 4) hardware queues; once RCCL has created its own streams the two compute streams can land
+# on the same queue and serialise (measured: -5.5 % with a process group initialised, back to par with 8 queues).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np
 import torch
@@ -120,7 +124,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback for the hot path)'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get('RFUSE_FORCE_DIST') in ('1', '2') and 'RANK' in os.environ   # dev: exercise RCCL with one rank
+    if world > 1 or force_dist:
         dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
 
     from rfuse import configs, ops, synthetic
@@ -134,6 +139,7 @@ def main():
     torch.manual_seed(0)
     emb, meta, vols = synthetic_database(cfg, n_patches, device)
     database = PatchDatabase(emb, meta, vols, device, rank, world)
+    database.force_collectives = force_dist and os.environ.get('RFUSE_FORCE_DIST') == '1'
     eng = RefinementEngine(cfg, device, database)
     # every rank refines its own B chunks (chunk-parallel replicas); inputs resident in HBM
     raws = np.stack([synthetic.make_chunk(10_000 + rank * B + b, cfg)['input_raw'] for b in range(B)])
@@ -146,7 +152,7 @@ def main():
     ops.conv_event_filter = lambda cin, cout, edge, n: cin == dom_cin and cout == dom_cout and edge == 8 and n == B * K * 64
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -162,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert torch.isfinite(df).all()
@@ -220,7 +226,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

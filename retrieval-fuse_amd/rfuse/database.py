@@ -111,6 +111,7 @@ class PatchDatabase:
         self.n_rows = emb.shape[0]
         self.dim = emb.shape[1]
         self.rank, self.world, self.group = rank, world, group
+        self.force_collectives = False          # dev/test: run the all-gather + merge protocol even with one rank
         self.lo, self.hi = shard_bounds(self.n_rows, rank, world)
         self.device = torch.device(device)
         shard = emb[self.lo:self.hi].to(self.device, torch.float32).contiguous()
@@ -154,7 +155,7 @@ class PatchDatabase:
     def search(self, q, k2):
         """Top-k2 over the whole database for this rank's queries.  One process: a single scan.  W processes:
         all-gather(queries) -> shard scans -> all-gather(candidates) -> merge."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return self.local_topk(q, k2)
         return allgather_merge(q, lambda qa: self.local_topk(qa, k2), ops.topk_merge, k2, self.group)
 
