@@ -107,6 +107,7 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
 // registers (list j: entry i in lane i of e[j]).  The first block initialises a list with a wave-wide sort; afterwards a
 // row enters only if it beats the list's current worst (ballot), which becomes rare quickly (~K2/b hits for block b).
 #define RF_QW (RF_TQ / 4)
+typedef float rf_f32x2 __attribute__((ext_vector_type(2)));
 template <int K2>
 __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, int nq, const float* __restrict__ db, long long n,
                                                  unsigned row_base, int blocks_per_slice, u64* __restrict__ parts) {
@@ -124,10 +125,12 @@ __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, in
 
     for (long long blk = blk_lo; blk < blk_hi; ++blk) {
         // this lane's DB row: 64 coalesced loads, one per dim (the 4 waves read the same block: L1/L2 hits)
-        float x[RF_DIM];
+        // kept as register PAIRS: the distance loop runs on the packed-fp32 VALU (v_pk_add_f32 / v_pk_fma_f32: two dims per
+        // instruction), queries as scalar-register pairs
+        rf_f32x2 x[RF_DIM / 2];
         const float* bp = db + (size_t)blk * RF_DIM * 64 + lane;
 #pragma unroll
-        for (int d = 0; d < RF_DIM; ++d) x[d] = bp[d * 64];
+        for (int d = 0; d < RF_DIM / 2; ++d) x[d] = (rf_f32x2){bp[(2 * d) * 64], bp[(2 * d + 1) * 64]};
         const long long row = blk * 64 + lane;
         const bool valid = row < n;
         const unsigned grow = row_base + (unsigned)row;
@@ -138,14 +141,14 @@ __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, in
             const int qi = q0 + j;
             if (qi < nq) {                                           // wave-uniform
                 const float* qp = q + (size_t)qi * RF_DIM;           // wave-uniform address -> scalar loads
-                float a0 = 0.f, a1 = 0.f;
+                rf_f32x2 acc = {0.f, 0.f};                           // even / odd dims: two independent fp32 FMA chains
 #pragma unroll
-                for (int d = 0; d < RF_DIM; d += 2) {
-                    const float t0 = qp[d] - x[d], t1 = qp[d + 1] - x[d + 1];
-                    a0 = fmaf(t0, t0, a0);
-                    a1 = fmaf(t1, t1, a1);
+                for (int d = 0; d < RF_DIM / 2; ++d) {
+                    const rf_f32x2 qv = {qp[2 * d], qp[2 * d + 1]};
+                    const rf_f32x2 t = qv - x[d];
+                    acc = __builtin_elementwise_fma(t, t, acc);
                 }
-                const u64 key = valid ? make_key(a0 + a1, grow) : RF_KEY_NONE;
+                const u64 key = valid ? make_key(acc[0] + acc[1], grow) : RF_KEY_NONE;
                 if (first) {
                     const u64 sorted = wave_sort64(key, lane);
                     e[j] = lane < K2 ? sorted : RF_KEY_NONE;
