@@ -172,3 +172,39 @@ def test_feature_cache_mode_matches_full_path(gpu):
     assert tuple(cache.shape) == (64 * 6 + 11, cfg['nf'], 8, 8, 8)
     cached = eng.refine(x, use_feature_cache=True)
     assert maxerr(cached.cpu(), full.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize('cfg_name,B', [('C1', 8), ('C3', 8), ('C4', 4), ('C5', 4)])
+def test_engine_fast_routes_match_plain_routes_at_bench_sizes(gpu, cfg_name, B):
+    """At batch sizes where the big-tile kernels engage (parity-split decoder conv, fused max-pool / pooled-only encoder
+    levels, volume-domain attention with the fused MLP), the engine must give the same field as the plain routes
+    (generic conv on the virtually upsampled source, stand-alone max-pool, per-layer linear + row-domain attention)."""
+    from rfuse import ops
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config(cfg_name)
+    _, trunc_t = rf_configs.truncations(cfg)
+    db = synthetic.make_database(5, cfg, 64 * 30)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {}
+    for name, m in eng.modules().items():
+        sds[name] = helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 77 + len(name))
+    eng.load_state_dicts(sds)
+    raws = np.stack([synthetic.make_chunk(4000 + b, cfg)['input_raw'] for b in range(B)])
+    x = torch.from_numpy(raws).to(gpu)
+    rows = B * cfg['attn_num_patch'] ** 3
+    noise = None
+    if cfg['attn_retrieval_mode']:
+        # large noise: the Gumbel-hard arg-max cannot flip on the ~1e-6 feature differences between the two MLP forms
+        noise = (-torch.empty(rows, cfg['K']).exponential_(generator=torch.Generator().manual_seed(1)).log() * 4.0).to(gpu)
+    fast = eng.refine(x, gumbel_noise=noise)
+    saved = (ops.USE_CONV_UP, ops.USE_FUSED_POOL, ops.USE_FUSED_ATTN_MLP)
+    ops.USE_CONV_UP, ops.USE_FUSED_POOL, ops.USE_FUSED_ATTN_MLP = False, False, False
+    try:
+        plain = eng.refine(x, gumbel_noise=noise)
+    finally:
+        ops.USE_CONV_UP, ops.USE_FUSED_POOL, ops.USE_FUSED_ATTN_MLP = saved
+    assert torch.isfinite(fast).all()
+    err = maxerr(fast.cpu(), plain.cpu())
+    print(f'\n{cfg_name} B={B}: fast vs plain routes df max abs diff {err:.2e} (trunc {trunc_t})')
+    assert err <= 0.2 * df_tolerance(trunc_t)
