@@ -22,6 +22,7 @@
 // was only 78 % busy on its own.  Small problems take 4 waves x MB=2 (128 voxels) to fill the chip.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((address_space(1))) const void* rf_gptr;
 typedef __attribute__((address_space(3))) void* rf_lptr;
@@ -124,6 +125,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
         int s, z, y, x;
         BoxOrder<TZ, TY, TX, NW, MB>::voxel(wave, mb, lane & 15, s, z, y, x);
         aoff[mb] = s * (CC * CH) + (z * HY + y) * HX + x + (lane >> 4) * CH;
+    }
+    // which of this wave's m-blocks lie on the first / last z slice of the volume (wave-uniform bit masks over mb).  All 16
+    // voxels of an m-block share z in the pooling order of the 8^3 box and when a z slice of the tile is a multiple of 16
+    // voxels.  ZSKIP_LO / ZSKIP_HI are the only non-empty masks the tile shape can produce (see the MFMA loop).
+    constexpr bool ZUNIFORM = BoxOrder<TZ, TY, TX, NW, MB>::POOLABLE || (TX * TY) % 16 == 0;
+    constexpr unsigned ZSKIP_LO = !ZUNIFORM ? 0u : BoxOrder<TZ, TY, TX, NW, MB>::POOLABLE ? 0x5u : (TX * TY == 16 ? 0x1u : (1u << MB) - 1u);
+    constexpr unsigned ZSKIP_HI = !ZUNIFORM ? 0u : BoxOrder<TZ, TY, TX, NW, MB>::POOLABLE ? 0xAu : (TX * TY == 16 ? (1u << (MB - 1)) : (1u << MB) - 1u);
+    unsigned zlo_mask = 0u, zhi_mask = 0u;
+    if (ZUNIFORM && a.ablate != 3) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            int s, z, y, x;
+            BoxOrder<TZ, TY, TX, NW, MB>::voxel(wave, mb, 0, s, z, y, x);
+            if (z0 + z == 0) zlo_mask |= 1u << mb;
+            if (z0 + z == edge - 1) zhi_mask |= 1u << mb;
+        }
     }
     // slab row r = tap*4 + k holds cout column col at float (col + ROT*(r&1)) % NCO: rows k and k+1 on different banks
     constexpr int ROT = NCO >= 32 ? 16 : 0;
@@ -251,6 +268,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     commit_rows(0, tid);
     __syncthreads();                                       // also drains the DMA (vmcnt(0) before the barrier)
 
+    // K loop + epilogue, instantiated per z-border variant of this wave (see the MFMA loop); barriers match across variants
+    auto run = [&](auto lo_c, auto hi_c) {
+    constexpr unsigned LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     int buf = 0;
     for (int cbase = 0; cbase < cin; cbase += CC) {
         const bool more = cbase + CC < cin && a.ablate != 1;
@@ -264,33 +284,43 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
         }
         if (a.ablate != 2) {
             const float* ws = wsb + buf * T::WSLAB_PAD;
-            // operand reads of tap t+1 are issued before the MFMAs of tap t (explicit double buffering: left to itself
-            // hipcc emits read -> s_waitcnt lgkmcnt(0) -> MFMAs per tap pair and exposes the whole LDS latency)
-            constexpr int KS = CC / 4;                         // MFMA k-steps per tap
-            float av[2][MB], bv[2][NB];
+            // The 27-tap MFMA loop, specialised at compile time on which m-blocks skip their dz = -1 (LO) / dz = +1 (HI) taps:
+            // an m-block on the first / last z slice of the VOLUME reads nothing but zero padding through those taps, so the
+            // MFMAs would add exact zeros -- same result bit for bit, 1/3 of that m-block's work saved.  LO / HI are
+            // parameters of the enclosing `run` lambda: the whole K loop + epilogue is instantiated per variant, because a
+            // run-time test (or a per-chunk variant switch) makes hipcc shuffle the accumulators through copies at every join.
+            {
+                // operand reads of tap t+1 are issued before the MFMAs of tap t (explicit double buffering: left to itself
+                // hipcc emits read -> s_waitcnt lgkmcnt(0) -> MFMAs per tap pair and exposes the whole LDS latency)
+                constexpr int KS = CC / 4;                         // MFMA k-steps per tap
+                float av[2][MB], bv[2][NB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff[mb]];
+                for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff[mb]];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bv[0][nb] = ws[boff[nb]];
+                for (int nb = 0; nb < NB; ++nb) bv[0][nb] = ws[boff[nb]];
 #pragma unroll
-            for (int st = 0; st < 27 * KS; ++st) {             // step = (tap, k-step)
-                const int cur = st & 1, nxt = cur ^ 1;
-                // keep the operand reads of later taps out of this step: left alone, hipcc pairs reads of neighbouring taps
-                // into ds_read2 far ahead of their use (long live ranges: +30..50 VGPRs, spills in the parity-split kernel)
-                asm volatile("" ::: "memory");
-                if (st + 1 < 27 * KS) {
-                    const int t1 = (st + 1) / KS, k1 = (st + 1) % KS;
-                    const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 + k1 * 4 * CH;
+                for (int st = 0; st < 27 * KS; ++st) {             // step = (tap, k-step)
+                    const int cur = st & 1, nxt = cur ^ 1;
+                    // keep the operand reads of later taps out of this step: left alone, hipcc pairs reads of neighbouring taps
+                    // into ds_read2 far ahead of their use (long live ranges: +30..50 VGPRs, spills in the parity-split kernel)
+                    asm volatile("" ::: "memory");
+                    if (st + 1 < 27 * KS) {
+                        const int t1 = (st + 1) / KS, k1 = (st + 1) % KS;
+                        const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 + k1 * 4 * CH;
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xs[aoff[mb] + toff];
+                        for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xs[aoff[mb] + toff];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + (t1 * CC + k1 * 4) * NCO];
+                        for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + (t1 * CC + k1 * 4) * NCO];
+                    }
+                    const int dz = (st / KS) / 9;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        if ((dz == 0 && ((LO >> mb) & 1u)) || (dz == 2 && ((HI >> mb) & 1u))) continue;     // compile-time
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                    }
                 }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
             }
         }
         __syncthreads();                                   // everyone is done reading xs / ws[buf]; loads + DMA have landed
@@ -455,6 +485,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
             }
         }
     }
+    };
+    using Zc = std::integral_constant<unsigned, 0u>;
+    if (ZSKIP_LO != 0u && zlo_mask == ZSKIP_LO && zhi_mask == 0u) run(std::integral_constant<unsigned, ZSKIP_LO>{}, Zc{});
+    else if (ZSKIP_HI != 0u && zhi_mask == ZSKIP_HI && zlo_mask == 0u) run(Zc{}, std::integral_constant<unsigned, ZSKIP_HI>{});
+    else run(Zc{}, Zc{});
 }
 
 template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, int CCT = 4>

@@ -24,6 +24,7 @@
 // conv3d_mfma.hip (float64, fixed order, per workgroup tile).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((address_space(1))) const void* rf_gptr;
 typedef __attribute__((address_space(3))) void* rf_lptr;
@@ -149,6 +150,13 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 
     constexpr int ROT = NCO >= 32 ? 16 : 0;                             // slab bank rotation, as conv3d_mfma.hip
 
+    // Everything from here on is instantiated per z-border variant of this wave: an m-block whose voxels lie on the first
+    // (LO) / last (HI) z slice of the VOLUME reads nothing but zero padding through its dz = -1 / +1 taps (phase A) and its
+    // low-res tz = 0 / 1 taps (phase B) -- those MFMAs add exact zeros and are left out (same result bit for bit).  With
+    // T = 8 the lattice plane Z of m-block mb is mb, so only mb 0 of the pz = 0 waves / mb 3 of the pz = 1 waves qualify.
+    // Whole-kernel variants (not a test inside the loop) keep the accumulators in place; barriers match across variants.
+    auto run = [&](auto lo_c, auto hi_c) {
+    constexpr unsigned LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     f32x4 acc[MB][NB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -281,10 +289,13 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                         for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + t1 * 4 * NCO];
                     }
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
+                    for (int mb = 0; mb < MB; ++mb) {
+                        // m-block on the first / last z slice of the volume: its dz = -1 / +1 taps read only zero padding
+                        if ((t / 9 == 0 && ((LO >> mb) & 1u)) || (t / 9 == 2 && ((HI >> mb) & 1u))) continue;      // compile-time
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();
@@ -430,11 +441,15 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff1[nb] + (st + 1) * 4 * NCO];
                     }
+                    const int tz = (2 * q + (st >> 1)) >> 2;             // low-res z tap of this step (compile-time)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
+                    for (int mb = 0; mb < MB; ++mb) {
+                        // low-res row Z-1 of the first lattice plane / Z+1 of the last one is zero padding of the volume
+                        if ((tz == 0 && ((LO >> mb) & 1u)) || (tz == 1 && ((HI >> mb) & 1u))) continue;            // compile-time
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                    }
                 }
             }
             if (more) {
@@ -532,6 +547,12 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             __syncthreads();
         }
     }
+    };
+    using Zc = std::integral_constant<unsigned, 0u>;
+    constexpr bool ZSKIP = TE == 8 && SPW == 1;
+    if (ZSKIP && pz == 0 && z0 == 0) run(std::integral_constant<unsigned, ZSKIP ? 0x1u : 0u>{}, Zc{});
+    else if (ZSKIP && pz == 1 && z0 + TE == edge) run(Zc{}, std::integral_constant<unsigned, ZSKIP ? (1u << (MB - 1)) : 0u>{});
+    else run(Zc{}, Zc{});
 }
 
 template <int TE, int SPW, int MB, int NB>
