@@ -96,6 +96,16 @@ __device__ __forceinline__ unsigned up_xcd_contiguous(unsigned b, unsigned g) { 
     return k * per + (k < rem ? k : rem) + (b >> 3);
 }
 
+// Order of a wave's parity lattice, v = mb*16 + i -> (sample, Z, Y, X).  The lattice plane Z is constant inside an m-block
+// (Z = mb): an m-block on the first / last plane then reads only zero padding through its z-border taps.
+//   T = 8 (one box, 4^3 lattice):      v = Z*16 + Y*4 + X
+//   T = 4 (four samples, 2^3 lattice): v = Z*16 + s*4 + Y*2 + X
+template <int TE>
+__device__ __forceinline__ void up_lattice(int v, int& s, int& Z, int& Y, int& X) {
+    if (TE == 8) { X = v & 3; Y = (v >> 2) & 3; Z = v >> 4; s = 0; }
+    else { X = v & 1; Y = (v >> 1) & 1; s = (v >> 2) & 3; Z = v >> 4; }
+}
+
 template <int TE, int SPW, int MB, int NB>
 struct UpTile {
     static constexpr int NW = 8, NT = 512;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
     // Everything from here on is instantiated per z-border variant of this wave: an m-block whose voxels lie on the first
     // (LO) / last (HI) z slice of the VOLUME reads nothing but zero padding through its dz = -1 / +1 taps (phase A) and its
     // low-res tz = 0 / 1 taps (phase B) -- those MFMAs add exact zeros and are left out (same result bit for bit).  With
-    // T = 8 the lattice plane Z of m-block mb is mb, so only mb 0 of the pz = 0 waves / mb 3 of the pz = 1 waves qualify.
+    // The lattice plane Z of m-block mb is mb (up_lattice), so only mb 0 of the pz = 0 waves / the last mb of the pz = 1 waves qualify.
     // Whole-kernel variants (not a test inside the loop) keep the accumulators in place; barriers match across variants.
     auto run = [&](auto lo_c, auto hi_c) {
     constexpr unsigned LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
@@ -174,7 +184,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int v = mb * 16 + li_a;
-            const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
+            int X, Y, Z, s;
+            up_lattice<TE>(v, s, Z, Y, X);
             aoff0[mb] = (s * 4 + kq_a) * CH0 + ((2 * Z + pz) * HE + (2 * Y + py)) * HE + (2 * X + px);
         }
         int boff[NB];
@@ -375,7 +386,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int v = mb * 16 + li;
-            const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
+            int X, Y, Z, s;
+            up_lattice<TE>(v, s, Z, Y, X);
             aoff1[mb] = (s * 8 + kq) * CH1 + ((Z + pz) * LH + (Y + py)) * LH + (X + px);
         }
         // This wave's weights: image rows [chunk][parity = wave][tap][k8] of cout16 floats.  They stream through a
@@ -478,7 +490,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int v = mb * 16 + kq * 4 + r;                      // D rows of this lane: voxels 4*kq + r of the m-block
-                const int X = v % L, Y = (v / L) % L, Z = (v / (L * L)) % L, s = v / (L * L * L);
+                int X, Y, Z, s;
+            up_lattice<TE>(v, s, Z, Y, X);
                 const int lin = s * TE3 + ((2 * Z + pz) * TE + (2 * Y + py)) * TE + (2 * X + px);
                 eb[li * (P + 1) + lin] = fmaxf(acc[mb][nb][r], 0.f);
             }
@@ -513,22 +526,17 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
                 if (lane < 16) { red[(wave * 16 + lane) * 2] = sm; red[(wave * 16 + lane) * 2 + 1] = sq; }
             } else {
-                // T = 4, four samples: voxel v = mb*16 + 4*kq + r belongs to sample v / 8 = 2*mb + (kq >> 1)
+                // T = 4, four samples: voxel v = mb*16 + 4*kq + r belongs to sample kq (both m-blocks = lattice planes)
+                double sm = 0.0, sq = 0.0;
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    double sm = 0.0, sq = 0.0;
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double v = (double)fmaxf(acc[mb][nb][r], 0.f);
                         sm += v; sq += v * v;
                     }
-                    sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);        // kq pairs {0,1} and {2,3}
-                    if ((lane & 16) == 0) {
-                        const int s = 2 * mb + (kq >> 1);
-                        red[((wave * SPW + s) * 16 + li) * 2] = sm;
-                        red[((wave * SPW + s) * 16 + li) * 2 + 1] = sq;
-                    }
-                }
+                red[((wave * SPW + kq) * 16 + li) * 2] = sm;
+                red[((wave * SPW + kq) * 16 + li) * 2 + 1] = sq;
             }
             __syncthreads();
             if (tid < SPW * 16) {
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
     }
     };
     using Zc = std::integral_constant<unsigned, 0u>;
-    constexpr bool ZSKIP = TE == 8 && SPW == 1;
+    constexpr bool ZSKIP = true;
     if (ZSKIP && pz == 0 && z0 == 0) run(std::integral_constant<unsigned, ZSKIP ? 0x1u : 0u>{}, Zc{});
     else if (ZSKIP && pz == 1 && z0 + TE == edge) run(Zc{}, std::integral_constant<unsigned, ZSKIP ? (1u << (MB - 1)) : 0u>{});
     else run(Zc{}, Zc{});
