@@ -201,7 +201,8 @@ def main():
                                    % (2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms,
-                         'flops_per_launch': kern_flops,          # multiply-adds the kernel executes: 2*(27*c0 + 8*c1)*cout per voxel
+                         'flops_per_launch': kern_flops,          # multiply-adds ISSUED (decoder form minus the skipped zero-padding taps)
+                         'decoder_form_flops_per_launch': 2.0 * (27 * 2 * nf + 8 * 4 * nf) * dom_cout * 512 * B * K * 64,
                          'direct_form_flops_per_launch': 2.0 * 27 * dom_cin * dom_cout * 512 * B * K * 64,
                          'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * (2 * nf * 512 + 4 * nf * 64 + dom_cout * 512)},
         }
