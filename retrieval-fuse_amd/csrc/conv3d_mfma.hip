@@ -647,6 +647,10 @@ extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) 
     return conv_use_big(n, edge, rf_round_up(cout, 16)) ? (edge / 8) * (edge / 8) * (edge / 8) : (edge / 4) * (edge / 4) * (edge / 8);
 }
 
+bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout);                       // conv3d_small.hip
+int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
+                          float* out, double* stats, void* stream);
+
 static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                        const float* scale, const float* shift, const float* w_packed, int cout,
                        float* out, double* stats, void* stream, float* pool_out = nullptr, double* pool_stats = nullptr, int pool_mode = 0) {
@@ -666,6 +670,9 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats); a.pool_mode = pool_mode;
     hipStream_t s = (hipStream_t)stream;
     if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
+    // whole 4^3 / 2^3 volumes: the position-major kernel (conv3d_small.hip) leaves out every zero-padding tap
+    if (!pool_mode && rf_conv3_small_takes(c0, c1, n, edge, cout))
+        return rf_conv3_small_launch(src0, c0, n, edge, scale, shift, w_packed, cout, out, stats, stream);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
     const bool big = conv_use_big(n, edge, a.cout16);
     if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, TILE_BIG>(a, s) : dispatch_nb<4, 4, 8, 1, TILE_SMALL>(a, s);

@@ -1,0 +1,302 @@
+// 3x3x3 conv + GroupNorm apply + ReLU on WHOLE 4^3 / 2^3 volumes, position-major: the third tiling of
+// rf_conv3d_k3_gn_relu (reference model/unet.py:19-76, the two coarsest levels of the retrieval backbone).
+//
+// In a 4^3 (2^3) volume 42 % (70 %) of the 27 taps of an output voxel read zero padding.  The generic kernel
+// (conv3d_mfma.hip) builds MFMA m-blocks from 16 voxels of one sample and can only leave out taps that are padding for the
+// whole m-block (the z border).  Here an m-block is ONE VOXEL POSITION of 16 DIFFERENT SAMPLES: whether tap (dz,dy,dx) of
+// position (z,y,x) is padding is then a property of the m-block, known at compile time, and every padding tap is simply
+// not issued -- no halo is staged either.  The MFMAs left out would have added exact zeros: the result is bit for bit
+// the one of the generic kernel.
+//
+//   4^3: a workgroup of 8 waves owns 16 samples; wave w owns the 8 positions z = w >> 1, y in {2*(w&1), 2*(w&1)+1}, x = 0..3
+//        (m-block mb: y = 2*(w&1) + (mb >> 2), x = mb & 3).  Which taps exist depends on the wave only through the class of
+//        z (first / interior / last slice) and the y half: 6 variants of the whole K loop + epilogue, a wave picks one.
+//   2^3: a workgroup owns 128 samples = 8 groups of 16; wave w owns group w, m-block mb = position mb (one variant).
+//
+// LDS: input chunk [position][4 ch][16 samples] (lane -> 16*k + sample: conflict-free operand reads, the tap is an
+// immediate offset), weight slabs [27][4][NB*16] by LDS-DMA, double buffered, as conv3d_mfma.hip.  Epilogue: accumulators
+// -> LDS -> contiguous float4 rows; GroupNorm statistics of the output for the next layer (float64, fixed order).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __attribute__((address_space(1))) const void* rf_gptr;
+typedef __attribute__((address_space(3))) void* rf_lptr;
+
+struct SmallArgs {
+    const float* src;
+    const float* scale;
+    const float* shift;
+    const float* wp;       // [27][cin4][cout16] (rf_conv3_pack_weight)
+    float* out;
+    int cin, n, cout, cin4, cout16;
+    double2* stats;        // optional [n][cout][1]
+};
+
+template <int E, int NB>
+struct SmallTile {
+    static constexpr int P = E * E * E;                       // positions per sample
+    static constexpr int NW = 8, NT = 512, MB = 8;
+    static constexpr int GROUPS = (NW * MB) / P;              // 16-sample groups per workgroup: 1 (4^3) or 8 (2^3)
+    static constexpr int SAMPLES = 16 * GROUPS;
+    static constexpr int NCO = NB * 16;
+    static constexpr int XS = GROUPS * P * 64;                // [group][position][4 ch][16 samples]
+    static constexpr int WSLAB = 27 * 4 * NCO;
+    static constexpr int WSLAB_PAD = (WSLAB + 255) / 256 * 256;
+    static constexpr int EROW = P + 1;                        // epilogue tile [16 cout][SAMPLES][P + 1]
+    static constexpr int EPI = 16 * SAMPLES * EROW;
+    static constexpr int MAIN = XS + 2 * WSLAB_PAD;
+    static constexpr size_t LDS_BYTES = (size_t)(MAIN > EPI ? MAIN : EPI) * sizeof(float);
+    static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
+    static_assert(E == 4 || E == 2, "whole 4^3 / 2^3 volumes");
+};
+
+// position of m-block mb of wave `wave` (4^3) / of any wave (2^3)
+template <int E>
+__device__ __forceinline__ constexpr int small_y(int yh, int mb) { return E == 4 ? 2 * yh + (mb >> 2) : (mb >> 1) & 1; }
+template <int E>
+__device__ __forceinline__ constexpr int small_x(int mb) { return E == 4 ? (mb & 3) : (mb & 1); }
+
+template <int E, int NB>
+__global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
+    using T = SmallTile<E, NB>;
+    constexpr int P = T::P, NCO = T::NCO, NT = T::NT, MB = T::MB, SAMPLES = T::SAMPLES, EROW = T::EROW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* wsb = smem + T::XS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * SAMPLES, cob = blockIdx.y * NCO;
+    const int kq = lane >> 4, li = lane & 15;
+    // 4^3: z slice and y half of this wave; 2^3: sample group of this wave
+    const int wz = E == 4 ? (wave >> 1) : 0, wyh = E == 4 ? (wave & 1) : 0, wgrp = E == 4 ? 0 : wave;
+
+    constexpr int ROT = NCO >= 32 ? 16 : 0;
+    int boff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) boff[nb] = kq * NCO + ((nb * 16 + li + ROT * (kq & 1)) % NCO);
+    // operand base: [group][position][k][sample]; the position of the input voxel is added as an immediate (+ z of the wave)
+    const int abase = (wgrp * P + (E == 4 ? wz * 16 : 0)) * 64 + kq * 16 + li;
+
+    constexpr int WF4 = T::WSLAB / 4, NPIECE = (WF4 + 63) / 64;
+    auto dma_weights = [&](int cbase, int buf, int lane_) {
+        float* dst = wsb + buf * T::WSLAB_PAD;
+#pragma unroll
+        for (int i = 0; i < (NPIECE + 7) / 8; ++i) {
+            const int q = wave + i * 8;
+            if (q < NPIECE) {
+                int idx = q * 64 + lane_;
+                if (idx >= WF4) idx = WF4 - 1;
+                const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
+                const int col = (slot + NCO - ROT * (r & 1)) % NCO;
+                int co = cob + col;
+                if (co >= a.cout16) co = col % a.cout16;
+                int ci = cbase + r % 4;
+                if (ci >= a.cin4) ci = a.cin4 - 1;
+                const float* src = a.wp + ((size_t)(r / 4) * a.cin4 + ci) * a.cout16 + co;
+                __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- input chunk: item = (sample, channel, run of 8 positions); 8 floats per item, GroupNorm applied at commit
+    constexpr int RUNS = P / 8;                                     // 8 (4^3) or 1 (2^3)
+    constexpr int ITEMS = SAMPLES * 4 * RUNS;                       // 512 either way
+    static_assert(ITEMS == NT, "one staging item per thread");
+    float xraw[8];
+    float xsc = 0.f, xsh = 0.f;
+    // thread -> (sample, k) fastest so that a wave's LDS writes of one position are conflict-free
+    const int it_s = tid % SAMPLES, it_k = (tid / SAMPLES) % 4, it_run = tid / (SAMPLES * 4);
+    auto issue_rows = [&](int cbase) {
+        const int nn = n0 + it_s, ci = cbase + it_k;
+        if (nn < a.n && ci < a.cin) {
+            const size_t si = (size_t)nn * a.cin + ci;
+            xsc = a.scale[si];
+            xsh = a.shift[si];
+            const float4* row = reinterpret_cast<const float4*>(a.src + si * P + it_run * 8);
+            const float4 t0 = row[0], t1 = row[1];
+            xraw[0] = t0.x; xraw[1] = t0.y; xraw[2] = t0.z; xraw[3] = t0.w;
+            xraw[4] = t1.x; xraw[5] = t1.y; xraw[6] = t1.z; xraw[7] = t1.w;
+        }
+    };
+    auto commit_rows = [&](int cbase) {
+        const int nn = n0 + it_s, ci = cbase + it_k;
+        const bool ok = nn < a.n && ci < a.cin;
+        float* dst = xs + ((it_s >> 4) * P + it_run * 8) * 64 + it_k * 16 + (it_s & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j * 64] = ok ? xraw[j] * xsc + xsh : 0.f;
+    };
+
+    // Everything below is instantiated per variant of this wave (ZC: 0 = first z slice, 1 = interior, 2 = last; YH: y half)
+    auto run = [&](auto zc_c, auto yh_c) {
+        constexpr int ZC = decltype(zc_c)::value, YH = decltype(yh_c)::value;
+        f32x4 acc[MB][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        dma_weights(0, 0, lane);
+        issue_rows(0);
+        commit_rows(0);
+        __syncthreads();
+
+        int buf = 0;
+        for (int cbase = 0; cbase < a.cin; cbase += 4) {
+            const bool more = cbase + 4 < a.cin;
+            if (more) {
+                issue_rows(cbase + 4);
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                dma_weights(cbase + 4, buf ^ 1, lane_o);
+            }
+            const float* ws = wsb + buf * T::WSLAB_PAD;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+                // z validity of this tap: the same for all 8 m-blocks of the wave (4^3), per m-block for 2^3
+                if (E == 4 && ((ZC == 0 && dz == 0) || (ZC == 2 && dz == 2))) continue;
+                asm volatile("" ::: "memory");                       // keep the operand reads of later taps out of this one
+                float bv[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bv[nb] = ws[boff[nb] + t * 4 * NCO];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int z = E == 4 ? 0 : (mb >> 2), y = small_y<E>(YH, mb), x = small_x<E>(mb);
+                    const int uy = y + dy - 1, ux = x + dx - 1, uz = z + dz - 1;        // input voxel (z relative to the wave's slice at 4^3)
+                    if (uy < 0 || uy >= E || ux < 0 || ux >= E) continue;              // compile-time: padding tap
+                    if (E == 2 && (uz < 0 || uz >= E)) continue;
+                    const int upos = (E == 4 ? (dz - 1) * 16 : uz * 4) + uy * E + ux;  // position offset from the operand base
+                    const float av = xs[abase + upos * 64];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[mb][nb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (more) commit_rows(cbase + 4);
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        // ---- epilogue: ReLU'd accumulators -> LDS [16 cout][sample][P + 1] -> contiguous float4 rows; statistics
+        float* eb = smem;
+        double* red = reinterpret_cast<double*>(smem);               // [8 waves][16 samples][16 cout][2] (4^3 only), after the stores
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int pos = E == 4 ? wz * 16 + small_y<E>(YH, mb) * 4 + small_x<E>(mb) : mb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int smp = wgrp * 16 + kq * 4 + r;          // D rows of this lane: samples 4*kq + r of the group
+                    eb[(li * SAMPLES + smp) * EROW + pos] = fmaxf(acc[mb][nb][r], 0.f);
+                }
+            }
+            __syncthreads();
+            for (int q = tid; q < 16 * SAMPLES * (P / 4); q += NT) {
+                const int p4 = q % (P / 4), smp = (q / (P / 4)) % SAMPLES, col = q / ((P / 4) * SAMPLES);
+                const int co = cob + nb * 16 + col, nn = n0 + smp;
+                if (co < a.cout && nn < a.n) {
+                    const float* e = eb + (col * SAMPLES + smp) * EROW + p4 * 4;
+                    *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * P + p4 * 4) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            __syncthreads();
+            if (a.stats) {
+                // per (sample, cout): sum over this wave's 8 positions in registers; 4^3: then over the 8 waves through LDS
+                double sm[4], sq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sm[r] = 0.0; sq[r] = 0.0;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const double v = (double)fmaxf(acc[mb][nb][r], 0.f);
+                        sm[r] += v; sq[r] += v * v;
+                    }
+                }
+                if (E == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = cob + nb * 16 + li, nn = n0 + wgrp * 16 + kq * 4 + r;
+                        if (co < a.cout && nn < a.n) a.stats[(size_t)nn * a.cout + co] = make_double2(sm[r], sq[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        red[((wave * 16 + kq * 4 + r) * 16 + li) * 2] = sm[r];
+                        red[((wave * 16 + kq * 4 + r) * 16 + li) * 2 + 1] = sq[r];
+                    }
+                    __syncthreads();
+                    if (tid < 256) {
+                        const int smp = tid >> 4, col = tid & 15;
+                        const int co = cob + nb * 16 + col, nn = n0 + smp;
+                        if (co < a.cout && nn < a.n) {
+                            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) {
+                                s0 += red[((w * 16 + smp) * 16 + col) * 2];
+                                s1 += red[((w * 16 + smp) * 16 + col) * 2 + 1];
+                            }
+                            a.stats[(size_t)nn * a.cout + co] = make_double2(s0, s1);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (E == 2) {
+        run(I1{}, I0{});
+    } else {
+        const int zc = wz == 0 ? 0 : (wz == E - 1 ? 2 : 1);
+        if (wyh == 0) {
+            if (zc == 0) run(I0{}, I0{}); else if (zc == 1) run(I1{}, I0{}); else run(I2{}, I0{});
+        } else {
+            if (zc == 0) run(I0{}, I1{}); else if (zc == 1) run(I1{}, I1{}); else run(I2{}, I1{});
+        }
+    }
+}
+
+template <int E, int NB>
+static int launch_small(const SmallArgs& a, hipStream_t stream) {
+    using T = SmallTile<E, NB>;
+    auto kern = k_conv3_small<E, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (T::LDS_BYTES > 65536) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+            if (e != hipSuccess) { rf_set_error("rf_conv3d_k3_gn_relu(small): cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
+        }
+        attr_set = true;
+    }
+    const unsigned gx = (unsigned)((a.n + T::SAMPLES - 1) / T::SAMPLES), gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(T::NT), T::LDS_BYTES, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu(small)");
+    return RF_OK;
+}
+
+// Takes whole 4^3 / 2^3 volumes with a single (full-resolution) source when there are enough samples to fill the chip.
+bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout) {
+    static const int knob = getenv("RFUSE_CONV_SMALL") ? atoi(getenv("RFUSE_CONV_SMALL")) : 1;     // dev knob: 0 = off
+    if (!knob || c1 != 0 || c0 <= 0 || (edge != 4 && edge != 2)) return false;
+    const long long gy = (rf_round_up(cout, 16) + 31) / 32;
+    const long long wgs = (edge == 4 ? (n + 15) / 16 : (n + 127) / 128) * gy;
+    return wgs >= 256;
+}
+
+int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
+                          float* out, double* stats, void* stream) {
+    SmallArgs a;
+    a.src = src; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.cin = cin; a.n = n; a.cout = cout; a.cin4 = rf_round_up(cin, 4); a.cout16 = rf_round_up(cout, 16);
+    a.stats = reinterpret_cast<double2*>(stats);
+    hipStream_t s = (hipStream_t)stream;
+    if (edge == 4) return a.cout16 <= 16 ? launch_small<4, 1>(a, s) : launch_small<4, 2>(a, s);
+    return a.cout16 <= 16 ? launch_small<2, 1>(a, s) : launch_small<2, 2>(a, s);
+}

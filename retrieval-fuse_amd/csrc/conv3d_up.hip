@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                     xsc[i] = a.scale[si];
                     xsh[i] = a.shift[si];
                     const float* row = a.src1 + ((((size_t)nn * a.c1 + ci) * half + z) * half + y) * half + X0;
-                    if (L == 4) {
+                    if constexpr (L == 4) {
                         const float4 t = *reinterpret_cast<const float4*>(row);
                         xraw[i][1] = t.x; xraw[i][2] = t.y; xraw[i][3] = t.z; xraw[i][4] = t.w;
                     } else {

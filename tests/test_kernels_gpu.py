@@ -169,6 +169,35 @@ def test_conv_with_fused_maxpool_epilogue(ops, case):
         close(fused[1], reread[1], 1e-6, 'shift from fused stats')
 
 
+@pytest.mark.parametrize('case', [(4100, 32, 4, 64, 8), (4099, 16, 4, 16, 8), (4104, 6, 4, 12, 6), (33000, 64, 2, 128, 8), (32770, 64, 2, 16, 8),
+                                  (8192, 64, 4, 72, 8)])
+def test_conv_small_volume_position_major_kernel(ops, case):
+    """Whole 4^3 / 2^3 volumes, many samples: the position-major kernel (conv3d_small.hip: every zero-padding tap left out)
+    must equal the generic kernel bit for bit (the generic one is reached by calling with few samples at a time), statistics
+    included; a slice is also checked against float64 torch."""
+    n, cin, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = rnd(gen, n, cin, edge, edge, edge).relu_().to(DEV)
+    gamma, beta = (1 + 0.2 * rnd(gen, cin)).to(DEV), (0.2 * rnd(gen, cin)).to(DEV)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin))
+    wp = ops.pack_conv3_weight(w.to(DEV))
+    sc, sh = ops.gn_scale_shift(x, None, gamma, beta, groups)
+    got = ops.conv3d_gn_relu(x, None, sc, sh, wp, cout)
+    step = 1000 if edge == 4 else 8000                          # few enough workgroups for the generic tiling
+    parts, stat_parts = [], []
+    for i in range(0, n, step):
+        y = ops.conv3d_gn_relu(x[i:i + step].contiguous(), None, sc[i:i + step].contiguous(), sh[i:i + step].contiguous(), wp, cout)
+        parts.append(y)
+        stat_parts.append(y._rf_stats[0])
+    want = torch.cat(parts)
+    assert torch.equal(got, want)
+    assert got._rf_stats[1] == 1
+    close(got._rf_stats[0], torch.cat(stat_parts), 1e-12, 'fused statistics')
+    sl = slice(n - 20, n)
+    ref = ref_gcr(x[sl].cpu().double(), None, gamma.cpu().double(), beta.cpu().double(), groups, w.double())
+    close(got[sl], ref.float(), 2e-5, 'vs float64 torch')
+
+
 def test_conv_identity_weight_is_transpose_detecting(ops):
     """centre-tap identity on an asymmetric ramp: catches swapped voxel axes / channel transposes exactly."""
     n, c, edge = 1, 16, 8
