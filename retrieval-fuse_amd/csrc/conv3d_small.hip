@@ -31,9 +31,15 @@ struct SmallArgs {
     float* out;
     int cin, n, cout, cin4, cout16;
     double2* stats;        // optional [n][cout][1]
+    // decoder form (4^3 only, template flag UP): `src` / `cin` are the skip source (may be 0 channels), `src1` [n][c1][2^3] the
+    // low-res source convolved with the parity-split, pre-summed taps of conv3d_up.hip; wp / wp1 = the two parts of the
+    // rf_conv3_up_pack_weight image; GroupNorm scale / shift are indexed over the cin + c1 concatenated channels
+    const float* src1;
+    const float* wp1;      // [c1_8/8][8 parities][8 taps][8 ch][cout16]
+    int c1, c1_8;
 };
 
-template <int E, int NB>
+template <int E, int NB, bool UP = false>
 struct SmallTile {
     static constexpr int P = E * E * E;                       // positions per sample
     static constexpr int NW = 8, NT = 512, MB = 8;
@@ -46,7 +52,12 @@ struct SmallTile {
     static constexpr int EROW = P + 1;                        // epilogue tile [16 cout][SAMPLES][P + 1]
     static constexpr int EPI = 16 * SAMPLES * EROW;
     static constexpr int MAIN = XS + 2 * WSLAB_PAD;
-    static constexpr size_t LDS_BYTES = (size_t)(MAIN > EPI ? MAIN : EPI) * sizeof(float);
+    static constexpr int XLOW = 2 * 8 * 64;                   // decoder form: two low-res chunks [2^3 positions][4 ch][16 samples]
+    static constexpr int BSLAB = 8 * 8 * 4 * NCO;             // ... and weight slabs [8 parities][8 taps][4 ch][NCO], double buffered
+    static constexpr int MAINB = UP ? XLOW + 2 * BSLAB : 0;
+    static constexpr int MAXAB = MAIN > MAINB ? MAIN : MAINB;
+    static constexpr size_t LDS_BYTES = (size_t)(MAXAB > EPI ? MAXAB : EPI) * sizeof(float);
+    static_assert(!UP || E == 4, "decoder form: 4^3 volumes");
     static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
     static_assert(E == 4 || E == 2, "whole 4^3 / 2^3 volumes");
 };
@@ -57,9 +68,9 @@ __device__ __forceinline__ constexpr int small_y(int yh, int mb) { return E == 4
 template <int E>
 __device__ __forceinline__ constexpr int small_x(int mb) { return E == 4 ? (mb & 3) : (mb & 1); }
 
-template <int E, int NB>
+template <int E, int NB, bool UP>
 __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
-    using T = SmallTile<E, NB>;
+    using T = SmallTile<E, NB, UP>;
     constexpr int P = T::P, NCO = T::NCO, NT = T::NT, MB = T::MB, SAMPLES = T::SAMPLES, EROW = T::EROW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
@@ -112,8 +123,9 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
         const int nn = n0 + it_s, ci = cbase + it_k;
         if (nn < a.n && ci < a.cin) {
             const size_t si = (size_t)nn * a.cin + ci;
-            xsc = a.scale[si];
-            xsh = a.shift[si];
+            const size_t gi = (size_t)nn * (a.cin + (UP ? a.c1 : 0)) + ci;
+            xsc = a.scale[gi];
+            xsh = a.shift[gi];
             const float4* row = reinterpret_cast<const float4*>(a.src + si * P + it_run * 8);
             const float4 t0 = row[0], t1 = row[1];
             xraw[0] = t0.x; xraw[1] = t0.y; xraw[2] = t0.z; xraw[3] = t0.w;
@@ -137,9 +149,11 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        dma_weights(0, 0, lane);
-        issue_rows(0);
-        commit_rows(0);
+        if (a.cin > 0) {
+            dma_weights(0, 0, lane);
+            issue_rows(0);
+            commit_rows(0);
+        }
         __syncthreads();
 
         int buf = 0;
@@ -178,6 +192,102 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
             if (more) commit_rows(cbase + 4);
             __syncthreads();
             buf ^= 1;
+        }
+
+        // ---- decoder form, phase B: the c1 channels of the low-res (2^3) source.  Output position (z,y,x) has parity
+        // p = (z&1, y&1, x&1) and lattice cell (Z,Y,X) = (z,y,x) >> 1; its low-res tap (tz,ty,tx) reads low-res voxel
+        // (Z + tz - 1 + pz, ...) with the pre-summed weight W'[parity][tap] -- or zero padding, which is not issued.
+        if constexpr (UP) {
+            float* xlow = smem;                                      // [2][8 positions][4 ch][16 samples]
+            float* bsl = smem + T::XLOW;                             // [2][(parity*8 + tap)*4 + k][NCO]
+            constexpr int BROT = NCO == 32 ? 16 : 0;                 // rows k, k+2 of a B read would share banks at NCO = 32
+            constexpr int BF4 = T::BSLAB / 4, BPIECE = BF4 / 64;
+            auto dma_b = [&](int c4, int bufb, int lane_) {          // c4: 4-channel chunk of c1
+                float* dst = bsl + bufb * T::BSLAB;
+#pragma unroll
+                for (int i = 0; i < (BPIECE + 7) / 8; ++i) {
+                    const int q = wave + i * 8;
+                    if (q < BPIECE) {
+                        const int idx = q * 64 + lane_;
+                        const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
+                        const int col = (slot + NCO - BROT * ((r >> 1) & 1)) % NCO;
+                        int co = cob + col;
+                        if (co >= a.cout16) co = col % a.cout16;
+                        const int k = r & 3, pt = r >> 2;            // pt = parity*8 + tap
+                        const float* src = a.wp1 + ((((size_t)(c4 >> 1) * 64 + pt) * 8) + (c4 & 1) * 4 + k) * a.cout16 + co;
+                        __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+                    }
+                }
+            };
+            float lraw[8];
+            float lsc = 0.f, lsh = 0.f;
+            const int ls = tid & 15, lk = (tid >> 4) & 3;            // threads 0..63 stage the low-res chunk
+            auto issue_low = [&](int c4) {
+                const int nn = n0 + ls, ci = c4 * 4 + lk;
+                if (tid < 64 && nn < a.n && ci < a.c1) {
+                    const size_t gi = (size_t)nn * (a.cin + a.c1) + a.cin + ci;
+                    lsc = a.scale[gi];
+                    lsh = a.shift[gi];
+                    const float4* row = reinterpret_cast<const float4*>(a.src1 + ((size_t)nn * a.c1 + ci) * 8);
+                    const float4 t0 = row[0], t1 = row[1];
+                    lraw[0] = t0.x; lraw[1] = t0.y; lraw[2] = t0.z; lraw[3] = t0.w;
+                    lraw[4] = t1.x; lraw[5] = t1.y; lraw[6] = t1.z; lraw[7] = t1.w;
+                }
+            };
+            auto commit_low = [&](int c4, int bufb) {
+                if (tid < 64) {
+                    const int nn = n0 + ls, ci = c4 * 4 + lk;
+                    const bool ok = nn < a.n && ci < a.c1;
+                    float* dst = xlow + bufb * 512 + lk * 16 + ls;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dst[j * 64] = ok ? lraw[j] * lsc + lsh : 0.f;
+                }
+            };
+            const int nchunk = a.c1_8 >> 2;
+            int bboff[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bboff[nb] = kq * NCO + ((nb * 16 + li + BROT * ((kq >> 1) & 1)) % NCO);
+            const int pz = wz & 1;                                   // z parity of this wave's slice (run time inside ZC == 1)
+            dma_b(0, 0, lane);
+            issue_low(0);
+            commit_low(0, 0);
+            __syncthreads();
+            int bufb = 0;
+            for (int c4 = 0; c4 < nchunk; ++c4) {
+                const bool more = c4 + 1 < nchunk;
+                if (more) {
+                    issue_low(c4 + 1);
+                    int lane_o = lane;
+                    asm volatile("" : "+v"(lane_o));
+                    dma_b(c4 + 1, bufb ^ 1, lane_o);
+                }
+                const float* xl = xlow + bufb * 512 + kq * 16 + li;
+                const float* wb = bsl + bufb * T::BSLAB + pz * (4 * 8 * 4 * NCO);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int tz = t >> 2, ty = (t >> 1) & 1, tx = t & 1;
+                    // low-res z of this tap: first slice (Z=0,pz=0): tz=0 is padding, tz=1 -> 0; last slice (Z=1,pz=1): tz=0 -> 1, tz=1
+                    // is padding; interior slices (Z=0,pz=1 / Z=1,pz=0): tz -> tz
+                    if ((ZC == 0 && tz == 0) || (ZC == 2 && tz == 1)) continue;
+                    const int uz = ZC == 0 ? 0 : (ZC == 2 ? 1 : tz);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const int y = small_y<E>(YH, mb), x = small_x<E>(mb);
+                        const int py = y & 1, px = x & 1;
+                        const int uy = (y >> 1) + ty - 1 + py, ux = (x >> 1) + tx - 1 + px;
+                        if (uy < 0 || uy > 1 || ux < 0 || ux > 1) continue;              // compile-time: padding tap
+                        const float av = xl[(uz * 4 + uy * 2 + ux) * 64];
+                        const int brow = ((py * 2 + px) * 8 + t) * 4;                    // + pz*4 parities through wb
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[brow * NCO + bboff[nb]], acc[mb][nb], 0, 0, 0);
+                    }
+                }
+                if (more) commit_low(c4 + 1, bufb ^ 1);
+                __syncthreads();
+                bufb ^= 1;
+            }
         }
 
         // ---- epilogue: ReLU'd accumulators -> LDS [16 cout][sample][P + 1] -> contiguous float4 rows; statistics
@@ -263,10 +373,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
     }
 }
 
-template <int E, int NB>
+template <int E, int NB, bool UP = false>
 static int launch_small(const SmallArgs& a, hipStream_t stream) {
-    using T = SmallTile<E, NB>;
-    auto kern = k_conv3_small<E, NB>;
+    using T = SmallTile<E, NB, UP>;
+    auto kern = k_conv3_small<E, NB, UP>;
     static bool attr_set = false;
     if (!attr_set) {
         if (T::LDS_BYTES > 65536) {
@@ -296,7 +406,28 @@ int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const floa
     a.src = src; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
     a.cin = cin; a.n = n; a.cout = cout; a.cin4 = rf_round_up(cin, 4); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
+    a.src1 = nullptr; a.wp1 = nullptr; a.c1 = 0; a.c1_8 = 0;
     hipStream_t s = (hipStream_t)stream;
     if (edge == 4) return a.cout16 <= 16 ? launch_small<4, 1>(a, s) : launch_small<4, 2>(a, s);
     return a.cout16 <= 16 ? launch_small<2, 1>(a, s) : launch_small<2, 2>(a, s);
+}
+
+// decoder form on whole 4^3 volumes (low-res source 2^3), weight image of rf_conv3_up_pack_weight
+bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout) {
+    static const int knob = getenv("RFUSE_CONV_SMALL") ? atoi(getenv("RFUSE_CONV_SMALL")) : 1;
+    if (!knob || c1 <= 0 || c0 < 0 || edge != 4) return false;
+    const long long gy = (rf_round_up(cout, 16) + 31) / 32;
+    return (long long)((n + 15) / 16) * gy >= 256;
+}
+
+int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
+                             const float* w_up_packed, int cout, float* out, double* stats, void* stream) {
+    SmallArgs a;
+    a.src = src0; a.scale = scale; a.shift = shift; a.wp = w_up_packed; a.out = out;
+    a.cin = c0; a.n = n; a.cout = cout; a.cin4 = rf_round_up(c0, 4); a.cout16 = rf_round_up(cout, 16);
+    a.stats = reinterpret_cast<double2*>(stats);
+    a.src1 = src1; a.c1 = c1; a.c1_8 = rf_round_up(c1, 8);
+    a.wp1 = w_up_packed + (size_t)27 * a.cin4 * a.cout16;
+    hipStream_t s = (hipStream_t)stream;
+    return a.cout16 <= 16 ? launch_small<4, 1, true>(a, s) : launch_small<4, 2, true>(a, s);
 }

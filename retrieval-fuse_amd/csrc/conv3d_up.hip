@@ -591,6 +591,10 @@ static int dispatch_up(const UpArgs& a, hipStream_t stream) {
 
 // Shapes the parity-split kernel takes: a low-res source, edge 4 (four samples per workgroup) or a multiple of 8, and
 // enough boxes to give the 256 CUs work (small launches stay on rf_conv3d_k3_gn_relu's 128-voxel tiles).
+bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout);                    // conv3d_small.hip
+int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
+                             const float* w_up_packed, int cout, float* out, double* stats, void* stream);
+
 extern "C" int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout) {
     static const int off = getenv("RFUSE_CONV_UP") ? atoi(getenv("RFUSE_CONV_UP")) == 0 : 0;       // dev knob: RFUSE_CONV_UP=0 disables
     if (off || c1 <= 0 || c0 < 0 || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 4 || edge > 128) return 0;
@@ -613,5 +617,8 @@ extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* s
     a.stats = reinterpret_cast<double2*>(stats);
     a.stats_tiles = stats ? rf_conv3d_up_stats_tiles(edge) : 0;
     hipStream_t s = (hipStream_t)stream;
+    // whole 4^3 volumes with enough samples: position-major form (conv3d_small.hip), every zero-padding tap left out
+    if (edge == 4 && rf_conv3_small_up_takes(c0, c1, n, edge, cout))
+        return rf_conv3_small_up_launch(src0, c0, src1, c1, n, scale, shift, w_packed, cout, out, stats, stream);
     return edge == 4 ? dispatch_up<4, 4, 2>(a, s) : dispatch_up<8, 1, 4>(a, s);
 }

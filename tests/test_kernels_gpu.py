@@ -105,6 +105,11 @@ UP_CASES = [
     (300, 8, 8, 8, 72, 8),      # cout16 = 80: two cout blocks
     (260, 4, 8, 8, 24, 4),      # NB = 2
     (1100, 16, 8, 4, 24, 8),
+    # many 4^3 samples: the position-major decoder form (conv3d_small.hip, UP instances)
+    (4100, 64, 128, 4, 64, 8),
+    (4099, 16, 8, 4, 24, 8),
+    (8200, 0, 16, 4, 16, 8),
+    (4104, 6, 12, 4, 12, 6),
 ]
 
 
