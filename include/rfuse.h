@@ -121,13 +121,13 @@ int rf_conv3d_k3_gn_relu_pool(const float* src0, int c0, const float* src1, int 
  * the skip source, then SingleConv 'gcr'): same inputs and result, but the c1 upsampled channels are convolved in LOW
  * resolution -- per output parity the 27 taps collapse to 2x2x2 taps with pre-summed weights (8/27 of the multiply-adds
  * for those channels).  Weight image: rf_conv3_up_pack_weight(OIDHW weight, cout, c0, c1) -> rf_conv3_up_packed_floats
- * floats (pre-sums in float64, rounded once).  stats: optional [n][cout][rf_conv3d_up_stats_tiles(edge)][2] float64
+ * floats (pre-sums in float64, rounded once).  stats: optional [n][cout][rf_conv3d_up_stats_tiles(...)][2] float64
  * (sum, sum of squares) of the output for rf_gn_from_stats, or NULL.  rf_conv3d_up_supported: 1 when this kernel takes
  * the shape (needs c1 > 0, edge 4 or a multiple of 8, and enough boxes to fill the chip), else use rf_conv3d_k3_gn_relu. */
 size_t rf_conv3_up_packed_floats(int cout, int c0, int c1);
 int rf_conv3_up_pack_weight(const float* w_oidhw, int cout, int c0, int c1, float* w_packed, void* stream);
 int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout);
-int rf_conv3d_up_stats_tiles(int edge);
+int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
                             const float* shift, const float* w_packed, int cout, float* out, double* stats, void* stream);
 

@@ -640,13 +640,19 @@ static bool conv_use_big(int n, int edge, int cout16) {
     return force_tile == 1 ? false : (force_tile == 2 ? true : wgs512 >= 1024);
 }
 
+bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout);
+
 extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) {
     if (edge < 2) return 0;                                    // direct path: no fused statistics
     if (conv_use_cin1(c0, c1, edge, cout)) return (edge / 4) * (edge / 16) * (edge / 16);
+    if (c1 == 0 && rf_conv3_pm8_takes(c0, 0, n, edge, cout)) return 8;      // one tile per z slice (conv3d_pm8.hip)
     if (edge <= 4) return 1;                                   // whole-volume tiles (always the 128-voxel form)
     return conv_use_big(n, edge, rf_round_up(cout, 16)) ? (edge / 8) * (edge / 8) * (edge / 8) : (edge / 4) * (edge / 4) * (edge / 8);
 }
 
+bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout);                         // conv3d_pm8.hip
+int rf_conv3_pm8_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
+                        const float* w_packed, int cout, float* out, double* stats, void* stream);
 bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout);                       // conv3d_small.hip
 int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
                           float* out, double* stats, void* stream);
@@ -673,6 +679,9 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     // whole 4^3 / 2^3 volumes: the position-major kernel (conv3d_small.hip) leaves out every zero-padding tap
     if (!pool_mode && rf_conv3_small_takes(c0, c1, n, edge, cout))
         return rf_conv3_small_launch(src0, c0, n, edge, scale, shift, w_packed, cout, out, stats, stream);
+    // whole 8^3 volumes, single source: position-major over z slices (conv3d_pm8.hip)
+    if (!pool_mode && c1 == 0 && rf_conv3_pm8_takes(c0, 0, n, edge, cout))
+        return rf_conv3_pm8_launch(src0, c0, nullptr, 0, n, scale, shift, w_packed, cout, out, stats, stream);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
     const bool big = conv_use_big(n, edge, a.cout16);
     if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, TILE_BIG>(a, s) : dispatch_nb<4, 4, 8, 1, TILE_SMALL>(a, s);

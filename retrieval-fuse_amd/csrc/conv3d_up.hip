@@ -591,6 +591,9 @@ static int dispatch_up(const UpArgs& a, hipStream_t stream) {
 
 // Shapes the parity-split kernel takes: a low-res source, edge 4 (four samples per workgroup) or a multiple of 8, and
 // enough boxes to give the 256 CUs work (small launches stay on rf_conv3d_k3_gn_relu's 128-voxel tiles).
+bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout);                         // conv3d_pm8.hip
+int rf_conv3_pm8_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
+                        const float* w_packed, int cout, float* out, double* stats, void* stream);
 bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout);                    // conv3d_small.hip
 int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
                              const float* w_up_packed, int cout, float* out, double* stats, void* stream);
@@ -603,7 +606,10 @@ extern "C" int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout)
     return boxes * gy >= 256;
 }
 
-extern "C" int rf_conv3d_up_stats_tiles(int edge) { return edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8); }
+extern "C" int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cout) {
+    if (rf_conv3_pm8_takes(c0, c1, n, edge, cout)) return 8;            // one tile per z slice (conv3d_pm8.hip)
+    return edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8);
+}
 
 extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
                                        const float* shift, const float* w_packed, int cout, float* out, double* stats, void* stream) {
@@ -615,8 +621,11 @@ extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* s
     a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
     a.c0_4 = rf_round_up(c0, 4); a.c1_8 = rf_round_up(c1, 8); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
-    a.stats_tiles = stats ? rf_conv3d_up_stats_tiles(edge) : 0;
+    a.stats_tiles = stats ? rf_conv3d_up_stats_tiles(c0, c1, n, edge, cout) : 0;
     hipStream_t s = (hipStream_t)stream;
+    // whole 8^3 volumes: position-major over z slices (conv3d_pm8.hip)
+    if (rf_conv3_pm8_takes(c0, c1, n, edge, cout))
+        return rf_conv3_pm8_launch(src0, c0, src1, c1, n, scale, shift, w_packed, cout, out, stats, stream);
     // whole 4^3 volumes with enough samples: position-major form (conv3d_small.hip), every zero-padding tap left out
     if (edge == 4 && rf_conv3_small_up_takes(c0, c1, n, edge, cout))
         return rf_conv3_small_up_launch(src0, c0, src1, c1, n, scale, shift, w_packed, cout, out, stats, stream);

@@ -232,7 +232,7 @@ def conv3d_up_gn_relu(src0, src1, scale, shift, w_up_packed, cout):
     lib = _lib.load()
     stats = None
     if USE_FUSED_STATS:
-        tiles = lib.rf_conv3d_up_stats_tiles(edge)
+        tiles = lib.rf_conv3d_up_stats_tiles(c0, c1, n, edge, cout)
         stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=out.device)
     timed = conv_event_filter is not None and conv_event_filter(c0 + c1, cout, edge, n)
     if timed:
