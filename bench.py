@@ -197,8 +197,8 @@ def main():
                        'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + RCCL all-gather of top-2K' % (world, world)},
             'roofline': {'bound': 'mfma',
                          'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4> (retrieval backbone decoder conv %d+%d->%d @8^3: '
-                                   '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, %d patches)'
-                                   % (2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
+                                   '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, z-border padding taps '
+                                   'left out, %d patches)' % (2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms,
                          'flops_per_launch': kern_flops,          # multiply-adds ISSUED (decoder form minus the skipped zero-padding taps)

@@ -128,6 +128,9 @@ size_t rf_conv3_up_packed_floats(int cout, int c0, int c1);
 int rf_conv3_up_pack_weight(const float* w_oidhw, int cout, int c0, int c1, float* w_packed, void* stream);
 int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cout);
+/* which tiling rf_conv3d_up_k3_gn_relu uses for a shape (0 parity-split boxes, 1 position-major 4^3, 2 position-major 8^3
+ * slices): they issue different numbers of multiply-adds (zero-padding taps left out), for reporting only */
+int rf_conv3d_up_variant(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
                             const float* shift, const float* w_packed, int cout, float* out, double* stats, void* stream);
 

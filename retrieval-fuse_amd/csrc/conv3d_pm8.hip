@@ -381,12 +381,13 @@ static int launch_pm8(const Pm8Args& a, hipStream_t stream) {
     return RF_OK;
 }
 
-// whole 8^3 volumes, enough samples to fill the chip.  RFUSE_CONV_PM8: 0 = off, 1 = decoder form only (default), 2 = plain
-// convs too.  Measured (B = 32): the three staged slices per chunk cost the plain convs what the skipped taps save (16->16
-// 496 vs 466 us box-tiled, 16->32 902 vs 887, 56->16 1561 vs 1533); the decoder form wins 2.5 % (5118 vs 5252 us): its
-// low-res phase skips 33 % of the taps instead of 12.5 %.
+// whole 8^3 volumes, enough samples to fill the chip.  RFUSE_CONV_PM8: 0 = off (default), 1 = decoder form, 2 = plain convs too.
+// Measured (B = 32, 8192 patches): staging three slices per chunk and per cout block costs what the skipped taps save --
+// plain convs 16->16 496 vs 466 us box-tiled, 16->32 902 vs 887, 56->16 1561 vs 1533; decoder form 32+64->56: 5.04 vs
+// 5.24 ms (-4 %), but with 5.0 GB instead of 1.0 GB fetched per launch (the input is re-read per slice and per cout block)
+// and the MFMA pipe 68 % instead of 81 % busy.  Kept as an option; the box-tiled kernels stay the default at 8^3.
 static int pm8_knob() {
-    static const int knob = getenv("RFUSE_CONV_PM8") ? atoi(getenv("RFUSE_CONV_PM8")) : 1;
+    static const int knob = getenv("RFUSE_CONV_PM8") ? atoi(getenv("RFUSE_CONV_PM8")) : 0;
     return knob;
 }
 bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout) {

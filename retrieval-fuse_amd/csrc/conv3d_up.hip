@@ -606,6 +606,14 @@ extern "C" int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout)
     return boxes * gy >= 256;
 }
 
+// which kernel rf_conv3d_up_k3_gn_relu launches for a shape: 0 = parity-split boxes (this file), 1 = position-major 4^3
+// (conv3d_small.hip), 2 = position-major 8^3 slices (conv3d_pm8.hip) -- for reporting (issued multiply-adds differ)
+extern "C" int rf_conv3d_up_variant(int c0, int c1, int n, int edge, int cout) {
+    if (rf_conv3_pm8_takes(c0, c1, n, edge, cout)) return 2;
+    if (edge == 4 && rf_conv3_small_up_takes(c0, c1, n, edge, cout)) return 1;
+    return 0;
+}
+
 extern "C" int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cout) {
     if (rf_conv3_pm8_takes(c0, c1, n, edge, cout)) return 8;            // one tile per z slice (conv3d_pm8.hip)
     return edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8);

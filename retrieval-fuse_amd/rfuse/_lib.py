@@ -46,6 +46,7 @@ SIGNATURES = {
     'rf_conv3_up_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_conv3d_up_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_up_stats_tiles': (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_up_variant': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_up_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p, c_p]),
     'rf_unfold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_fold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),

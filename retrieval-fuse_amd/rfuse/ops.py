@@ -242,10 +242,17 @@ def conv3d_up_gn_relu(src0, src1, scale, shift, w_up_packed, cout):
                                            _p(stats), _stream()), 'rf_conv3d_up_k3_gn_relu')
     if timed:
         ev1.record()
-        # multiply-adds the kernel ISSUES: decoder form 27*c0 + 8*c1 per (voxel, cout), minus the z-border taps that read only
-        # zero padding and are skipped (conv3d_up.hip): edge 4: 1/6 of the skip-channel and 1/4 of the low-res taps; edge >= 8:
-        # 1/12 and 1/8 of them in the first / last box along z, i.e. divided by the number of boxes along z
-        fa, fb = (1.0 / 6, 1.0 / 4) if edge == 4 else (1.0 / (12 * (edge // 8)), 1.0 / (8 * (edge // 8)))
+        # multiply-adds the kernel ISSUES: decoder form 27*c0 + 8*c1 per (voxel, cout) minus the zero-padding taps it leaves out.
+        # Position-major tilings leave out all of them (valid fraction ((3e-2)/(3e))^3 of the 27 taps and ((2h-1)/(2h))^3 of
+        # the 8 low-res taps, e = edge, h = edge/2 ... at 4^3: (1.5/2)^3); the parity-split boxes only the z-border ones
+        # (edge 4: 1/6 and 1/4; edge >= 8: 1/12 and 1/8 in the first / last box along z).
+        variant = lib.rf_conv3d_up_variant(c0, c1, n, edge, cout)
+        if variant == 2:
+            fa, fb = 1 - (22.0 / 24) ** 3, 1 - (7.0 / 8) ** 3
+        elif variant == 1:
+            fa, fb = 1 - (10.0 / 12) ** 3, 1 - (1.5 / 2) ** 3
+        else:
+            fa, fb = (1.0 / 6, 1.0 / 4) if edge == 4 else (1.0 / (12 * (edge // 8)), 1.0 / (8 * (edge // 8)))
         conv_events.append((ev0, ev1, 2.0 * (27 * c0 * (1 - fa) + 8 * c1 * (1 - fb)) * cout * edge ** 3 * n))
     if stats is not None:
         out._rf_stats = (stats, tiles, out._version)

@@ -5,8 +5,8 @@ profiles/<round>_pmc_bench_C2_B32.csv (per kernel x grid size, per-launch averag
     python tools/pmc_summary.py [pmc_dir] [round_tag]
 
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): every pass is its own run,
-counter values are already summed over the 8 XCDs, FETCH_SIZE counts 32-byte... is reported in KB and under-counts by 2x on
-gfx950 (so fetch bytes = 2 * FETCH_SIZE * 1024), WRITE_SIZE is KB; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (per-XCD
+counter values are already summed over the 8 XCDs, FETCH_SIZE is reported in KB and under-counts by 2x on gfx950 (so fetch
+bytes = 2 * FETCH_SIZE * 1024), WRITE_SIZE is KB; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (per-XCD
 GRBM_GUI_ACTIVE * 1024 SIMDs) with GRBM_GUI_ACTIVE / 8 = cycles of one XCD.
 """
 import collections
