@@ -60,7 +60,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_pm8(Pm8Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = y of this wave's row
-    const int z = blockIdx.x & 7, n0 = (blockIdx.x >> 3) * 16, cob = blockIdx.y * NCO;
+    // the 8 z slices of a sample group re-read each other's input slices: keep them on one XCD (one L2).  Workgroups go to the
+    // XCDs round-robin by linear id and gridDim.x is a multiple of 8, so XCD k must walk a contiguous range of (group, z) ids
+    const unsigned lb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int z = lb & 7, n0 = (lb >> 3) * 16, cob = blockIdx.y * NCO;
     const int kq = lane >> 4, li = lane & 15;
     const int ctot = a.cin + (UP ? a.c1 : 0);
     constexpr bool PFX = true;                                       // prefetch the next chunk's rows through registers under the MFMA loop
