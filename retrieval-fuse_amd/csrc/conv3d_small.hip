@@ -397,7 +397,7 @@ bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout) {
     if (!knob || c1 != 0 || c0 <= 0 || (edge != 4 && edge != 2)) return false;
     const long long gy = (rf_round_up(cout, 16) + 31) / 32;
     const long long wgs = (edge == 4 ? (n + 15) / 16 : (n + 127) / 128) * gy;
-    return wgs >= 256;
+    return wgs >= 128;                                               // half a wave of workgroups per CU still beats the box tiling
 }
 
 int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,

@@ -1,14 +1,25 @@
-"""Dev tool: timeline of the first N kernels of the last complete step in a rocprofv3 kernel trace (gaps = GPU idle, all streams)."""
-import csv, sys
+"""Dev tool: per-stream busy time and launch gaps of the last complete step in a rocprofv3 kernel trace."""
+import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_query_windows' in r['Kernel_Name']]
-start = idx[-4] if len(idx) >= 4 else idx[0]
-t0 = int(rows[start]['Start_Timestamp'])
-end_max = 0
-for r in rows[start:start + N]:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    gap = (s - end_max) / 1e3 if end_max else 0.0
-    print('%9.1f us  gap %7.1f  dur %8.1f  st %-3s %s' % ((s - t0) / 1e3, gap, (e - s) / 1e3, r.get('Stream_Id', '?'), r['Kernel_Name'][:60]))
-    end_max = max(end_max, e)
+a, b = idx[-4], idx[-2]
+step = rows[a:b]
+t0, t1 = int(step[0]['Start_Timestamp']), int(rows[b]['Start_Timestamp'])
+print('step wall %.1f us, %d kernels' % ((t1 - t0) / 1e3, len(step)))
+by = collections.defaultdict(list)
+for r in step:
+    by[r.get('Stream_Id', '?')].append(r)
+for sid, rs in by.items():
+    busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rs) / 1e3
+    gaps = [(int(rs[i + 1]['Start_Timestamp']) - int(rs[i]['End_Timestamp'])) / 1e3 for i in range(len(rs) - 1)]
+    pos = [g for g in gaps if g > 0]
+    print('stream %s: %d kernels, busy %.1f us, sum of gaps %.1f us, median gap %.2f us, max gap %.1f us' % (sid, len(rs), busy, sum(pos), sorted(pos)[len(pos) // 2] if pos else 0, max(pos) if pos else 0))
+main = max(by.items(), key=lambda kv: sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in kv[1]))[1]
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in main:
+    k = r['Kernel_Name'].split('(')[0][-60:]
+    agg[k][0] += 1
+    agg[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print('%9.1f us  x%-3d %s' % (t, n, k))
