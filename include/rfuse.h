@@ -111,7 +111,8 @@ size_t rf_convv_packed_floats(int cout, int cin, int k);
  * writes pool_out [n][cout][(edge/2)^3] = maxpool2(out) and, when pool_stats is non-NULL, its (sum, sum of squares)
  * [n][cout][rf_conv3d_stats_tiles(...)][2] for rf_gn_from_stats.  out == NULL: only the pooled tensor is written (an
  * encoder level whose full-resolution output nobody reads: UNet3D with remove_n_final_layers, model/unet.py:500-507);
- * stats must then be NULL.  Only shapes with rf_conv3d_pool_supported(...) == 1 (the 8^3-box tiling). */
+ * stats must then be NULL.  Only shapes with rf_conv3d_pool_supported(...) == 1 (the 8^3-box tiling; whole 4^3 volumes on
+ * the position-major kernel). */
 int rf_conv3d_pool_supported(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_k3_gn_relu_pool(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                               const float* scale, const float* shift, const float* w_packed, int cout,

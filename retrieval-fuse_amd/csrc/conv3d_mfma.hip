@@ -655,7 +655,7 @@ int rf_conv3_pm8_launch(const float* src0, int c0, const float* src1, int c1, in
                         const float* w_packed, int cout, float* out, double* stats, void* stream);
 bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout);                       // conv3d_small.hip
 int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
-                          float* out, double* stats, void* stream);
+                          float* out, double* stats, void* stream, float* pool_out, double* pool_stats);
 
 static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                        const float* scale, const float* shift, const float* w_packed, int cout,
@@ -677,8 +677,8 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     hipStream_t s = (hipStream_t)stream;
     if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
     // whole 4^3 / 2^3 volumes: the position-major kernel (conv3d_small.hip) leaves out every zero-padding tap
-    if (!pool_mode && rf_conv3_small_takes(c0, c1, n, edge, cout))
-        return rf_conv3_small_launch(src0, c0, n, edge, scale, shift, w_packed, cout, out, stats, stream);
+    if ((!pool_mode || edge == 4) && rf_conv3_small_takes(c0, c1, n, edge, cout))
+        return rf_conv3_small_launch(src0, c0, n, edge, scale, shift, w_packed, cout, out, stats, stream, pool_out, pool_stats);
     // whole 8^3 volumes, single source: position-major over z slices (conv3d_pm8.hip)
     if (!pool_mode && c1 == 0 && rf_conv3_pm8_takes(c0, 0, n, edge, cout))
         return rf_conv3_pm8_launch(src0, c0, nullptr, 0, n, scale, shift, w_packed, cout, out, stats, stream);
@@ -701,6 +701,7 @@ extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1
 
 // fused MaxPool3d(2): only the 8^3-box tiling (edge >= 8, enough boxes, not the cin == 1 kernel) holds whole pooling cells
 extern "C" int rf_conv3d_pool_supported(int c0, int c1, int n, int edge, int cout) {
+    if (edge == 4) return rf_conv3_small_takes(c0, c1, n, edge, cout);      // position-major kernel pools from its epilogue tile
     return edge >= 8 && rf_is_pow2(edge) && edge <= 128 && !conv_use_cin1(c0, c1, edge, cout) && conv_use_big(n, edge, rf_round_up(cout, 16));
 }
 

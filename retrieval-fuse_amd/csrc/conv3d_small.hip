@@ -37,6 +37,8 @@ struct SmallArgs {
     const float* src1;
     const float* wp1;      // [c1_8/8][8 parities][8 taps][8 ch][cout16]
     int c1, c1_8;
+    float* pool_out;       // optional (4^3): MaxPool3d(2) of the output [n][cout][2^3] and its statistics [n][cout][1]; `out` may then be NULL
+    double2* pool_stats;
 };
 
 template <int E, int NB, bool UP = false>
@@ -308,9 +310,34 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
             for (int q = tid; q < 16 * SAMPLES * (P / 4); q += NT) {
                 const int p4 = q % (P / 4), smp = (q / (P / 4)) % SAMPLES, col = q / ((P / 4) * SAMPLES);
                 const int co = cob + nb * 16 + col, nn = n0 + smp;
-                if (co < a.cout && nn < a.n) {
+                if (co < a.cout && nn < a.n && a.out) {
                     const float* e = eb + (col * SAMPLES + smp) * EROW + p4 * 4;
                     *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * P + p4 * 4) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            if (E == 4 && a.pool_out) {
+                // fused MaxPool3d(2) (4^3 -> 2^3) straight from the tile, and the pooled tensor's GroupNorm statistics: one thread per
+                // (cout, sample), fixed order
+                if (tid < 256) {
+                    const int smp = tid >> 4, col = tid & 15;
+                    const int co = cob + nb * 16 + col, nn = n0 + smp;
+                    if (co < a.cout && nn < a.n) {
+                        const float* e = eb + (col * SAMPLES + smp) * EROW;
+                        float pv[8];
+                        double sm = 0.0, sq = 0.0;
+#pragma unroll
+                        for (int cell = 0; cell < 8; ++cell) {
+                            const int base = (cell >> 2) * 32 + ((cell >> 1) & 1) * 8 + (cell & 1) * 2;      // (2Z, 2Y, 2X)
+                            float m = fmaxf(fmaxf(e[base], e[base + 1]), fmaxf(e[base + 4], e[base + 5]));
+                            m = fmaxf(m, fmaxf(fmaxf(e[base + 16], e[base + 17]), fmaxf(e[base + 20], e[base + 21])));
+                            pv[cell] = m;
+                            sm += (double)m; sq += (double)m * (double)m;
+                        }
+                        float4* po = reinterpret_cast<float4*>(a.pool_out + ((size_t)nn * a.cout + co) * 8);
+                        po[0] = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                        po[1] = make_float4(pv[4], pv[5], pv[6], pv[7]);
+                        if (a.pool_stats) a.pool_stats[(size_t)nn * a.cout + co] = make_double2(sm, sq);
+                    }
                 }
             }
             __syncthreads();
@@ -401,12 +428,13 @@ bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout) {
 }
 
 int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
-                          float* out, double* stats, void* stream) {
+                          float* out, double* stats, void* stream, float* pool_out, double* pool_stats) {
     SmallArgs a;
     a.src = src; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
     a.cin = cin; a.n = n; a.cout = cout; a.cin4 = rf_round_up(cin, 4); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
     a.src1 = nullptr; a.wp1 = nullptr; a.c1 = 0; a.c1_8 = 0;
+    a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
     hipStream_t s = (hipStream_t)stream;
     if (edge == 4) return a.cout16 <= 16 ? launch_small<4, 1>(a, s) : launch_small<4, 2>(a, s);
     return a.cout16 <= 16 ? launch_small<2, 1>(a, s) : launch_small<2, 2>(a, s);
@@ -427,6 +455,7 @@ int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c
     a.cin = c0; a.n = n; a.cout = cout; a.cin4 = rf_round_up(c0, 4); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
     a.src1 = src1; a.c1 = c1; a.c1_8 = rf_round_up(c1, 8);
+    a.pool_out = nullptr; a.pool_stats = nullptr;
     a.wp1 = w_up_packed + (size_t)27 * a.cin4 * a.cout16;
     hipStream_t s = (hipStream_t)stream;
     return a.cout16 <= 16 ? launch_small<4, 1, true>(a, s) : launch_small<4, 2, true>(a, s);

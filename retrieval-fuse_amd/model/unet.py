@@ -92,7 +92,7 @@ class SingleConv(nn.Module):
         cout = self.conv.out_channels
         scale, shift = ops.gn_scale_shift(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
-        if pool is not None and upsampled is None and not _direct and edge >= 8 and ops.conv_pool_supported(x, None, cout):
+        if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
             return ops.conv3d_gn_relu_pool(x, None, scale, shift, self.conv.packed(), cout, keep_full=(pool == 'also'))
         if _direct or edge == 1:
             out = ops.conv3d_gn_relu(x, upsampled, scale, shift, None, cout, direct_weight=self.conv.weight)

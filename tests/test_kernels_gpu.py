@@ -151,7 +151,8 @@ def test_conv3d_up_parity_split_decoder_kernel(ops, case):
     close(fused[1], plain[1], 1e-6, 'shift from fused stats')
 
 
-@pytest.mark.parametrize('case', [(300, 8, 16, 16, 8), (1100, 16, 8, 32, 8), (2, 16, 64, 16, 8), (130, 6, 16, 12, 6), (520, 16, 8, 72, 8)])
+@pytest.mark.parametrize('case', [(300, 8, 16, 16, 8), (1100, 16, 8, 32, 8), (2, 16, 64, 16, 8), (130, 6, 16, 12, 6), (520, 16, 8, 72, 8),
+                                  (4100, 32, 4, 64, 8), (2100, 16, 4, 16, 8), (2050, 6, 4, 12, 6)])
 def test_conv_with_fused_maxpool_epilogue(ops, case):
     """rf_conv3d_k3_gn_relu_pool == conv followed by the stand-alone MaxPool3d(2) kernel, bit for bit, with and without the
     full-resolution output; the pooled tensor's fused statistics give the same GroupNorm fold as re-reading it."""
