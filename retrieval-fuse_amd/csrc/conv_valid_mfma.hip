@@ -45,6 +45,7 @@ struct ConvVArgs {
     float* out;
     int n, cin, s, cout, cout16, k, stride, so, kpad;
     float slope;
+    unsigned gx, gz;     // voxel blocks per window, cout blocks (the grid is 1-D: gx * gz * n workgroups)
 };
 
 template <int MB, int NB>
@@ -54,9 +55,15 @@ __global__ __launch_bounds__(256) void k_convv_mfma(ConvVArgs a) {
     const int so = a.so, s = a.s, cin = a.cin, k = a.k;
     const int ovol = so * so * so;
     const size_t ivol = (size_t)s * s * s;
-    const int nn = blockIdx.y;
-    const int cob = blockIdx.z * (NB * 16);
-    const int m_wave = (blockIdx.x * 4 + wave) * (MB * 16);
+    // 1-D grid, XCD-aware: workgroups go to the 8 XCDs round-robin by id, each XCD with its own L2.  Every input value of a window is
+    // re-read k^3 * (cout blocks) times by different workgroups: remap so that XCD k walks whole windows one after the other
+    // (voxel blocks fastest, then cout blocks, then windows) and the window's input stays in that one L2.
+    const unsigned total = gridDim.x, per = total >> 3, rem = total & 7u, xk = blockIdx.x & 7u;
+    const unsigned lb = xk * per + (xk < rem ? xk : rem) + (blockIdx.x >> 3);
+    const unsigned xb = lb % a.gx, zb = (lb / a.gx) % a.gz;
+    const int nn = (int)(lb / (a.gx * a.gz));
+    const int cob = (int)zb * (NB * 16);
+    const int m_wave = ((int)xb * 4 + wave) * (MB * 16);
     if (m_wave >= ovol) return;                                  // whole wave past the end (no barriers in this kernel)
 
     int base[MB];
@@ -77,6 +84,48 @@ __global__ __launch_bounds__(256) void k_convv_mfma(ConvVArgs a) {
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int K = k * k * k * cin;
+    if ((cin & 3) == 0) {
+        // cin a multiple of 4: K index = tap*cin + ci walks taps in the outer loop and 4-channel steps inside it -- no integer
+        // divisions in the loop (the generic form below spends more issue slots on tap = kidx / cin than on MFMAs)
+        const size_t cstep = 4 * ivol;
+        const int nc4 = cin >> 2, nsteps = k * k * k * nc4;
+        // operands of step i+1 are loaded while step i multiplies (the loads are L1/L2 gathers: latency, not bandwidth)
+        int dz = 0, dy = 0, dx = 0, c4 = 0;
+        const float* xt = xin + (size_t)kq * ivol;
+        const float* wt = wl + (size_t)kq * a.cout16;
+        float av[2][MB], bv[2][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[0][mb] = xt[base[mb]];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[0][nb] = (cob + nb * 16 < a.cout16) ? wt[nb * 16] : 0.f;
+        for (int i = 0; i < nsteps; i += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (i + h < nsteps) {
+                    // advance to step i+h+1: next 4 channels, or the next tap
+                    wt += (size_t)4 * a.cout16;
+                    if (++c4 == nc4) {
+                        c4 = 0;
+                        if (++dx == k) { dx = 0; if (++dy == k) { dy = 0; ++dz; } }
+                        xt = xin + (size_t)kq * ivol + ((size_t)dz * s + dy) * s + dx;
+                    } else {
+                        xt += cstep;
+                    }
+                    if (i + h + 1 < nsteps) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) av[h ^ 1][mb] = xt[base[mb]];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[h ^ 1][nb] = (cob + nb * 16 < a.cout16) ? wt[nb * 16] : 0.f;
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][mb], bv[h][nb], acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+    } else
     for (int ks = 0; ks < a.kpad; ks += 4) {
         int kidx = ks + kq;
         const bool live = kidx < K;                              // padded k rows carry zero weights; keep the address valid
@@ -130,12 +179,13 @@ extern "C" int rf_conv3d_valid_leaky_mfma(const float* x, int n, int cin, int s,
     hipStream_t st = (hipStream_t)stream;
     // 4 waves x MB m-blocks of 16 voxels per workgroup; small outputs take MB = 1 so tiny windows still spread over waves
     if (a.cout16 <= 16) {
-        if (ovol >= 4096) hipLaunchKernelGGL((k_convv_mfma<4, 1>), dim3((unsigned)((ovol + 255) / 256), n, 1), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_convv_mfma<1, 1>), dim3((unsigned)((ovol + 63) / 64), n, 1), dim3(256), 0, st, a);
+        a.gz = 1;
+        if (ovol >= 4096) { a.gx = (unsigned)((ovol + 255) / 256); hipLaunchKernelGGL((k_convv_mfma<4, 1>), dim3(a.gx * a.gz * n), dim3(256), 0, st, a); }
+        else { a.gx = (unsigned)((ovol + 63) / 64); hipLaunchKernelGGL((k_convv_mfma<1, 1>), dim3(a.gx * a.gz * n), dim3(256), 0, st, a); }
     } else {
-        const unsigned gz = (unsigned)((a.cout16 + 31) / 32);
-        if (ovol >= 4096) hipLaunchKernelGGL((k_convv_mfma<4, 2>), dim3((unsigned)((ovol + 255) / 256), n, gz), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_convv_mfma<1, 2>), dim3((unsigned)((ovol + 63) / 64), n, gz), dim3(256), 0, st, a);
+        a.gz = (unsigned)((a.cout16 + 31) / 32);
+        if (ovol >= 4096) { a.gx = (unsigned)((ovol + 255) / 256); hipLaunchKernelGGL((k_convv_mfma<4, 2>), dim3(a.gx * a.gz * n), dim3(256), 0, st, a); }
+        else { a.gx = (unsigned)((ovol + 63) / 64); hipLaunchKernelGGL((k_convv_mfma<1, 2>), dim3(a.gx * a.gz * n), dim3(256), 0, st, a); }
     }
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_mfma");
     return RF_OK;
