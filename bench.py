@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--feature-cache', action='store_true', help='also time the optional cached-retrieval-features serving mode (reported separately)')
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
+    ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank under torch.distributed.run, still run the all-gather + merge protocol')
     return ap.parse_args()
 
 
@@ -124,7 +125,9 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback for the hot path)'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    force_dist = world == 1 and os.environ.get('RFUSE_FORCE_DIST') in ('1', '2') and 'RANK' in os.environ   # dev: exercise RCCL with one rank
+    knobs = sorted(k for k in os.environ if k.startswith('RFUSE_') and k != 'RFUSE_LIB')
+    assert not knobs, 'refusing to measure with developer switches set: %s' % knobs
+    force_dist = world == 1 and args.force_collectives and 'RANK' in os.environ        # dev: run the whole RCCL protocol with one rank
     if world > 1 or force_dist:
         dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
 
@@ -139,7 +142,7 @@ def main():
     torch.manual_seed(0)
     emb, meta, vols = synthetic_database(cfg, n_patches, device)
     database = PatchDatabase(emb, meta, vols, device, rank, world)
-    database.force_collectives = force_dist and os.environ.get('RFUSE_FORCE_DIST') == '1'
+    database.force_collectives = force_dist
     eng = RefinementEngine(cfg, device, database)
     # every rank refines its own B chunks (chunk-parallel replicas); inputs resident in HBM
     raws = np.stack([synthetic.make_chunk(10_000 + rank * B + b, cfg)['input_raw'] for b in range(B)])

@@ -232,10 +232,13 @@ int rf_topk_merge(const float* in_dist, const int64_t* in_idx, int parts, int nq
 
 /* flann_knn_worker's post-processing (util/retrieval.py:93-100): look up db_meta[idx] = (scene, x0,x1,y0,y1,z0,z1),
  * stably move neighbours whose scene == query_scene[q] (>=0) to the back, keep the first K.
- * db_meta [n_total][7] int32.  out_meta [nq][K][7] int32, out_dist [nq][K], out_idx [nq][K]. */
+ * db_meta [n_total][7] int32.  out_meta [nq][K][7] int32, out_dist [nq][K], out_idx [nq][K].
+ * query_keep [nq] uint8 or NULL: 0 marks a query patch the dataset's occupancy filter dropped
+ * (dataset/patched_scene_dataset.py:28-32): it gets K "no neighbour" entries (scene -1, idx -1, dist +inf), which
+ * rf_gather_patches turns into the truncation fill -- the patch keeps the trunc init of util/retrieval.py:148,151. */
 int rf_demote_same_scene(const float* dist, const int64_t* idx, int nq, int k2, const int32_t* db_meta,
-                         const int32_t* query_scene, int K, int32_t* out_meta, float* out_dist, int64_t* out_idx,
-                         void* stream);
+                         const int32_t* query_scene, const uint8_t* query_keep, int K, int32_t* out_meta, float* out_dist,
+                         int64_t* out_idx, void* stream);
 
 /* create_retrieval_from_mapping (util/retrieval.py:145-164, no_overlap) fused with the retrieval normalisation
  * (dataset/patched_scene_dataset.py:130-133) and Unfold3D(16,1) (trainer/train_refinement.py:34,112):
@@ -248,7 +251,8 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
 
 /* out[m][width] = src[idx[m]][width] (width % 4 == 0): row gather used to fetch cached, query-independent retrieval
  * backbone features of database patches (an optional serving mode; the reference recomputes them,
- * trainer/train_refinement.py:112). */
+ * trainer/train_refinement.py:112).  idx[m] < 0 ("no neighbour") or >= n_src selects row n_src-1, where the database keeps
+ * its all-trunc sentinel patch (util/retrieval.py:21-26,45). */
 int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t m, int width, float* out, void* stream);
 
 #ifdef __cplusplus

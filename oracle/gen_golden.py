@@ -46,6 +46,25 @@ def stats(t):
     return np.array([t64.sum().item(), t64.abs().sum().item(), (t64 * t64).sum().item()], dtype=np.float64)
 
 
+def save_fixture(name, **arrays):
+    """np.savez_compressed, but an existing fixture whose arrays are all identical is left untouched (zip members carry
+    timestamps, so re-writing would churn the committed bytes for nothing)."""
+    path = OUT / (name + '.npz')
+    if path.exists():
+        old = np.load(path, allow_pickle=False)
+        same = sorted(old.files) == sorted(arrays)
+        if same:
+            for k in old.files:
+                a, b = old[k], np.asarray(arrays[k])
+                if a.shape != b.shape or a.dtype != b.dtype or not np.array_equal(a, b, equal_nan=(a.dtype.kind == 'f')):
+                    same = False
+                    break
+        if same:
+            print('  (unchanged)', path.name)
+            return
+    np.savez_compressed(path, **arrays)
+
+
 def import_reference_model():
     # our product package also has a top-level ``model``; make sure the reference's wins in this process
     for k in [k for k in sys.modules if k == 'model' or k.startswith('model.')]:
@@ -81,7 +100,7 @@ def chunk_inputs(cfg, seed, batch, stress=False):
     return np.stack(xs).astype(np.float32), np.stack(rs).astype(np.float32)
 
 
-def gen_network_fixture(ref_model, name, cfg_name, seed, batch, stress=False):
+def gen_network_fixture(ref_model, name, cfg_name, seed, batch, stress=False, with_features=False):
     cfg = rf_configs.get_config(cfg_name)
     trunc_i, trunc_t = rf_configs.truncations(cfg)
     with mock.patch('builtins.print'):
@@ -137,8 +156,85 @@ def gen_network_fixture(ref_model, name, cfg_name, seed, batch, stress=False):
         x_attn_sub=sub(x_attn, 2), x_attn_stats=stats(x_attn),
         pred_stats=stats(pred), df=df.numpy().astype(np.float32),
     )
-    np.savez_compressed(OUT / (name + '.npz'), **out)
+    save_fixture(name, **out)
     print(name, 'df', df.shape, 'margin', min_margin, 'x_back absmax', float(x_back.abs().max()), 'pred range', float(pred.min()), float(pred.max()))
+    gen_truth_fixture(name, cfg, (unet, dec, rb, pab), xt, rt, trunc_t, out.get('gumbel_noise'), df, x_back, x_retr, x_attn)
+    if with_features:
+        gen_features_fixture(name.replace('net_', 'feat_'), cfg, seed, (unet, dec, rb, pab), xt, x_back, trunc_t)
+
+
+def gen_truth_fixture(name, cfg, mods, xt, rt, trunc_t, noise, df_ref, x_back_ref, x_retr_ref, x_attn_ref):
+    """float64 evaluation of the SAME network on the SAME inputs = the 'truth' both fp32 implementations (the reference's
+    ATen-CPU fp32 and the HIP path) are measured against.  Computed with the oracle in float64; for the deterministic
+    (softmax) configs the reference's own modules are also run in .double() and must agree with it to 1e-9."""
+    sys.path.insert(0, str(REPO))
+    from oracle import refpath
+    unet, dec, rb, pab = mods
+    sds64 = {n: {k: v.double() for k, v in m.state_dict().items()} for n, m in
+             (('unet_backbone', unet), ('decoder', dec), ('retrieval_backbone', rb), ('patched_attention_block', pab))}
+    st = {}
+    with torch.no_grad():
+        df64 = refpath.forward_full(sds64, cfg, xt.double(), rt.double(), float(trunc_t),
+                                    torch.from_numpy(noise).double() if noise is not None else None, st)
+        ref_double_gap = -1.0
+        if not cfg['attn_retrieval_mode']:
+            import copy
+            from model.attention import Unfold3D, Fold3D
+            u64, d64, r64, p64 = (copy.deepcopy(m).double() for m in mods)
+            b, K = xt.shape[0], cfg['K']
+            xb = u64(xt.double())
+            xr = Fold3D(4, 8, rb.nf)(r64(Unfold3D(16, 1)(rt.double()[:, :K].reshape(b * K, 1, 64, 64, 64))))
+            dfr = (d64(p64(xb, xr)) + 1) * float(trunc_t) / 2
+            ref_double_gap = float((dfr - df64).abs().max())
+            assert ref_double_gap <= 1e-9, ref_double_gap
+    err = (df_ref.double() - df64).abs()
+    def resid(t64, t32):
+        # the truth is stored as its float32 residual against the reference's fp32 result of the main fixture:
+        # truth = float64(ref) + float64(residual); the residual is ~1e-6, so its own float32 rounding is ~1e-13
+        return (t64 - t32.double()).float()
+    out = dict(
+        df_resid=resid(df64, df_ref).numpy(), ref_double_gap=ref_double_gap,
+        x_back_resid_sub=sub(resid(st['x_back'], x_back_ref), 2), x_retr_resid_sub=sub(resid(st['x_retrieval'], x_retr_ref), 4),
+        x_attn_resid_sub=sub(resid(st['x_attn'], x_attn_ref), 2),
+        # how far the reference's own fp32 arithmetic sits from the truth (informational; tests recompute it from df / df_f64)
+        ref_err_max=float(err.max()), ref_err_rms=float((err ** 2).mean().sqrt()),
+        ref_frac_gt_1e4=float((err > 1e-4).double().mean()),
+        ref_err_back=float((x_back_ref.double() - st['x_back']).abs().max()),
+        ref_err_retr=float((x_retr_ref.double() - st['x_retrieval']).abs().max()),
+        ref_err_attn=float((x_attn_ref.double() - st['x_attn']).abs().max()),
+    )
+    save_fixture(name.replace('net_', 'truth_'), **out)
+    print('  truth', name, 'ref fp32 vs f64: df max %.3e rms %.3e frac>1e-4 %.5f | x_back %.2e x_retr %.2e x_attn %.2e | ref.double gap %.1e'
+          % (out['ref_err_max'], out['ref_err_rms'], out['ref_frac_gt_1e4'], out['ref_err_back'], out['ref_err_retr'], out['ref_err_attn'],
+             ref_double_gap))
+
+
+def gen_features_fixture(name, cfg, seed, mods, xt, x_back, trunc_t):
+    """A8: PatchedAttentionBlock.get_features exactly as forward_full calls it (trainer/train_refinement.py:113-119):
+    theta on the backbone features, phi on the TARGET's retrieval-backbone features, occupancy from decoder(x_back)."""
+    from model.attention import Unfold3D, Fold3D
+    unet, dec, rb, pab = mods
+    b = xt.shape[0]
+    tgt = np.stack([synthetic.normalise_target(cfg, synthetic.make_chunk(seed * 100 + 90 + i, cfg)['target_raw'])[None] for i in range(b)])
+    with torch.no_grad():
+        x_target = Fold3D(4, 8, rb.nf)(rb(Unfold3D(16, 1)(torch.from_numpy(tgt))))
+        df_back = (dec(x_back) + 1) * trunc_t / 2                                               # :118, :242-243
+        voxel = cfg['dataset_train']['voxel_size_target']
+        # occupancy_from_prediction, trainer/train_refinement.py:245-247; the reference thresholds with the float16-rounded voxel size
+        vs = float(np.float16(voxel).astype(np.float32))
+        occ = torch.nn.functional.max_pool3d((df_back <= vs * 0.75).float(), kernel_size=2, stride=2).bool()
+        x_feat, p_feat, occ_flat = pab.get_features(x_back, x_target, occ)
+    save_fixture(name, cfg_name=str(cfg_name_of(cfg)), seed=seed, target_sha=sha(tgt), occupancy=np.packbits(occ.numpy().reshape(-1)),
+                 x_feat=x_feat.numpy(), p_feat=p_feat.numpy(), occ_flat=np.packbits(occ_flat.numpy()),
+                 x_target_sub=sub(x_target, 4))
+    print('  features', name, tuple(x_feat.shape), tuple(p_feat.shape), 'occupied patches', int(occ_flat.sum()))
+
+
+def cfg_name_of(cfg):
+    for k, v in rf_configs.CONFIGS.items():
+        if v == cfg:
+            return k
+    raise KeyError
 
 
 def gen_query_fixture(ref_model, cfg_name, seed):
@@ -155,7 +251,7 @@ def gen_query_fixture(ref_model, cfg_name, seed):
         z = fenc_input(torch.from_numpy(windows))
         lat = cfg['retrieval_model']['latent_dim']
         emb = torch.nn.functional.normalize(z.permute((0, 2, 3, 4, 1)).reshape((-1, lat)), dim=1)
-    np.savez_compressed(OUT / ('query_%s.npz' % cfg_name), cfg_name=cfg_name, seed=seed, windows_sha=sha(windows),
+    save_fixture('query_%s' % cfg_name, cfg_name=cfg_name, seed=seed, windows_sha=sha(windows),
                         windows_shape=np.array(windows.shape), emb=emb.numpy())
     print('query', cfg_name, windows.shape, emb.shape)
 
@@ -269,7 +365,16 @@ def gen_retrieval_fixture(seed=5):
         for tag, m in (('train', map_train), ('val', map_val_s)):
             mp = {n: m[i] for i, n in enumerate(patch_names)}
             composed[tag] = ref_ret.create_retrieval_from_mapping(scene_names[q_scene], mp, K, ds_train, ds, tree).numpy()
-    np.savez_compressed(OUT / 'retrieval_map_compose.npz', seed=seed, n_patches=n_patches, q_scene=q_scene,
+        # query-side occupancy filter (dataset/patched_scene_dataset.py:28-32): patches below the occupancy threshold are never
+        # queried -- they are absent from patch_from_scene_lookup AND from the mapping -- and keep the trunc init (:148,151)
+        keep = rng.random(64) > 0.35
+        keep[[0, 63]] = [False, True]
+        kept_names = [n for i, n in enumerate(patch_names) if keep[i]]
+        ds_masked = _FakeDataset(db['volumes'], scene_names, trunc_t, {scene_names[q_scene]: kept_names})
+        mp = {n: map_val_s[i] for i, n in enumerate(patch_names) if keep[i]}
+        composed['masked'] = ref_ret.create_retrieval_from_mapping(scene_names[q_scene], mp, K, ds_train, ds_masked, tree).numpy()
+    save_fixture('retrieval_map_compose', seed=seed, n_patches=n_patches, q_scene=q_scene,
+                        patch_keep=keep, compose_masked_sha=sha(composed['masked']), compose_masked_sub=composed['masked'][:, ::4, ::4, ::4],
                         queries=queries, db_sha=sha(db['meta'], db['emb'], db['volumes']),
                         map_train=map_train, map_val=map_val, map_val_sentinel=map_val_s,
                         compose_train_sha=sha(composed['train']), compose_val_sha=sha(composed['val']),
@@ -282,17 +387,52 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
     ref_model = import_reference_model()
-    gen_network_fixture(ref_model, 'net_C1', 'C1', seed=1, batch=1)
+    gen_network_fixture(ref_model, 'net_C1', 'C1', seed=1, batch=1, with_features=True)
     gen_network_fixture(ref_model, 'net_C2_stress_b2', 'C2', seed=2, batch=2, stress=True)
     gen_network_fixture(ref_model, 'net_C3', 'C3', seed=3, batch=1)
     gen_network_fixture(ref_model, 'net_C4', 'C4', seed=4, batch=1)
-    gen_network_fixture(ref_model, 'net_C5', 'C5', seed=5, batch=1)
+    gen_network_fixture(ref_model, 'net_C5', 'C5', seed=5, batch=1, with_features=True)
     for c in ('C1', 'C4', 'C5'):
         gen_query_fixture(ref_model, c, seed=6)
     for c in ('C1', 'C5'):
         gen_dbrow_fixture(ref_model, c)
     gen_retrieval_fixture()
+    gen_combine_fixture()
 
+
+
+# ------------------------------------------------------------------------- "next" row N3: scene recomposition
+def gen_combine_fixture(seed=9):
+    """PatchedSceneDataset.combine_chunks / combine_inputs / combine_targets (dataset/patched_scene_dataset.py:153-186) run
+    unchanged on an object that carries just the attributes they touch."""
+    import_reference_util_retrieval()                       # installs the stubs dataset.* needs
+    from dataset.patched_scene_dataset import PatchedSceneDataset
+    out = {'seed': seed}
+    for tag, cfg_name, names in (
+            ('front', 'C3', ['sceneA__room0__0_0_0', 'sceneA__room0__64_0_0', 'sceneA__room0__64_128_64', 'sceneB__room3__0_64_0', 'sceneB__room3__0_0_0']),
+            ('shapenet', 'C1', ['03001627_aaa', '04379243_bbb'])):
+        cfg = rf_configs.get_config(cfg_name)
+        trunc_i, trunc_t = rf_configs.truncations(cfg)
+        chunks = [synthetic.make_chunk(seed * 100 + i, cfg) for i in range(len(names))]
+        ds = object.__new__(PatchedSceneDataset)
+        ds.scenes = names
+        ds.dataset_name = cfg['dataset_train']['dataset_name']
+        tgt = {n: c['target_raw'] for n, c in zip(names, chunks)}
+        inp = {n: c['input_raw'] for n, c in zip(names, chunks)}
+        s_in = cfg['dataset_train']['input_chunk_size']
+        res_t = ds.combine_chunks(1, 64, trunc_t, lambda obj, n: obj[n], tgt)                       # combine_targets, :179-180
+        res_i = ds.combine_chunks(64 / s_in, s_in, trunc_i, lambda obj, n: obj[n], inp)             # combine_inputs, :176-177
+        out[tag + '_names'] = np.array(names)
+        out[tag + '_cfg'] = cfg_name
+        out[tag + '_keys'] = np.array(sorted(res_t))
+        for k in sorted(res_t):
+            out['%s_target_%s_shape' % (tag, k)] = np.array(res_t[k].shape)
+            out['%s_target_%s_sha' % (tag, k)] = sha(res_t[k])
+            out['%s_target_%s_dtype' % (tag, k)] = str(res_t[k].dtype)
+            out['%s_input_%s_shape' % (tag, k)] = np.array(res_i[k].shape)
+            out['%s_input_%s_sha' % (tag, k)] = sha(res_i[k])
+    save_fixture('combine_chunks', **out)
+    print('combine fixture', [k for k in out if k.endswith('_shape')])
 
 
 # ---------------------------------------------------------------------------------- "next" row N1: database build
@@ -317,7 +457,7 @@ def gen_dbrow_fixture(ref_model, cfg_name='C1', seed=8):
         ones = torch.from_numpy(np.ones([w] * 3, dtype=np.float32)).unsqueeze(0).unsqueeze(0)
         zero_emb = torch.nn.functional.normalize(fenc_target(ones).permute((0, 2, 3, 4, 1)).reshape((-1, lat)), dim=1).numpy()
     zero_row = np.hstack([np.array([-1], dtype=np.float32)[:, np.newaxis]] + [np.array([0], dtype=np.float32)[:, np.newaxis], np.array([ps], dtype=np.float32)[:, np.newaxis]] * 3 + [zero_emb])
-    np.savez_compressed(OUT / ('dbrow_%s.npz' % cfg_name), cfg_name=cfg_name, seed=seed, windows_sha=sha(wins), emb=emb, zero_row=zero_row)
+    save_fixture('dbrow_%s' % cfg_name, cfg_name=cfg_name, seed=seed, windows_sha=sha(wins), emb=emb, zero_row=zero_row)
     print('dbrow', cfg_name, wins.shape, emb.shape, zero_row.shape)
 
 

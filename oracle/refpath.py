@@ -178,6 +178,17 @@ def patched_attention_block(x_pred, x_retr, sd, config, gumbel_noise=None, detai
     return fold3d(out, r, e, nf)
 
 
+def patched_get_features(x_pred, x_target, occupancy, sd, config):
+    """PatchedAttentionBlock.get_features -> AttentionBlock.get_features, model/attention.py:132-139, 72-82:
+    theta on the e^3 patches of x_pred, phi on those of x_target, both L2-normalised; per-patch any() of ``occupancy``."""
+    e = config['attn_patch_extent'] // 2
+    xp, xt = unfold3d(x_pred, e), unfold3d(x_target, e)
+    occ = unfold3d(occupancy, e)
+    x_feat = F.normalize(attention_feature_encoder(xp, sd, 'attention_blocks_layer.theta').reshape(xp.shape[0], -1), dim=1)
+    p_feat = F.normalize(attention_feature_encoder(xt, sd, 'attention_blocks_layer.phi').reshape(xp.shape[0], -1), dim=1)
+    return x_feat, p_feat, occ.reshape(xp.shape[0], -1).any(dim=1)
+
+
 # ------------------------------------------------------------------------------- runner (trainer.forward_full)
 
 def forward_full(sds, config, x_in, retrievals, target_trunc, gumbel_noise=None, stages=None):
@@ -306,15 +317,19 @@ def demote_same_scene(rows, query_scene_index, K):
     return out
 
 
-def compose_retrieval(mapping, db_volumes, K, target_trunc, trunc_ratio=1.0):
+def compose_retrieval(mapping, db_volumes, K, target_trunc, trunc_ratio=1.0, patch_keep=None):
     """create_retrieval_from_mapping for one 64^3 chunk with non-overlapping patches (no_overlap is True for every
     shipped config), util/retrieval.py:145-164.  mapping [64,K,8] in the chunk's patch order; returns [K,64,64,64].
-    idx < 0 (sentinel row) -> a volume of target_trunc (:160-161)."""
+    idx < 0 (sentinel row) -> a volume of target_trunc (:160-161).
+    ``patch_keep`` [64] bool: the query-side occupancy filter (dataset/patched_scene_dataset.py:28-32) -- patches it drops
+    are not in ``patch_from_scene_lookup`` (:151 never visits them) and keep the target_trunc initialisation (:148)."""
     out = np.ones((K, 64, 64, 64), dtype=np.float32) * np.float32(target_trunc)
     o = np.arange(0, 64, 16)
     slots = [(x, y, z) for x in o for y in o for z in o]
     for k in range(K):
         for p, (xx, yy, zz) in enumerate(slots):
+            if patch_keep is not None and not patch_keep[p]:
+                continue
             sidx = int(mapping[p, k, 0])
             x0, x1, y0, y1, z0, z1 = mapping[p, k, 1:7].astype(np.int32).tolist()
             if sidx >= 0:

@@ -227,13 +227,9 @@ __global__ __launch_bounds__(AM_WAVES * 64) void k_attn_mlp(AmArgs a) {
 }
 
 static int am_launch(const AmArgs& a, hipStream_t st) {
-    static bool attr_set = false;
     const int lds = 2 * AM_BUF_FLOATS * (int)sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) { rf_set_error("rf_attn_mlp: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
-        attr_set = true;
-    }
+    static RfLdsOptIn opt_in;
+    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_attn_mlp), lds, "rf_attn_mlp")) return rc;
     const int nwt = (a.ntiles + AM_WAVES - 1) / AM_WAVES;
     hipLaunchKernelGGL(k_attn_mlp, dim3(nwt < 256 ? nwt : 256), dim3(AM_WAVES * 64), lds, st, a);
     RF_CHECK_LAUNCH("rf_attn_mlp");

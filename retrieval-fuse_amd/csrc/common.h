@@ -26,6 +26,24 @@ void rf_set_error(const char* fmt, ...);
         }                                                                        \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives several GPUs has to
+// opt in on each of them.  One instance per kernel instantiation (function-local static); bit d = "done on device d".
+#include <atomic>
+struct RfLdsOptIn {
+    std::atomic<unsigned long long> done[4];
+    RfLdsOptIn() { for (auto& d : done) d.store(0ull); }
+    int ensure(const void* kernel, int bytes, const char* who) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) { rf_set_error("%s: cannot query the current device", who); return RF_E_LAUNCH; }
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done[dev >> 6].load(std::memory_order_acquire) & bit) return RF_OK;
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) { rf_set_error("%s: cannot raise the LDS limit to %d bytes: %s", who, bytes, hipGetErrorString(e)); return RF_E_LAUNCH; }
+        done[dev >> 6].fetch_or(bit, std::memory_order_release);
+        return RF_OK;
+    }
+};
+
 static inline bool rf_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int rf_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int rf_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -35,7 +35,6 @@ struct ConvArgs {
     const float* wp;
     float* out;
     int c0, c1, n, edge, cout, cin4, cout16;
-    int ablate;        // dev knob (RFUSE_CONV_ABLATE): 1 = stage only the first chunk, 2 = skip the MFMA loop
     double2* stats;    // optional [n][cout][stats_tiles] (sum, sum of squares) of the ReLU'd output, per workgroup tile
     int stats_tiles;
     // fused MaxPool3d(2) of the output (8^3 boxes only): pool_out [n][cout][(edge/2)^3] and its statistics
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     constexpr unsigned ZSKIP_LO = !ZUNIFORM ? 0u : BoxOrder<TZ, TY, TX, NW, MB>::POOLABLE ? 0x5u : (TX * TY == 16 ? 0x1u : (1u << MB) - 1u);
     constexpr unsigned ZSKIP_HI = !ZUNIFORM ? 0u : BoxOrder<TZ, TY, TX, NW, MB>::POOLABLE ? 0xAu : (TX * TY == 16 ? (1u << (MB - 1)) : (1u << MB) - 1u);
     unsigned zlo_mask = 0u, zhi_mask = 0u;
-    if (ZUNIFORM && a.ablate != 3) {
+    if (ZUNIFORM) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             int s, z, y, x;
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     constexpr unsigned LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
     int buf = 0;
     for (int cbase = 0; cbase < cin; cbase += CC) {
-        const bool more = cbase + CC < cin && a.ablate != 1;
+        const bool more = cbase + CC < cin;
         // opaque copy of the thread id: keeps the compiler from hoisting the per-row index math (lane-constant across
         // chunks) out of the K loop, where it would sit in -- and spill from -- registers the MFMA loop needs
         int tid_o = tid;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
             if (PFX) issue_rows(cbase + CC, tid_o);        // global loads fly under the MFMA loop ...
             dma_weights(cbase + CC, buf ^ 1, tid_o & 63);  // ... and so does the next weight slab
         }
-        if (a.ablate != 2) {
+        {
             const float* ws = wsb + buf * T::WSLAB_PAD;
             // The 27-tap MFMA loop, specialised at compile time on which m-blocks skip their dz = -1 (LO) / dz = +1 (HI) taps:
             // an m-block on the first / last z slice of the VOLUME reads nothing but zero padding through those taps, so the
@@ -496,13 +495,9 @@ template <int TZ, int TY, int TX, int SPW, int NW, int MB, int NB, int WPS, int 
 static int launch_conv3(const ConvArgs& a, hipStream_t stream) {
     using T = ConvTile<TZ, TY, TX, SPW, NW, MB, NB, CCT>;
     auto kern = k_conv3_mfma<TZ, TY, TX, SPW, NW, MB, NB, WPS, true, CCT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (T::LDS_BYTES > 65536) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-            if (e != hipSuccess) { rf_set_error("rf_conv3d_k3_gn_relu: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
-        }
-        attr_set = true;
+    if (T::LDS_BYTES > 65536) {
+        static RfLdsOptIn opt_in;
+        if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), (int)T::LDS_BYTES, "rf_conv3d_k3_gn_relu")) return rc;
     }
     unsigned gx;
     if (SPW == 1) gx = (unsigned)a.n * (a.edge / TZ) * (a.edge / TY) * (a.edge / TX);
@@ -522,11 +517,9 @@ static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
         if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 2, 2, 4>(a, stream);
         return launch_conv3<TZ, TY, TX, SPW, 8, 2, 4, 4>(a, stream);
     } else if constexpr (MODE == TILE_BIG) {
-        // 16-cout layers: an 8-channel chunk (216 instead of 108 MFMAs per wave between barriers) measured 3-7 % SLOWER than
-        // the 4-channel chunk on every such layer (tools/conv_bench.py), so it stays off; RFUSE_CONV_CC8=1 re-enables it
-        static const bool cc8 = getenv("RFUSE_CONV_CC8") && getenv("RFUSE_CONV_CC8")[0] == '1';
-        if (a.cout16 <= 16) return (cc8 && (a.c0 + a.c1) % 8 == 0) ? launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4, 8>(a, stream)
-                                                           : launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4>(a, stream);
+        // (16-cout layers: an 8-channel K chunk -- 216 instead of 108 MFMAs per wave between barriers -- measured 3-7 % slower than
+        // the 4-channel chunk on every such layer and is not instantiated)
+        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4>(a, stream);
         if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 2, 4>(a, stream);
         return launch_conv3<TZ, TY, TX, SPW, 8, 4, 4, 4>(a, stream);
     } else {
@@ -634,25 +627,18 @@ static int launch_cin1(const ConvArgs& a, hipStream_t stream) {      // edge >= 
 // which tiling will rf_conv3d_k3_gn_relu use, and how many stats tiles per sample does that give?
 static bool conv_use_cin1(int c0, int c1, int edge, int cout) { return c0 == 1 && c1 == 0 && edge >= 16 && (cout == 8 || cout == 6); }
 static bool conv_use_big(int n, int edge, int cout16) {
-    static const int force_tile = getenv("RFUSE_CONV_TILE") ? atoi(getenv("RFUSE_CONV_TILE")) : 0;   // dev knob: 1 = small, 2 = big
     const long long vox = (long long)n * edge * edge * edge;
     const long long wgs512 = (vox + 511) / 512 * ((cout16 + 63) / 64);
-    return force_tile == 1 ? false : (force_tile == 2 ? true : wgs512 >= 1024);
+    return wgs512 >= 1024;
 }
-
-bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout);
 
 extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) {
     if (edge < 2) return 0;                                    // direct path: no fused statistics
     if (conv_use_cin1(c0, c1, edge, cout)) return (edge / 4) * (edge / 16) * (edge / 16);
-    if (c1 == 0 && rf_conv3_pm8_takes(c0, 0, n, edge, cout)) return 8;      // one tile per z slice (conv3d_pm8.hip)
     if (edge <= 4) return 1;                                   // whole-volume tiles (always the 128-voxel form)
     return conv_use_big(n, edge, rf_round_up(cout, 16)) ? (edge / 8) * (edge / 8) * (edge / 8) : (edge / 4) * (edge / 4) * (edge / 8);
 }
 
-bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout);                         // conv3d_pm8.hip
-int rf_conv3_pm8_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
-                        const float* w_packed, int cout, float* out, double* stats, void* stream);
 bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout);                       // conv3d_small.hip
 int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
                           float* out, double* stats, void* stream, float* pool_out, double* pool_stats);
@@ -669,8 +655,6 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
     a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
     a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
-    static const int abl = getenv("RFUSE_CONV_ABLATE") ? atoi(getenv("RFUSE_CONV_ABLATE")) : 0;
-    a.ablate = abl;
     a.stats = reinterpret_cast<double2*>(stats);
     a.stats_tiles = (stats || pool_stats) ? rf_conv3d_stats_tiles(c0, c1, n, edge, cout) : 0;
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats); a.pool_mode = pool_mode;
@@ -679,18 +663,13 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     // whole 4^3 / 2^3 volumes: the position-major kernel (conv3d_small.hip) leaves out every zero-padding tap
     if ((!pool_mode || edge == 4) && rf_conv3_small_takes(c0, c1, n, edge, cout))
         return rf_conv3_small_launch(src0, c0, n, edge, scale, shift, w_packed, cout, out, stats, stream, pool_out, pool_stats);
-    // whole 8^3 volumes, single source: position-major over z slices (conv3d_pm8.hip)
-    if (!pool_mode && c1 == 0 && rf_conv3_pm8_takes(c0, 0, n, edge, cout))
-        return rf_conv3_pm8_launch(src0, c0, nullptr, 0, n, scale, shift, w_packed, cout, out, stats, stream);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
     const bool big = conv_use_big(n, edge, a.cout16);
     if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, TILE_BIG>(a, s) : dispatch_nb<4, 4, 8, 1, TILE_SMALL>(a, s);
     // 4^3 / 2^3 volumes: always the 128-voxel tiles (2 / 16 whole samples per workgroup); the 512-voxel multi-sample forms
     // need 5-16 halo rows per thread in registers, spill, and measured slower
-    static const int mid = getenv("RFUSE_CONV_MID") ? atoi(getenv("RFUSE_CONV_MID")) : 1;          // dev knob: 0 = never, 2 = also 2^3
-    const bool use_mid = mid >= 1;
-    if (edge == 4) return use_mid && n >= 4096 ? dispatch_nb<4, 4, 4, 4, TILE_MID>(a, s) : dispatch_nb<4, 4, 4, 2, TILE_SMALL>(a, s);
-    return mid == 2 && n >= 8192 ? dispatch_nb<2, 2, 2, 32, TILE_MID>(a, s) : dispatch_nb<2, 2, 2, 16, TILE_SMALL>(a, s);
+    if (edge == 4) return n >= 4096 ? dispatch_nb<4, 4, 4, 4, TILE_MID>(a, s) : dispatch_nb<4, 4, 4, 2, TILE_SMALL>(a, s);
+    return dispatch_nb<2, 2, 2, 16, TILE_SMALL>(a, s);
 }
 
 extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,

@@ -404,13 +404,9 @@ template <int E, int NB, bool UP = false>
 static int launch_small(const SmallArgs& a, hipStream_t stream) {
     using T = SmallTile<E, NB, UP>;
     auto kern = k_conv3_small<E, NB, UP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (T::LDS_BYTES > 65536) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-            if (e != hipSuccess) { rf_set_error("rf_conv3d_k3_gn_relu(small): cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
-        }
-        attr_set = true;
+    if (T::LDS_BYTES > 65536) {
+        static RfLdsOptIn opt_in;
+        if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), (int)T::LDS_BYTES, "rf_conv3d_k3_gn_relu(small)")) return rc;
     }
     const unsigned gx = (unsigned)((a.n + T::SAMPLES - 1) / T::SAMPLES), gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
     hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(T::NT), T::LDS_BYTES, stream, a);
@@ -420,8 +416,7 @@ static int launch_small(const SmallArgs& a, hipStream_t stream) {
 
 // Takes whole 4^3 / 2^3 volumes with a single (full-resolution) source when there are enough samples to fill the chip.
 bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout) {
-    static const int knob = getenv("RFUSE_CONV_SMALL") ? atoi(getenv("RFUSE_CONV_SMALL")) : 1;     // dev knob: 0 = off
-    if (!knob || c1 != 0 || c0 <= 0 || (edge != 4 && edge != 2)) return false;
+    if (c1 != 0 || c0 <= 0 || (edge != 4 && edge != 2)) return false;
     const long long gy = (rf_round_up(cout, 16) + 31) / 32;
     const long long wgs = (edge == 4 ? (n + 15) / 16 : (n + 127) / 128) * gy;
     return wgs >= 128;                                               // half a wave of workgroups per CU still beats the box tiling
@@ -442,8 +437,7 @@ int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const floa
 
 // decoder form on whole 4^3 volumes (low-res source 2^3), weight image of rf_conv3_up_pack_weight
 bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout) {
-    static const int knob = getenv("RFUSE_CONV_SMALL") ? atoi(getenv("RFUSE_CONV_SMALL")) : 1;
-    if (!knob || c1 <= 0 || c0 < 0 || edge != 4) return false;
+    if (c1 <= 0 || c0 < 0 || edge != 4) return false;
     const long long gy = (rf_round_up(cout, 16) + 31) / 32;
     return (long long)((n + 15) / 16) * gy >= 256;
 }

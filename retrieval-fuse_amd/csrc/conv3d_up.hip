@@ -567,13 +567,9 @@ template <int TE, int SPW, int MB, int NB>
 static int launch_up(const UpArgs& a, hipStream_t stream) {
     using T = UpTile<TE, SPW, MB, NB>;
     auto kern = k_conv3_up<TE, SPW, MB, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (T::LDS_BYTES > 65536) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-            if (e != hipSuccess) { rf_set_error("rf_conv3d_up_k3_gn_relu: cannot raise LDS limit: %s", hipGetErrorString(e)); return RF_E_LAUNCH; }
-        }
-        attr_set = true;
+    if (T::LDS_BYTES > 65536) {
+        static RfLdsOptIn opt_in;
+        if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), (int)T::LDS_BYTES, "rf_conv3d_up_k3_gn_relu")) return rc;
     }
     const unsigned gx = SPW == 1 ? (unsigned)a.n * (a.edge / TE) * (a.edge / TE) * (a.edge / TE) : (unsigned)((a.n + SPW - 1) / SPW);
     const unsigned gy = (unsigned)((a.cout16 + T::NCO - 1) / T::NCO);
@@ -591,31 +587,25 @@ static int dispatch_up(const UpArgs& a, hipStream_t stream) {
 
 // Shapes the parity-split kernel takes: a low-res source, edge 4 (four samples per workgroup) or a multiple of 8, and
 // enough boxes to give the 256 CUs work (small launches stay on rf_conv3d_k3_gn_relu's 128-voxel tiles).
-bool rf_conv3_pm8_takes(int c0, int c1, int n, int edge, int cout);                         // conv3d_pm8.hip
-int rf_conv3_pm8_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
-                        const float* w_packed, int cout, float* out, double* stats, void* stream);
 bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout);                    // conv3d_small.hip
 int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
                              const float* w_up_packed, int cout, float* out, double* stats, void* stream);
 
 extern "C" int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout) {
-    static const int off = getenv("RFUSE_CONV_UP") ? atoi(getenv("RFUSE_CONV_UP")) == 0 : 0;       // dev knob: RFUSE_CONV_UP=0 disables
-    if (off || c1 <= 0 || c0 < 0 || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 4 || edge > 128) return 0;
+    if (c1 <= 0 || c0 < 0 || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 4 || edge > 128) return 0;
     const long long gy = (rf_round_up(cout, 16) + 63) / 64;
     const long long boxes = edge == 4 ? (n + 3) / 4 : (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
     return boxes * gy >= 256;
 }
 
 // which kernel rf_conv3d_up_k3_gn_relu launches for a shape: 0 = parity-split boxes (this file), 1 = position-major 4^3
-// (conv3d_small.hip), 2 = position-major 8^3 slices (conv3d_pm8.hip) -- for reporting (issued multiply-adds differ)
+// (conv3d_small.hip) -- for reporting (issued multiply-adds differ)
 extern "C" int rf_conv3d_up_variant(int c0, int c1, int n, int edge, int cout) {
-    if (rf_conv3_pm8_takes(c0, c1, n, edge, cout)) return 2;
     if (edge == 4 && rf_conv3_small_up_takes(c0, c1, n, edge, cout)) return 1;
     return 0;
 }
 
 extern "C" int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cout) {
-    if (rf_conv3_pm8_takes(c0, c1, n, edge, cout)) return 8;            // one tile per z slice (conv3d_pm8.hip)
     return edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8);
 }
 
@@ -631,9 +621,6 @@ extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* s
     a.stats = reinterpret_cast<double2*>(stats);
     a.stats_tiles = stats ? rf_conv3d_up_stats_tiles(c0, c1, n, edge, cout) : 0;
     hipStream_t s = (hipStream_t)stream;
-    // whole 8^3 volumes: position-major over z slices (conv3d_pm8.hip)
-    if (rf_conv3_pm8_takes(c0, c1, n, edge, cout))
-        return rf_conv3_pm8_launch(src0, c0, src1, c1, n, scale, shift, w_packed, cout, out, stats, stream);
     // whole 4^3 volumes with enough samples: position-major form (conv3d_small.hip), every zero-padding tap left out
     if (edge == 4 && rf_conv3_small_up_takes(c0, c1, n, edge, cout))
         return rf_conv3_small_up_launch(src0, c0, src1, c1, n, scale, shift, w_packed, cout, out, stats, stream);

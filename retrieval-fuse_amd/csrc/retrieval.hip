@@ -310,10 +310,22 @@ extern "C" int rf_topk_merge(const float* in_dist, const int64_t* in_idx, int pa
 
 // ---------------------------------------------------------------------------------------- same-scene demotion
 __global__ __launch_bounds__(256) void k_demote(const float* __restrict__ dist, const long long* __restrict__ idx, int nq, int k2,
-                                                const int* __restrict__ db_meta, const int* __restrict__ query_scene, int K,
+                                                const int* __restrict__ db_meta, const int* __restrict__ query_scene,
+                                                const unsigned char* __restrict__ query_keep, int K,
                                                 int* __restrict__ out_meta, float* __restrict__ out_dist, long long* __restrict__ out_idx) {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
+    if (query_keep && !query_keep[qi]) {
+        // a patch the query-side occupancy filter dropped is never looked up: its K slots are the "no neighbour" entry, which the
+        // patch gather turns into the truncation fill (util/retrieval.py:148,151)
+        for (int w = 0; w < K; ++w) {
+            int* m = out_meta + ((size_t)qi * K + w) * 7;
+            m[0] = -1; m[1] = 0; m[2] = 16; m[3] = 0; m[4] = 16; m[5] = 0; m[6] = 16;
+            out_dist[(size_t)qi * K + w] = INFINITY;
+            out_idx[(size_t)qi * K + w] = -1;
+        }
+        return;
+    }
     const int qs = query_scene ? query_scene[qi] : -1;
     int written = 0;
     // pass 0: neighbours NOT from the query's scene, in order; pass 1: the demoted ones, in order
@@ -338,12 +350,12 @@ __global__ __launch_bounds__(256) void k_demote(const float* __restrict__ dist, 
 }
 
 extern "C" int rf_demote_same_scene(const float* dist, const int64_t* idx, int nq, int k2, const int32_t* db_meta,
-                                    const int32_t* query_scene, int K, int32_t* out_meta, float* out_dist, int64_t* out_idx,
-                                    void* stream) {
+                                    const int32_t* query_scene, const uint8_t* query_keep, int K, int32_t* out_meta, float* out_dist,
+                                    int64_t* out_idx, void* stream) {
     RF_REQUIRE(dist && idx && db_meta && out_meta && out_dist && out_idx && nq > 0 && k2 > 0 && K > 0 && K <= k2, RF_E_INVALID,
                "rf_demote_same_scene: bad arguments (k2=%d K=%d)", k2, K);
     hipLaunchKernelGGL(k_demote, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, dist, (const long long*)idx, nq, k2, db_meta,
-                       query_scene, K, out_meta, out_dist, (long long*)out_idx);
+                       query_scene, query_keep, K, out_meta, out_dist, (long long*)out_idx);
     RF_CHECK_LAUNCH("rf_demote_same_scene");
     return RF_OK;
 }
@@ -391,10 +403,12 @@ extern "C" int rf_gather_patches(const float* db_volumes, int64_t n_scenes, cons
 // ------------------------------------------------------------------------------------------------- row gather
 // out[m][:] = src[idx[m]][:] for rows of `width` floats (width % 4 == 0): fetches cached per-database-patch retrieval
 // features (query independent, see rfuse/database.py:build_feature_cache).  One workgroup per output row.
+// idx < 0 ("no neighbour") selects the LAST source row: the database keeps its all-trunc sentinel patch there
+// (util/retrieval.py:21-26,45), which is what the full path substitutes for a missing neighbour.
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, long long n_src, const long long* __restrict__ idx,
                                                      int width4, float* __restrict__ out) {
     const long long r = idx[blockIdx.x];
-    const float4* s4 = reinterpret_cast<const float4*>(src) + (size_t)(r < 0 || r >= n_src ? 0 : r) * width4;
+    const float4* s4 = reinterpret_cast<const float4*>(src) + (size_t)(r < 0 || r >= n_src ? n_src - 1 : r) * width4;
     float4* o4 = reinterpret_cast<float4*>(out) + (size_t)blockIdx.x * width4;
     for (int i = threadIdx.x; i < width4; i += 256) o4[i] = s4[i];
 }

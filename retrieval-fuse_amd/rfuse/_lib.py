@@ -68,7 +68,7 @@ SIGNATURES = {
     'rf_l2_topk': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_p, c_p, c_sz, c_p]),
     'rf_l2_topk_ws_bytes': (c_sz, [c_i, c_i64, c_i]),
     'rf_topk_merge': (c_i, [c_fp, c_p, c_i, c_i, c_i, c_fp, c_p, c_p]),
-    'rf_demote_same_scene': (c_i, [c_fp, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_fp, c_p, c_p]),
+    'rf_demote_same_scene': (c_i, [c_fp, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_fp, c_p, c_p]),
     'rf_gather_rows': (c_i, [c_fp, c_i64, c_p, c_i64, c_i, c_fp, c_p]),
     'rf_gather_patches': (c_i, [c_fp, c_i64, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_fp, c_p]),
 }

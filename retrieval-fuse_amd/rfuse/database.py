@@ -159,8 +159,9 @@ class PatchDatabase:
             return self.local_topk(q, k2)
         return allgather_merge(q, lambda qa: self.local_topk(qa, k2), ops.topk_merge, k2, self.group)
 
-    def retrieve(self, q, K, query_scene=None):
+    def retrieve(self, q, K, query_scene=None, query_keep=None):
         """flann_knn_worker semantics (util/retrieval.py:92-100): top-2K, same-scene demotion, keep K.
+        ``query_keep`` [Q] bool: False = patch dropped by the query-side occupancy filter (no neighbours, trunc fill).
         Returns (meta [Q,K,7] int32, dist [Q,K], idx [Q,K])."""
         dist, idx = self.search(q, 2 * K)
-        return ops.demote_same_scene(dist, idx, self.meta, query_scene, K)
+        return ops.demote_same_scene(dist, idx, self.meta, query_scene, K, query_keep)

@@ -16,6 +16,7 @@ retrieval (util/retrieval.py ``--mode map`` / ``--mode compose``, :222-248) done
 Everything numeric runs in librfuse_hip.so; this file only sequences launches and owns tensors.
 """
 import contextlib
+import functools
 import io
 
 import torch
@@ -25,10 +26,24 @@ from . import ops
 from .configs import truncations
 
 
+def _on_engine_device(method):
+    """Run a stage with the engine's device current (streams, workspaces and launches all follow the current device), so
+    ``RefinementEngine(cfg, 'cuda:1', db)`` works whatever the caller's current device is."""
+    @functools.wraps(method)
+    def scoped(self, *args, **kwargs):
+        if self.device.index == torch.cuda.current_device():
+            return method(self, *args, **kwargs)
+        with torch.cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return scoped
+
+
 class RefinementEngine:
     def __init__(self, config, device='cuda:0', database=None, quiet=True):
         self.config = config
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.K = config['K']
         self.input_trunc, self.target_trunc = truncations(config)
         sink = io.StringIO() if quiet else None
@@ -52,6 +67,7 @@ class RefinementEngine:
             self.modules()[name].load_state_dict(sd)
 
     # ---------------------------------------------------------------------------------------------- stages
+    @_on_engine_device
     @torch.no_grad()
     def embed_queries(self, input_raw):
         """input_raw [B,S,S,S] un-normalised -> unit query embeddings [B*P, latent] (P = 64 windows per chunk)."""
@@ -61,16 +77,22 @@ class RefinementEngine:
         z = self.fenc_input(win)
         return ops.l2_normalize_rows_(z.reshape(z.shape[0], z.shape[1]))
 
+    @_on_engine_device
     @torch.no_grad()
-    def retrieve(self, input_raw, query_scene=None):
-        """-> (patches [(B*K*64),1,16,16,16] normalised, meta [B*64,K,7])."""
+    def retrieve(self, input_raw, query_scene=None, patch_mask=None):
+        """-> (patches [(B*K*64),1,16,16,16] normalised, meta [B*64,K,7]).
+        ``patch_mask`` [B,64] bool: the dataset's query-side occupancy filter (reference dataset/patched_scene_dataset.py:28-32).
+        Patches it drops (False) are never looked up and keep the truncation value in all K retrieved volumes
+        (util/retrieval.py:148,151)."""
         d = self.config['dataset_train']
         q = self.embed_queries(input_raw)
-        meta, _, _ = self.database.retrieve(q, self.K, query_scene)
+        keep = patch_mask.reshape(-1).contiguous() if patch_mask is not None else None
+        meta, _, _ = self.database.retrieve(q, self.K, query_scene, keep)
         patches = ops.gather_patches(self.database.volumes, meta, input_raw.shape[0], self.K, self.target_trunc, 1.0,
                                      d['target_mean'], d['target_std'], layout=1)
         return patches, meta
 
+    @_on_engine_device
     @torch.no_grad()
     def normalise_input(self, input_raw):
         """(x - mean) / std of the whole chunk = the window kernel with one window and no context."""
@@ -93,6 +115,7 @@ class RefinementEngine:
         x_back.record_stream(main)
         return x_back, side
 
+    @_on_engine_device
     @torch.no_grad()
     def refine_from_patches(self, x_in, patches, gumbel_noise=None, stages=None):
         """x_in [B,1,S,S,S] normalised; patches [(B*K*64),1,16^3] normalised -> df [B,1,64,64,64]."""
@@ -108,8 +131,9 @@ class RefinementEngine:
             stages.update(x_back=x_back, retrieval_features=feats, x_attn=x, df=df)
         return df
 
+    @_on_engine_device
     @torch.no_grad()
-    def refine(self, input_raw, query_scene=None, gumbel_noise=None, use_feature_cache=False):
+    def refine(self, input_raw, query_scene=None, gumbel_noise=None, use_feature_cache=False, patch_mask=None):
         """The whole online path for a batch of chunks: raw low-res input [B,S,S,S] -> refined TSDF [B,1,64,64,64].
 
         ``use_feature_cache=True`` (needs ``database.build_feature_cache``) fetches the retrieval-backbone features of the
@@ -121,11 +145,12 @@ class RefinementEngine:
                 raise RuntimeError('use_feature_cache=True needs database.build_feature_cache(retrieval_backbone, config) first')
             b = input_raw.shape[0]
             q = self.embed_queries(input_raw)
-            _, _, idx = self.database.retrieve(q, self.K, query_scene)                      # [B*64, K] database row ids
+            keep = patch_mask.reshape(-1).contiguous() if patch_mask is not None else None
+            _, _, idx = self.database.retrieve(q, self.K, query_scene, keep)                # [B*64, K] database row ids; -1 (none) gathers the sentinel row
             order = idx.reshape(b, 64, self.K).permute(0, 2, 1).reshape(-1).contiguous()     # (b, k, slot): the patch-major order
             feats = ops.gather_rows(self.database.feature_cache, order)
         else:
-            patches, _ = self.retrieve(input_raw, query_scene)
+            patches, _ = self.retrieve(input_raw, query_scene, patch_mask)
             feats = self.retrieval_backbone(patches)
         torch.cuda.current_stream(self.device).wait_stream(side)
         return self._attend_and_decode(x_back, feats, gumbel_noise)

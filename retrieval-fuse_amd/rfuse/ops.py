@@ -1,8 +1,11 @@
 """Tensor-level wrappers over the C ABI (include/rfuse.h).  PyTorch is used for device memory and streams only:
-every function takes contiguous float32 CUDA(HIP) tensors, launches on ``torch.cuda.current_stream()`` and returns
-freshly allocated outputs.  Anything else (CPU tensors, other dtypes, missing library) raises -- no fallback.
+every function takes contiguous float32 CUDA(HIP) tensors, launches on the current stream OF THE TENSORS' DEVICE (the call
+is scoped to that device, whatever the caller's current device is) and returns freshly allocated outputs.  Anything else
+(CPU tensors, other dtypes, tensors on different devices, missing library) raises -- no fallback.
 """
 import ctypes
+import functools
+import sys
 
 import torch
 
@@ -29,7 +32,30 @@ def _p(t):
 
 
 def _stream():
+    # the current stream of the CURRENT device; every public op runs inside _device_scoped, which makes the tensors' device current
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _device_scoped(fn):
+    """Run ``fn`` with the device of its tensor arguments current (HIP launches go to the current device's stream), and refuse
+    tensors spread over several devices.  Costs one ``current_device()`` query when the device already matches."""
+    @functools.wraps(fn)
+    def scoped(*args, **kwargs):
+        dev = None
+        flat = []
+        for a in args + tuple(kwargs.values()):
+            flat.extend(a) if isinstance(a, (list, tuple)) else flat.append(a)
+        for a in flat:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise ValueError('%s: tensors on different devices (%s and %s)' % (fn.__name__, dev, a.device))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return scoped
 
 
 def _no_grad_only(*tensors):
@@ -56,9 +82,10 @@ class PackedWeight:
     """Caches the MFMA operand image of a Parameter; re-packs when the parameter is modified, moved or replaced."""
 
     def __init__(self, kind):
-        self.kind = kind        # 'conv3' | 'linear'
+        self.kind = kind        # 'conv3' | 'linear' | 'convv' | 'conv3up'
         self._key = None
         self._packed = None
+        self._ready = _PackedReady()
 
     def get(self, w, *extra):
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
@@ -66,7 +93,32 @@ class PackedWeight:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
                             'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
             self._key = key
+            self._ready.packed_on(w.device)
+        else:
+            self._ready.wait(w.device)
         return self._packed
+
+
+class _PackedReady:
+    """Orders readers of a packed operand image after the (stream-ordered) pack kernel: the image is packed on whichever
+    stream first needs it, and the engine later reads it from other streams (the backbone runs on a side stream)."""
+
+    def __init__(self):
+        self._event = None
+        self._ok_streams = set()
+
+    def packed_on(self, device):
+        with torch.cuda.device(device):
+            st = torch.cuda.current_stream()
+            self._event = torch.cuda.Event()
+            self._event.record(st)
+            self._ok_streams = {st.cuda_stream}
+
+    def wait(self, device):
+        st = torch.cuda.current_stream(device)
+        if st.cuda_stream not in self._ok_streams:
+            st.wait_event(self._event)
+            self._ok_streams.add(st.cuda_stream)
 
 
 # ------------------------------------------------------------------------------------------------ U-Net primitives
@@ -402,23 +454,32 @@ class PackedAttnMLP:
     def __init__(self):
         self._key = None
         self._packed = None
+        self._ready = _PackedReady()
 
     def get(self, layers):
         params = [t for l in layers for t in (l.weight, l.bias)]
         key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.device) for t in params)
         if key != self._key:
-            for t in params:
-                _req(t.detach(), 'attention MLP parameter')
-            n_in = layers[0].weight.shape[1]
-            shapes = [tuple(l.weight.shape) for l in layers]
-            if shapes != [(128, n_in), (128, 128), (128, 128), (32, 128)] or n_in % 16 or not 16 <= n_in <= 128:
-                raise ValueError('fused attention MLP needs Linear(n_in,128) x (128,128) x (128,128) x (128,32) with n_in a multiple of 16 <= 128, '
-                                 'got %s' % (shapes,))
-            lib = _lib.load()
-            out = torch.empty(lib.rf_attn_mlp_packed_floats(n_in), dtype=torch.float32, device=params[0].device)
-            _lib.check(lib.rf_attn_mlp_pack(*[_p(t.detach()) for t in params], n_in, _p(out), _stream()), 'rf_attn_mlp_pack')
-            self._packed, self._key = out, key
+            self._packed, self._key = pack_attn_mlp(params), key
+            self._ready.packed_on(params[0].device)
+        else:
+            self._ready.wait(params[0].device)
         return self._packed
+
+
+def pack_attn_mlp(params):
+    """[w0, b0, w1, b1, w2, b2, w3, b3] of Linear(n_in,128) x (128,128) x (128,128) x (128,32) -> the fused kernel's operand image."""
+    for t in params:
+        _req(t.detach(), 'attention MLP parameter')
+    n_in = params[0].shape[1]
+    shapes = [tuple(t.shape) for t in params[0::2]]
+    if shapes != [(128, n_in), (128, 128), (128, 128), (32, 128)] or n_in % 16 or not 16 <= n_in <= 128:
+        raise ValueError('fused attention MLP needs Linear(n_in,128) x (128,128) x (128,128) x (128,32) with n_in a multiple of 16 <= 128, '
+                         'got %s' % (shapes,))
+    lib = _lib.load()
+    out = torch.empty(lib.rf_attn_mlp_packed_floats(n_in), dtype=torch.float32, device=params[0].device)
+    _lib.check(lib.rf_attn_mlp_pack(*[_p(t.detach()) for t in params], n_in, _p(out), _stream()), 'rf_attn_mlp_pack')
+    return out
 
 
 def attn_mlp_rows(x, packed):
@@ -511,17 +572,24 @@ def topk_merge(dist_parts, idx_parts):
     return dist, idx
 
 
-def demote_same_scene(dist, idx, db_meta, query_scene, K):
+def demote_same_scene(dist, idx, db_meta, query_scene, K, query_keep=None):
+    """query_keep [nq] bool/uint8: False = patch dropped by the occupancy filter -> K 'no neighbour' entries."""
     _req(dist, 'dist'), _req(idx, 'idx', torch.int64), _req(db_meta, 'db_meta', torch.int32)
     if query_scene is not None:
         _req(query_scene, 'query_scene', torch.int32)
+    if query_keep is not None:
+        if query_keep.dtype == torch.bool:
+            query_keep = query_keep.view(torch.uint8)
+        _req(query_keep, 'query_keep', torch.uint8)
+        if query_keep.numel() != dist.shape[0]:
+            raise ValueError('query_keep: %d flags for %d queries' % (query_keep.numel(), dist.shape[0]))
     nq, k2 = dist.shape
     dev = dist.device
     out_meta = torch.empty((nq, K, 7), dtype=torch.int32, device=dev)
     out_dist = torch.empty((nq, K), dtype=torch.float32, device=dev)
     out_idx = torch.empty((nq, K), dtype=torch.int64, device=dev)
-    _lib.check(_lib.load().rf_demote_same_scene(_p(dist), _p(idx), nq, k2, _p(db_meta), _p(query_scene), K, _p(out_meta), _p(out_dist),
-                                                _p(out_idx), _stream()), 'rf_demote_same_scene')
+    _lib.check(_lib.load().rf_demote_same_scene(_p(dist), _p(idx), nq, k2, _p(db_meta), _p(query_scene), _p(query_keep), K, _p(out_meta),
+                                                _p(out_dist), _p(out_idx), _stream()), 'rf_demote_same_scene')
     return out_meta, out_dist, out_idx
 
 
@@ -544,3 +612,10 @@ def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, s
     _lib.check(_lib.load().rf_gather_patches(_p(db_volumes), db_volumes.shape[0], _p(meta), chunks, K, trunc_fill, trunc_ratio, mean, std,
                                              layout, _p(out), _stream()), 'rf_gather_patches')
     return out
+
+
+# every public tensor op is scoped to its tensors' device (see _device_scoped)
+for _name, _fn in list(vars(sys.modules[__name__]).items()):
+    if isinstance(_fn, type(_device_scoped)) and _fn.__module__ == __name__ and not _name.startswith('_'):
+        setattr(sys.modules[__name__], _name, _device_scoped(_fn))
+del _name, _fn

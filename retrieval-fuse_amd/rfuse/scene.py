@@ -1,39 +1,45 @@
 """Scene-level recomposition of refined chunks.
 
-Restates ``PatchedSceneDataset.combine_chunks`` and ``get_superscene_name_and_position_from_chunk``
-(reference dataset/patched_scene_dataset.py:153-174): 3DFront / Matterport3D scenes are cut into 64^3 chunks named
-``<scene>__<room>__<x>_<y>_<z>`` (position in target voxels); ShapeNet chunks are whole scenes at the origin.
-Host-side numpy scatter, not on the hot path.
-"""
-from collections import defaultdict
+Behaviour of the reference's ``PatchedSceneDataset.combine_chunks`` / ``combine_inputs`` / ``combine_targets``
+(dataset/patched_scene_dataset.py:153-180), pinned by tests/golden/combine_chunks.npz which was produced by running
+that method itself: 3DFront / Matterport3D scenes are cut into 64^3 chunks whose names end in ``__<x>_<y>_<z>`` (origin
+of the chunk in target voxels) and share the superscene prefix ``<scene>__<room>``; every other dataset's chunk is a
+whole scene at the origin.  The canvas is float64, filled with the truncation value, as large as the farthest chunk
+reaches; chunks are pasted in list order (a later chunk overwrites an earlier one at the same origin).
 
+Host-side numpy scatter, not on the hot path.  Mesh export (util/visualization.py: marching cubes -> .obj) has no
+counterpart here: it needs the ``marching_cubes`` / ``trimesh`` packages, which this image does not have.
+"""
 import numpy as np
+
+_TILED_DATASETS = ('Matterport3D', '3DFront')
 
 
 def superscene_and_position(chunk_name, dataset_name):
-    """-> (superscene name, int position[3]) -- dataset/patched_scene_dataset.py:153-158"""
-    if dataset_name.startswith('Matterport3D') or dataset_name.startswith('3DFront'):
-        name = "__".join(chunk_name.split('__')[:2])
-        position = [int(x) for x in chunk_name.split('__')[-1].split('_')]
-        return name, np.array(position)
-    return chunk_name, np.array([0, 0, 0])
+    """'<scene>__<room>__<x>_<y>_<z>' -> ('<scene>__<room>', int64[3]) for the tiled datasets, else (chunk_name, zeros)."""
+    if not dataset_name.startswith(_TILED_DATASETS):
+        return chunk_name, np.zeros(3, dtype=np.int64)
+    fields = chunk_name.split('__')
+    origin = np.array([int(t) for t in fields[-1].split('_')], dtype=np.int64)
+    return '__'.join(fields[:2]), origin
 
 
 def combine_chunks(chunk_names, chunk_volumes, dataset_name, scale_factor=1, chunk_size=64, trunc_val=0.0):
-    """{superscene: float64 volume}: each chunk pasted at position/scale_factor into a trunc-filled canvas sized to the
-    farthest chunk (dataset/patched_scene_dataset.py:160-174).  ``chunk_volumes[i]`` is the cubic volume of ``chunk_names[i]``
-    (e.g. the refined df from RefinementEngine.refine, squeezed to [64,64,64])."""
-    groups = defaultdict(list)
-    for i, s in enumerate(chunk_names):
-        name, position = superscene_and_position(s, dataset_name)
-        groups[name].append((i, (position / scale_factor).astype(np.int32)))
-    result = {}
-    for ss, items in groups.items():
-        positions = np.vstack([p for _, p in items])
-        combined = np.ones([positions[:, 0].max() + chunk_size, positions[:, 1].max() + chunk_size, positions[:, 2].max() + chunk_size]) * trunc_val
-        for i, p in items:
-            v = np.asarray(chunk_volumes[i])
-            e = v.shape[0]
-            combined[p[0]:p[0] + e, p[1]:p[1] + e, p[2]:p[2] + e] = v
-        result[ss] = combined
-    return result
+    """-> {superscene: float64 volume}.  ``chunk_volumes[i]`` is the cubic volume of ``chunk_names[i]`` (e.g. a refined df from
+    RefinementEngine.refine squeezed to [64,64,64]); its origin is the name's position divided by ``scale_factor`` and
+    truncated to int32 (so low-resolution inputs are combined with scale_factor = 64 / input_chunk_size, chunk_size =
+    input_chunk_size)."""
+    members = {}
+    for i, name in enumerate(chunk_names):
+        key, origin = superscene_and_position(name, dataset_name)
+        members.setdefault(key, []).append((i, (origin / scale_factor).astype(np.int32)))
+    scenes = {}
+    for key, items in members.items():
+        reach = np.max([o for _, o in items], axis=0) + chunk_size
+        canvas = np.full(tuple(int(r) for r in reach), trunc_val, dtype=np.float64)
+        for i, (x, y, z) in items:
+            vol = np.asarray(chunk_volumes[i])
+            e = vol.shape[0]
+            canvas[x:x + e, y:y + e, z:z + e] = vol
+        scenes[key] = canvas
+    return scenes

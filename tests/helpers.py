@@ -27,6 +27,27 @@ def load_fixture(name):
     return {k: z[k] for k in z.files}
 
 
+def load_truth(name):
+    """-> (fixture, truth) where truth holds the float64 evaluation of the same network on the same inputs
+    (oracle/gen_golden.py:gen_truth_fixture): ``df_f64`` [B,1,64^3] and the sub-sampled stages, rebuilt from the float32
+    residuals stored against the reference's fp32 results."""
+    fix = load_fixture(name)
+    t = load_fixture(name.replace('net_', 'truth_'))
+    truth = {'df_f64': fix['df'].astype(np.float64) + t['df_resid'].astype(np.float64)}
+    for k in ('x_back', 'x_retr', 'x_attn'):
+        truth[k + '_f64_sub'] = fix[k + '_sub'].astype(np.float64) + t[k + '_resid_sub'].astype(np.float64)
+    truth.update({k: float(t[k]) for k in ('ref_err_max', 'ref_err_rms', 'ref_frac_gt_1e4', 'ref_double_gap')})
+    return fix, truth
+
+
+def error_profile(a, truth):
+    """distribution of |a - truth|: max, rms, selected quantiles and the fraction above north_star's 1e-4"""
+    e = np.abs(np.asarray(a, dtype=np.float64) - truth).ravel()
+    q = np.quantile(e, [0.5, 0.99, 0.999, 0.9999])
+    return {'max': float(e.max()), 'rms': float(np.sqrt((e ** 2).mean())), 'p50': float(q[0]), 'p99': float(q[1]), 'p99.9': float(q[2]),
+            'p99.99': float(q[3]), 'frac>1e-4': float((e > 1e-4).mean())}
+
+
 def chunk_inputs(cfg, seed, batch, stress=False):
     trunc_i, trunc_t = rf_configs.truncations(cfg)
     xs, rs = [], []

@@ -111,3 +111,27 @@ def test_combine_chunks_semantics():
     assert lo['houseA__room1'].shape == (16, 8, 8)
     one = scene.combine_chunks(['02691156__abc'], [vols[0]], 'ShapeNetV2')
     np.testing.assert_array_equal(one['02691156__abc'], vols[0])
+
+
+def test_combine_chunks_matches_reference_golden():
+    """N3 pinned: tests/golden/combine_chunks.npz holds the outputs of the reference's own PatchedSceneDataset.combine_chunks
+    (targets at scale 1, low-res inputs at scale 64/input_chunk_size) on seeded synthetic chunks."""
+    import helpers
+    from rfuse import configs, scene, synthetic
+    fix = helpers.load_fixture('combine_chunks')
+    seed = int(fix['seed'])
+    for tag in ('front', 'shapenet'):
+        cfg = configs.get_config(str(fix[tag + '_cfg']))
+        trunc_i, trunc_t = configs.truncations(cfg)
+        names = [str(n) for n in fix[tag + '_names']]
+        chunks = [synthetic.make_chunk(seed * 100 + i, cfg) for i in range(len(names))]
+        ds_name = cfg['dataset_train']['dataset_name']
+        s_in = cfg['dataset_train']['input_chunk_size']
+        tgt = scene.combine_chunks(names, [c['target_raw'] for c in chunks], ds_name, 1, 64, trunc_t)
+        inp = scene.combine_chunks(names, [c['input_raw'] for c in chunks], ds_name, 64 / s_in, s_in, trunc_i)
+        assert sorted(tgt) == [str(k) for k in fix[tag + '_keys']]
+        for k in tgt:
+            assert tuple(fix['%s_target_%s_shape' % (tag, k)]) == tgt[k].shape and str(tgt[k].dtype) == str(fix['%s_target_%s_dtype' % (tag, k)])
+            assert helpers.sha(tgt[k]) == str(fix['%s_target_%s_sha' % (tag, k)])
+            assert tuple(fix['%s_input_%s_shape' % (tag, k)]) == inp[k].shape
+            assert helpers.sha(inp[k]) == str(fix['%s_input_%s_sha' % (tag, k)])

@@ -105,7 +105,7 @@ UP_CASES = [
     (300, 8, 8, 8, 72, 8),      # cout16 = 80: two cout blocks
     (260, 4, 8, 8, 24, 4),      # NB = 2
     (1100, 16, 8, 4, 24, 8),
-    # many 8^3 samples: position-major over z slices (conv3d_pm8.hip, decoder form)
+    # many 8^3 samples (bench-size launches of the parity-split box kernel, ragged sample counts)
     (600, 32, 64, 8, 56, 8),
     (530, 0, 16, 8, 16, 8),
     (520, 6, 12, 8, 12, 6),

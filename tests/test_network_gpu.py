@@ -18,13 +18,45 @@ DEV = 'cuda:0'
 DF_TOL = 1e-4          # abs, on reconstructed TSDF values (north_star)
 
 
+def df_bar(name):
+    """The parity bar on ``df`` for a golden fixture, DERIVED FROM COMMITTED DATA instead of chosen by hand.
+
+    north_star asks for <= 1e-4 abs against the reference.  The reference result is itself an fp32 evaluation; the committed
+    truth_*.npz fixtures hold the float64 evaluation of the same network on the same inputs, so the distance of the
+    reference's own arithmetic from the truth is known per fixture.  Where that distance is below 1e-4 (ShapeNetV2, 3DFront:
+    <= 5e-6) the bar is north_star's 1e-4 against the reference.  Where it is NOT (Matterport3D: distances in units 180x
+    larger, trunc 11.25, softmax sharpness 1024 -- the reference sits 4.1e-4 from the truth, 0.17 % of the voxels above
+    1e-4), "within 1e-4 of the reference" is not a property an exact evaluation would have; there the HIP path must be no
+    further from the truth than the reference is:  max|gpu - f64| <= 1.25 max|ref - f64|  and
+    frac(|gpu - ref| > 1e-4) <= 2 frac(|ref - f64| > 1e-4)."""
+    fix, truth = helpers.load_truth(name)
+    ref_prof = helpers.error_profile(fix['df'], truth['df_f64'])
+    return fix, truth, ref_prof, ref_prof['max'] <= 0.1 * DF_TOL
+
+
+def assert_df_parity(name, df_gpu, label='df'):
+    fix, truth, ref_prof, plain_bar = df_bar(name)
+    gpu_prof = helpers.error_profile(df_gpu, truth['df_f64'])
+    vs_ref = helpers.error_profile(df_gpu, fix['df'].astype(np.float64))
+    fmt = lambda p: '  '.join('%s %.2e' % (k, v) for k, v in p.items())
+    print(f'\n{name} {label}\n   ref vs f64: {fmt(ref_prof)}\n   gpu vs f64: {fmt(gpu_prof)}\n   gpu vs ref: {fmt(vs_ref)}')
+    if plain_bar:
+        assert vs_ref['max'] <= DF_TOL, f'{label} max abs err vs reference {vs_ref["max"]:.3e}'
+    else:
+        assert gpu_prof['max'] <= 1.25 * ref_prof['max'], f'gpu is {gpu_prof["max"]:.3e} from the float64 truth, the reference {ref_prof["max"]:.3e}'
+        assert vs_ref['frac>1e-4'] <= 2 * ref_prof['frac>1e-4'], f'{vs_ref["frac>1e-4"]:.5f} of the voxels differ from the reference by > 1e-4'
+        assert gpu_prof['rms'] <= 1.25 * ref_prof['rms']
+    return gpu_prof, vs_ref
+
+
 def df_tolerance(trunc):
-    """1e-4 abs on df (north_star) for the datasets whose truncation is O(0.1) scene units (ShapeNetV2 0.0625, 3DFront
-    0.1625).  Matterport3D stores distances in units 180x larger (voxel 3.75, trunc 11.25): there the reference's OWN fp32
-    arithmetic sits 4.1e-4 from a float64 evaluation of the same network (measured with the oracle in float64 against the
-    golden df, see DESIGN.md 'Parity'), so 1e-4 abs is below the reference's noise floor; the bar there is the same
-    relative accuracy, 1.25e-4 * trunc = 1.4e-3 (about 3x that floor)."""
-    return DF_TOL if trunc <= 1.0 else 1.25e-4 * trunc
+    """engine-vs-oracle comparisons on problems that have no float64 truth fixture: 1e-4 abs (north_star) where the truncation
+    is O(0.1) scene units (ShapeNetV2 0.0625, 3DFront 0.1625); for Matterport3D (trunc 11.25) twice the reference's own
+    measured distance from the truth on the committed C4 fixture (truth_C4.npz: ref_err_max) -- both sides of such a
+    comparison are fp32 evaluations."""
+    if trunc <= 1.0:
+        return DF_TOL
+    return 2.0 * float(helpers.load_fixture('truth_C4')['ref_err_max'])
 
 
 @pytest.fixture(scope='module')
@@ -76,12 +108,18 @@ def test_modules_match_reference_golden(gpu, name):
     e_retr = maxerr(x_retr[..., ::4, ::4, ::4].cpu(), fix['x_retr_sub'])
     e_attn = maxerr(x_attn[..., ::2, ::2, ::2].cpu(), fix['x_attn_sub'])
     e_df = maxerr(df.cpu(), fix['df'])
-    print(f'\n{name}: x_back {e_back:.2e}  x_retr {e_retr:.2e}  x_attn {e_attn:.2e}  df {e_df:.2e}  (trunc {trunc_t}, tol {df_tolerance(trunc_t):.2e})')
+    print(f'\n{name}: x_back {e_back:.2e}  x_retr {e_retr:.2e}  x_attn {e_attn:.2e}  df {e_df:.2e}  (trunc {trunc_t})')
     # intermediates: fp32 round-off chained through ~20 GroupNorm+conv layers (per-layer error is ~1e-6, tools/debug_layers.py)
     assert e_back <= 1e-4 * max(1.0, float(np.abs(fix['x_back_sub']).max()))
     assert e_retr <= 1e-4 * max(1.0, float(np.abs(fix['x_retr_sub']).max()))
     assert torch.equal(x_attn, x_attn2) and torch.equal(df, df2), 'patch-major route must equal the folded route bit for bit'
-    assert e_df <= df_tolerance(trunc_t), f'df max abs err {e_df:.3e}'
+    assert_df_parity(name, df.cpu().numpy())
+    # the stages against the float64 truth, next to the reference's own distance from it
+    _, truth = helpers.load_truth(name)
+    t = helpers.load_fixture(name.replace('net_', 'truth_'))
+    for tag, got, key, stride in (('x_back', x_back, 'ref_err_back', 2), ('x_retr', x_retr, 'ref_err_retr', 4), ('x_attn', x_attn, 'ref_err_attn', 2)):
+        g = maxerr(got[..., ::stride, ::stride, ::stride].cpu(), truth[tag + '_f64_sub'])
+        print(f'   {tag}: gpu vs f64 {g:.2e} (sub-sampled)   ref vs f64 {float(t[key]):.2e} (full)')
 
 
 @pytest.mark.parametrize('cfg_name', ['C1', 'C4', 'C5'])
@@ -208,3 +246,109 @@ def test_engine_fast_routes_match_plain_routes_at_bench_sizes(gpu, cfg_name, B):
     err = maxerr(fast.cpu(), plain.cpu())
     print(f'\n{cfg_name} B={B}: fast vs plain routes df max abs diff {err:.2e} (trunc {trunc_t})')
     assert err <= 0.2 * df_tolerance(trunc_t)
+
+
+@pytest.mark.parametrize('name', ['feat_C1', 'feat_C5'])
+def test_get_features_matches_reference_golden(gpu, name):
+    """A8: PatchedAttentionBlock.get_features as forward_full calls it (reference trainer/train_refinement.py:113-119,
+    model/attention.py:132-139, 72-82): theta on the backbone features, phi on the TARGET's retrieval-backbone features,
+    per-patch any() of the occupancy grid."""
+    from model.attention import Unfold3D, Fold3D
+    ffix = helpers.load_fixture(name)
+    nfix = helpers.load_fixture(name.replace('feat_', 'net_'))
+    cfg0 = rf_configs.get_config(str(nfix['cfg_name']))
+    mods = build_modules(cfg0)
+    shapes = {k: {n: tuple(v.shape) for n, v in m.state_dict().items()} for k, m in mods.items()}
+    cfg, x_in, retr, sds = helpers.fixture_problem(nfix, shapes)
+    for k, m in mods.items():
+        m.load_state_dict(sds[k])
+        m.to(gpu).eval()
+    seed = int(ffix['seed'])
+    tgt = np.stack([synthetic.normalise_target(cfg, synthetic.make_chunk(seed * 100 + 90, cfg)['target_raw'])[None]])
+    assert helpers.sha(tgt) == str(ffix['target_sha'])
+    occ = torch.from_numpy(np.unpackbits(ffix['occupancy'])[:32 ** 3].astype(bool).reshape(1, 1, 32, 32, 32)).to(gpu)
+    with torch.no_grad():
+        x_back = mods['unet_backbone'](torch.from_numpy(x_in).to(gpu))
+        x_target = Fold3D(4, 8, cfg['nf'])(mods['retrieval_backbone'](Unfold3D(16, 1)(torch.from_numpy(tgt).to(gpu))))
+        xf, pf, of = mods['patched_attention_block'].get_features(x_back, x_target, occ)
+    assert maxerr(x_target[..., ::4, ::4, ::4].cpu(), ffix['x_target_sub']) <= 1e-4
+    e_x, e_p = maxerr(xf.cpu(), ffix['x_feat']), maxerr(pf.cpu(), ffix['p_feat'])
+    print(f'\n{name}: theta feats {e_x:.2e}  phi feats {e_p:.2e} (unit vectors)')
+    assert tuple(xf.shape) == tuple(ffix['x_feat'].shape) and e_x <= 2e-5 and e_p <= 2e-5
+    assert of.dtype == torch.bool
+    np.testing.assert_array_equal(of.cpu().numpy(), np.unpackbits(ffix['occ_flat'])[:of.numel()].astype(bool))
+
+
+def test_engine_patch_mask_matches_reference_compose(gpu):
+    """A15: patches the query-side occupancy filter drops (reference dataset/patched_scene_dataset.py:28-32) are never looked
+    up and keep the truncation value in all K retrieved volumes (util/retrieval.py:148,151).  Golden: the reference's own
+    create_retrieval_from_mapping driven with a patch_from_scene_lookup that lacks those patches."""
+    from rfuse import ops
+    fix = helpers.load_fixture('retrieval_map_compose')
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    K = cfg['K']
+    db = synthetic.make_database(int(fix['seed']), cfg, int(fix['n_patches']))
+    keep = fix['patch_keep']
+    q = torch.from_numpy(fix['queries']).to(gpu)
+    from rfuse.database import PatchDatabase
+    pdb = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu)
+    meta, dist, idx = pdb.retrieve(q, K, None, torch.from_numpy(keep).to(gpu))
+    m = meta.cpu().numpy()
+    np.testing.assert_array_equal(m[keep], fix['map_val'][keep][..., :7].astype(np.int32))
+    assert (m[~keep, :, 0] == -1).all() and (idx.cpu().numpy()[~keep] == -1).all() and torch.isinf(dist[~torch.from_numpy(keep).to(gpu)]).all()
+    # composed volumes: un-normalised (mean 0, std 1) so the reference's raw output compares bit for bit
+    meta[5, 1] = torch.tensor(fix['map_val_sentinel'][5, 1, :7].astype(np.int32))        # the fixture's sentinel hit
+    composed = ops.gather_patches(pdb.volumes, meta, 1, K, trunc_t, 1.0, 0.0, 1.0, layout=0).cpu().numpy()[0]
+    assert helpers.sha(composed) == str(fix['compose_masked_sha'])
+    np.testing.assert_array_equal(composed[:, ::4, ::4, ::4], fix['compose_masked_sub'])
+
+
+def test_engine_patch_mask_end_to_end(gpu):
+    """refine(patch_mask=...) == the oracle composing with the same dropped patches, then the networks"""
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C3')
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    K, B = cfg['K'], 2
+    db = synthetic.make_database(22, cfg, 64 * 20)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 500 + len(n)) for n, m in eng.modules().items()}
+    eng.load_state_dicts(sds)
+    raws = np.stack([synthetic.make_chunk(800 + b, cfg)['input_raw'] for b in range(B)])
+    mask = np.random.default_rng(3).random((B, 64)) > 0.5
+    df = eng.refine(torch.from_numpy(raws).to(gpu), patch_mask=torch.from_numpy(mask).to(gpu)).cpu().numpy()
+    with torch.no_grad():
+        q = torch.cat([refpath.embed_queries(refpath.extract_query_windows(r, cfg, trunc_i), sds['fenc_input'], cfg) for r in raws]).numpy()
+        idx, dist = refpath.knn_exact(q, db['emb'], 2 * K)
+        mapping = refpath.demote_same_scene(refpath.mapping_rows(idx, dist, db['meta']), np.full(B * 64, -1), K)
+        d = cfg['dataset_train']
+        retr = np.stack([refpath.compose_retrieval(mapping[b * 64:(b + 1) * 64], db['volumes'], K, trunc_t, patch_keep=mask[b]) for b in range(B)])
+        retr = ((retr - np.float32(d['target_mean'])) / np.float32(d['target_std'])).astype(np.float32)
+        x_in = np.stack([synthetic.normalise_input(cfg, r)[None] for r in raws])
+        ref = refpath.forward_full(sds, cfg, torch.from_numpy(x_in), torch.from_numpy(retr), trunc_t).numpy()
+        full = eng.refine(torch.from_numpy(raws).to(gpu)).cpu().numpy()
+    assert maxerr(df, ref) <= df_tolerance(trunc_t)
+    assert maxerr(df, full) > 1e-3, 'the mask must change the result'
+
+
+def test_engine_on_a_non_current_device():
+    """RefinementEngine(cfg, 'cuda:1', db) with current device 0: every launch, stream and workspace must follow the tensors'
+    device (_stream() used the current device).  Needs two GPUs; skipped on the 1-GPU test box."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C3')
+    db = synthetic.make_database(3, cfg, 640)
+    raws = torch.from_numpy(np.stack([synthetic.make_chunk(123 + b, cfg)['input_raw'] for b in range(2)]))
+    outs = []
+    torch.cuda.set_device(0)
+    for dev in ('cuda:0', 'cuda:1'):
+        eng = RefinementEngine(cfg, dev, PatchDatabase(db['emb'], db['meta'], db['volumes'], dev))
+        eng.load_state_dicts({n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 70 + i)
+                              for i, (n, m) in enumerate(eng.modules().items())})
+        assert torch.cuda.current_device() == 0
+        outs.append(eng.refine(raws.to(dev)).cpu())
+        torch.cuda.synchronize(dev)
+    assert torch.equal(outs[0], outs[1])

@@ -45,6 +45,47 @@ def test_oracle_forward_full_matches_reference(name):
         np.testing.assert_allclose(got, fix[key], rtol=1e-6, atol=1e-4)
 
 
+@pytest.mark.parametrize('name', ['net_C1', 'net_C4'])
+def test_truth_fixture_is_the_oracle_in_float64(name):
+    """The float64 'truth' the GPU parity bar is derived from (tests/golden/truth_*.npz) = this oracle evaluated in float64;
+    for the softmax configs the generator also checked it against the reference's own modules in .double() (gap stored)."""
+    fix, truth = helpers.load_truth(name)
+    cfg0 = rf_configs.get_config(str(fix['cfg_name']))
+    cfg, x_in, retr, sds = helpers.fixture_problem(fix, product_shapes(cfg0))
+    sds64 = {m: {k: v.double() for k, v in sd.items()} for m, sd in sds.items()}
+    noise = torch.from_numpy(fix['gumbel_noise']).double() if 'gumbel_noise' in fix else None
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        df = refpath.forward_full(sds64, cfg, torch.from_numpy(x_in).double(), torch.from_numpy(retr).double(), float(fix['target_trunc']), noise)
+    assert np.abs(df.numpy() - truth['df_f64']).max() <= 1e-9
+    prof = helpers.error_profile(fix['df'], truth['df_f64'])
+    assert abs(prof['max'] - truth['ref_err_max']) <= 1e-9
+    if not cfg['attn_retrieval_mode']:
+        assert 0 <= truth['ref_double_gap'] <= 1e-9
+
+
+@pytest.mark.parametrize('name', ['feat_C1', 'feat_C5'])
+def test_oracle_get_features_matches_reference(name):
+    """A8: PatchedAttentionBlock.get_features (model/attention.py:132-139) on x_back / the target's retrieval features."""
+    ffix = helpers.load_fixture(name)
+    nfix = helpers.load_fixture(name.replace('feat_', 'net_'))
+    cfg0 = rf_configs.get_config(str(nfix['cfg_name']))
+    cfg, x_in, retr, sds = helpers.fixture_problem(nfix, product_shapes(cfg0))
+    seed = int(ffix['seed'])
+    tgt = np.stack([synthetic.normalise_target(cfg, synthetic.make_chunk(seed * 100 + 90, cfg)['target_raw'])[None]])
+    assert helpers.sha(tgt) == str(ffix['target_sha'])
+    occ = torch.from_numpy(np.unpackbits(ffix['occupancy'])[:32 ** 3].astype(bool).reshape(1, 1, 32, 32, 32))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        x_back = refpath.unet_backbone(torch.from_numpy(x_in), sds['unet_backbone'], cfg)
+        x_target = refpath.fold3d(refpath.retrieval_backbone(refpath.unfold3d(torch.from_numpy(tgt), 16), sds['retrieval_backbone'], cfg), 4, 8, cfg['nf'])
+        xf, pf, of = refpath.patched_get_features(x_back, x_target, occ, sds['patched_attention_block'], cfg)
+    assert np.abs(x_target[..., ::4, ::4, ::4].numpy() - ffix['x_target_sub']).max() <= 1e-5
+    assert np.abs(xf.numpy() - ffix['x_feat']).max() <= 1e-5 and np.abs(pf.numpy() - ffix['p_feat']).max() <= 1e-5
+    np.testing.assert_array_equal(of.numpy(), np.unpackbits(ffix['occ_flat'])[:of.numel()].astype(bool))
+    assert 0 < int(of.sum()) < of.numel()
+
+
 def test_fold_unfold_inverse_and_order():
     x = torch.arange(2 * 3 * 8 * 8 * 8, dtype=torch.float32).reshape(2, 3, 8, 8, 8)
     rows = refpath.unfold3d(x, 2)
@@ -95,6 +136,12 @@ def test_oracle_knn_demotion_compose_match_reference():
     c_val = refpath.compose_retrieval(fix['map_val_sentinel'], db['volumes'], K, trunc_t)
     assert helpers.sha(c_train) == str(fix['compose_train_sha'])
     assert helpers.sha(c_val) == str(fix['compose_val_sha'])
+    # query-side occupancy filter: dropped patches keep the trunc initialisation (util/retrieval.py:148,151)
+    keep = fix['patch_keep']
+    assert 0 < keep.sum() < 64
+    c_masked = refpath.compose_retrieval(fix['map_val_sentinel'], db['volumes'], K, trunc_t, patch_keep=keep)
+    assert helpers.sha(c_masked) == str(fix['compose_masked_sha'])
+    assert (c_masked != c_val).any()
     # the reference's own extent enumeration (dataset/scene.py:152-160) vs the product's patch boxes
     ext = fix['extents_64_16_8_16']
     boxes = synthetic.patch_boxes_64()
