@@ -44,15 +44,19 @@ const char* rf_last_error(void);
 int rf_conv3_pack_weight(const float* w_oidhw, int cout, int cin, float* w_packed, void* stream);
 size_t rf_conv3_packed_floats(int cout, int cin);
 
-/* GroupNorm statistics of the conv INPUT folded into per-(sample, channel) scale/shift:
- *   y = x * scale[n][c] + shift[n][c]  ==  GroupNorm(G, C, eps, affine)(x)         model/unet.py:54-66 ('g' before 'c')
+/* GroupNorm statistics of the conv INPUT folded into a per-(sample, channel) affine triple, gn_affine [n][c0+c1][4] floats
+ * = (center, scale, shift, 0):
+ *   y = (x - center) * scale + shift  ==  GroupNorm(G, C, eps, affine)(x)          model/unet.py:54-66 ('g' before 'c')
+ * with center = fl32(mean), scale = fl32(gamma*rstd), shift = fl32(beta - (mean - center)*gamma*rstd), mean / rstd in float64.
+ * (The centred form keeps the rounding error at eps*|y|; x*scale' + shift' would carry eps*|mean*rstd*gamma|, which on a
+ * near-constant input -- a truncation-saturated TSDF patch -- is 100x larger.)
  * The input is the virtual tensor cat(src0[n][c0][edge^3], nearest_upsample_x2(src1[n][c1][(edge/2)^3])) along
  * channels -- Decoder.forward's interpolate + concat, model/unet.py:297-308,354-360 -- with c0 or c1 possibly 0.
  * groups collapses to 1 when (c0+c1) < groups (model/unet.py:62-63) -- done by the CALLER; here groups divides c0+c1.
- * Biased variance, float64 accumulation.  scale/shift: [n][c0+c1]. */
+ * Biased variance, float64 accumulation. */
 int rf_gn_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                 const float* gamma, const float* beta, int groups, float eps,
-                float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
+                float* gn_affine, void* ws, size_t ws_bytes, void* stream);
 size_t rf_gn_stats_ws_bytes(int n, int groups);
 
 /* out[n][cout][edge^3] = ReLU( conv3d_k3_pad1( GN(cat(src0, up2(src1))) ) ), no bias.
@@ -60,26 +64,26 @@ size_t rf_gn_stats_ws_bytes(int n, int groups);
  * (model/unet.py:297-308) when c1 > 0.  Zero padding applies to the NORMALISED tensor.  fp32 MFMA
  * (v_mfma_f32_16x16x4_f32), exact fp32 FMA chains.  w_packed from rf_conv3_pack_weight. */
 int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                         const float* scale, const float* shift, const float* w_packed, int cout,
+                         const float* gn_affine, const float* w_packed, int cout,
                          float* out, void* stream);
 
 /* Same convolution, additionally emitting the GroupNorm statistics of its (ReLU'd) output for the NEXT layer:
  * stats [n][cout][tiles] pairs of float64 (sum, sum of squares) per workgroup tile, tiles = rf_conv3d_stats_tiles(...)
  * (0 = this shape takes a path without fused statistics).  Deterministic (fixed reduction order, no atomics). */
 int rf_conv3d_k3_gn_relu_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                               const float* scale, const float* shift, const float* w_packed, int cout,
+                               const float* gn_affine, const float* w_packed, int cout,
                                float* out, double* stats, void* stream);
 int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout);
 
 /* rf_gn_stats's result from producer-side statistics instead of re-reading the tensors: stats0 [n][c0][tiles0],
  * stats1 [n][c1][tiles1] (the low-res source; its sums count 8x).  edge = full resolution.  model/unet.py:54-66. */
 int rf_gn_from_stats(const double* stats0, int c0, int tiles0, const double* stats1, int c1, int tiles1, int n, int edge,
-                     const float* gamma, const float* beta, int groups, float eps, float* scale, float* shift, void* stream);
+                     const float* gamma, const float* beta, int groups, float eps, float* gn_affine, void* stream);
 
 /* Same contract on the plain VALU path (one thread per output); the kernels' own cross-check and the path for
  * 1^3 volumes.  Takes the ORIGINAL OIDHW weight. */
 int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                const float* scale, const float* shift, const float* w_oidhw, int cout,
+                                const float* gn_affine, const float* w_oidhw, int cout,
                                 float* out, void* stream);
 
 /* MaxPool3d(kernel 2, stride 2): Encoder.forward, model/unet.py:237,249-251.  x [n][c][edge^3] -> [n][c][(edge/2)^3] */
@@ -115,7 +119,7 @@ size_t rf_convv_packed_floats(int cout, int cin, int k);
  * the position-major kernel). */
 int rf_conv3d_pool_supported(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_k3_gn_relu_pool(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                              const float* scale, const float* shift, const float* w_packed, int cout,
+                              const float* gn_affine, const float* w_packed, int cout,
                               float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
 
 /* Decoder form of rf_conv3d_k3_gn_relu (model/unet.py:297-308: nearest x2 upsample of the low-res source, concat after
@@ -129,11 +133,10 @@ size_t rf_conv3_up_packed_floats(int cout, int c0, int c1);
 int rf_conv3_up_pack_weight(const float* w_oidhw, int cout, int c0, int c1, float* w_packed, void* stream);
 int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cout);
-/* which tiling rf_conv3d_up_k3_gn_relu uses for a shape (0 parity-split boxes, 1 position-major 4^3, 2 position-major 8^3
- * slices): they issue different numbers of multiply-adds (zero-padding taps left out), for reporting only */
+/* which tiling rf_conv3d_up_k3_gn_relu uses for a shape (0 parity-split boxes, 1 position-major 4^3): they issue different numbers of multiply-adds (zero-padding taps left out), for reporting only */
 int rf_conv3d_up_variant(int c0, int c1, int n, int edge, int cout);
-int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
-                            const float* shift, const float* w_packed, int cout, float* out, double* stats, void* stream);
+int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                            const float* gn_affine, const float* w_packed, int cout, float* out, double* stats, void* stream);
 
 /* --------------------------------------------------------------------------------------------- fold / unfold */
 

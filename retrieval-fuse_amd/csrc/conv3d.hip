@@ -102,10 +102,22 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ sr
     }
 }
 
-// pass 2: fixed-order reduction of the slices, then scale = gamma*rstd, shift = beta - mean*scale per (n, c)
+// GroupNorm as the conv kernels apply it: y = (x - center) * scale + shift with, per (sample, channel),
+//   center = fl32(mean),  scale = fl32(gamma * rstd),  shift = fl32(beta - (mean - center) * gamma * rstd).
+// Subtracting the (fp32-representable) centre first keeps the product at the magnitude of the RESULT: the plain two-term form
+// x*scale' + shift' carries an absolute error of eps * |mean * rstd * gamma|, which for near-constant inputs (a truncation-
+// saturated TSDF patch: rstd up to 316) is 100x the fp32 resolution of y and was the largest single error source of the path
+// (tools/error_budget.py, first layer of the retrieval backbone).  What fl32(mean) loses is folded into `shift` in float64.
+__device__ __forceinline__ float4 gn_affine(double mean, double rstd, float gamma, float beta) {
+    const double sc = (double)gamma * rstd;
+    const float center = (float)mean;
+    return make_float4(center, (float)sc, (float)((double)beta - (mean - (double)center) * sc), 0.f);
+}
+
+// pass 2: fixed-order reduction of the slices, then the affine triple per (n, c)
 __global__ void k_gn_finalize(const double2* __restrict__ part, int n, int C, int groups, int cpg, int slices, double count,
                               const float* __restrict__ gamma, const float* __restrict__ beta, double eps,
-                              float* __restrict__ scale, float* __restrict__ shift) {
+                              float4* __restrict__ affine) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * C) return;
     const int nn = i / C, c = i % C, g = c / cpg;
@@ -119,9 +131,7 @@ __global__ void k_gn_finalize(const double2* __restrict__ part, int n, int C, in
     double var = b / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + eps);
-    const double sc = (double)gamma[c] * rstd;
-    scale[i] = (float)sc;
-    shift[i] = (float)((double)beta[c] - mean * sc);
+    affine[i] = gn_affine(mean, rstd, gamma[c], beta[c]);
 }
 
 static int gn_slices(size_t group_elems) {
@@ -135,11 +145,11 @@ extern "C" size_t rf_gn_stats_ws_bytes(int n, int groups) { return (size_t)n * g
 
 extern "C" int rf_gn_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                            const float* gamma, const float* beta, int groups, float eps,
-                           float* scale, float* shift, void* ws, size_t ws_bytes, void* stream) {
+                           float* gn_affine, void* ws, size_t ws_bytes, void* stream) {
     const int C = c0 + c1;
     RF_REQUIRE(n > 0 && C > 0 && groups > 0 && C % groups == 0, RF_E_INVALID, "rf_gn_stats: channels %d not divisible by groups %d", C, groups);
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_gn_stats: edge %d must be a power of two <= 128", edge);
-    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && gamma && beta && scale && shift && ws, RF_E_INVALID, "rf_gn_stats: null pointer");
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && gamma && beta && gn_affine && ws, RF_E_INVALID, "rf_gn_stats: null pointer");
     RF_REQUIRE(c1 == 0 || edge >= 2, RF_E_INVALID, "rf_gn_stats: upsampled source needs edge >= 2");
     RF_REQUIRE(ws_bytes >= rf_gn_stats_ws_bytes(n, groups), RF_E_WORKSPACE, "rf_gn_stats: workspace too small");
     const size_t vol0 = (size_t)edge * edge * edge, vol1 = vol0 / 8;
@@ -149,16 +159,16 @@ extern "C" int rf_gn_stats(const float* src0, int c0, const float* src1, int c1,
                        groups, cpg, slices, (double2*)ws);
     RF_CHECK_LAUNCH("rf_gn_stats(partial)");
     hipLaunchKernelGGL(k_gn_finalize, dim3((n * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double2*)ws, n, C, groups, cpg,
-                       slices, (double)cpg * (double)vol0, gamma, beta, (double)eps, scale, shift);
+                       slices, (double)cpg * (double)vol0, gamma, beta, (double)eps, reinterpret_cast<float4*>(gn_affine));
     RF_CHECK_LAUNCH("rf_gn_stats(finalize)");
     return RF_OK;
 }
 
-static int conv_check(const char* who, const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
-                      const float* shift, const float* w, int cout, float* out) {
+static int conv_check(const char* who, const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
+                      const float* w, int cout, float* out) {
     RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "%s: bad sizes", who);
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "%s: edge %d must be a power of two <= 128", who, edge);
-    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w && out, RF_E_INVALID, "%s: null pointer", who);
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && gn_affine && w && out, RF_E_INVALID, "%s: null pointer", who);
     RF_REQUIRE(c1 == 0 || edge >= 2, RF_E_INVALID, "%s: upsampled source needs edge >= 2", who);
     return RF_OK;
 }
@@ -166,7 +176,7 @@ static int conv_check(const char* who, const float* src0, int c0, const float* s
 // ----------------------------------------------------------------------------------------------- conv, direct
 // One thread per output element; plain fp32 FMAs in (ci, tap) order.  Cross-check path and the 1^3 path.
 __global__ __launch_bounds__(256) void k_conv3_direct(const float* __restrict__ src0, int c0, const float* __restrict__ src1, int c1, int n,
-                                                      int edge, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      int edge, const float4* __restrict__ affine,
                                                       const float* __restrict__ w, int cout, float* __restrict__ out) {
     const size_t vol = (size_t)edge * edge * edge;
     const size_t total = (size_t)n * cout * vol;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void k_conv3_direct(const float* __restrict__ 
         const int co = (int)((i / vol) % cout), nn = (int)(i / (vol * cout));
         float acc = 0.f;
         for (int ci = 0; ci < cin; ++ci) {
-            const float sc = scale[(size_t)nn * cin + ci], sh = shift[(size_t)nn * cin + ci];
+            const float4 af = affine[(size_t)nn * cin + ci];
             const float* wk = w + ((size_t)co * cin + ci) * 27;
             for (int dz = 0; dz < 3; ++dz) {
                 const int zz = z + dz - 1;
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void k_conv3_direct(const float* __restrict__ 
                         float r;
                         if (ci < c0) r = src0[(((size_t)nn * c0 + ci) * edge + zz) * edge * edge + (size_t)yy * edge + xx];
                         else r = src1[(((size_t)nn * c1 + (ci - c0)) * half + (zz >> 1)) * half * half + (size_t)(yy >> 1) * half + (xx >> 1)];
-                        acc = fmaf(r * sc + sh, wk[(dz * 3 + dy) * 3 + dx], acc);
+                        acc = fmaf(fmaf(r - af.x, af.y, af.z), wk[(dz * 3 + dy) * 3 + dx], acc);
                     }
                 }
             }
@@ -200,15 +210,15 @@ __global__ __launch_bounds__(256) void k_conv3_direct(const float* __restrict__ 
 }
 
 extern "C" int rf_conv3d_k3_gn_relu_direct(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                           const float* scale, const float* shift, const float* w_oidhw, int cout,
+                                           const float* gn_affine, const float* w_oidhw, int cout,
                                            float* out, void* stream) {
-    int rc = conv_check("rf_conv3d_k3_gn_relu_direct", src0, c0, src1, c1, n, edge, scale, shift, w_oidhw, cout, out);
+    int rc = conv_check("rf_conv3d_k3_gn_relu_direct", src0, c0, src1, c1, n, edge, gn_affine, w_oidhw, cout, out);
     if (rc) return rc;
     const size_t total = (size_t)n * cout * edge * edge * edge;
     const size_t want = (total + 255) / 256;
     const int blocks = (int)(want < 8192 ? want : 8192);
-    hipLaunchKernelGGL(k_conv3_direct, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src0, c0, src1, c1, n, edge, scale, shift, w_oidhw,
-                       cout, out);
+    hipLaunchKernelGGL(k_conv3_direct, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src0, c0, src1, c1, n, edge, reinterpret_cast<const float4*>(gn_affine),
+                       w_oidhw, cout, out);
     RF_CHECK_LAUNCH("rf_conv3d_k3_gn_relu_direct");
     return RF_OK;
 }
@@ -287,8 +297,7 @@ extern "C" int rf_maxpool3d_2_stats(const float* x, int n, int c, int edge, floa
 template <int LPU>
 __global__ __launch_bounds__(256) void k_gn_from_stats(const double2* __restrict__ st0, int c0, int t0, const double2* __restrict__ st1, int c1,
                                                        int t1, int units, int groups, int cpg, double count, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, double eps, float* __restrict__ scale,
-                                                       float* __restrict__ shift) {
+                                                       const float* __restrict__ beta, double eps, float4* __restrict__ affine) {
     const int gtid = blockIdx.x * 256 + threadIdx.x;
     const int unit = gtid / LPU, lane = gtid % LPU;
     if (unit >= units) return;
@@ -322,18 +331,14 @@ __global__ __launch_bounds__(256) void k_gn_from_stats(const double2* __restrict
     double var = sq / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + eps);
-    for (int c = ca + lane; c < cb; c += LPU) {
-        const double sc = (double)gamma[c] * rstd;
-        scale[(size_t)nn * C + c] = (float)sc;
-        shift[(size_t)nn * C + c] = (float)((double)beta[c] - mean * sc);
-    }
+    for (int c = ca + lane; c < cb; c += LPU) affine[(size_t)nn * C + c] = gn_affine(mean, rstd, gamma[c], beta[c]);
 }
 
 extern "C" int rf_gn_from_stats(const double* stats0, int c0, int tiles0, const double* stats1, int c1, int tiles1, int n, int edge,
-                                const float* gamma, const float* beta, int groups, float eps, float* scale, float* shift, void* stream) {
+                                const float* gamma, const float* beta, int groups, float eps, float* gn_affine, void* stream) {
     const int C = c0 + c1;
     RF_REQUIRE(n > 0 && C > 0 && groups > 0 && C % groups == 0, RF_E_INVALID, "rf_gn_from_stats: channels %d not divisible by groups %d", C, groups);
-    RF_REQUIRE((c0 == 0 || (stats0 && tiles0 > 0)) && (c1 == 0 || (stats1 && tiles1 > 0)) && gamma && beta && scale && shift, RF_E_INVALID,
+    RF_REQUIRE((c0 == 0 || (stats0 && tiles0 > 0)) && (c1 == 0 || (stats1 && tiles1 > 0)) && gamma && beta && gn_affine, RF_E_INVALID,
                "rf_gn_from_stats: null pointer / zero tiles");
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_gn_from_stats: edge %d", edge);
     const int cpg = C / groups;
@@ -342,11 +347,11 @@ extern "C" int rf_gn_from_stats(const double* stats0, int c0, int tiles0, const 
     if (entries <= 128 && units >= 1024)
         hipLaunchKernelGGL(k_gn_from_stats<1>, dim3((units + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(stats0), c0,
                            tiles0, reinterpret_cast<const double2*>(stats1), c1, tiles1, units, groups, cpg, (double)cpg * edge * edge * edge, gamma,
-                           beta, (double)eps, scale, shift);
+                           beta, (double)eps, reinterpret_cast<float4*>(gn_affine));
     else
         hipLaunchKernelGGL(k_gn_from_stats<64>, dim3((units + 3) / 4), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(stats0), c0,
                            tiles0, reinterpret_cast<const double2*>(stats1), c1, tiles1, units, groups, cpg, (double)cpg * edge * edge * edge, gamma,
-                           beta, (double)eps, scale, shift);
+                           beta, (double)eps, reinterpret_cast<float4*>(gn_affine));
     RF_CHECK_LAUNCH("rf_gn_from_stats");
     return RF_OK;
 }

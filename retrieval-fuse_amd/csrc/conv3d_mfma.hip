@@ -30,8 +30,7 @@ typedef __attribute__((address_space(3))) void* rf_lptr;
 struct ConvArgs {
     const float* src0;
     const float* src1;
-    const float* scale;
-    const float* shift;
+    const float4* affine;   // GroupNorm per (sample, input channel): (center, scale, shift, -) -> y = (x - center) * scale + shift
     const float* wp;
     float* out;
     int c0, c1, n, edge, cout, cin4, cout16;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     constexpr int ROWS = SPW * CC * T::HZ * HY;
     constexpr int RPT = (ROWS + NT - 1) / NT;
     float xraw[RPT][TX + 2];       // [left halo | TX interior (or TX/2 low-res values) | right halo]
-    float xsc[RPT], xsh[RPT];
+    float xce[RPT], xsc[RPT], xsh[RPT];
     const bool has_l = x0 > 0, has_r = x0 + TX < edge;
 
     auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
@@ -196,8 +195,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
             int s, c, hz, hy, nn, ci, z, y;
             if (row_coords(tid + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
                 const size_t si = (size_t)nn * cin + ci;
-                xsc[i] = a.scale[si];
-                xsh[i] = a.shift[si];
+                { const float4 af = a.affine[si]; xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
                 if (ci < a.c0) {
                     const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
                     if (TX >= 4) {
@@ -240,16 +238,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
             if (r < ROWS) {
                 float v[TX + 2];
                 if (ok) {
-                    const float sc = xsc[i], sh = xsh[i];
+                    const float ce = xce[i], sc = xsc[i], sh = xsh[i];
                     if (ci < a.c0) {
 #pragma unroll
-                        for (int j = 1; j <= TX; ++j) v[j] = xraw[i][j] * sc + sh;
+                        for (int j = 1; j <= TX; ++j) v[j] = fmaf(xraw[i][j] - ce, sc, sh);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < TX; ++j) v[1 + j] = xraw[i][1 + (j >> 1)] * sc + sh;
+                        for (int j = 0; j < TX; ++j) v[1 + j] = fmaf(xraw[i][1 + (j >> 1)] - ce, sc, sh);
                     }
-                    v[0] = has_l ? xraw[i][0] * sc + sh : 0.f;
-                    v[TX + 1] = has_r ? xraw[i][TX + 1] * sc + sh : 0.f;
+                    v[0] = has_l ? fmaf(xraw[i][0] - ce, sc, sh) : 0.f;
+                    v[TX + 1] = has_r ? fmaf(xraw[i][TX + 1] - ce, sc, sh) : 0.f;
                 } else {
 #pragma unroll
                     for (int j = 0; j < TX + 2; ++j) v[j] = 0.f;
@@ -550,14 +548,14 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
     const int z0 = (t % tz) * TZ; t /= tz;
     const int nn = t;
     for (int i = tid; i < 27 * 8; i += 256) wl[i] = (i % 8) < COUT ? a.wp[(size_t)(i / 8) * a.cin4 * a.cout16 + (i % 8)] : 0.f;   // packed [tap][ci=0][co]
-    const float sc = a.scale[nn], sh = a.shift[nn];
+    const float4 af = a.affine[nn];
     const float* src = a.src0 + (size_t)nn * edge * edge * edge;
     for (int i = tid; i < HZ * HY * HX; i += 256) {
         const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
         const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
         float v = 0.f;
         if ((unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge)
-            v = src[((size_t)z * edge + y) * edge + x] * sc + sh;
+            v = fmaf(src[((size_t)z * edge + y) * edge + x] - af.x, af.y, af.z);
         xs[i] = v;
     }
     __syncthreads();
@@ -640,19 +638,19 @@ extern "C" int rf_conv3d_stats_tiles(int c0, int c1, int n, int edge, int cout) 
 }
 
 bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout);                       // conv3d_small.hip
-int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
+int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* gn_affine, const float* w_packed, int cout,
                           float* out, double* stats, void* stream, float* pool_out, double* pool_stats);
 
 static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                       const float* scale, const float* shift, const float* w_packed, int cout,
+                       const float* gn_affine, const float* w_packed, int cout,
                        float* out, double* stats, void* stream, float* pool_out = nullptr, double* pool_stats = nullptr, int pool_mode = 0) {
     RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "rf_conv3d_k3_gn_relu: bad sizes");
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_conv3d_k3_gn_relu: edge %d must be a power of two <= 128", edge);
-    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && scale && shift && w_packed && (out || pool_mode == 2), RF_E_INVALID,
+    RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && gn_affine && w_packed && (out || pool_mode == 2), RF_E_INVALID,
                "rf_conv3d_k3_gn_relu: null pointer");
     RF_REQUIRE(edge >= 2, RF_E_UNSUPPORTED, "rf_conv3d_k3_gn_relu: 1^3 volumes take the direct path (rf_conv3d_k3_gn_relu_direct)");
     ConvArgs a;
-    a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = w_packed; a.out = out;
     a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
     a.cin4 = rf_round_up(c0 + c1, 4); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
@@ -662,7 +660,7 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
     // whole 4^3 / 2^3 volumes: the position-major kernel (conv3d_small.hip) leaves out every zero-padding tap
     if ((!pool_mode || edge == 4) && rf_conv3_small_takes(c0, c1, n, edge, cout))
-        return rf_conv3_small_launch(src0, c0, n, edge, scale, shift, w_packed, cout, out, stats, stream, pool_out, pool_stats);
+        return rf_conv3_small_launch(src0, c0, n, edge, gn_affine, w_packed, cout, out, stats, stream, pool_out, pool_stats);
     // 512-voxel workgroup tiles when that still gives the 256 CUs a few workgroups each; otherwise 128-voxel tiles
     const bool big = conv_use_big(n, edge, a.cout16);
     if (edge >= 8) return big ? dispatch_nb<8, 8, 8, 1, TILE_BIG>(a, s) : dispatch_nb<4, 4, 8, 1, TILE_SMALL>(a, s);
@@ -673,9 +671,9 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
 }
 
 extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                    const float* scale, const float* shift, const float* w_packed, int cout,
+                                    const float* gn_affine, const float* w_packed, int cout,
                                     float* out, void* stream) {
-    return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, nullptr, stream);
+    return conv3d_impl(src0, c0, src1, c1, n, edge, gn_affine, w_packed, cout, out, nullptr, stream);
 }
 
 // fused MaxPool3d(2): only the 8^3-box tiling (edge >= 8, enough boxes, not the cin == 1 kernel) holds whole pooling cells
@@ -685,18 +683,18 @@ extern "C" int rf_conv3d_pool_supported(int c0, int c1, int n, int edge, int cou
 }
 
 extern "C" int rf_conv3d_k3_gn_relu_pool(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                         const float* scale, const float* shift, const float* w_packed, int cout,
+                                         const float* gn_affine, const float* w_packed, int cout,
                                          float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
     RF_REQUIRE(pool_out, RF_E_INVALID, "rf_conv3d_k3_gn_relu_pool: null pooled output");
     RF_REQUIRE(rf_conv3d_pool_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
                "rf_conv3d_k3_gn_relu_pool: shape not on the 8^3-box tiling (ask rf_conv3d_pool_supported)");
     RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_k3_gn_relu_pool: statistics of an output that is not written");
-    return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, stats, stream, pool_out, pool_stats, out ? 1 : 2);
+    return conv3d_impl(src0, c0, src1, c1, n, edge, gn_affine, w_packed, cout, out, stats, stream, pool_out, pool_stats, out ? 1 : 2);
 }
 
 extern "C" int rf_conv3d_k3_gn_relu_stats(const float* src0, int c0, const float* src1, int c1, int n, int edge,
-                                          const float* scale, const float* shift, const float* w_packed, int cout,
+                                          const float* gn_affine, const float* w_packed, int cout,
                                           float* out, double* stats, void* stream) {
     RF_REQUIRE(stats, RF_E_INVALID, "rf_conv3d_k3_gn_relu_stats: null stats buffer");
-    return conv3d_impl(src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out, stats, stream);
+    return conv3d_impl(src0, c0, src1, c1, n, edge, gn_affine, w_packed, cout, out, stats, stream);
 }

@@ -25,8 +25,7 @@ typedef __attribute__((address_space(3))) void* rf_lptr;
 
 struct SmallArgs {
     const float* src;
-    const float* scale;
-    const float* shift;
+    const float4* affine;   // GroupNorm per (sample, input channel): (center, scale, shift, -) -> y = (x - center) * scale + shift
     const float* wp;       // [27][cin4][cout16] (rf_conv3_pack_weight)
     float* out;
     int cin, n, cout, cin4, cout16;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
     constexpr int ITEMS = SAMPLES * 4 * RUNS;                       // 512 either way
     static_assert(ITEMS == NT, "one staging item per thread");
     float xraw[8];
-    float xsc = 0.f, xsh = 0.f;
+    float xce = 0.f, xsc = 0.f, xsh = 0.f;
     // thread -> (sample, k) fastest so that a wave's LDS writes of one position are conflict-free
     const int it_s = tid % SAMPLES, it_k = (tid / SAMPLES) % 4, it_run = tid / (SAMPLES * 4);
     auto issue_rows = [&](int cbase) {
@@ -126,8 +125,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
         if (nn < a.n && ci < a.cin) {
             const size_t si = (size_t)nn * a.cin + ci;
             const size_t gi = (size_t)nn * (a.cin + (UP ? a.c1 : 0)) + ci;
-            xsc = a.scale[gi];
-            xsh = a.shift[gi];
+            { const float4 af = a.affine[gi]; xce = af.x; xsc = af.y; xsh = af.z; }
             const float4* row = reinterpret_cast<const float4*>(a.src + si * P + it_run * 8);
             const float4 t0 = row[0], t1 = row[1];
             xraw[0] = t0.x; xraw[1] = t0.y; xraw[2] = t0.z; xraw[3] = t0.w;
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
         const bool ok = nn < a.n && ci < a.cin;
         float* dst = xs + ((it_s >> 4) * P + it_run * 8) * 64 + it_k * 16 + (it_s & 15);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j * 64] = ok ? xraw[j] * xsc + xsh : 0.f;
+        for (int j = 0; j < 8; ++j) dst[j * 64] = ok ? fmaf(xraw[j] - xce, xsc, xsh) : 0.f;
     };
 
     // Everything below is instantiated per variant of this wave (ZC: 0 = first z slice, 1 = interior, 2 = last; YH: y half)
@@ -222,14 +220,13 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
                 }
             };
             float lraw[8];
-            float lsc = 0.f, lsh = 0.f;
+            float lce = 0.f, lsc = 0.f, lsh = 0.f;
             const int ls = tid & 15, lk = (tid >> 4) & 3;            // threads 0..63 stage the low-res chunk
             auto issue_low = [&](int c4) {
                 const int nn = n0 + ls, ci = c4 * 4 + lk;
                 if (tid < 64 && nn < a.n && ci < a.c1) {
                     const size_t gi = (size_t)nn * (a.cin + a.c1) + a.cin + ci;
-                    lsc = a.scale[gi];
-                    lsh = a.shift[gi];
+                    { const float4 af = a.affine[gi]; lce = af.x; lsc = af.y; lsh = af.z; }
                     const float4* row = reinterpret_cast<const float4*>(a.src1 + ((size_t)nn * a.c1 + ci) * 8);
                     const float4 t0 = row[0], t1 = row[1];
                     lraw[0] = t0.x; lraw[1] = t0.y; lraw[2] = t0.z; lraw[3] = t0.w;
@@ -242,7 +239,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
                     const bool ok = nn < a.n && ci < a.c1;
                     float* dst = xlow + bufb * 512 + lk * 16 + ls;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dst[j * 64] = ok ? lraw[j] * lsc + lsh : 0.f;
+                    for (int j = 0; j < 8; ++j) dst[j * 64] = ok ? fmaf(lraw[j] - lce, lsc, lsh) : 0.f;
                 }
             };
             const int nchunk = a.c1_8 >> 2;
@@ -422,10 +419,10 @@ bool rf_conv3_small_takes(int c0, int c1, int n, int edge, int cout) {
     return wgs >= 128;                                               // half a wave of workgroups per CU still beats the box tiling
 }
 
-int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* scale, const float* shift, const float* w_packed, int cout,
+int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const float* gn_affine, const float* w_packed, int cout,
                           float* out, double* stats, void* stream, float* pool_out, double* pool_stats) {
     SmallArgs a;
-    a.src = src; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.src = src; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = w_packed; a.out = out;
     a.cin = cin; a.n = n; a.cout = cout; a.cin4 = rf_round_up(cin, 4); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
     a.src1 = nullptr; a.wp1 = nullptr; a.c1 = 0; a.c1_8 = 0;
@@ -442,10 +439,10 @@ bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout) {
     return (long long)((n + 15) / 16) * gy >= 256;
 }
 
-int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
+int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* gn_affine,
                              const float* w_up_packed, int cout, float* out, double* stats, void* stream) {
     SmallArgs a;
-    a.src = src0; a.scale = scale; a.shift = shift; a.wp = w_up_packed; a.out = out;
+    a.src = src0; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = w_up_packed; a.out = out;
     a.cin = c0; a.n = n; a.cout = cout; a.cin4 = rf_round_up(c0, 4); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
     a.src1 = src1; a.c1 = c1; a.c1_8 = rf_round_up(c1, 8);

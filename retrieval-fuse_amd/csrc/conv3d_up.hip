@@ -82,8 +82,7 @@ extern "C" int rf_conv3_up_pack_weight(const float* w_oidhw, int cout, int c0, i
 struct UpArgs {
     const float* src0;
     const float* src1;
-    const float* scale;
-    const float* shift;
+    const float4* affine;   // GroupNorm per (sample, input channel): (center, scale, shift, -) -> y = (x - center) * scale + shift
     const float* wp;
     float* out;
     int c0, c1, n, edge, cout, c0_4, c1_8, cout16;
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
         constexpr int ROWS = SPW * 4 * HE * HE;
         constexpr int RPT = (ROWS + NT - 1) / NT;
         float xraw[RPT][TE + 2];
-        float xsc[RPT], xsh[RPT];
+        float xce[RPT], xsc[RPT], xsh[RPT];
         const bool has_l = x0 > 0, has_r = x0 + TE < edge;
         auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
             hy = r % HE; hz = (r / HE) % HE; c = (r / (HE * HE)) % 4; s = r / (HE * HE * 4);
@@ -227,8 +226,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 int s, c, hz, hy, nn, ci, z, y;
                 if (row_coords(tid_ + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
                     const size_t si = (size_t)nn * cin + ci;
-                    xsc[i] = a.scale[si];
-                    xsh[i] = a.shift[si];
+                    { const float4 af = a.affine[si]; xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
                     const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
 #pragma unroll
                     for (int q = 0; q < TE / 4; ++q) {
@@ -249,11 +247,11 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 if (r < ROWS) {
                     float v[TE + 2];
                     if (ok) {
-                        const float sc = xsc[i], sh = xsh[i];
+                        const float ce = xce[i], sc = xsc[i], sh = xsh[i];
 #pragma unroll
-                        for (int j = 1; j <= TE; ++j) v[j] = xraw[i][j] * sc + sh;
-                        v[0] = has_l ? xraw[i][0] * sc + sh : 0.f;
-                        v[TE + 1] = has_r ? xraw[i][TE + 1] * sc + sh : 0.f;
+                        for (int j = 1; j <= TE; ++j) v[j] = fmaf(xraw[i][j] - ce, sc, sh);
+                        v[0] = has_l ? fmaf(xraw[i][0] - ce, sc, sh) : 0.f;
+                        v[TE + 1] = has_r ? fmaf(xraw[i][TE + 1] - ce, sc, sh) : 0.f;
                     } else {
 #pragma unroll
                         for (int j = 0; j < TE + 2; ++j) v[j] = 0.f;
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
         constexpr int ROWS = SPW * 8 * LH * LH;                         // rows of LH floats
         constexpr int RPT = (ROWS + NT - 1) / NT;
         float xraw[RPT][LH];
-        float xsc[RPT], xsh[RPT];
+        float xce[RPT], xsc[RPT], xsh[RPT];
         const int Z0 = z0 >> 1, Y0 = y0 >> 1, X0 = x0 >> 1;
         const bool has_l = X0 > 0, has_r = X0 + L < half;
         auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
@@ -339,8 +337,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 int s, c, hz, hy, nn, ci, z, y;
                 if (row_coords(tid_ + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
                     const size_t si = (size_t)nn * cin + a.c0 + ci;
-                    xsc[i] = a.scale[si];
-                    xsh[i] = a.shift[si];
+                    { const float4 af = a.affine[si]; xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
                     const float* row = a.src1 + ((((size_t)nn * a.c1 + ci) * half + z) * half + y) * half + X0;
                     if constexpr (L == 4) {
                         const float4 t = *reinterpret_cast<const float4*>(row);
@@ -363,11 +360,11 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 if (r < ROWS) {
                     float v[LH];
                     if (ok) {
-                        const float sc = xsc[i], sh = xsh[i];
+                        const float ce = xce[i], sc = xsc[i], sh = xsh[i];
 #pragma unroll
-                        for (int j = 1; j <= L; ++j) v[j] = xraw[i][j] * sc + sh;
-                        v[0] = has_l ? xraw[i][0] * sc + sh : 0.f;
-                        v[L + 1] = has_r ? xraw[i][L + 1] * sc + sh : 0.f;
+                        for (int j = 1; j <= L; ++j) v[j] = fmaf(xraw[i][j] - ce, sc, sh);
+                        v[0] = has_l ? fmaf(xraw[i][0] - ce, sc, sh) : 0.f;
+                        v[L + 1] = has_r ? fmaf(xraw[i][L + 1] - ce, sc, sh) : 0.f;
                     } else {
 #pragma unroll
                         for (int j = 0; j < LH; ++j) v[j] = 0.f;
@@ -588,7 +585,7 @@ static int dispatch_up(const UpArgs& a, hipStream_t stream) {
 // Shapes the parity-split kernel takes: a low-res source, edge 4 (four samples per workgroup) or a multiple of 8, and
 // enough boxes to give the 256 CUs work (small launches stay on rf_conv3d_k3_gn_relu's 128-voxel tiles).
 bool rf_conv3_small_up_takes(int c0, int c1, int n, int edge, int cout);                    // conv3d_small.hip
-int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* scale, const float* shift,
+int rf_conv3_small_up_launch(const float* src0, int c0, const float* src1, int c1, int n, const float* gn_affine,
                              const float* w_up_packed, int cout, float* out, double* stats, void* stream);
 
 extern "C" int rf_conv3d_up_supported(int c0, int c1, int n, int edge, int cout) {
@@ -609,13 +606,12 @@ extern "C" int rf_conv3d_up_stats_tiles(int c0, int c1, int n, int edge, int cou
     return edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8);
 }
 
-extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* scale,
-                                       const float* shift, const float* w_packed, int cout, float* out, double* stats, void* stream) {
+extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine, const float* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_supported(c0, c1, n, edge, cout) || (c1 > 0 && c0 >= 0 && n > 0 && cout > 0 && rf_is_pow2(edge) && edge >= 4 && edge <= 128),
                RF_E_UNSUPPORTED, "rf_conv3d_up_k3_gn_relu: needs a low-res source and a power-of-two edge in 4..128 (got c1=%d edge=%d)", c1, edge);
-    RF_REQUIRE((c0 == 0 || src0) && src1 && scale && shift && w_packed && out, RF_E_INVALID, "rf_conv3d_up_k3_gn_relu: null pointer");
+    RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_up_k3_gn_relu: null pointer");
     UpArgs a;
-    a.src0 = src0; a.src1 = src1; a.scale = scale; a.shift = shift; a.wp = w_packed; a.out = out;
+    a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = w_packed; a.out = out;
     a.c0 = c0; a.c1 = c1; a.n = n; a.edge = edge; a.cout = cout;
     a.c0_4 = rf_round_up(c0, 4); a.c1_8 = rf_round_up(c1, 8); a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
@@ -623,6 +619,6 @@ extern "C" int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* s
     hipStream_t s = (hipStream_t)stream;
     // whole 4^3 volumes with enough samples: position-major form (conv3d_small.hip), every zero-padding tap left out
     if (edge == 4 && rf_conv3_small_up_takes(c0, c1, n, edge, cout))
-        return rf_conv3_small_up_launch(src0, c0, src1, c1, n, scale, shift, w_packed, cout, out, stats, stream);
+        return rf_conv3_small_up_launch(src0, c0, src1, c1, n, gn_affine, w_packed, cout, out, stats, stream);
     return edge == 4 ? dispatch_up<4, 4, 2>(a, s) : dispatch_up<8, 1, 4>(a, s);
 }

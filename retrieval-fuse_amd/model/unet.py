@@ -5,7 +5,7 @@ Same class names, constructor arguments and ``state_dict`` keys as the reference
 Abstract3DUNet/UNet3D), so reference checkpoints load unchanged.  The modules only HOLD parameters; ``forward`` runs
 the gfx950 kernels of librfuse_hip.so through ``rfuse.ops``:
 
-  SingleConv('gcr')  = rf_gn_stats  +  rf_conv3d_k3_gn_relu  (GroupNorm apply, upsample+concat read, ReLU fused in)
+  SingleConv('gcr')  = rf_gn_stats / rf_gn_from_stats  +  rf_conv3d_k3_gn_relu  (GroupNorm apply, upsample+concat read, ReLU fused in)
   Encoder pooling    = rf_maxpool3d_2
   Decoder upsample + concat: never materialised -- the conv reads (skip, low-res) as two sources.
 
@@ -90,17 +90,17 @@ class SingleConv(nn.Module):
         ops._no_grad_only(x, upsampled, self.conv.weight)
         gn = self.groupnorm
         cout = self.conv.out_channels
-        scale, shift = ops.gn_scale_shift(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
+        aff = ops.gn_affine(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
         if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
-            return ops.conv3d_gn_relu_pool(x, None, scale, shift, self.conv.packed(), cout, keep_full=(pool == 'also'))
+            return ops.conv3d_gn_relu_pool(x, None, aff, self.conv.packed(), cout, keep_full=(pool == 'also'))
         if _direct or edge == 1:
-            out = ops.conv3d_gn_relu(x, upsampled, scale, shift, None, cout, direct_weight=self.conv.weight)
+            out = ops.conv3d_gn_relu(x, upsampled, aff, None, cout, direct_weight=self.conv.weight)
         elif ops.conv_up_supported(x, upsampled, cout):
             c0 = x.shape[1] if x is not None else 0
-            out = ops.conv3d_up_gn_relu(x, upsampled, scale, shift, self.conv.packed_up(c0), cout)
+            out = ops.conv3d_up_gn_relu(x, upsampled, aff, self.conv.packed_up(c0), cout)
         else:
-            out = ops.conv3d_gn_relu(x, upsampled, scale, shift, self.conv.packed(), cout)
+            out = ops.conv3d_gn_relu(x, upsampled, aff, self.conv.packed(), cout)
         return out if pool is None else (out, ops.maxpool2(out))
 
 

@@ -25,15 +25,15 @@ SIGNATURES = {
     'rf_last_error': (ctypes.c_char_p, []),
     'rf_conv3_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),
     'rf_conv3_packed_floats': (c_sz, [c_i, c_i]),
-    'rf_gn_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_p, c_sz, c_p]),
+    'rf_gn_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_p, c_sz, c_p]),
     'rf_gn_stats_ws_bytes': (c_sz, [c_i, c_i]),
-    'rf_conv3d_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
-    'rf_conv3d_k3_gn_relu_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p, c_p]),
+    'rf_conv3d_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_conv3d_k3_gn_relu_stats': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_p]),
     'rf_conv3d_stats_tiles': (c_i, [c_i, c_i, c_i, c_i, c_i]),
-    'rf_gn_from_stats': (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_p]),
+    'rf_gn_from_stats': (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_p]),
     'rf_maxpool3d_2_stats': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_p]),
     'rf_maxpool_stats_tiles': (c_i, [c_i]),
-    'rf_conv3d_k3_gn_relu_direct': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_conv3d_k3_gn_relu_direct': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p]),
     'rf_maxpool3d_2': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_conv1x1_tanh': (c_i, [c_fp, c_i, c_i, c_sz, c_fp, c_fp, c_f, c_f, c_fp, c_p]),
     'rf_conv3d_valid_leaky': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
@@ -41,13 +41,13 @@ SIGNATURES = {
     'rf_convv_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_convv_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_pool_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
-    'rf_conv3d_k3_gn_relu_pool': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p, c_fp, c_p, c_p]),
+    'rf_conv3d_k3_gn_relu_pool': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_conv3_up_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3_up_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_conv3d_up_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_up_stats_tiles': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_up_variant': (c_i, [c_i, c_i, c_i, c_i, c_i]),
-    'rf_conv3d_up_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_fp, c_p, c_p]),
+    'rf_conv3d_up_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_p]),
     'rf_unfold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_fold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_linear_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),

@@ -145,8 +145,9 @@ def _src_dims(src0, src1):
     return n, c0, c1, edge
 
 
-def gn_scale_shift(src0, src1, gamma, beta, groups, eps=1e-5):
-    """GroupNorm of cat(src0, up2(src1)) folded to per-(n, c) scale/shift.  Either source may be None."""
+def gn_affine(src0, src1, gamma, beta, groups, eps=1e-5):
+    """GroupNorm of cat(src0, up2(src1)) folded to the per-(n, c) triple the conv kernels apply: [n, C, 4] float32 =
+    (center, scale, shift, 0) with y = (x - center) * scale + shift.  Either source may be None."""
     for t, nm in ((src0, 'src0'), (src1, 'src1')):
         if t is not None:
             _req(t, nm)
@@ -157,20 +158,26 @@ def gn_scale_shift(src0, src1, gamma, beta, groups, eps=1e-5):
         groups = 1                                           # model/unet.py:62-63
     dev = gamma.device
     lib = _lib.load()
-    scale = torch.empty((n, c), dtype=torch.float32, device=dev)
-    shift = torch.empty((n, c), dtype=torch.float32, device=dev)
+    aff = torch.empty((n, c, 4), dtype=torch.float32, device=dev)
     st0, st1 = _fresh_stats(src0), _fresh_stats(src1)
     if USE_FUSED_STATS and (src0 is None or st0 is not None) and (src1 is None or st1 is not None):
         # the producers (conv / max-pool epilogues) already emitted per-tile sums: no re-read of the activations
         _lib.check(lib.rf_gn_from_stats(_p(st0[0]) if st0 else _p(None), c0, st0[1] if st0 else 0,
                                         _p(st1[0]) if st1 else _p(None), c1, st1[1] if st1 else 0, n, edge,
-                                        _p(gamma.detach()), _p(beta.detach()), groups, eps, _p(scale), _p(shift), _stream()), 'rf_gn_from_stats')
-        return scale, shift
+                                        _p(gamma.detach()), _p(beta.detach()), groups, eps, _p(aff), _stream()), 'rf_gn_from_stats')
+        return aff
     nbytes = lib.rf_gn_stats_ws_bytes(n, groups)
     ws = _workspace(dev, nbytes)
     _lib.check(lib.rf_gn_stats(_p(src0), c0, _p(src1), c1, n, edge, _p(gamma.detach()), _p(beta.detach()), groups, eps,
-                               _p(scale), _p(shift), _p(ws), ws.numel(), _stream()), 'rf_gn_stats')
-    return scale, shift
+                               _p(aff), _p(ws), ws.numel(), _stream()), 'rf_gn_stats')
+    return aff
+
+
+def _check_affine(aff, n, c):
+    _req(aff, 'gn affine')
+    if tuple(aff.shape) != (n, c, 4):
+        raise ValueError('gn affine: expected [%d, %d, 4] (from ops.gn_affine), got %s' % (n, c, tuple(aff.shape)))
+    return aff.device
 
 
 USE_FUSED_STATS = True          # producers attach (stats, tiles, version) to their outputs as ``tensor._rf_stats``
@@ -182,16 +189,16 @@ def _fresh_stats(t):
     return st if st is not None and st[2] == t._version else None
 
 
-def _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out):
+def _conv_launch(lib, src0, c0, src1, c1, n, edge, aff, w_packed, cout, out):
     """MFMA conv launch; emits the output's GroupNorm statistics for the next layer when the tiling supports it."""
     tiles = lib.rf_conv3d_stats_tiles(c0, c1, n, edge, cout) if USE_FUSED_STATS else 0
     if tiles > 0:
         stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=out.device)
-        _lib.check(lib.rf_conv3d_k3_gn_relu_stats(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
+        _lib.check(lib.rf_conv3d_k3_gn_relu_stats(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(w_packed), cout, _p(out),
                                                   _p(stats), _stream()), 'rf_conv3d_k3_gn_relu_stats')
         out._rf_stats = (stats, tiles, out._version)
     else:
-        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out),
+        _lib.check(lib.rf_conv3d_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(w_packed), cout, _p(out),
                                             _stream()), 'rf_conv3d_k3_gn_relu')
 
 
@@ -200,24 +207,24 @@ conv_event_filter = None        # callable(cin, cout, edge, n) -> bool
 conv_events = []                # [(start_event, end_event, flops)]
 
 
-def conv3d_gn_relu(src0, src1, scale, shift, w_packed, cout, direct_weight=None):
+def conv3d_gn_relu(src0, src1, aff, w_packed, cout, direct_weight=None):
     """ReLU(conv3(GN(cat(src0, up2(src1))))).  1^3 volumes (and ``direct_weight`` calls) use the direct kernel."""
     n, c0, c1, edge = _src_dims(src0, src1)
-    dev = scale.device
+    dev = _check_affine(aff, n, c0 + c1)
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev)
     lib = _lib.load()
     if conv_event_filter is not None and direct_weight is None and conv_event_filter(c0 + c1, cout, edge, n):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out)
+        _conv_launch(lib, src0, c0, src1, c1, n, edge, aff, w_packed, cout, out)
         ev1.record()
         conv_events.append((ev0, ev1, 2.0 * 27 * (c0 + c1) * cout * edge ** 3 * n))
         return out
     if direct_weight is not None:
-        _lib.check(lib.rf_conv3d_k3_gn_relu_direct(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(direct_weight.detach()),
+        _lib.check(lib.rf_conv3d_k3_gn_relu_direct(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(direct_weight.detach()),
                                                    cout, _p(out), _stream()), 'rf_conv3d_k3_gn_relu_direct')
     else:
-        _conv_launch(lib, src0, c0, src1, c1, n, edge, scale, shift, w_packed, cout, out)
+        _conv_launch(lib, src0, c0, src1, c1, n, edge, aff, w_packed, cout, out)
     return out
 
 
@@ -232,10 +239,10 @@ def conv_pool_supported(src0, src1, cout):
     return bool(_lib.load().rf_conv3d_pool_supported(c0, c1, n, edge, cout))
 
 
-def conv3d_gn_relu_pool(src0, src1, scale, shift, w_packed, cout, keep_full=True):
+def conv3d_gn_relu_pool(src0, src1, aff, w_packed, cout, keep_full=True):
     """(ReLU(conv3(GN(x))) or None, its MaxPool3d(2)); with keep_full=False the full-resolution tensor is never written."""
     n, c0, c1, edge = _src_dims(src0, src1)
-    dev = scale.device
+    dev = _check_affine(aff, n, c0 + c1)
     lib = _lib.load()
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if keep_full else None
     pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev)
@@ -245,7 +252,7 @@ def conv3d_gn_relu_pool(src0, src1, scale, shift, w_packed, cout, keep_full=True
         pstats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev)
         if keep_full:
             stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev)
-    _lib.check(lib.rf_conv3d_k3_gn_relu_pool(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_packed), cout, _p(out), _p(stats),
+    _lib.check(lib.rf_conv3d_k3_gn_relu_pool(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(w_packed), cout, _p(out), _p(stats),
                                              _p(pooled), _p(pstats), _stream()), 'rf_conv3d_k3_gn_relu_pool')
     if stats is not None:
         out._rf_stats = (stats, tiles, out._version)
@@ -277,10 +284,10 @@ def conv_up_supported(src0, src1, cout):
 USE_CONV_UP = True              # False: decoder convs run the generic kernel on the (virtually) upsampled source
 
 
-def conv3d_up_gn_relu(src0, src1, scale, shift, w_up_packed, cout):
+def conv3d_up_gn_relu(src0, src1, aff, w_up_packed, cout):
     """ReLU(conv3(GN(cat(src0, up2(src1))))) with the upsampled channels convolved in low resolution."""
     n, c0, c1, edge = _src_dims(src0, src1)
-    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=scale.device)
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=_check_affine(aff, n, c0 + c1))
     lib = _lib.load()
     stats = None
     if USE_FUSED_STATS:
@@ -290,7 +297,7 @@ def conv3d_up_gn_relu(src0, src1, scale, shift, w_up_packed, cout):
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(lib.rf_conv3d_up_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(scale), _p(shift), _p(w_up_packed), cout, _p(out),
+    _lib.check(lib.rf_conv3d_up_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(w_up_packed), cout, _p(out),
                                            _p(stats), _stream()), 'rf_conv3d_up_k3_gn_relu')
     if timed:
         ev1.record()

@@ -32,6 +32,14 @@ def close(got, ref, tol=2e-5, what=''):
     assert err <= bound, f'{what}: max abs err {err:.3e} > {bound:.3e}'
 
 
+def same_affine(a, b, what=''):
+    """two GroupNorm affine triples [n, C, 4] describe the same map y = (x - center) * scale + shift (to 1e-6): the scales
+    agree and the two-term shifts  shift - center * scale  agree (the centre itself may differ by an fp32 rounding flip)"""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    close(a[..., 1], b[..., 1], 1e-6, what + ' (scale)')
+    close(a[..., 2] - a[..., 0] * a[..., 1], b[..., 2] - b[..., 0] * b[..., 1], 1e-6, what + ' (shift)')
+
+
 def ref_gcr(src0, src1, gamma, beta, groups, w):
     parts = []
     if src0 is not None:
@@ -74,8 +82,8 @@ def test_conv3d_gn_relu(ops, case):
     ref = ref_gcr(src0, src1, gamma, beta, groups, w)
     d0 = src0.to(DEV) if src0 is not None else None
     d1 = src1.to(DEV) if src1 is not None else None
-    scale, shift = ops.gn_scale_shift(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
-    # GroupNorm folding itself
+    aff = ops.gn_affine(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
+    # GroupNorm folding itself: (center, scale, shift) with y = (x - center) * scale + shift
     g = 1 if cin < groups else groups
     xcat = torch.cat([t for t in (src0, F.interpolate(src1, scale_factor=2, mode='nearest') if src1 is not None else None) if t is not None], 1)
     xg = xcat.double().reshape(n, g, -1)
@@ -84,13 +92,18 @@ def test_conv3d_gn_relu(ops, case):
     cpg = cin // g
     sc_ref = gamma.double()[None] * rstd.repeat_interleave(cpg, 1)
     sh_ref = beta.double()[None] - mean.repeat_interleave(cpg, 1) * sc_ref
-    close(scale, sc_ref, 1e-6, 'gn scale')
-    close(shift, sh_ref, 1e-6, 'gn shift')
+    mean_c = mean.repeat_interleave(cpg, 1)
+    a64 = aff.cpu().double()
+    close(aff[..., 1], sc_ref, 1e-6, 'gn scale')
+    assert torch.equal(aff[..., 0].cpu(), mean_c.float()), 'centre = fp32-rounded float64 mean'
+    close(a64[..., 2] - a64[..., 0] * a64[..., 1], sh_ref, 1e-6, 'gn shift (folded back to the two-term form)')
+    # what fl32(mean) loses must be carried by `shift`: the composite equals GroupNorm to ~eps*|y|, not eps*|mean*scale|
+    close(a64[..., 2], beta.double()[None] - (mean_c - mean_c.float().double()) * sc_ref, 1e-7, 'gn shift')
     wd = w.to(DEV)
-    direct = ops.conv3d_gn_relu(d0, d1, scale, shift, None, cout, direct_weight=wd)
+    direct = ops.conv3d_gn_relu(d0, d1, aff, None, cout, direct_weight=wd)
     close(direct, ref, 2e-5, 'direct conv vs torch')
     if edge >= 2:
-        mfma = ops.conv3d_gn_relu(d0, d1, scale, shift, ops.pack_conv3_weight(wd), cout)
+        mfma = ops.conv3d_gn_relu(d0, d1, aff, ops.pack_conv3_weight(wd), cout)
         close(mfma, ref, 2e-5, 'mfma conv vs torch')
         close(mfma, direct, 2e-5, 'mfma conv vs direct conv')
 
@@ -132,10 +145,10 @@ def test_conv3d_up_parity_split_decoder_kernel(ops, case):
     d0 = src0.to(DEV) if src0 is not None else None
     d1 = src1.to(DEV)
     assert ops.conv_up_supported(d0, d1, cout)
-    scale, shift = ops.gn_scale_shift(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
+    aff = ops.gn_affine(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
     wd = w.to(DEV)
-    got = ops.conv3d_up_gn_relu(d0, d1, scale, shift, ops.pack_conv3_up_weight(wd, c0), cout)
-    generic = ops.conv3d_gn_relu(d0, d1, scale, shift, ops.pack_conv3_weight(wd), cout)
+    got = ops.conv3d_up_gn_relu(d0, d1, aff, ops.pack_conv3_up_weight(wd, c0), cout)
+    generic = ops.conv3d_gn_relu(d0, d1, aff, ops.pack_conv3_weight(wd), cout)
     close(got, generic, 1e-5, 'parity-split vs generic kernel')
     sub = slice(0, min(n, 24))                                 # float64 reference on a slice (CPU time)
     sub_tail = slice(max(0, n - 5), n)
@@ -145,10 +158,9 @@ def test_conv3d_up_parity_split_decoder_kernel(ops, case):
     g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
     g = groups if cout % groups == 0 else 1
     assert getattr(got, '_rf_stats', None) is not None
-    fused = ops.gn_scale_shift(got, None, g2, b2, g)
-    plain = ops.gn_scale_shift(got.clone(), None, g2, b2, g)
-    close(fused[0], plain[0], 1e-6, 'scale from fused stats')
-    close(fused[1], plain[1], 1e-6, 'shift from fused stats')
+    fused = ops.gn_affine(got, None, g2, b2, g)
+    plain = ops.gn_affine(got.clone(), None, g2, b2, g)
+    same_affine(fused, plain, 'scale from fused stats')
 
 
 @pytest.mark.parametrize('case', [(300, 8, 16, 16, 8), (1100, 16, 8, 32, 8), (2, 16, 64, 16, 8), (130, 6, 16, 12, 6), (520, 16, 8, 72, 8),
@@ -161,23 +173,22 @@ def test_conv_with_fused_maxpool_epilogue(ops, case):
     x = rnd(gen, n, cin, edge, edge, edge).relu_().to(DEV)
     gamma, beta = (1 + 0.2 * rnd(gen, cin)).to(DEV), (0.2 * rnd(gen, cin)).to(DEV)
     w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin)).to(DEV)
-    sc, sh = ops.gn_scale_shift(x, None, gamma, beta, groups)
+    aff = ops.gn_affine(x, None, gamma, beta, groups)
     wp = ops.pack_conv3_weight(w)
     assert ops.conv_pool_supported(x, None, cout)
-    plain = ops.conv3d_gn_relu(x, None, sc, sh, wp, cout)
+    plain = ops.conv3d_gn_relu(x, None, aff, wp, cout)
     want_pool = ops.maxpool2(plain)
-    full, pooled = ops.conv3d_gn_relu_pool(x, None, sc, sh, wp, cout, keep_full=True)
+    full, pooled = ops.conv3d_gn_relu_pool(x, None, aff, wp, cout, keep_full=True)
     assert torch.equal(full, plain) and torch.equal(pooled, want_pool)
-    none, pooled_only = ops.conv3d_gn_relu_pool(x, None, sc, sh, wp, cout, keep_full=False)
+    none, pooled_only = ops.conv3d_gn_relu_pool(x, None, aff, wp, cout, keep_full=False)
     assert none is None and torch.equal(pooled_only, want_pool)
     g = groups if cout % groups == 0 else 1
     g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
     for t in (pooled, pooled_only, full):
         assert getattr(t, '_rf_stats', None) is not None
-        fused = ops.gn_scale_shift(t, None, g2, b2, g)
-        reread = ops.gn_scale_shift(t.clone(), None, g2, b2, g)
-        close(fused[0], reread[0], 1e-6, 'scale from fused stats')
-        close(fused[1], reread[1], 1e-6, 'shift from fused stats')
+        fused = ops.gn_affine(t, None, g2, b2, g)
+        reread = ops.gn_affine(t.clone(), None, g2, b2, g)
+        same_affine(fused, reread, 'scale from fused stats')
 
 
 @pytest.mark.parametrize('case', [(4100, 32, 4, 64, 8), (4099, 16, 4, 16, 8), (4104, 6, 4, 12, 6), (33000, 64, 2, 128, 8), (32770, 64, 2, 16, 8),
@@ -192,12 +203,12 @@ def test_conv_small_volume_position_major_kernel(ops, case):
     gamma, beta = (1 + 0.2 * rnd(gen, cin)).to(DEV), (0.2 * rnd(gen, cin)).to(DEV)
     w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin))
     wp = ops.pack_conv3_weight(w.to(DEV))
-    sc, sh = ops.gn_scale_shift(x, None, gamma, beta, groups)
-    got = ops.conv3d_gn_relu(x, None, sc, sh, wp, cout)
+    aff = ops.gn_affine(x, None, gamma, beta, groups)
+    got = ops.conv3d_gn_relu(x, None, aff, wp, cout)
     step = {8: 500, 4: 500, 2: 3000}[edge]                      # few enough samples (< 128 workgroups) for the box-tiled kernel
     parts, stat_parts = [], []
     for i in range(0, n, step):
-        y = ops.conv3d_gn_relu(x[i:i + step].contiguous(), None, sc[i:i + step].contiguous(), sh[i:i + step].contiguous(), wp, cout)
+        y = ops.conv3d_gn_relu(x[i:i + step].contiguous(), None, aff[i:i + step].contiguous(), wp, cout)
         parts.append(y)
         stat_parts.append(y._rf_stats[0])
     want = torch.cat(parts)
@@ -215,9 +226,9 @@ def test_conv_identity_weight_is_transpose_detecting(ops):
     w = torch.zeros(c, c, 3, 3, 3)
     for i in range(c):
         w[(i * 5) % c, i, 1, 1, 1] = 1.0                  # a channel permutation, not the identity
-    scale = torch.ones(n, c, device=DEV)
-    shift = torch.zeros(n, c, device=DEV)
-    out = ops.conv3d_gn_relu(x.to(DEV), None, scale, shift, ops.pack_conv3_weight(w.to(DEV)), c)
+    aff = torch.zeros(n, c, 4, device=DEV)
+    aff[..., 1] = 1.0                                     # centre 0, scale 1, shift 0: identity
+    out = ops.conv3d_gn_relu(x.to(DEV), None, aff, ops.pack_conv3_weight(w.to(DEV)), c)
     ref = F.conv3d(x, w, padding=1)
     assert torch.equal(out.cpu(), ref)
 
@@ -556,28 +567,25 @@ def test_fused_groupnorm_statistics_match_recomputed(ops, case):
     x = rnd(gen, n, cin, edge, edge, edge).relu_().to(DEV)
     gamma, beta = (1 + 0.2 * rnd(gen, cin)).to(DEV), (0.2 * rnd(gen, cin)).to(DEV)
     w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin)).to(DEV)
-    sc, sh = ops.gn_scale_shift(x, None, gamma, beta, groups)
-    y = ops.conv3d_gn_relu(x, None, sc, sh, ops.pack_conv3_weight(w), cout)
+    aff = ops.gn_affine(x, None, gamma, beta, groups)
+    y = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(w), cout)
     assert getattr(y, '_rf_stats', None) is not None, 'conv did not emit statistics'
     g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
-    fused = ops.gn_scale_shift(y, None, g2, b2, groups)
-    plain = ops.gn_scale_shift(y.clone(), None, g2, b2, groups)            # clone(): no attached statistics -> re-read path
-    close(fused[0], plain[0], 1e-6, 'scale from fused stats')
-    close(fused[1], plain[1], 1e-6, 'shift from fused stats')
+    fused = ops.gn_affine(y, None, g2, b2, groups)
+    plain = ops.gn_affine(y.clone(), None, g2, b2, groups)            # clone(): no attached statistics -> re-read path
+    same_affine(fused, plain, 'scale from fused stats')
     if edge >= 4:
         pooled = ops.maxpool2(y)
         g3, b3 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
-        f2 = ops.gn_scale_shift(pooled, None, g3, b3, groups)
-        p2 = ops.gn_scale_shift(pooled.clone(), None, g3, b3, groups)
-        close(f2[0], p2[0], 1e-6, 'scale from pooled stats')
-        close(f2[1], p2[1], 1e-6, 'shift from pooled stats')
+        f2 = ops.gn_affine(pooled, None, g3, b3, groups)
+        p2 = ops.gn_affine(pooled.clone(), None, g3, b3, groups)
+        same_affine(f2, p2, 'scale from pooled stats')
         # decoder read: skip = y (full res), upsampled = a conv output at half resolution
-        z = ops.conv3d_gn_relu(pooled, None, f2[0], f2[1], ops.pack_conv3_weight(rnd(gen, 2 * cout, cout, 3, 3, 3, scale=0.1).to(DEV)), 2 * cout)
+        z = ops.conv3d_gn_relu(pooled, None, f2, ops.pack_conv3_weight(rnd(gen, 2 * cout, cout, 3, 3, 3, scale=0.1).to(DEV)), 2 * cout)
         g4, b4 = (1 + 0.2 * rnd(gen, 3 * cout)).to(DEV), (0.2 * rnd(gen, 3 * cout)).to(DEV)
-        f3 = ops.gn_scale_shift(y, z, g4, b4, groups)
-        p3 = ops.gn_scale_shift(y.clone(), z.clone(), g4, b4, groups)
-        close(f3[0], p3[0], 1e-6, 'scale, two sources')
-        close(f3[1], p3[1], 1e-6, 'shift, two sources')
+        f3 = ops.gn_affine(y, z, g4, b4, groups)
+        p3 = ops.gn_affine(y.clone(), z.clone(), g4, b4, groups)
+        same_affine(f3, p3, 'scale, two sources')
     y.mul_(2.0)                                                            # in-place edit invalidates the attached statistics
-    stale = ops.gn_scale_shift(y, None, g2, b2, groups)
-    close(stale[0], ops.gn_scale_shift(y.clone(), None, g2, b2, groups)[0], 1e-6, 'stale stats must not be used')
+    stale = ops.gn_affine(y, None, g2, b2, groups)
+    same_affine(stale, ops.gn_affine(y.clone(), None, g2, b2, groups), 'stale stats must not be used')

@@ -352,3 +352,47 @@ def test_engine_on_a_non_current_device():
         outs.append(eng.refine(raws.to(dev)).cpu())
         torch.cuda.synchronize(dev)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('cfg_name', ['C3', 'C2'])
+def test_engine_at_the_bench_batch_size_matches_oracle(gpu, cfg_name):
+    """bench.py runs B = 32 chunks per step, where the big-tile / position-major / parity-split kernels are selected
+    (dispatch depends on the sample count); the kernel tests cover them one by one, this one checks the whole online path at
+    that batch size against the oracle on a few chunks of the batch (GroupNorm is per sample: a chunk's result does not
+    depend on its batch mates).  C2 is Gumbel-hard: explicit noise, scaled so the arg-max cannot flip on fp32 differences."""
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config(cfg_name)
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    K, B = cfg['K'], 32
+    db = synthetic.make_database(31, cfg, 64 * 50)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 1300 + len(n)) for n, m in eng.modules().items()}
+    eng.load_state_dicts(sds)
+    raws = np.stack([synthetic.make_chunk(5000 + b, cfg)['input_raw'] for b in range(B)])
+    rows = cfg['attn_num_patch'] ** 3
+    noise = None
+    if cfg['attn_retrieval_mode']:
+        noise = -torch.empty(B * rows, K).exponential_(generator=torch.Generator().manual_seed(5)).log() * 4.0
+    df = eng.refine(torch.from_numpy(raws).to(gpu), gumbel_noise=noise.to(gpu) if noise is not None else None).cpu().numpy()
+    d = cfg['dataset_train']
+    sds64 = {m: {k: v.double() for k, v in sd.items()} for m, sd in sds.items()}
+    worst = worst32 = oracle32 = 0.0
+    for b in (0, 13, 31):
+        with torch.no_grad():
+            q = refpath.embed_queries(refpath.extract_query_windows(raws[b], cfg, trunc_i), sds['fenc_input'], cfg).numpy()
+            idx, dist = refpath.knn_exact(q, db['emb'], 2 * K)
+            mapping = refpath.demote_same_scene(refpath.mapping_rows(idx, dist, db['meta']), np.full(64, -1), K)
+            retr = refpath.compose_retrieval(mapping, db['volumes'], K, trunc_t)[None]
+            retr = ((retr - np.float32(d['target_mean'])) / np.float32(d['target_std'])).astype(np.float32)
+            x_in = synthetic.normalise_input(cfg, raws[b])[None, None]
+            nb = noise[b * rows:(b + 1) * rows] if noise is not None else None
+            ref32 = refpath.forward_full(sds, cfg, torch.from_numpy(x_in), torch.from_numpy(retr), trunc_t, nb).numpy()
+            # the oracle in float64 = the truth; its own fp32 evaluation (what the reference computes) is printed next to it
+            ref64 = refpath.forward_full(sds64, cfg, torch.from_numpy(x_in).double(), torch.from_numpy(retr).double(), trunc_t,
+                                         nb.double() if nb is not None else None).numpy()
+        worst = max(worst, maxerr(df[b:b + 1], ref64))
+        worst32 = max(worst32, maxerr(df[b:b + 1], ref32))
+        oracle32 = max(oracle32, maxerr(ref32, ref64))
+    print(f'\n{cfg_name} B={B}, chunks 0/13/31: df max abs err vs float64 oracle {worst:.2e}, vs fp32 oracle {worst32:.2e} (fp32 oracle vs float64: {oracle32:.2e})')
+    assert worst <= DF_TOL and worst32 <= DF_TOL + oracle32

@@ -18,15 +18,15 @@ for name, n, c0, c1, edge, cout in CASES:
     cin = c0 + c1
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
     wp = ops.pack_conv3_up_weight(w, c0)
-    scale, shift = torch.ones(n, cin, device=dev), torch.zeros(n, cin, device=dev)
+    aff = torch.zeros(n, cin, 4, device=dev); aff[..., 1] = 1.0
     for _ in range(3):
-        ops.conv3d_up_gn_relu(s0, s1, scale, shift, wp, cout)
+        ops.conv3d_up_gn_relu(s0, s1, aff, wp, cout)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 10
     e0.record()
     for _ in range(reps):
-        ops.conv3d_up_gn_relu(s0, s1, scale, shift, wp, cout)
+        ops.conv3d_up_gn_relu(s0, s1, aff, wp, cout)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
