@@ -4,14 +4,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the whole hot path over a batch of B synthetic 64^3 chunks per GPU:
-query windows -> query encoder -> exact L2 top-2K over the patch database (sharded N ways, RCCL all-gather of the
-per-shard candidates when N > 1) -> same-scene demotion -> patch gather -> retrieval backbone (K*64 patches per chunk)
+query windows -> query encoder -> exact L2 top-2K over the patch database (sharded N ways, one RCCL all-gather of the
+per-shard candidate keys when N > 1) -> same-scene demotion -> patch gather -> retrieval backbone (K*64 patches per chunk)
 || U-Net backbone -> patch attention -> decoder -> df.  Inputs, weights and the database are resident in HBM before
 the timed region; weights are random-init (torch.manual_seed(0)), data synthetic (no datasets / checkpoints here).
 
 Workload at N=1 (default): BASELINE.json configs[1] -- ShapeNetV2 super-res 008->064, synthetic batch, K=4, DB=50k patches.
-Prints ONE JSON line (rank 0) with the bench contract fields plus `roofline` (dominant kernel, live HIP-event timing)
-and `cpu_baseline` (the oracle -- a CPU port of the reference path -- timed on the host cores, N=1 only).
+Prints ONE JSON line (rank 0) with the bench contract fields plus
+  roofline      the dominant kernel, timed live with HIP events on its launch stream inside the timed region
+  cpu_baseline  the oracle (a CPU port of the reference path) timed on the host cores (N=1 only)
+  recall_at_k   the exact search against a float64 brute force on a query subset of the bench batch (k = 1, 4, 8)
+  parity_max_abs  df of chunks of the bench batch against the oracle (explicit Gumbel noise for the ShapeNet configs)
+  kernels       per-entry-point time / achieved / peak of the five most expensive launches (HIP events, a separate serial pass)
+  batch_sweep   chunks/s at B = 1, 8, 64 (B = 1 also replayed from a captured HIP graph)           (N=1 only)
 """
 import argparse
 import json
@@ -34,7 +39,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA (= fp32 vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA (= packed-fp32 vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0              # HBM3E, same guide
 
 
 def parse():
@@ -46,6 +52,7 @@ def parse():
     ap.add_argument('--config', default='C2')
     ap.add_argument('--db', type=int, default=0, help='database patches (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip recall / parity / kernel table / batch sweep (profiling runs)')
     ap.add_argument('--feature-cache', action='store_true', help='also time the optional cached-retrieval-features serving mode (reported separately)')
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
     ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank under torch.distributed.run, still run the all-gather + merge protocol')
@@ -60,35 +67,43 @@ def synthetic_database(cfg, n_patches, device, seed=1234):
     g = torch.Generator(device=device).manual_seed(seed)
     emb = torch.randn(n_patches + 1, 64, generator=g, device=device, dtype=torch.float32)
     emb = emb / emb.norm(dim=1, keepdim=True).clamp_min(1e-12)
-    meta = torch.from_numpy(synthetic.make_database(seed, cfg, n_patches, with_volumes=False)['meta'])
+    meta = torch.from_numpy(synthetic.make_database(seed, cfg, n_patches, with_volumes=False, with_embeddings=False)['meta'])
     n_scenes = (n_patches + 63) // 64
-    vols = (torch.rand(n_scenes, 64, 64, 64, generator=g, device=device) * trunc_t).half().float()
+    vols = torch.empty(n_scenes, 64, 64, 64, device=device)
+    for lo in range(0, n_scenes, 1024):                        # in pieces: the fp16 round trip of 1 M patches would need 3 x 16 GB at once
+        hi = min(lo + 1024, n_scenes)
+        vols[lo:hi] = (torch.rand(hi - lo, 64, 64, 64, generator=g, device=device) * trunc_t).half().float()
     return emb, meta, vols
+
+
+def oracle_chunk(refpath, cfg, state, db_host, raw, noise, knn):
+    """the oracle's version of one chunk of a step: query embed -> kNN -> demotion -> compose -> networks -> df"""
+    from rfuse import configs, synthetic
+    trunc_i, trunc_t = configs.truncations(cfg)
+    d, K = cfg['dataset_train'], cfg['K']
+    with torch.no_grad():
+        q = refpath.embed_queries(refpath.extract_query_windows(raw, cfg, trunc_i), state['fenc_input'], cfg).numpy()
+        idx, dd = knn(q, db_host['emb'], 2 * K)
+        mapping = refpath.demote_same_scene(refpath.mapping_rows(idx, dd, db_host['meta']), np.full(q.shape[0], -1), K)
+        retr = refpath.compose_retrieval(mapping, db_host['volumes'], K, trunc_t)[None]
+        retr = ((retr - np.float32(d['target_mean'])) / np.float32(d['target_std'])).astype(np.float32)
+        x_in = synthetic.normalise_input(cfg, raw)[None, None]
+        return refpath.forward_full(state, cfg, torch.from_numpy(x_in), torch.from_numpy(retr), trunc_t, noise)
 
 
 def cpu_baseline(cfg, eng_state, db_host, raws, target_s=15.0, n_chunks=0):
     """The oracle (CPU port of the reference path, oracle/refpath.py) on the host cores: same stages as one GPU step.
     kNN = torch.cdist + topk fp32; everything else the pinned oracle."""
     from oracle import refpath
-    from rfuse import configs, synthetic
-    trunc_i, trunc_t = configs.truncations(cfg)
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    d, K = cfg['dataset_train'], cfg['K']
+    K = cfg['K']
     noise_gen = torch.Generator().manual_seed(0)
 
     def one_chunk(raw):
-        with torch.no_grad():
-            q = refpath.embed_queries(refpath.extract_query_windows(raw, cfg, trunc_i), eng_state['fenc_input'], cfg).numpy()
-            idx, dd = refpath.knn_cdist_f32(q, db_host['emb'], 2 * K)
-            mapping = refpath.demote_same_scene(refpath.mapping_rows(idx, dd, db_host['meta']), np.full(q.shape[0], -1), K)
-            retr = refpath.compose_retrieval(mapping, db_host['volumes'], K, trunc_t)[None]
-            retr = ((retr - np.float32(d['target_mean'])) / np.float32(d['target_std'])).astype(np.float32)
-            x_in = synthetic.normalise_input(cfg, raw)[None, None]
-            noise = None
-            if cfg['attn_retrieval_mode']:
-                noise = -torch.empty(cfg['attn_num_patch'] ** 3, K).exponential_(generator=noise_gen).log()
-            return refpath.forward_full(eng_state, cfg, torch.from_numpy(x_in), torch.from_numpy(retr), trunc_t, noise)
+        noise = None
+        if cfg['attn_retrieval_mode']:
+            noise = -torch.empty(cfg['attn_num_patch'] ** 3, K).exponential_(generator=noise_gen).log()
+        return oracle_chunk(refpath, cfg, eng_state, db_host, raw, noise, refpath.knn_cdist_f32)
 
     # PyTorch-CPU on these small volumes is fastest well below the core count (oversubscription): probe a few thread
     # counts with one chunk each and keep the best -- the baseline should be the CPU path at its best, not at its worst.
@@ -114,6 +129,175 @@ def cpu_baseline(cfg, eng_state, db_host, raws, target_s=15.0, n_chunks=0):
                       % (n, best_threads, cores, el)}
 
 
+# ------------------------------------------------------------------------------------------------------ evidence
+def recall_at_k(eng, database, emb_full, raw_dev, K, n_sub=128):
+    """the search the engine ran (exact fp32 scan, sharded or not) against a float64 brute force over the FULL embedding matrix
+    on a subset of this rank's queries; recall@k = |top-k(gpu) & top-k(f64)| / k averaged over the subset"""
+    q = eng.embed_queries(raw_dev)
+    dist_g, idx_g = database.search(q, 2 * K)
+    step = max(1, q.shape[0] // n_sub)
+    sub = torch.arange(0, q.shape[0], step, device=q.device)
+    ref = torch.empty((sub.numel(), 2 * K), dtype=torch.int64, device=q.device)
+    e64 = emb_full.double()
+    en = (e64 * e64).sum(1)[None]
+    for lo in range(0, sub.numel(), 16):                        # float64 distances in row blocks: [16, N] doubles at a time
+        qs = q[sub[lo:lo + 16]].double()
+        d64 = (qs * qs).sum(1, keepdim=True) + en - 2.0 * qs @ e64.T
+        ref[lo:lo + 16] = torch.topk(d64, 2 * K, dim=1, largest=False, sorted=True).indices
+    got = idx_g[sub]
+    out = {}
+    for k in sorted({1, K, 2 * K}):
+        hit = (got[:, :k, None] == ref[:, None, :k]).any(dim=2).float().mean().item()
+        out['recall@%d' % k] = hit
+    out['exact_order'] = (got == ref).all(dim=1).float().mean().item()
+    out['queries'] = int(sub.numel())
+    out['reference'] = 'float64 brute force over all %d rows' % emb_full.shape[0]
+    return out
+
+
+def parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev, chunks=(0, 17)):
+    """df of the bench batch itself against the oracle: the engine refines the whole batch once more with EXPLICIT Gumbel
+    noise (scaled so that the hard arg-max cannot flip on fp32 differences; None for the softmax configs) and ``chunks`` of
+    it are compared with the oracle run on the same chunk, noise and database (float64 exact kNN)."""
+    from oracle import refpath
+    B, K = raws.shape[0], cfg['K']
+    rows = cfg['attn_num_patch'] ** 3
+    noise = None
+    if cfg['attn_retrieval_mode']:
+        noise = -torch.empty(B * rows, K).exponential_(generator=torch.Generator().manual_seed(11)).log() * 4.0
+    df = eng.refine(raw_dev, gumbel_noise=noise.to(raw_dev.device) if noise is not None else None)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    worst = 0.0
+    for b in chunks:
+        if b >= B:
+            continue
+        nb = noise[b * rows:(b + 1) * rows] if noise is not None else None
+        ref = oracle_chunk(refpath, cfg, state, db_host, raws[b], nb, refpath.knn_exact)
+        worst = max(worst, float((df[b:b + 1].cpu() - ref).abs().max()))
+    return {'value': worst, 'chunks': [b for b in chunks if b < B], 'against': 'oracle/refpath.py (fp32 torch-CPU networks, float64 exact kNN)',
+            'bar': 1e-4}
+
+
+def kernel_work(name, a, cfg):
+    """(bound, work per launch, unit) of one C-ABI launch from its integer arguments, or None when the launch is bookkeeping"""
+    if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_k3_gn_relu_direct'):
+        c0, c1, n, edge, cout = a[:5]
+        if c0 + c1 == 1:                                         # first layer: reads 4 B, writes 4*cout B per voxel
+            return 'hbm', 4.0 * n * edge ** 3 * (1 + cout), 'bytes'
+        return 'mfma', 2.0 * 27 * (c0 + c1) * cout * edge ** 3 * n, 'flop, direct form (the kernels leave out zero-padding taps of border voxels: issued work is lower)'
+    if name == 'rf_conv3d_up_k3_gn_relu':
+        c0, c1, n, edge, cout = a[:5]
+        from rfuse import ops
+        return 'mfma', ops.conv_up_issued_flops(c0, c1, n, edge, cout), 'flop ISSUED (decoder form, 8 pre-summed taps for the upsampled channels, minus the skipped padding taps)'
+    if name in ('rf_attn_mlp_volume',):
+        b, kv, c, s, t = a[:5]
+        return 'mfma', b * kv * (s // 2) ** 3 * 2.0 * (c * 8 * 128 + 2 * 128 * 128 + 128 * 32), 'flop'
+    if name == 'rf_attn_mlp_rows':
+        rows, n_in = a[:2]
+        return 'mfma', rows * 2.0 * (n_in * 128 + 2 * 128 * 128 + 128 * 32), 'flop'
+    if name in ('rf_l2_topk', 'rf_l2_topk_keys'):
+        nq, dim, n = a[:3]
+        return 'mfma', 2.0 * nq * n * dim, 'flop (q.x per pair)'
+    if name == 'rf_conv3d_valid_leaky_mfma':
+        n, cin, s, cout, k, stride = a[:6]
+        so = (s - k) // stride + 1
+        return 'mfma', 2.0 * cin * k ** 3 * cout * so ** 3 * n, 'flop'
+    if name == 'rf_linear':
+        rows, nin, nout = a[:3]
+        return 'mfma', 2.0 * rows * nin * nout, 'flop'
+    if name == 'rf_conv1x1_tanh':
+        n, c, vox = a[:3]
+        return 'hbm', 4.0 * n * vox * (c + 1), 'bytes'
+    if name == 'rf_attn_blend':
+        b, k, c, s, t = a[:5]
+        return 'hbm', 4.0 * b * c * s ** 3 * (2 + k), 'bytes'
+    if name == 'rf_gather_patches':
+        n_scenes, chunks, K = a[:3]
+        return 'hbm', 8.0 * chunks * K * 64 * 4096, 'bytes'
+    if name == 'rf_query_windows':
+        b, s, ps, ctx = a[:4]
+        return 'hbm', 8.0 * b * (s // ps) ** 3 * (ps + 2 * ctx) ** 3, 'bytes'
+    if name in ('rf_maxpool3d_2', 'rf_maxpool3d_2_stats'):
+        n, c, edge = a[:3]
+        return 'hbm', 4.0 * n * c * edge ** 3 * 1.125, 'bytes'
+    return None
+
+
+def kernel_table(eng, raw_dev, cfg, steps=3, top=5):
+    """per entry point (and shape) HIP-event time over ``steps`` serial steps (backbone on the main stream: no overlap)"""
+    from rfuse import _lib
+    lib = _lib.load()
+    eng.serial = True
+    eng.refine(raw_dev)
+    torch.cuda.synchronize()
+    records = []
+    lib.start_profile(records)
+    try:
+        for _ in range(steps):
+            eng.refine(raw_dev)
+        torch.cuda.synchronize()
+    finally:
+        lib.stop_profile()
+        eng.serial = False
+    agg = {}
+    for name, ints, e0, e1 in records:
+        key = (name, ints[:6])
+        t = agg.setdefault(key, [0.0, 0])
+        t[0] += e0.elapsed_time(e1)
+        t[1] += 1
+    total = sum(v[0] for v in agg.values()) / steps
+    rows = []
+    for (name, ints), (ms, calls) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+        per_launch = ms / calls
+        row = {'entry': name, 'args': list(ints), 'launches_per_step': calls / steps, 'ms_per_step': ms / steps, 'share': (ms / steps) / total}
+        w = kernel_work(name, ints, cfg)
+        if w:
+            bound, work, unit = w
+            if bound == 'mfma':
+                ach = work / (per_launch * 1e-3) / 1e12
+                row.update(bound='mfma', achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / FP32_MFMA_PEAK_TFLOPS, work=unit)
+            else:
+                ach = work / (per_launch * 1e-3) / 1e9
+                row.update(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, work='algorithmic ' + unit)
+        rows.append(row)
+    return {'serial_ms_per_step': total, 'top': rows,
+            'note': 'HIP events around each C-ABI launch, backbone kept on the main stream for this pass; a launch = all kernels of that entry point'}
+
+
+def batch_sweep(cfg, database, state, device, sizes=(1, 8, 64), steps=10):
+    from rfuse import synthetic
+    from rfuse.engine import RefinementEngine
+    eng = RefinementEngine(cfg, device, database)
+    eng.load_state_dicts(state)
+    out = {}
+    for b in sizes:
+        raws = torch.from_numpy(np.stack([synthetic.make_chunk(20_000 + i, cfg)['input_raw'] for i in range(b)])).to(device)
+        n = steps if b > 1 else 5 * steps
+        for _ in range(3):
+            eng.refine(raws)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.refine(raws)
+        torch.cuda.synchronize()
+        out['B=%d' % b] = b * n / (time.perf_counter() - t0)
+        if b == 1:
+            try:
+                graph, _, _ = eng.capture_graph(raws)
+                for _ in range(3):
+                    graph.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    graph.replay()
+                torch.cuda.synchronize()
+                out['B=1 (HIP graph replay)'] = n / (time.perf_counter() - t0)
+            except Exception as e:                                  # capture is an optimisation of the launch-bound case, not the metric
+                out['B=1 (HIP graph replay)'] = 'capture failed: %s' % (str(e).splitlines()[0][:120],)
+    out['unit'] = 'chunks/s'
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -123,10 +307,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback for the hot path)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
     knobs = sorted(k for k in os.environ if k.startswith('RFUSE_') and k != 'RFUSE_LIB')
     assert not knobs, 'refusing to measure with developer switches set: %s' % knobs
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
     force_dist = world == 1 and args.force_collectives and 'RANK' in os.environ        # dev: run the whole RCCL protocol with one rank
     if world > 1 or force_dist:
         dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
@@ -143,6 +327,7 @@ def main():
     emb, meta, vols = synthetic_database(cfg, n_patches, device)
     database = PatchDatabase(emb, meta, vols, device, rank, world)
     database.force_collectives = force_dist
+    collective_events = [] if (world > 1 or force_dist) else None
     eng = RefinementEngine(cfg, device, database)
     # every rank refines its own B chunks (chunk-parallel replicas); inputs resident in HBM
     raws = np.stack([synthetic.make_chunk(10_000 + rank * B + b, cfg)['input_raw'] for b in range(B)])
@@ -162,6 +347,7 @@ def main():
         eng.refine(raw_dev)
     torch.cuda.synchronize()
     ops.conv_events.clear()
+    database.collective_events = collective_events
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -175,6 +361,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert torch.isfinite(df).all()
+    database.collective_events = None
 
     ev = list(ops.conv_events)
     ops.conv_event_filter = None
@@ -182,13 +369,19 @@ def main():
     kern_flops = ev[0][2] if ev else 0.0
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if ev else float('nan')
 
+    # every rank computes its own recall (collective-free for world == 1; with shards the search itself is a collective)
+    recall = None
+    if not args.no_extras:
+        recall = recall_at_k(eng, database, emb, raw_dev, K)
+
     if rank == 0:
         value = world * B * args.steps / elapsed
-        # HBM traffic of the dominant kernel: PMC-measured (separate rocprofv3 --pmc passes, FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, committed under profiles/), scaled per patch to this launch; None when no summary is committed
+        # HBM traffic of the dominant kernel: OFFLINE PMC (separate rocprofv3 --pmc passes of this same command, FETCH_SIZE x2
+        # gfx950 correction + WRITE_SIZE, summary committed under profiles/), scaled per patch to this launch; None when no
+        # summary is committed for this config family
         traffic = None
-        pmc_file = REPO / 'profiles' / 'r01_dominant_kernel.json'
-        if pmc_file.exists() and args.config in ('C1', 'C2', 'C3'):
+        pmc_file = next((f for f in (REPO / 'profiles' / 'r02_dominant_kernel.json', REPO / 'profiles' / 'r01_dominant_kernel.json') if f.exists()), None)
+        if pmc_file is not None and args.config in ('C1', 'C2', 'C3'):
             traffic = json.loads(pmc_file.read_text())['traffic_bytes_per_patch'] * B * K * 64
         out = {
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',
@@ -197,18 +390,31 @@ def main():
             'config': {'workload': '%s: %s super-res/recon ->064, synthetic chunks, K=%d, DB=%d patches (exact L2 top-%d), '
                                    'random-init weights' % (args.config, cfg['dataset_train']['dataset_name'], K, n_patches, 2 * K),
                        'chunks_per_gpu_per_step': B, 'db_patches': n_patches,
-                       'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + RCCL all-gather of top-2K' % (world, world)},
+                       'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + one RCCL all-gather of the packed top-2K keys' % (world, world)},
             'roofline': {'bound': 'mfma',
                          'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4> (retrieval backbone decoder conv %d+%d->%d @8^3: '
                                    '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, z-border padding taps '
                                    'left out, %d patches)' % (2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC)', 'launch_ms': kern_ms,
+                         'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_file.name if pmc_file else 'none'),
+                         'launch_ms': kern_ms,
                          'flops_per_launch': kern_flops,          # multiply-adds ISSUED (decoder form minus the skipped zero-padding taps)
                          'decoder_form_flops_per_launch': 2.0 * (27 * 2 * nf + 8 * 4 * nf) * dom_cout * 512 * B * K * 64,
                          'direct_form_flops_per_launch': 2.0 * 27 * dom_cin * dom_cout * 512 * B * K * 64,
                          'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * (2 * nf * 512 + 4 * nf * 64 + dom_cout * 512)},
+            'recall_at_k': recall,
         }
+        if collective_events:
+            q_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in collective_events]))
+            k_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in collective_events]))
+            out['collectives'] = {'rccl_ranks': world, 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_gather_keys_ms': k_ms,
+                                  'keys_bytes_per_rank': world * B * 64 * 2 * K * 8,
+                                  'note': 'HIP events on the issuing stream around each all_gather_into_tensor (includes waiting for the slowest rank)'}
+        state = None
+        if world == 1 and not args.no_extras:
+            state = {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}
+            out['kernels'] = kernel_table(eng, raw_dev, cfg)
+            out['batch_sweep'] = batch_sweep(cfg, database, state, device)
         if args.feature_cache and world == 1 and n_patches <= 200_000:
             # Reported separately, NEVER as `value`: optional serving mode that fetches per-database-row retrieval-backbone
             # features (query independent) from a 32 KB/row HBM cache instead of recomputing them (skips 87 % of the FLOPs).
@@ -223,12 +429,17 @@ def main():
             out['feature_cache_mode'] = {'value': B * args.steps / (time.perf_counter() - t1), 'unit': 'chunks/s',
                                          'note': 'optional mode, work skipped (retrieval backbone replaced by a gather of cached '
                                                  'features); not the headline metric', 'cache_bytes': int(database.feature_cache.numel() * 4)}
-        if world == 1 and not args.no_cpu_baseline:
-            state = {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}
+        host_db_ok = n_patches <= 200_000                        # the oracle needs the voxel store on the host (16 GB at 1 M patches)
+        if world == 1 and host_db_ok and not (args.no_cpu_baseline and args.no_extras):
+            state = state or {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}
             db_host = {'emb': emb.cpu().numpy(), 'meta': meta.numpy(), 'volumes': vols.cpu().numpy()}
-            out['cpu_baseline'] = cpu_baseline(cfg, state, db_host, raws, n_chunks=args.cpu_chunks)
+            if not args.no_extras:
+                out['parity_max_abs'] = parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev)
+            out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(cfg, state, db_host, raws, n_chunks=args.cpu_chunks)
         else:
             out['cpu_baseline'] = None
+            if world == 1 and not host_db_ok:
+                out['cpu_baseline_note'] = 'skipped: the oracle needs the %d-patch voxel store on the host' % n_patches
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

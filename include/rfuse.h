@@ -215,18 +215,29 @@ int rf_attn_blend(const float* x, const float* retrieved, int b, int k, int c, i
 int rf_query_windows(const float* raw, int b, int s, int ps, int ctx, float pad_value, float mean, float stddev,
                      float* out, void* stream);
 
-/* Database embedding image for the scan: emb [n][dim] row-major -> blocked [ceil(n/64)][dim][64] (rows beyond n
- * are filled with +inf-distance padding).  DB rows: util/retrieval.py:32,39-45 (columns 7..70). */
+/* Database embedding image for the scans: emb [n][dim] row-major (dim = 64) -> rf_db_packed_floats(n, dim) floats holding
+ * the blocked view [ceil(n/64)][dim][64] of the VALU scan, the chunk-permuted row view [n32][64] of the MFMA-filtered scan and
+ * its per-row half norms [n32] (n32 = n rounded up to 32; padding rows can never be returned).
+ * DB rows: util/retrieval.py:32,39-45 (columns 7..70). */
 int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float* packed, void* stream);
 size_t rf_db_packed_floats(int64_t n, int dim);
 
 /* Exact squared-L2 top-k2 of q[nq][dim] against one DB shard (packed image of `n` rows whose global row ids start
  * at row_base): stands where the reference calls FLANN nn_index(feats, 2K) (util/retrieval.py:92).
- * dist = sum_d (q_d - x_d)^2 in fp32, ascending, ties -> lower global row id.
+ * dist = sum_d (q_d - x_d)^2 in fp32 (four fixed FMA chains, the same bits on every code path), ascending, ties -> lower
+ * global row id.  algo: 0 = pick by shard size, 1 = VALU scan (every pair evaluated exactly), 2 = MFMA-filtered scan (fp32
+ * matrix-core dot products discard the pairs that provably cannot enter a list, the rest is evaluated exactly): both return
+ * the same bits.
  * out_dist [nq][k2] float32, out_idx [nq][k2] int64 (global ids); missing candidates (n < k2): dist=+inf, idx=-1. */
-int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2,
+int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
                float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
 size_t rf_l2_topk_ws_bytes(int nq, int64_t n, int k2);
+/* The same search emitting packed 64-bit keys  (float bits of dist) << 32 | global row id  (all ones = no candidate):
+ * unsigned order of the keys = (dist, row id) order, so ONE all-gather of out_keys [nq][k2] exchanges a shard's candidates
+ *  and rf_topk_merge_keys reduces in_keys [parts][nq][k2] to the global top-k2. */
+int rf_l2_topk_keys(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
+                    uint64_t* out_keys, void* ws, size_t ws_bytes, void* stream);
+int rf_topk_merge_keys(const uint64_t* in_keys, int parts, int nq, int k2, float* out_dist, int64_t* out_idx, void* stream);
 
 /* Merge `parts` candidate lists per query (e.g. the all-gathered per-shard top-k2): in_dist/in_idx [parts][nq][k2]
  * -> out [nq][k2] ascending by (dist, idx).  New (the reference searches one index); defines the sharded-DB merge. */

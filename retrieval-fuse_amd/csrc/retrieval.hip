@@ -53,29 +53,66 @@ extern "C" int rf_query_windows(const float* raw, int b, int s, int ps, int ctx,
 }
 
 // ------------------------------------------------------------------------------------------------- DB packing
-__global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, long long n, int dim, float* __restrict__ packed) {
-    const long long nblk = (n + 63) / 64;
-    const size_t total = (size_t)nblk * dim * 64;
+// The packed image holds three views of the shard's embedding matrix (dim = 64):
+//   blocked  [ceil(n/64)][64 dims][64 rows]      the VALU scan: one coalesced 256-byte load per dim per wave
+//   rows     [n32][64], n32 = n rounded up to 32   the MFMA scan's A operand: position 16*g + m of a row holds dim 4*m + g, so
+//                                                the 64 contiguous bytes lane (row, g) loads are the dims {4m + g} = the g-th
+//                                                summation chain of the exact distance (see rf_exact_dist below)
+//   hd       [n32]                               (1 - 2^-15) * |row|^2 / 2, +inf for the padding rows (they never pass the filter)
+#define RF_DIM 64
+#define RF_EPS_FILTER 3.0517578125e-05f            // 2^-15, see the error bound at k_l2_topk_mfma
+
+static inline size_t rf_blocked_floats(int64_t n) { return (size_t)((n + 63) / 64) * RF_DIM * 64; }
+static inline int64_t rf_rows32(int64_t n) { return (n + 31) / 32 * 32; }
+
+__global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, long long n, float* __restrict__ blocked, float* __restrict__ rows,
+                                                 float* __restrict__ hd) {
+    const long long nblk = (n + 63) / 64, n32 = (n + 31) / 32 * 32;
+    const size_t total = (size_t)nblk * RF_DIM * 64;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i % 64), d = (int)((i / 64) % dim);
-        const long long row = (long long)(i / ((size_t)64 * dim)) * 64 + r;
-        packed[i] = row < n ? emb[(size_t)row * dim + d] : 0.f;
+        const int r = (int)(i % 64), d = (int)((i / 64) % RF_DIM);
+        const long long row = (long long)(i / ((size_t)64 * RF_DIM)) * 64 + r;
+        blocked[i] = row < n ? emb[(size_t)row * RF_DIM + d] : 0.f;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n32 * RF_DIM; i += (size_t)gridDim.x * blockDim.x) {
+        const long long row = (long long)(i / RF_DIM);
+        const int p = (int)(i % RF_DIM), g = p >> 4, m = p & 15;
+        rows[i] = row < n ? emb[(size_t)row * RF_DIM + 4 * m + g] : 0.f;
+    }
+    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < n32; row += (long long)gridDim.x * blockDim.x) {
+        float h = INFINITY;
+        if (row < n) {
+            double nd = 0.0;
+            for (int d = 0; d < RF_DIM; ++d) { const double v = emb[(size_t)row * RF_DIM + d]; nd += v * v; }
+            h = (float)((1.0 - (double)RF_EPS_FILTER) * 0.5 * nd);
+        }
+        hd[row] = h;
     }
 }
 
-extern "C" size_t rf_db_packed_floats(int64_t n, int dim) { return (size_t)((n + 63) / 64) * dim * 64; }
+extern "C" size_t rf_db_packed_floats(int64_t n, int dim) {
+    (void)dim;
+    return rf_blocked_floats(n) + (size_t)rf_rows32(n) * RF_DIM + (size_t)rf_rows32(n);
+}
 
 extern "C" int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float* packed, void* stream) {
-    RF_REQUIRE(emb && packed && n > 0 && dim > 0, RF_E_INVALID, "rf_db_pack_embeddings: bad arguments");
-    const size_t want = (rf_db_packed_floats(n, dim) + 255) / 256;
-    hipLaunchKernelGGL(k_db_pack, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, emb, (long long)n, dim, packed);
+    RF_REQUIRE(emb && packed && n > 0, RF_E_INVALID, "rf_db_pack_embeddings: bad arguments");
+    RF_REQUIRE(dim == RF_DIM, RF_E_UNSUPPORTED, "rf_db_pack_embeddings: embedding dim %d (only 64, the latent_dim of every shipped config)", dim);
+    float* rows = packed + rf_blocked_floats(n);
+    float* hd = rows + (size_t)rf_rows32(n) * RF_DIM;
+    const size_t want = (rf_blocked_floats(n) + 255) / 256;
+    hipLaunchKernelGGL(k_db_pack, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, emb, (long long)n, packed, rows, hd);
     RF_CHECK_LAUNCH("rf_db_pack_embeddings");
     return RF_OK;
 }
 
-// --------------------------------------------------------------------------------------------------- the scan
-#define RF_DIM 64
-#define RF_TQ 64          // queries per workgroup tile
+// --------------------------------------------------------------------------------------------------- the scans
+// THE exact distance of the path (both scans, every code path): four fp32 FMA chains, chain c over the dims d = 4m + c in
+// the order m = 0..15 with t = q_d - x_d (rounded), acc = fma(t, t, acc) from 0; dist = (c0 + c2) + (c1 + c3).
+// The VALU scan runs the chains as two packed-fp32 accumulators {c0,c1}, {c2,c3} over dim pairs (4m, 4m+1), (4m+2, 4m+3);
+// the MFMA scan's re-check runs chain g on the lane that holds row chunk g.  Same bits everywhere, so a (query, row) pair has
+// ONE distance no matter which scan, slice or shard evaluates it.
+#define RF_TQ 64          // queries per workgroup tile of the VALU scan
 
 // cooperative sorted insert of one wave-uniform candidate into the list held by lanes 0..K2-1 (ascending keys)
 template <int K2>
@@ -102,10 +139,11 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
     return key;
 }
 
-// One workgroup = (DB slice, tile of RF_TQ queries); its 4 waves SPLIT THE QUERIES (RF_QW each) and every wave walks all
-// 64-row blocks of the slice, so there is exactly one candidate list per (slice, query).  A wave's lists live in
+// VALU scan.  One workgroup = (DB slice, tile of RF_TQ queries); its 4 waves SPLIT THE QUERIES (RF_QW each) and every wave walks
+// all 64-row blocks of the slice, so there is exactly one candidate list per (slice, query).  A wave's lists live in
 // registers (list j: entry i in lane i of e[j]).  The first block initialises a list with a wave-wide sort; afterwards a
 // row enters only if it beats the list's current worst (ballot), which becomes rare quickly (~K2/b hits for block b).
+// Every pair costs 64 packed VALU instructions: the right tool for small shards (<= ~100 k rows per GPU).
 #define RF_QW (RF_TQ / 4)
 typedef float rf_f32x2 __attribute__((ext_vector_type(2)));
 template <int K2>
@@ -124,9 +162,9 @@ __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, in
     for (int j = 0; j < RF_QW; ++j) e[j] = RF_KEY_NONE;
 
     for (long long blk = blk_lo; blk < blk_hi; ++blk) {
-        // this lane's DB row: 64 coalesced loads, one per dim (the 4 waves read the same block: L1/L2 hits)
-        // kept as register PAIRS: the distance loop runs on the packed-fp32 VALU (v_pk_add_f32 / v_pk_fma_f32: two dims per
-        // instruction), queries as scalar-register pairs
+        // this lane's DB row: 64 coalesced loads, one per dim (the 4 waves read the same block: L1/L2 hits), kept as register
+        // PAIRS of consecutive dims: the distance loop runs on the packed-fp32 VALU (v_pk_add_f32 / v_pk_fma_f32), queries as
+        // scalar-register pairs
         rf_f32x2 x[RF_DIM / 2];
         const float* bp = db + (size_t)blk * RF_DIM * 64 + lane;
 #pragma unroll
@@ -141,14 +179,16 @@ __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, in
             const int qi = q0 + j;
             if (qi < nq) {                                           // wave-uniform
                 const float* qp = q + (size_t)qi * RF_DIM;           // wave-uniform address -> scalar loads
-                rf_f32x2 acc = {0.f, 0.f};                           // even / odd dims: two independent fp32 FMA chains
+                rf_f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};     // chains {c0, c1} and {c2, c3} (see "THE exact distance")
 #pragma unroll
-                for (int d = 0; d < RF_DIM / 2; ++d) {
-                    const rf_f32x2 qv = {qp[2 * d], qp[2 * d + 1]};
-                    const rf_f32x2 t = qv - x[d];
-                    acc = __builtin_elementwise_fma(t, t, acc);
+                for (int m = 0; m < RF_DIM / 4; ++m) {
+                    const rf_f32x2 qa = {qp[4 * m], qp[4 * m + 1]}, qb = {qp[4 * m + 2], qp[4 * m + 3]};
+                    const rf_f32x2 ta = qa - x[2 * m], tb = qb - x[2 * m + 1];
+                    acc01 = __builtin_elementwise_fma(ta, ta, acc01);
+                    acc23 = __builtin_elementwise_fma(tb, tb, acc23);
                 }
-                const u64 key = valid ? make_key(acc[0] + acc[1], grow) : RF_KEY_NONE;
+                const rf_f32x2 sum = acc01 + acc23;                  // {c0 + c2, c1 + c3}
+                const u64 key = valid ? make_key(sum[0] + sum[1], grow) : RF_KEY_NONE;
                 if (first) {
                     const u64 sorted = wave_sort64(key, lane);
                     e[j] = lane < K2 ? sorted : RF_KEY_NONE;
@@ -176,10 +216,203 @@ __global__ __launch_bounds__(256) void k_l2_topk(const float* __restrict__ q, in
     }
 }
 
-// bitonic sort of up to CAP keys per query in LDS; the first k2 are the answer
+// MFMA-filtered scan for large shards.  q.x for a 32-row x 64-query tile costs 128 v_mfma_f32_16x16x4_f32 (the VALU scan spends
+// 2 x 64 packed instructions PER PAIR); the dot product only FILTERS -- whatever survives is re-evaluated with THE exact
+// distance and inserted by key, so the lists are bit-identical to the VALU scan's:
+//   * wave = 64 queries (4 n-blocks), stationary in 64 VGPRs as B operands (lane (n, g) holds dims {4j + g} of query n);
+//     DB rows stream through as A operands, 2 m-blocks of 16 rows per step, lane (r, g) loading the 64 contiguous bytes of
+//     row r's chunk g from the `rows` image (double buffered in registers); 4 waves of a workgroup = 256 queries on the same
+//     slice (L1/L2 hits), no LDS staging, no barrier anywhere.
+//   * the accumulators start at -hd[row], so after the 16 k-steps  s' = q.x - (1-eps)|x|^2/2.  With T the current k2-th best
+//     EXACT distance of the query's list:  |q-x|^2 < T  =>  s' >= a_q := (1-eps)|q|^2/2 - T/2   (eps = 2^-15; proof below).
+//     One v_cmp per accumulator register; a step without a passing pair (almost all of them) costs nothing else.
+//   * a passing pair (~k2 * ln(rows per slice / k2) per query and slice) is re-evaluated from the registers that already hold
+//     it: the query chunk comes over by ds_bpermute, chain g runs on lane (r, g), four readlanes combine.  Then the usual
+//     cooperative sorted insert into the wave-private list in LDS and a_q is refreshed.
+//   * the lists start EMPTY with a threshold from a sample pass: rf_l2_topk first runs the VALU scan over the shard's first
+//     rows (n/64, 1 k..16 k of them); T0[q] = the sample's k2-th best exact distance bounds the final k2-th distance from above,
+//     so only pairs with distance <= T0 can matter (the scan covers the sample rows again).  Without it every one of the up to 64
+//     slices would re-discover the threshold: ~k2 ln(rows per slice / k2) re-checks per query and slice instead of
+//     ~k2 * n / sample per query over the whole shard (1 M rows, 2048 queries: 3840 -> 490 re-checks per query).
+// Error bound (why nothing is missed): for fp32 chains of length <= 66 the computed s' differs from the real q.x - hd by at
+// most 66*2^-24 * (sum|q_d x_d| + hd) <= 3.0e-6 (|q|^2+|x|^2); THE exact distance differs from the real |q-x|^2 by at most
+// 66*2^-24 |q-x|^2 <= 7.9e-6 (|q|^2+|x|^2); hd and a_q add rounding of 2^-24.  Real |q-x|^2 = |q|^2 + |x|^2 - 2 q.x, so a pair
+// whose exact distance is below T has  s' >= (|q|^2+|x|^2)(1/2 - 7.0e-6) - T/2 - (1-eps)|x|^2/2 >= a_q  as soon as
+// eps/2 >= 7.0e-6 + 3.0e-6, i.e. eps >= 2.0e-5; eps = 2^-15 = 3.05e-5.  (Rows are visited in ascending id order, so a pair
+// that TIES the list's worst distance can never enter: "<" is enough.)
+template <int K2>
+__global__ __launch_bounds__(256, 2) void k_l2_topk_mfma(const float* __restrict__ q, int nq, const float* __restrict__ rows_img,
+                                                         const float* __restrict__ hd, long long n, unsigned row_base, int rows_per_slice,
+                                                         const float* __restrict__ t0, int t0_stride, u64* __restrict__ parts) {
+    __shared__ u64 s_lists[4][64 * K2];
+    __shared__ float s_aq[4][64], s_hq[4][64], s_t0[4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x;
+    const int q0 = (blockIdx.y * 4 + wave) * 64;                     // this wave's 64 queries
+    if (q0 >= nq) return;                                            // no barrier in this kernel: a wave may leave
+    const long long n32 = (n + 31) / 32 * 32;
+    const long long r_lo = (long long)slice * rows_per_slice;        // multiple of 64
+    long long r_hi = r_lo + rows_per_slice;
+    if (r_hi > n32) r_hi = n32;
+    u64* lists = s_lists[wave];
+    float* aqs = s_aq[wave];
+    float* hqs = s_hq[wave];
+    float* t0s = s_t0[wave];
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---------------------------------------------------------------- lists start empty, thresholds from the sample pass
+    // t0[q] = k2-th best exact distance among the shard's first rows (rf_l2_topk's sample pass, VALU scan): an upper bound of
+    // the final k2-th distance (+inf when the sample holds fewer than k2 rows).
+    for (int ql = lane; ql < 64; ql += 64) {
+        const int qi = q0 + ql;
+        float hq = 0.f, a = INFINITY;                                // a query that does not exist: nothing passes
+        if (qi < nq) {
+            const float* qp = q + (size_t)qi * RF_DIM;
+            float nqn = 0.f;
+#pragma unroll
+            for (int d = 0; d < RF_DIM; ++d) nqn = fmaf(qp[d], qp[d], nqn);
+            hq = (1.f - RF_EPS_FILTER) * 0.5f * nqn;
+            const float t = t0[(size_t)qi * t0_stride];
+            a = hq - 0.5f * t;                                       // t = +inf (sample smaller than k2): -inf, everything passes
+        }
+        hqs[ql] = hq;
+        aqs[ql] = a;
+        t0s[ql] = qi < nq ? t0[(size_t)qi * t0_stride] : 0.f;
+    }
+    for (int i = lane; i < 64 * K2; i += 64) lists[i] = RF_KEY_NONE;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---------------------------------------------------------------- the filtered scan
+    float b[4][16];                                                  // B operands: b[nb][j] = dim 4j + g of query q0 + nb*16 + n
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int qi = q0 + nb * 16 + li;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[nb][j] = qi < nq ? q[(size_t)qi * RF_DIM + 4 * j + lg] : 0.f;
+    }
+    float aq[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
+
+    auto load_tile = [&](long long row0, float (&a)[2][16], f32x4 (&h)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float4* rp = reinterpret_cast<const float4*>(rows_img + (size_t)(row0 + mb * 16 + li) * RF_DIM + 16 * lg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float4 t = rp[k]; a[mb][4 * k] = t.x; a[mb][4 * k + 1] = t.y; a[mb][4 * k + 2] = t.z; a[mb][4 * k + 3] = t.w; }
+            const float4 t = *reinterpret_cast<const float4*>(hd + row0 + mb * 16 + 4 * lg);
+            h[mb] = (f32x4){-t.x, -t.y, -t.z, -t.w};
+        }
+    };
+
+    auto scan_tile = [&](long long row0, const float (&a)[2][16], const f32x4 (&h)[2]) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = h[mb];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][j], b[nb][j], acc[mb][nb], 0, 0, 0);
+        // does ANY pair of the tile pass?  per accumulator register one v_cmp whose lane mask is OR-ed on the scalar unit
+        unsigned long long anyhit = 0ull;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) anyhit |= __ballot(acc[mb][nb][i] >= aq[nb]);
+        if (anyhit == 0ull) return;
+        unsigned m = 0u;                                              // bit (mb*4 + nb)*4 + i: D row 4*lg + i of m-block mb, query column li of n-block nb
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m |= (acc[mb][nb][i] >= aq[nb] ? 1u : 0u) << ((mb * 4 + nb) * 4 + i);
+        // ---- some pair passed the filter: exact re-check from the registers that hold it
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const unsigned m4 = (m >> ((mb * 4 + nb) * 4)) & 15u;
+                unsigned long long bal = __ballot(m4 != 0u);
+                while (bal) {
+                    const int src = __ffsll((long long)bal) - 1;     // lane (n_, g_) of the D tile
+                    bal &= bal - 1;
+                    unsigned mi = __builtin_amdgcn_readlane(m4, src);
+                    const int n_ = src & 15, g_ = src >> 4;
+                    const int ql = nb * 16 + n_;
+                    while (mi) {
+                        const int i = __ffs((int)mi) - 1;
+                        mi &= mi - 1;
+                        const int r = 4 * g_ + i;                     // row of the m-block
+                        const long long row = row0 + mb * 16 + r;
+                        if (row >= n) continue;
+                        // chain g of THE exact distance on lane (r, g): the query chunk comes from lane (n_, g)
+                        float P = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float qv = __shfl(b[nb][j], n_ + (lane & 48), 64);
+                            const float t = qv - a[mb][j];
+                            P = fmaf(t, t, P);
+                        }
+                        const unsigned Pb = __float_as_uint(P);        // readlane moves 32-bit patterns
+                        const float c0 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r)), c1 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 16));
+                        const float c2 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 32)), c3 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 48));
+                        const float dist = (c0 + c2) + (c1 + c3);
+                        const u64 key = make_key(dist, row_base + (unsigned)row);
+                        u64 e = lane < K2 ? lists[ql * K2 + lane] : RF_KEY_NONE;
+                        const unsigned wlo = __builtin_amdgcn_readlane((unsigned)(e & 0xffffffffu), K2 - 1);
+                        const unsigned whi = __builtin_amdgcn_readlane((unsigned)(e >> 32), K2 - 1);
+                        if (key < (((u64)whi << 32) | wlo) && dist <= t0s[ql]) {          // (<=: the sample's own k2-th row must get in)
+                            list_insert<K2>(e, lane, key);
+                            if (lane < K2) lists[ql * K2 + lane] = e;
+                            if (lane == K2 - 1) {                    // T = min(sample bound, the list's k2-th distance once it is full)
+                                const float tl = e == RF_KEY_NONE ? INFINITY : __uint_as_float((unsigned)(e >> 32));
+                                aqs[ql] = hqs[ql] - 0.5f * fminf(tl, t0s[ql]);
+                            }
+                        }
+                    }
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
+    };
+
+    float a0[2][16], a1[2][16];
+    f32x4 h0[2], h1[2];
+    long long row0 = r_lo;
+    if (row0 < r_hi) load_tile(row0, a0, h0);
+    while (row0 < r_hi) {
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, h1);
+        scan_tile(row0, a0, h0);
+        row0 += 32;
+        if (row0 >= r_hi) break;
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a0, h0);
+        scan_tile(row0, a1, h1);
+        row0 += 32;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // publish: parts[slice][q][K2]
+    for (int ql = 0; ql < 64; ++ql) {
+        const int qi = q0 + ql;
+        if (qi < nq && lane < K2) parts[((size_t)slice * nq + qi) * K2 + lane] = lists[ql * K2 + lane];
+    }
+}
+
+// bitonic sort of up to CAP keys per query in LDS; the first k2 are the answer (as (dist, idx) pairs and / or packed keys)
 template <int CAP>
 __global__ __launch_bounds__(256) void k_merge_keys(const u64* __restrict__ parts, int nparts, int nq, int width, int k2,
-                                                    float* __restrict__ out_dist, long long* __restrict__ out_idx) {
+                                                    float* __restrict__ out_dist, long long* __restrict__ out_idx, u64* __restrict__ out_keys) {
     __shared__ u64 keys[CAP];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int total = nparts * width;
@@ -204,55 +437,106 @@ __global__ __launch_bounds__(256) void k_merge_keys(const u64* __restrict__ part
     if (tid < k2) {
         const u64 key = keys[tid];
         const bool none = key == RF_KEY_NONE;
-        out_dist[(size_t)qi * k2 + tid] = none ? INFINITY : __uint_as_float((unsigned)(key >> 32));
-        out_idx[(size_t)qi * k2 + tid] = none ? -1ll : (long long)(unsigned)(key & 0xffffffffu);
+        if (out_keys) out_keys[(size_t)qi * k2 + tid] = key;
+        if (out_dist) out_dist[(size_t)qi * k2 + tid] = none ? INFINITY : __uint_as_float((unsigned)(key >> 32));
+        if (out_idx) out_idx[(size_t)qi * k2 + tid] = none ? -1ll : (long long)(unsigned)(key & 0xffffffffu);
     }
-}
-
-static int pick_slices(long long nblk, int qtiles) {
-    // enough workgroups to fill 256 CUs a few times over, at most 64 slices (= lists per query to merge)
-    long long s = (1024 + qtiles - 1) / qtiles;
-    if (s > 64) s = 64;
-    if (s > (nblk + 3) / 4) s = (nblk + 3) / 4;                     // at least 4 blocks per list
-    if (s < 1) s = 1;
-    return (int)s;
 }
 
 extern "C" size_t rf_l2_topk_ws_bytes(int nq, int64_t n, int k2) {
     (void)n;
     const int k2p = k2 <= 8 ? 8 : 16;
-    return (size_t)64 * (size_t)nq * k2p * sizeof(u64);           // one K2-wide list per (slice <= 64, query)
+    return (size_t)64 * (size_t)nq * k2p * sizeof(u64)            // one K2-wide list per (slice <= 64, query)
+           + (size_t)nq * k2p * (sizeof(float) + sizeof(int64_t));   // + the sample pass's result (MFMA-filtered scan)
 }
 
-static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2, float* out_dist, int64_t* out_idx, hipStream_t s, const char* who) {
+static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2, float* out_dist, int64_t* out_idx, u64* out_keys, hipStream_t s,
+                        const char* who) {
     const int total = nparts * width;
     RF_REQUIRE(total <= 4096, RF_E_UNSUPPORTED, "%s: %d candidates per query exceed the merge capacity 4096", who, total);
-    if (total <= 256) hipLaunchKernelGGL(k_merge_keys<256>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, (long long*)out_idx);
-    else if (total <= 1024) hipLaunchKernelGGL(k_merge_keys<1024>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, (long long*)out_idx);
-    else hipLaunchKernelGGL(k_merge_keys<4096>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, (long long*)out_idx);
+    long long* oi = (long long*)out_idx;
+    if (total <= 256) hipLaunchKernelGGL(k_merge_keys<256>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, oi, out_keys);
+    else if (total <= 1024) hipLaunchKernelGGL(k_merge_keys<1024>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, oi, out_keys);
+    else hipLaunchKernelGGL(k_merge_keys<4096>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, oi, out_keys);
     RF_CHECK_LAUNCH(who);
     return RF_OK;
 }
 
-extern "C" int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2,
-                          float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream) {
-    RF_REQUIRE(q && db_packed && out_dist && out_idx && ws && nq > 0 && n > 0, RF_E_INVALID, "rf_l2_topk: bad arguments");
+// Which scan (measured on MI355X, tools/topk_bench.py; k2 = 8): 2048 queries -- 50 k rows: VALU 0.47 ms / MFMA 0.59 ms, 125 k: 0.92 / 0.79,
+// 1 M: 6.3 / 2.7;  16384 queries (8 ranks' queries against one shard) -- 50 k: 2.8 / 2.0, 125 k: 6.4 / 3.4.
+static bool use_mfma_scan(int nq, int64_t n) { return n >= 100000 || (nq >= 8192 && n >= 40000); }
+
+// workspace: [per-slice lists: 64 x nq x k2p keys][sample pass: nq x k2p (dist f32, idx i64)]
+static int topk_impl(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
+                     float* out_dist, int64_t* out_idx, u64* out_keys, void* ws, size_t ws_bytes, void* stream) {
+    RF_REQUIRE(q && db_packed && (out_keys || (out_dist && out_idx)) && ws && nq > 0 && n > 0, RF_E_INVALID, "rf_l2_topk: bad arguments");
     RF_REQUIRE(dim == RF_DIM, RF_E_UNSUPPORTED, "rf_l2_topk: embedding dim %d (only 64, the latent_dim of every shipped config)", dim);
     RF_REQUIRE(k2 >= 1 && k2 <= 16, RF_E_UNSUPPORTED, "rf_l2_topk: k2=%d outside 1..16", k2);
+    RF_REQUIRE(algo >= 0 && algo <= 2, RF_E_INVALID, "rf_l2_topk: algo %d (0 auto, 1 VALU scan, 2 MFMA-filtered scan)", algo);
     RF_REQUIRE(row_base >= 0 && row_base + n <= 0xFFFFFFFELL, RF_E_UNSUPPORTED, "rf_l2_topk: global row ids must fit 32 bits");
     RF_REQUIRE(ws_bytes >= rf_l2_topk_ws_bytes(nq, n, k2), RF_E_WORKSPACE, "rf_l2_topk: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const long long nblk = (n + 63) / 64;
-    const int qtiles = (nq + RF_TQ - 1) / RF_TQ;
-    const int slices = pick_slices(nblk, qtiles);
-    const int bps = (int)((nblk + slices - 1) / slices);
     const int k2p = k2 <= 8 ? 8 : 16;
     u64* parts = (u64*)ws;
-    if (k2p == 8) hipLaunchKernelGGL(k_l2_topk<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, db_packed, (long long)n, (unsigned)row_base, bps, parts);
-    else hipLaunchKernelGGL(k_l2_topk<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, db_packed, (long long)n, (unsigned)row_base, bps, parts);
-    RF_CHECK_LAUNCH("rf_l2_topk(scan)");
+    int slices;
+    const bool mfma = algo == 2 || (algo == 0 && use_mfma_scan(nq, n));
+    if (mfma) {
+        // one wave per (slice, 64 queries); two waves per SIMD on 256 CUs = 2048 waves; at least 128 rows per list, at most 64 lists
+        const int qgroups = (nq + 63) / 64, qtiles = (qgroups + 3) / 4;
+        long long sl = (2048 + qgroups - 1) / qgroups;
+        if (sl > 64) sl = 64;
+        if (sl > nblk / 2) sl = nblk / 2;
+        if (sl < 1) sl = 1;
+        const long long bps = (nblk + sl - 1) / sl;
+        slices = (int)((nblk + bps - 1) / bps);
+        const float* rows_img = db_packed + rf_blocked_floats(n);
+        const float* hd = rows_img + (size_t)rf_rows32(n) * RF_DIM;
+        // sample pass: exact top-k2p of the shard's first n/64 rows (1 k..16 k, whole 64-row blocks) with the VALU scan; the
+        // blocked view of the first rows of the shard IS the blocked view of the sample
+        long long sample = n / 64;
+        if (sample < 1024) sample = 1024;
+        if (sample > 16384) sample = 16384;
+        sample = (sample + 63) / 64 * 64;
+        if (sample > n) sample = n;
+        float* t_dist = reinterpret_cast<float*>(parts + (size_t)64 * nq * k2p);
+        int64_t* t_idx = reinterpret_cast<int64_t*>(t_dist + (size_t)nq * k2p) ;
+        int rc = topk_impl(q, nq, dim, db_packed, sample, row_base, k2p, 1, t_dist, t_idx, nullptr, ws, ws_bytes, stream);
+        if (rc != RF_OK) return rc;
+        const float* t0 = t_dist + (k2 - 1);                         // the k2-th best of query qi: t0[qi * k2p]
+        if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+        else hipLaunchKernelGGL(k_l2_topk_mfma<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+        RF_CHECK_LAUNCH("rf_l2_topk(mfma scan)");
+    } else {
+        const int qtiles = (nq + RF_TQ - 1) / RF_TQ;
+        // enough workgroups to fill 256 CUs a few times over, at most 64 slices (= lists per query to merge), at least 4 blocks per list
+        long long sl = (1024 + qtiles - 1) / qtiles;
+        if (sl > 64) sl = 64;
+        if (sl > (nblk + 3) / 4) sl = (nblk + 3) / 4;
+        if (sl < 1) sl = 1;
+        const int bps = (int)((nblk + sl - 1) / sl);
+        slices = (int)((nblk + bps - 1) / bps);
+        if (k2p == 8) hipLaunchKernelGGL(k_l2_topk<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, db_packed, (long long)n, (unsigned)row_base, bps, parts);
+        else hipLaunchKernelGGL(k_l2_topk<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, db_packed, (long long)n, (unsigned)row_base, bps, parts);
+        RF_CHECK_LAUNCH("rf_l2_topk(scan)");
+    }
     // merge the per-slice lists (each k2p wide) and emit the first k2
-    return launch_merge(parts, slices, nq, k2p, k2, out_dist, out_idx, s, "rf_l2_topk(merge)");
+    return launch_merge(parts, slices, nq, k2p, k2, out_dist, out_idx, out_keys, s, "rf_l2_topk(merge)");
+}
+
+extern "C" int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
+                          float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream) {
+    return topk_impl(q, nq, dim, db_packed, n, row_base, k2, algo, out_dist, out_idx, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int rf_l2_topk_keys(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
+                               uint64_t* out_keys, void* ws, size_t ws_bytes, void* stream) {
+    return topk_impl(q, nq, dim, db_packed, n, row_base, k2, algo, nullptr, nullptr, (u64*)out_keys, ws, ws_bytes, stream);
+}
+
+extern "C" int rf_topk_merge_keys(const uint64_t* in_keys, int parts, int nq, int k2, float* out_dist, int64_t* out_idx, void* stream) {
+    RF_REQUIRE(in_keys && out_dist && out_idx && parts > 0 && nq > 0 && k2 > 0, RF_E_INVALID, "rf_topk_merge_keys: bad arguments");
+    return launch_merge((const u64*)in_keys, parts, nq, k2, k2, out_dist, out_idx, nullptr, (hipStream_t)stream, "rf_topk_merge_keys");
 }
 
 // merge from (dist, idx) arrays: the all-gathered per-shard results

@@ -65,7 +65,9 @@ SIGNATURES = {
     'rf_query_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_p]),
     'rf_db_pack_embeddings': (c_i, [c_fp, c_i64, c_i, c_fp, c_p]),
     'rf_db_packed_floats': (c_sz, [c_i64, c_i]),
-    'rf_l2_topk': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_fp, c_p, c_p, c_sz, c_p]),
+    'rf_l2_topk': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_i, c_fp, c_p, c_p, c_sz, c_p]),
+    'rf_l2_topk_keys': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    'rf_topk_merge_keys': (c_i, [c_p, c_i, c_i, c_i, c_fp, c_p, c_p]),
     'rf_l2_topk_ws_bytes': (c_sz, [c_i, c_i64, c_i]),
     'rf_topk_merge': (c_i, [c_fp, c_p, c_i, c_i, c_i, c_fp, c_p, c_p]),
     'rf_demote_same_scene': (c_i, [c_fp, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_fp, c_p, c_p]),
@@ -74,6 +76,40 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+class _Library:
+    """The bound entry points as plain attributes (no indirection on the hot path).  ``start_profile`` swaps every stream-ordered
+    entry point for a wrapper that brackets the call with HIP events on the launch stream and records
+    (name, integer arguments, start, end) -- bench.py's per-kernel table; ``stop_profile`` restores the direct bindings."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._direct = {}
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)      # AttributeError here == header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+            self._direct[name] = fn
+            setattr(self, name, fn)
+
+    def start_profile(self, records):
+        def timed(name, fn):
+            def call(*args):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args)
+                e1.record()
+                records.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1))
+                return rc
+            return call
+        for name, (res, args) in SIGNATURES.items():
+            if res is c_i and args and name not in ('rf_abi_version',):     # int-returning launches (all take the stream last)
+                setattr(self, name, timed(name, self._direct[name]))
+
+    def stop_profile(self):
+        for name, fn in self._direct.items():
+            setattr(self, name, fn)
 
 
 def load():
@@ -85,13 +121,8 @@ def load():
         raise RuntimeError(
             'librfuse_hip.so not found at %s -- build it with `python retrieval-fuse_amd/csrc/build.py` '
             '(or __graft_entry__.build()).  There is no CPU fallback for the refinement hot path.' % LIB_PATH)
-    lib = ctypes.CDLL(str(LIB_PATH))
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)      # AttributeError here == header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Library(ctypes.CDLL(str(LIB_PATH)))
+    return _lib
 
 
 def check(rc, what):

@@ -25,31 +25,86 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allgather_merge(q_local, local_topk, merge, k2, group=None):
-    """The sharded search protocol, independent of how the local scan / merge are computed (so it runs on gloo/CPU
-    in tests with numpy callables and on RCCL with the HIP kernels):
+_checked_query_counts = set()
 
-      1. all-gather the queries (every shard must see every query)
-      2. local_topk(all_queries) -> (dist [Q,k2] f32, idx [Q,k2] i64 global ids) over this rank's rows
-      3. all-gather the candidate lists -> [W,Q,k2]
-      4. merge(dist_parts, idx_parts) restricted to this rank's own queries -> ([q_local,k2], [q_local,k2])
 
-    All ranks must pass the same number of local queries (chunk batches are split evenly)."""
+def _check_equal_query_counts(nq, group):
+    """all_gather_into_tensor needs the same number of queries on every rank (chunk batches are split evenly); unequal
+    counts would hang or mis-slice silently.  Checked once per (group, count) -- it costs a host round trip."""
+    import torch.distributed as dist
+    key = (id(group), nq)
+    if key in _checked_query_counts:
+        return
+    counts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(counts, int(nq), group=group)
+    if len(set(counts)) != 1:
+        raise ValueError('sharded search: every rank must pass the same number of queries, got %s' % (counts,))
+    _checked_query_counts.add(key)
+
+
+def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings=None):
+    """The sharded search protocol, independent of how the local scan / merge are computed (so it runs on
+    gloo/CPU in tests with numpy stand-ins of the same contract, and on RCCL with the HIP kernels):
+
+      1. all-gather the queries (every shard must see every query)                              [W * nq, 64] float32
+      2. local_topk_keys(all_queries) -> packed 64-bit keys (dist bits << 32 | GLOBAL row id, -1 = none) over this rank's rows
+      3. ONE all-gather of the candidate keys                                                  [W, W * nq, k2] int64
+      4. merge_keys(parts restricted to this rank's own queries) -> (dist [nq, k2], idx [nq, k2])
+
+    The unsigned order of the keys is the (distance, row id) order, so the merge of W shard lists equals a single scan
+    bit for bit.  ``timings``: optional list; (start, end) CUDA event pairs of the two collectives are appended."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq = q_local.shape[0]
+    _check_equal_query_counts(nq, group)
+    q_local = q_local.contiguous()
+    ev = None
+    if timings is not None and q_local.is_cuda:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     q_all = torch.empty((world * nq,) + tuple(q_local.shape[1:]), dtype=q_local.dtype, device=q_local.device)
-    dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
-    d_loc, i_loc = local_topk(q_all)
-    nq_all, k2_ = d_loc.shape
-    d_flat = torch.empty((world * nq_all, k2_), dtype=d_loc.dtype, device=d_loc.device)      # rank-major concatenation
-    i_flat = torch.empty((world * nq_all, k2_), dtype=i_loc.dtype, device=i_loc.device)
-    dist.all_gather_into_tensor(d_flat, d_loc.contiguous(), group=group)
-    dist.all_gather_into_tensor(i_flat, i_loc.contiguous(), group=group)
-    d_all, i_all = d_flat.view(world, nq_all, k2_), i_flat.view(world, nq_all, k2_)
-    mine = slice(rank * nq, (rank + 1) * nq)
-    return merge(d_all[:, mine].contiguous(), i_all[:, mine].contiguous())
+    if ev:
+        ev[0].record()
+    dist.all_gather_into_tensor(q_all, q_local, group=group)
+    if ev:
+        ev[1].record()
+    keys = local_topk_keys(q_all).contiguous()                                  # [W*nq, k2] int64
+    flat = torch.empty((world * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)      # rank-major concatenation
+    if ev:
+        ev[2].record()
+    dist.all_gather_into_tensor(flat, keys, group=group)
+    if ev:
+        ev[3].record()
+        timings.append((ev[0], ev[1], ev[2], ev[3]))
+    mine = flat.view(world, keys.shape[0], keys.shape[1])[:, rank * nq:(rank + 1) * nq].contiguous()
+    return merge_keys(mine)
+
+
+class HipSearchBackend:
+    """The product's scan / merge: librfuse_hip.so through rfuse.ops.  (tests/test_distributed_cpu.py injects a numpy object with
+    the same four methods to run the protocol over gloo; the product has no CPU path.)"""
+
+    @staticmethod
+    def pack(emb_shard):
+        return ops.db_pack_embeddings(emb_shard) if emb_shard.shape[0] else None
+
+    @staticmethod
+    def topk(q, packed, n, row_base, k2):
+        return ops.l2_topk(q, packed, n, row_base, k2)
+
+    @staticmethod
+    def topk_keys(q, packed, n, row_base, k2):
+        if n == 0:                                                              # empty shard (fewer rows than ranks): no candidates
+            return torch.full((q.shape[0], k2), -1, dtype=torch.int64, device=q.device)
+        return ops.l2_topk_keys(q, packed, n, row_base, k2)
+
+    @staticmethod
+    def merge_keys(key_parts):
+        return ops.topk_merge_keys(key_parts)
+
+    @staticmethod
+    def demote(dist, idx, meta, query_scene, K, query_keep):
+        return ops.demote_same_scene(dist, idx, meta, query_scene, K, query_keep)
 
 
 @torch.no_grad()
@@ -104,10 +159,12 @@ class PatchDatabase:
         emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
         return cls(emb, meta, volumes, device, rank, world, group)
 
-    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None):
+    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend):
         """emb [N+1,64] float32 (unit rows), meta [N+1,7] int32, volumes [S,64,64,64] float32 -- host or device tensors /
         numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes."""
         emb = torch.as_tensor(emb)
+        self.backend = backend
+        self.collective_events = None    # bench.py: a list to collect (start, end) event pairs of the two all-gathers
         self.n_rows = emb.shape[0]
         self.dim = emb.shape[1]
         self.rank, self.world, self.group = rank, world, group
@@ -115,7 +172,7 @@ class PatchDatabase:
         self.lo, self.hi = shard_bounds(self.n_rows, rank, world)
         self.device = torch.device(device)
         shard = emb[self.lo:self.hi].to(self.device, torch.float32).contiguous()
-        self.emb_packed = ops.db_pack_embeddings(shard)
+        self.emb_packed = backend.pack(shard)
         self.meta = torch.as_tensor(meta).to(self.device, torch.int32).contiguous()
         self.volumes = torch.as_tensor(volumes).to(self.device, torch.float32).contiguous()
         self.n_scenes = self.volumes.shape[0]
@@ -149,19 +206,25 @@ class PatchDatabase:
         return feats
 
     def local_topk(self, q, k2):
-        """Exact squared-L2 top-k2 of q against this rank's shard, global row ids."""
-        return ops.l2_topk(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2)
+        """Exact squared-L2 top-k2 of q against this rank's shard, global row ids -> (dist, idx)."""
+        return self.backend.topk(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2)
+
+    def local_topk_keys(self, q, k2):
+        """... as packed 64-bit keys [Q, k2] int64 (what the ranks exchange)."""
+        return self.backend.topk_keys(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2)
 
     def search(self, q, k2):
         """Top-k2 over the whole database for this rank's queries.  One process: a single scan.  W processes:
-        all-gather(queries) -> shard scans -> all-gather(candidates) -> merge."""
+        all-gather(queries) -> shard scans -> ONE all-gather of the packed candidate keys -> merge (sharded_search).
+        The collectives are issued from the caller's stream (torch runs them on RCCL's own stream, ordered by events), so the
+        U-Net backbone the engine forked onto its side stream keeps the GPU busy while they are in flight."""
         if self.world == 1 and not self.force_collectives:
             return self.local_topk(q, k2)
-        return allgather_merge(q, lambda qa: self.local_topk(qa, k2), ops.topk_merge, k2, self.group)
+        return sharded_search(q, lambda qa: self.local_topk_keys(qa, k2), self.backend.merge_keys, k2, self.group, self.collective_events)
 
     def retrieve(self, q, K, query_scene=None, query_keep=None):
         """flann_knn_worker semantics (util/retrieval.py:92-100): top-2K, same-scene demotion, keep K.
         ``query_keep`` [Q] bool: False = patch dropped by the query-side occupancy filter (no neighbours, trunc fill).
         Returns (meta [Q,K,7] int32, dist [Q,K], idx [Q,K])."""
         dist, idx = self.search(q, 2 * K)
-        return ops.demote_same_scene(dist, idx, self.meta, query_scene, K, query_keep)
+        return self.backend.demote(dist, idx, self.meta, query_scene, K, query_keep)

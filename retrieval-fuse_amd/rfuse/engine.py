@@ -57,6 +57,7 @@ class RefinementEngine:
             m.to(self.device).eval()
         self.database = database
         self._side_streams = {}          # one helper stream per caller stream (several batches may be in flight)
+        self.serial = False              # True: keep the U-Net backbone on the caller's stream (per-kernel timing wants no overlap)
 
     def modules(self):
         return {'unet_backbone': self.unet_backbone, 'decoder': self.decoder, 'retrieval_backbone': self.retrieval_backbone,
@@ -105,14 +106,17 @@ class RefinementEngine:
         launches (1^3..32^3 volumes of a few chunks) that cannot fill 256 CUs, and so runs in the shadow of the
         retrieval path (top-k scan, patch gather, retrieval backbone) on the main stream."""
         main = torch.cuda.current_stream(self.device)
+        if self.serial:
+            return self.unet_backbone(x_in), main
         side = self._side_streams.get(main.cuda_stream)
         if side is None:
             side = self._side_streams[main.cuda_stream] = torch.cuda.Stream(self.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             x_back = self.unet_backbone(x_in)
-        x_in.record_stream(side)
-        x_back.record_stream(main)
+        if not torch.cuda.is_current_stream_capturing():         # (a captured graph keeps its private pool alive by itself)
+            x_in.record_stream(side)
+            x_back.record_stream(main)
         return x_back, side
 
     @_on_engine_device
@@ -154,3 +158,23 @@ class RefinementEngine:
             feats = self.retrieval_backbone(patches)
         torch.cuda.current_stream(self.device).wait_stream(side)
         return self._attend_and_decode(x_back, feats, gumbel_noise)
+
+    @_on_engine_device
+    def capture_graph(self, input_raw, query_scene=None, patch_mask=None):
+        """Capture one whole refine() step for a FIXED batch shape into a HIP graph: -> (graph, static_input, static_output).
+        Replaying costs one launch instead of ~150: the step of a single chunk is launch-bound (host enqueue ~2 ms against
+        ~1.5 ms of GPU work).  Copy new chunks into ``static_input`` and ``graph.replay()``; the result is in ``static_output``.
+        Weights must not be re-packed afterwards (load_state_dict -> capture again)."""
+        static_in = input_raw.clone()
+        cur = torch.cuda.current_stream(self.device)
+        warm = torch.cuda.Stream(self.device)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):                                # warm-up off the capture stream: packs weights, sizes workspaces
+            for _ in range(2):
+                self.refine(static_in, query_scene, patch_mask=patch_mask)
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self.refine(static_in, query_scene, patch_mask=patch_mask)
+        return graph, static_in, static_out

@@ -116,7 +116,7 @@ class _PackedReady:
 
     def wait(self, device):
         st = torch.cuda.current_stream(device)
-        if st.cuda_stream not in self._ok_streams:
+        if st.cuda_stream not in self._ok_streams and not torch.cuda.is_current_stream_capturing():
             st.wait_event(self._event)
             self._ok_streams.add(st.cuda_stream)
 
@@ -301,21 +301,23 @@ def conv3d_up_gn_relu(src0, src1, aff, w_up_packed, cout):
                                            _p(stats), _stream()), 'rf_conv3d_up_k3_gn_relu')
     if timed:
         ev1.record()
-        # multiply-adds the kernel ISSUES: decoder form 27*c0 + 8*c1 per (voxel, cout) minus the zero-padding taps it leaves out.
-        # Position-major tilings leave out all of them (valid fraction ((3e-2)/(3e))^3 of the 27 taps and ((2h-1)/(2h))^3 of
-        # the 8 low-res taps, e = edge, h = edge/2 ... at 4^3: (1.5/2)^3); the parity-split boxes only the z-border ones
-        # (edge 4: 1/6 and 1/4; edge >= 8: 1/12 and 1/8 in the first / last box along z).
-        variant = lib.rf_conv3d_up_variant(c0, c1, n, edge, cout)
-        if variant == 2:
-            fa, fb = 1 - (22.0 / 24) ** 3, 1 - (7.0 / 8) ** 3
-        elif variant == 1:
-            fa, fb = 1 - (10.0 / 12) ** 3, 1 - (1.5 / 2) ** 3
-        else:
-            fa, fb = (1.0 / 6, 1.0 / 4) if edge == 4 else (1.0 / (12 * (edge // 8)), 1.0 / (8 * (edge // 8)))
-        conv_events.append((ev0, ev1, 2.0 * (27 * c0 * (1 - fa) + 8 * c1 * (1 - fb)) * cout * edge ** 3 * n))
+        conv_events.append((ev0, ev1, conv_up_issued_flops(c0, c1, n, edge, cout)))
     if stats is not None:
         out._rf_stats = (stats, tiles, out._version)
     return out
+
+
+def conv_up_issued_flops(c0, c1, n, edge, cout):
+    """multiply-adds rf_conv3d_up_k3_gn_relu ISSUES (x2 = flop): decoder form 27*c0 + 8*c1 per (voxel, cout) minus the
+    zero-padding taps it leaves out.  The position-major 4^3 tiling leaves out all of them (valid fraction (10/12)^3 of the 27
+    taps and (1.5/2)^3 of the 8 low-res taps); the parity-split boxes only the z-border ones (edge 4: 1/6 and 1/4; edge >= 8:
+    1/12 and 1/8 in the first / last box along z)."""
+    variant = _lib.load().rf_conv3d_up_variant(c0, c1, n, edge, cout)
+    if variant == 1:
+        fa, fb = 1 - (10.0 / 12) ** 3, 1 - (1.5 / 2) ** 3
+    else:
+        fa, fb = (1.0 / 6, 1.0 / 4) if edge == 4 else (1.0 / (12 * (edge // 8)), 1.0 / (8 * (edge // 8)))
+    return 2.0 * (27 * c0 * (1 - fa) + 8 * c1 * (1 - fb)) * cout * edge ** 3 * n
 
 
 def maxpool2(x):
@@ -557,7 +559,11 @@ def db_pack_embeddings(emb):
     return out
 
 
-def l2_topk(q, db_packed, n, row_base, k2):
+TOPK_AUTO, TOPK_VALU_SCAN, TOPK_MFMA_SCAN = 0, 1, 2
+
+
+def l2_topk(q, db_packed, n, row_base, k2, algo=TOPK_AUTO):
+    """exact squared-L2 top-k2 -> (dist [nq,k2] f32, idx [nq,k2] i64 global row ids); both scans return the same bits"""
     _req(q, 'q'), _req(db_packed, 'db_packed')
     nq, dim = q.shape
     lib = _lib.load()
@@ -565,7 +571,29 @@ def l2_topk(q, db_packed, n, row_base, k2):
     idx = torch.empty((nq, k2), dtype=torch.int64, device=q.device)
     nbytes = lib.rf_l2_topk_ws_bytes(nq, n, k2)
     ws = _workspace(q.device, nbytes)
-    _lib.check(lib.rf_l2_topk(_p(q), nq, dim, _p(db_packed), n, row_base, k2, _p(dist), _p(idx), _p(ws), ws.numel(), _stream()), 'rf_l2_topk')
+    _lib.check(lib.rf_l2_topk(_p(q), nq, dim, _p(db_packed), n, row_base, k2, algo, _p(dist), _p(idx), _p(ws), ws.numel(), _stream()), 'rf_l2_topk')
+    return dist, idx
+
+
+def l2_topk_keys(q, db_packed, n, row_base, k2, algo=TOPK_AUTO):
+    """the same search as packed keys [nq,k2] int64 (bit pattern: dist bits << 32 | global row id; -1 = no candidate)"""
+    _req(q, 'q'), _req(db_packed, 'db_packed')
+    nq, dim = q.shape
+    lib = _lib.load()
+    keys = torch.empty((nq, k2), dtype=torch.int64, device=q.device)
+    nbytes = lib.rf_l2_topk_ws_bytes(nq, n, k2)
+    ws = _workspace(q.device, nbytes)
+    _lib.check(lib.rf_l2_topk_keys(_p(q), nq, dim, _p(db_packed), n, row_base, k2, algo, _p(keys), _p(ws), ws.numel(), _stream()), 'rf_l2_topk_keys')
+    return keys
+
+
+def topk_merge_keys(key_parts):
+    """[parts, nq, k2] int64 packed keys -> (dist [nq,k2], idx [nq,k2]) best by (dist, row id)"""
+    _req(key_parts, 'key_parts', torch.int64)
+    parts, nq, k2 = key_parts.shape
+    dist = torch.empty((nq, k2), dtype=torch.float32, device=key_parts.device)
+    idx = torch.empty((nq, k2), dtype=torch.int64, device=key_parts.device)
+    _lib.check(_lib.load().rf_topk_merge_keys(_p(key_parts), parts, nq, k2, _p(dist), _p(idx), _stream()), 'rf_topk_merge_keys')
     return dist, idx
 
 

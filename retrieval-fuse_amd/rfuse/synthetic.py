@@ -115,7 +115,7 @@ def patch_boxes_64():
     return np.stack([x, x + 16, y, y + 16, z, z + 16], axis=1).astype(np.int32)
 
 
-def make_database(seed, config, n_patches, latent_dim=64, with_volumes=True):
+def make_database(seed, config, n_patches, latent_dim=64, with_volumes=True, with_embeddings=True):
     """Synthetic retrieval database with the reference's row semantics (util/retrieval.py:32,39-45):
 
       meta  [N+1,7] int32  (scene_idx, x0,x1,y0,y1,z0,z1)  un-padded 16^3 boxes; last row = sentinel (-1, 0,16,0,16,0,16)
@@ -132,10 +132,11 @@ def make_database(seed, config, n_patches, latent_dim=64, with_volumes=True):
     meta = np.concatenate([scene_idx[:, None], box_rows], axis=1)
     sentinel = np.array([[-1, 0, 16, 0, 16, 0, 16]], dtype=np.int32)
     meta = np.concatenate([meta, sentinel], axis=0).astype(np.int32)
-    emb = rng.standard_normal(size=(n_patches + 1, latent_dim)).astype(np.float32)
-    emb /= np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-12)
-    emb = emb.astype(np.float32)
-    out = {'meta': meta, 'emb': emb, 'n_scenes': n_scenes}
+    out = {'meta': meta, 'n_scenes': n_scenes}
+    if with_embeddings:
+        emb = rng.standard_normal(size=(n_patches + 1, latent_dim)).astype(np.float32)
+        emb /= np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-12)
+        out['emb'] = emb.astype(np.float32)
     if with_volumes:
         vols = np.empty((n_scenes, 64, 64, 64), dtype=np.float32)
         for s in range(n_scenes):

@@ -1,7 +1,10 @@
-"""CPU, world_size 2 over gloo: the sharded-database search protocol (rfuse.database.allgather_merge) -- all-gather
-of queries, per-shard top-2K with global row ids, all-gather of the candidate lists, per-rank merge -- gives every
-rank exactly the single-process result.  The local scan / merge are numpy stand-ins with the SAME contract as the
-HIP kernels (rf_l2_topk / rf_topk_merge), so what is tested here is the wiring that runs over RCCL on the GPUs."""
+"""CPU, world_size 2 over gloo: the sharded-database search exactly as the product runs it -- ``PatchDatabase.search`` /
+``retrieve`` -> ``sharded_search``: all-gather of queries, per-shard top-2K as packed 64-bit keys with global row ids, ONE
+all-gather of the keys, per-rank merge, same-scene demotion -- gives every rank exactly the single-process result.
+
+The scan / merge / demotion kernels are replaced AT THE BACKEND SEAM (rfuse.database.HipSearchBackend) by numpy stand-ins
+with the same contracts (test infrastructure, defined here), so what runs on the CPU is the product's own wiring that runs
+over RCCL on the GPUs.  tests/test_multigpu.py runs the same thing with the HIP backend on 2 GPUs when they exist."""
 import os
 import socket
 import sys
@@ -14,6 +17,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 REPO = Path(__file__).resolve().parents[1]
+NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def _free_port():
@@ -22,68 +26,129 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _np_topk(q, emb, row_base, k2):
-    d = ((q[:, None, :].astype(np.float64) - emb[None].astype(np.float64)) ** 2).sum(-1)
-    order = np.argsort(d, axis=1, kind='stable')[:, :k2]
-    dist_ = np.take_along_axis(d, order, 1).astype(np.float32)
-    idx = (order + row_base).astype(np.int64)
-    if emb.shape[0] < k2:                                   # contract: missing candidates are (inf, -1)
-        pad = k2 - emb.shape[0]
-        dist_ = np.concatenate([dist_, np.full((q.shape[0], pad), np.inf, np.float32)], 1)
-        idx = np.concatenate([idx, np.full((q.shape[0], pad), -1, np.int64)], 1)
-    return torch.from_numpy(dist_), torch.from_numpy(idx)
+class NumpySearchBackend:
+    """rf_l2_topk_keys / rf_topk_merge_keys / rf_demote_same_scene contracts in numpy (float64 distances rounded to fp32)."""
+
+    @staticmethod
+    def pack(emb_shard):
+        return emb_shard
+
+    @staticmethod
+    def _keys(q, emb, row_base, k2):
+        q, emb = q.numpy(), emb.numpy()
+        keys = np.full((q.shape[0], k2), NONE, dtype=np.uint64)
+        if emb.shape[0]:
+            d = ((q[:, None, :].astype(np.float64) - emb[None].astype(np.float64)) ** 2).sum(-1).astype(np.float32)
+            all_keys = (d.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.arange(emb.shape[0], dtype=np.uint64) + np.uint64(row_base))[None]
+            all_keys.sort(axis=1)
+            m = min(k2, emb.shape[0])
+            keys[:, :m] = all_keys[:, :m]
+        return keys
+
+    @classmethod
+    def topk_keys(cls, q, packed, n, row_base, k2):
+        return torch.from_numpy(cls._keys(q, packed, row_base, k2).view(np.int64))
+
+    @staticmethod
+    def _unpack(keys):
+        none = keys == NONE
+        d = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+        i = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        return torch.from_numpy(np.where(none, np.float32(np.inf), d)), torch.from_numpy(np.where(none, -1, i))
+
+    @classmethod
+    def topk(cls, q, packed, n, row_base, k2):
+        return cls._unpack(cls._keys(q, packed, row_base, k2))
+
+    @classmethod
+    def merge_keys(cls, key_parts):
+        k = key_parts.numpy().view(np.uint64)                           # [parts, nq, k2]
+        parts, nq, k2 = k.shape
+        flat = np.sort(k.transpose(1, 0, 2).reshape(nq, parts * k2), axis=1)[:, :k2]
+        return cls._unpack(flat)
+
+    @staticmethod
+    def demote(dist_, idx, meta, query_scene, K, query_keep):
+        sys.path.insert(0, str(REPO))
+        from oracle import refpath
+        idx_n, meta_n = idx.numpy(), meta.numpy()
+        rows = np.concatenate([np.where(idx_n[..., None] >= 0, meta_n[np.maximum(idx_n, 0)], np.array([-1, 0, 16, 0, 16, 0, 16])).astype(np.float32),
+                               dist_.numpy()[..., None]], axis=-1)
+        qs = query_scene.numpy() if query_scene is not None else np.full(idx_n.shape[0], -1)
+        out = refpath.demote_same_scene(rows, qs, K)
+        return torch.from_numpy(out[..., :7].astype(np.int32)), torch.from_numpy(out[..., 7].copy()), None
 
 
-def _np_merge(d_parts, i_parts):
-    parts, nq, k2 = d_parts.shape
-    d = d_parts.permute(1, 0, 2).reshape(nq, parts * k2).numpy()
-    i = i_parts.permute(1, 0, 2).reshape(nq, parts * k2).numpy()
-    key_i = np.where(i < 0, np.iinfo(np.int64).max, i)
-    order = np.lexsort((key_i, d), axis=1)[:, :k2]          # by (dist, idx), as the 64-bit key compare does
-    return torch.from_numpy(np.take_along_axis(d, order, 1)), torch.from_numpy(np.take_along_axis(i, order, 1))
+def _problem(n_rows, world, nq_local):
+    rng = np.random.default_rng(0)
+    emb = rng.standard_normal((n_rows, 64)).astype(np.float32)
+    if n_rows > 12:
+        emb[11] = emb[3]                                     # a tie inside a shard ... and one across shards:
+        emb[n_rows - 2] = emb[3]
+    q_all = rng.standard_normal((world * nq_local, 64)).astype(np.float32)
+    if n_rows > 12:
+        q_all[0] = emb[3]
+    meta = np.concatenate([np.repeat(np.arange((n_rows + 63) // 64), 64)[:n_rows, None], np.tile([0, 16, 0, 16, 0, 16], (n_rows, 1))], 1).astype(np.int32)
+    qscene = np.where(np.arange(world * nq_local) % 3 == 0, 0, -1).astype(np.int32)     # every third query comes from scene 0
+    return emb, meta, q_all, qscene
 
 
-def _worker(rank, world, port, n_rows, nq_local, k2, out_dir):
+def _worker(rank, world, port, n_rows, nq_local, K, out_dir, unequal):
     for p in (str(REPO), str(REPO / 'retrieval-fuse_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from rfuse.database import allgather_merge, shard_bounds
-    rng = np.random.default_rng(0)
-    emb = rng.standard_normal((n_rows, 64)).astype(np.float32)
-    emb[11] = emb[3]                                         # a tie across... the same shard; and one across shards:
-    emb[n_rows - 2] = emb[3]
-    q_all = rng.standard_normal((world * nq_local, 64)).astype(np.float32)
-    q_all[0] = emb[3]
-    lo, hi = shard_bounds(n_rows, rank, world)
-    q_local = torch.from_numpy(q_all[rank * nq_local:(rank + 1) * nq_local])
-    d, i = allgather_merge(q_local, lambda qa: _np_topk(qa.numpy(), emb[lo:hi], lo, k2), _np_merge, k2)
-    np.savez(Path(out_dir) / f'rank{rank}.npz', d=d.numpy(), i=i.numpy())
+    from rfuse.database import PatchDatabase
+    emb, meta, q_all, qscene = _problem(n_rows, world, nq_local)
+    db = PatchDatabase(emb, meta, np.zeros((1, 64, 64, 64), np.float32), 'cpu', rank, world, None, backend=NumpySearchBackend)
+    sl = slice(rank * nq_local, (rank + 1) * nq_local)
+    q_local = torch.from_numpy(q_all[sl])
+    if unequal:
+        try:
+            db.search(q_local[: nq_local - rank], 2 * K)
+            msg = 'no error'
+        except ValueError as e:
+            msg = str(e)
+        Path(out_dir, f'rank{rank}.txt').write_text(msg)
+    else:
+        d, i = db.search(q_local, 2 * K)
+        m, dd, _ = db.retrieve(q_local, K, torch.from_numpy(qscene[sl]))
+        np.savez(Path(out_dir) / f'rank{rank}.npz', d=d.numpy(), i=i.numpy(), meta=m.numpy(), dk=dd.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_rows,nq_local,k2', [(1001, 64, 8), (13, 5, 8)])
-def test_sharded_search_world2_equals_single_process(tmp_path, n_rows, nq_local, k2):
+@pytest.mark.parametrize('n_rows,nq_local,K', [(1001, 64, 4), (13, 5, 4), (1, 3, 4)])
+def test_sharded_search_world2_equals_single_process(tmp_path, n_rows, nq_local, K):
+    """(1 row, 2 ranks): rank 1's shard is EMPTY -- it contributes all-NONE lists."""
     world = 2
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, n_rows, nq_local, k2, str(tmp_path)), nprocs=world, join=True)
-    rng = np.random.default_rng(0)
-    emb = rng.standard_normal((n_rows, 64)).astype(np.float32)
-    emb[11] = emb[3]
-    emb[n_rows - 2] = emb[3]
-    q_all = rng.standard_normal((world * nq_local, 64)).astype(np.float32)
-    q_all[0] = emb[3]
-    d_ref, i_ref = _np_topk(q_all, emb, 0, k2)
+    mp.spawn(_worker, args=(world, _free_port(), n_rows, nq_local, K, str(tmp_path), False), nprocs=world, join=True)
+    sys.path.insert(0, str(REPO / 'retrieval-fuse_amd'))
+    emb, meta, q_all, qscene = _problem(n_rows, world, nq_local)
+    B = NumpySearchBackend
+    d_ref, i_ref = B.topk(torch.from_numpy(q_all), torch.from_numpy(emb), n_rows, 0, 2 * K)
+    m_ref, dk_ref, _ = B.demote(d_ref, i_ref, torch.from_numpy(meta), torch.from_numpy(qscene), K, None)
     for rank in range(world):
         z = np.load(tmp_path / f'rank{rank}.npz')
         sl = slice(rank * nq_local, (rank + 1) * nq_local)
         np.testing.assert_array_equal(z['i'], i_ref.numpy()[sl])
         np.testing.assert_array_equal(z['d'], d_ref.numpy()[sl])
+        np.testing.assert_array_equal(z['meta'], m_ref.numpy()[sl])
+        np.testing.assert_array_equal(z['dk'], dk_ref.numpy()[sl])
     z0 = np.load(tmp_path / 'rank0.npz')
     if n_rows > 100:
         assert z0['i'][0, :3].tolist() == [3, 11, n_rows - 2], 'ties must resolve to the lower global row id across shards'
+        assert (z0['meta'][0, :, 0] != 0).all(), 'query 0 comes from scene 0: its same-scene neighbours are demoted'
+    if n_rows == 1:
+        assert (z0['i'][:, 0] == 0).all() and (z0['i'][:, 1:] == -1).all()
+
+
+def test_unequal_query_counts_are_refused(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), 100, 6, 4, str(tmp_path), True), nprocs=world, join=True)
+    for rank in range(world):
+        assert 'same number of queries' in (tmp_path / f'rank{rank}.txt').read_text()
 
 
 def test_shard_bounds_cover_rows_exactly():

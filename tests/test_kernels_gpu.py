@@ -457,8 +457,10 @@ def check_topk(idx_got, dist_got, q, emb, k2, row_base=0):
     return exact / (nq * n_valid)
 
 
-@pytest.mark.parametrize('n,nq,k2', [(1000, 64, 8), (50_001, 128, 8), (4097, 70, 16), (5, 3, 8), (64, 1, 8)])
-def test_l2_topk(ops, n, nq, k2):
+@pytest.mark.parametrize('algo', [1, 2])
+@pytest.mark.parametrize('n,nq,k2', [(1000, 64, 8), (50_001, 128, 8), (4097, 70, 16), (5, 3, 8), (64, 1, 8), (131, 300, 8)])
+def test_l2_topk(ops, n, nq, k2, algo):
+    """both scans (1 = VALU, every pair exact; 2 = MFMA dot-product filter + exact re-check) against the float64 oracle"""
     rng = np.random.default_rng(n + nq)
     emb = rng.standard_normal((n, 64)).astype(np.float32)
     emb /= np.linalg.norm(emb, axis=1, keepdims=True)
@@ -469,7 +471,7 @@ def test_l2_topk(ops, n, nq, k2):
         emb[9] = emb[4]                                         # an exact tie: lower row id must win
         q[1 % nq] = emb[4]
     packed = ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV))
-    dist, idx = ops.l2_topk(torch.from_numpy(q).to(DEV), packed, n, 0, k2)
+    dist, idx = ops.l2_topk(torch.from_numpy(q).to(DEV), packed, n, 0, k2, algo)
     frac = check_topk(idx, dist, q, emb, k2)
     assert frac > 0.999
     if n < k2:
@@ -479,22 +481,94 @@ def test_l2_topk(ops, n, nq, k2):
         assert row[0] == 4 and row[1] == 9
 
 
-def test_sharded_topk_merge_equals_single_scan(ops):
+@pytest.mark.parametrize('n,nq,k2,kind', [(20_000, 200, 8, 'unit'), (70_001, 64, 16, 'unit'), (30_000, 100, 8, 'dups'), (9_000, 130, 8, 'big'),
+                                          (300_000, 512, 8, 'unit')])
+def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind):
+    """The matrix-core dot product only FILTERS; every survivor is re-evaluated with the one exact distance of the path, so the
+    MFMA scan must return the same bits (distances and row ids) as the VALU scan that evaluates every pair exactly -- on unit
+    vectors, on a database full of duplicate rows (ties at the list threshold, lower row id wins), and on rows of very
+    different norms (the filter margin scales with |q|^2 + |x|^2).  Also through the packed-key outputs."""
+    rng = np.random.default_rng(n + nq)
+    emb = rng.standard_normal((n, 64)).astype(np.float32)
+    q = rng.standard_normal((nq, 64)).astype(np.float32)
+    if kind != 'big':
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    else:
+        emb *= (10.0 ** rng.uniform(-2, 2, size=(n, 1))).astype(np.float32)
+        q *= (10.0 ** rng.uniform(-1, 1, size=(nq, 1))).astype(np.float32)
+    if kind == 'dups':
+        emb[rng.integers(0, n, size=n // 2)] = emb[17]          # half the database is one row: massive ties
+        emb[n // 3: n // 3 + 3000] = emb[5]
+        q[0], q[1] = emb[17], emb[5]
+        q[2] = emb[17] + 1e-4 * rng.standard_normal(64).astype(np.float32)
+    qd = torch.from_numpy(q).to(DEV)
+    packed = ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV))
+    d1, i1 = ops.l2_topk(qd, packed, n, 1000, k2, ops.TOPK_VALU_SCAN)
+    d2, i2 = ops.l2_topk(qd, packed, n, 1000, k2, ops.TOPK_MFMA_SCAN)
+    assert torch.equal(i1, i2), f'{(i1 != i2).sum().item()} row ids differ'
+    assert torch.equal(d1, d2)
+    keys = ops.l2_topk_keys(qd, packed, n, 1000, k2, ops.TOPK_MFMA_SCAN)
+    assert torch.equal(keys & 0xffffffff, i1) and torch.equal((keys >> 32).to(torch.int32).view(torch.float32), d1)
+    dm, im = ops.topk_merge_keys(keys[None].contiguous())
+    assert torch.equal(im, i1) and torch.equal(dm, d1)
+    if kind == 'dups':
+        dup_rows = np.sort(np.where((emb == emb[17]).all(axis=1))[0])[:k2] + 1000
+        assert i1[0].cpu().tolist() == dup_rows.tolist()         # ties resolved towards the lower row id
+
+
+@pytest.mark.parametrize('algo', [1, 2])
+def test_sharded_topk_merge_equals_single_scan(ops, algo):
     rng = np.random.default_rng(1)
     n, nq, k2, shards = 10_000, 96, 8, 4
     emb = rng.standard_normal((n, 64)).astype(np.float32)
     emb /= np.linalg.norm(emb, axis=1, keepdims=True)
     q = rng.standard_normal((nq, 64)).astype(np.float32)
     qd = torch.from_numpy(q).to(DEV)
-    full_d, full_i = ops.l2_topk(qd, ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV)), n, 0, k2)
+    full_d, full_i = ops.l2_topk(qd, ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV)), n, 0, k2, algo)
     from rfuse.database import shard_bounds
-    ds, is_ = [], []
+    ds, is_, ks = [], [], []
     for r in range(shards):
         lo, hi = shard_bounds(n, r, shards)
-        d, i = ops.l2_topk(qd, ops.db_pack_embeddings(torch.from_numpy(emb[lo:hi]).to(DEV)), hi - lo, lo, k2)
-        ds.append(d), is_.append(i)
+        packed = ops.db_pack_embeddings(torch.from_numpy(emb[lo:hi]).to(DEV))
+        d, i = ops.l2_topk(qd, packed, hi - lo, lo, k2, 3 - algo)        # the shards with the OTHER scan: same bits
+        ds.append(d), is_.append(i), ks.append(ops.l2_topk_keys(qd, packed, hi - lo, lo, k2, algo))
     md, mi = ops.topk_merge(torch.stack(ds), torch.stack(is_))
     assert torch.equal(mi, full_i) and torch.equal(md, full_d)
+    md, mi = ops.topk_merge_keys(torch.stack(ks))
+    assert torch.equal(mi, full_i) and torch.equal(md, full_d)
+
+
+def test_topk_million_row_database(ops):
+    """BASELINE config 3's database size on one device: 1 000 001 rows, 2048 queries (a 32-chunk batch).  A 256-query subset is
+    checked against the float64 oracle; the single scan must equal the merge of 8 shard scans (what 8 GPUs exchange)."""
+    n, nq, k2 = 1_000_001, 2048, 8
+    g = torch.Generator(device=DEV).manual_seed(7)
+    emb = torch.randn(n, 64, generator=g, device=DEV)
+    emb = emb / emb.norm(dim=1, keepdim=True)
+    q = torch.randn(nq, 64, generator=g, device=DEV)
+    q = q / q.norm(dim=1, keepdim=True)
+    q[3] = emb[n - 1]                                            # the very last row is reachable
+    packed = ops.db_pack_embeddings(emb)
+    dist, idx = ops.l2_topk(q, packed, n, 0, k2)
+    assert idx[3, 0].item() == n - 1 and dist[3, 0].item() == 0.0
+    sub = torch.arange(0, nq, 8, device=DEV)
+    d64 = torch.cdist(q[sub].double(), emb.double()) ** 2        # float64 brute force on the device (oracle arithmetic, knn_exact)
+    ref_d, ref_i = torch.topk(d64, k2, dim=1, largest=False, sorted=True)
+    got_i, got_d = idx[sub], dist[sub]
+    same = got_i == ref_i
+    # where the order differs the float64 gap must be below fp32 resolution (near-tie), as in check_topk
+    gap = (torch.gather(d64, 1, got_i) - ref_d).abs()
+    assert (same | (gap < 1e-6)).all()
+    assert same.float().mean().item() > 0.999
+    assert (got_d.double() - ref_d).abs().max().item() < 1e-5
+    from rfuse.database import shard_bounds
+    ks = []
+    for r in range(8):
+        lo, hi = shard_bounds(n, r, 8)
+        ks.append(ops.l2_topk_keys(q, ops.db_pack_embeddings(emb[lo:hi].contiguous()), hi - lo, lo, k2))
+    md, mi = ops.topk_merge_keys(torch.stack(ks))
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
 
 
 def test_demote_and_gather_match_oracle(ops):
