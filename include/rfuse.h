@@ -111,6 +111,16 @@ int rf_conv3d_valid_leaky_mfma(const float* x, int n, int cin, int s, const floa
 int rf_convv_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream);
 size_t rf_convv_packed_floats(int cout, int cin, int k);
 
+/* The same layer as an LDS-staged implicit GEMM for the LARGE layers (output edge >= 8: the first four layers of PCPatch48 /
+ * Patch32, model/retrieval.py:221-228, 8-15): whole output rows per workgroup, the input tile of <= 2 channels staged in LDS,
+ * K walked in groups of four taps of one channel.  rf_conv3d_valid_lds_supported: 1 when this form takes the shape, else use
+ * rf_conv3d_valid_leaky_mfma.  w_packed: rf_convv_lds_pack_weight image [cin][ceil(k^3/4)][4][cout -> 16]. */
+int rf_conv3d_valid_lds_supported(int n, int cin, int s, int cout, int k, int stride);
+int rf_conv3d_valid_leaky_lds(const float* x, int n, int cin, int s, const float* w_packed, const float* bias, int cout, int k,
+                              int stride, float slope, float* out, void* stream);
+int rf_convv_lds_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream);
+size_t rf_convv_lds_packed_floats(int cout, int cin, int k);
+
 /* rf_conv3d_k3_gn_relu with the encoder's MaxPool3d(2) (model/unet.py:230-253) fused into the epilogue: additionally
  * writes pool_out [n][cout][(edge/2)^3] = maxpool2(out) and, when pool_stats is non-NULL, its (sum, sum of squares)
  * [n][cout][rf_conv3d_stats_tiles(...)][2] for rf_gn_from_stats.  out == NULL: only the pooled tensor is written (an

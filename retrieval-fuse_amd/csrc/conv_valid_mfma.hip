@@ -190,3 +190,325 @@ extern "C" int rf_conv3d_valid_leaky_mfma(const float* x, int n, int cin, int s,
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_mfma");
     return RF_OK;
 }
+
+// ====================================================================================================================
+// LDS-staged form for the LARGE layers of the patch encoders (output edge >= 8: PCPatch48's 1->12 k5 @48^3, 12->24 k3 @44^3,
+// 24->48 k3 s2 @42^3, 48->48 k3 s2 @20^3; Patch32's first four layers) -- the gather form above re-reads every input value
+// k^3 * cout/16 times through L1/L2 and tops out at 30-50 TFLOP/s on them.
+//
+//   * workgroup (8 waves x MB 4 m-blocks = 512 output voxels) = tz x ty whole output rows of one window (x runs over the full
+//     row, so any edge -- 44, 42, 20, 9 -- tiles without a ragged x border; the host picks (tz, ty) for the least waste) and
+//     NB <= 3 cout blocks; M index = linear voxel of the tile, so an m-block may wrap rows: a lane's LDS base is computed once.
+//   * K is walked channel by channel in groups of FOUR TAPS (k^3 padded up to a multiple of 4 with zero-weight taps: 27 -> 28,
+//     125 -> 128, 8, 64): one MFMA k-step multiplies 4 taps of one channel.  That keeps only CC <= 2 channels of the input tile
+//     in LDS at a time (a stride-2 layer's tile is (2 tz + 1)(2 ty + 1) rows: 4 channels would not fit) and makes cin = 1 the same
+//     code path.  The 4 lane groups of an A operand read base + tapoff[4 g + kq] (table in LDS).
+//   * input rows and the chunk's weight rows [cc][g][kq][cout] are loaded into registers before the MFMA loop of the previous
+//     chunk and committed to LDS after it (one LDS buffer, two barriers per chunk); operand reads are double buffered in
+//     registers as in conv3d_mfma.hip.
+// Weight image: rf_convv_lds_pack_weight -> [cin][G = ceil(k^3/4)][4][cout16].
+struct ConvVLArgs {
+    const float* x;
+    const float* wp;
+    const float* bias;
+    float* out;
+    int n, cin, s, cout, cout16, k, stride, so;
+    float slope;
+    int tz, ty, ntz, nty, gz;      // output rows per tile, tiles per dim, cout blocks
+    int zi, yi, ch;                // staged input rows per channel (z, y extents), LDS floats per channel
+    int G;                         // tap groups per channel
+    int P, seg;                    // threads per staged input row, floats per thread
+};
+
+__global__ void k_convv_lds_pack(const float* __restrict__ w, int cout, int cin, int k3, int G, int cout16, float* __restrict__ wp) {
+    const size_t total = (size_t)cin * G * 4 * cout16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout16);
+        const int tap = (int)((i / cout16) % (4 * G));
+        const int ci = (int)(i / ((size_t)cout16 * 4 * G));
+        wp[i] = (co < cout && tap < k3) ? w[((size_t)co * cin + ci) * k3 + tap] : 0.f;
+    }
+}
+
+extern "C" size_t rf_convv_lds_packed_floats(int cout, int cin, int k) {
+    return (size_t)cin * ((k * k * k + 3) / 4) * 4 * rf_round_up(cout, 16);
+}
+
+extern "C" int rf_convv_lds_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream) {
+    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && cin > 0 && k > 0, RF_E_INVALID, "rf_convv_lds_pack_weight: bad arguments");
+    const size_t want = (rf_convv_lds_packed_floats(cout, cin, k) + 255) / 256;
+    hipLaunchKernelGGL(k_convv_lds_pack, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin, k * k * k,
+                       (k * k * k + 3) / 4, rf_round_up(cout, 16), w_packed);
+    RF_CHECK_LAUNCH("rf_convv_lds_pack_weight");
+    return RF_OK;
+}
+
+#define RF_VL_SEG 24          // staged floats per thread (one segment of one input row)
+template <int NB, int CC>
+__global__ __launch_bounds__(512) void k_convv_lds(ConvVLArgs a) {
+    constexpr int NT = 512, MB = 4, NCO = NB * 16;
+    constexpr int WS = NCO + ((NCO % 32) == 0 ? 16 : 0);           // weight row stride: the 4 k rows of a B read sit on different banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int so = a.so, s = a.s, st = a.stride, G = a.G;
+    float* xs = smem;                                               // [CC][ch]
+    float* wsl = xs + CC * a.ch;                                    // [CC][G][4][WS]
+    int* toff = reinterpret_cast<int*>(wsl + CC * G * 4 * WS);      // [G * 4]
+
+    // XCD-aware 1-D grid as in the gather form: an XCD walks whole windows (tiles fastest, then cout blocks)
+    const unsigned total = gridDim.x, per = total >> 3, rem = total & 7u, xk = blockIdx.x & 7u;
+    const unsigned lb = xk * per + (xk < rem ? xk : rem) + (blockIdx.x >> 3);
+    const unsigned tiles = (unsigned)(a.ntz * a.nty);
+    const unsigned tb = lb % tiles, zb = (lb / tiles) % (unsigned)a.gz;
+    const int nn = (int)(lb / (tiles * (unsigned)a.gz));
+    const int z0 = (int)(tb / (unsigned)a.nty) * a.tz, y0 = (int)(tb % (unsigned)a.nty) * a.ty;
+    const int cob = (int)zb * NCO;
+    const int V = a.tz * a.ty * so;
+
+    // this lane's output voxels: m-block (wave*MB + mb), voxel j -> LDS base of its (z, y, x) corner
+    int base[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        int m = (wave * MB + mb) * 16 + j;
+        if (m >= V) m = 0;                                          // computed, never stored
+        const int x = m % so, r = m / so, ly = r % a.ty, lz = r / a.ty;
+        base[mb] = ((lz * st) * a.yi + ly * st) * s + x * st;
+    }
+    for (int i = tid; i < G * 4; i += NT) {
+        int t = i < a.k * a.k * a.k ? i : 0;                        // zero-weight pad taps read tap 0
+        toff[i] = ((t / (a.k * a.k)) * a.yi + (t / a.k) % a.k) * s + t % a.k;
+    }
+
+    // ---- staging: one (input row, segment) item per thread
+    const size_t ivol = (size_t)s * s * s;
+    const float* xin = a.x + (size_t)nn * a.cin * ivol;
+    const int rows_c = a.zi * a.yi;                                 // rows per channel
+    const int item_row = tid / a.P, item_p = tid % a.P;
+    const int it_c = item_row / rows_c, it_r = item_row % rows_c;
+    const int it_z = it_r / a.yi, it_y = it_r % a.yi;
+    const int iz = z0 * st + it_z, iy = y0 * st + it_y, ix = item_p * a.seg;
+    const bool it_inside = iz < s && iy < s;                        // rows past the volume (ragged last tile) are staged as zeros
+    int it_cnt = it_c < CC ? s - ix : 0;                            // floats of this thread's segment
+    if (it_cnt > a.seg) it_cnt = a.seg;
+    if (it_cnt < 0) it_cnt = 0;
+    const float* it_src = xin + (size_t)it_c * ivol + ((size_t)iz * s + iy) * s + ix;
+    float* it_dst = xs + it_c * a.ch + (it_z * a.yi + it_y) * s + ix;
+    float stage[RF_VL_SEG];
+    float4 wstage[2];
+    const int wrow_f4 = NCO / 4;                                    // float4 per weight row
+    const int wtotal = CC * G * 4 * wrow_f4;                        // float4 of a chunk's slab (unpadded rows)
+
+    auto issue = [&](int c0) {
+        if (it_inside && c0 + it_c < a.cin) {
+            const float* src = it_src + (size_t)c0 * ivol;
+#pragma unroll
+            for (int i = 0; i < RF_VL_SEG; ++i) if (i < it_cnt) stage[i] = src[i];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f = tid + h * NT;
+            if (f < wtotal) {
+                const int row = f / wrow_f4, c4 = f % wrow_f4;      // row = (cc*G + g)*4 + kq
+                const int cc = row / (G * 4);
+                int co = cob + c4 * 4;
+                if (co >= a.cout16) co = 0;                          // block wider than the image: masked at the store
+                wstage[h] = (c0 + cc < a.cin) ? *reinterpret_cast<const float4*>(a.wp + ((size_t)c0 * G * 4 + row) * a.cout16 + co)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto commit = [&](int c0) {
+        const bool real = it_inside && c0 + it_c < a.cin;
+#pragma unroll
+        for (int i = 0; i < RF_VL_SEG; ++i) if (i < it_cnt) it_dst[i] = real ? stage[i] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f = tid + h * NT;
+            if (f < wtotal) {
+                const int row = f / wrow_f4, c4 = f % wrow_f4;
+                *reinterpret_cast<float4*>(wsl + row * WS + c4 * 4) = wstage[h];
+            }
+        }
+    };
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    commit(0);
+    __syncthreads();
+    const float* wl = wsl + kq * WS + j;
+    for (int c0 = 0; c0 < a.cin; c0 += CC) {
+        const bool more = c0 + CC < a.cin;
+        if (more) issue(c0 + CC);
+        const int ccn = a.cin - c0 < CC ? a.cin - c0 : CC;
+        const int nst = ccn * G;                                    // k-steps of this chunk: (cc, g)
+        float av[2][MB], bv[2][NB];
+        {
+            const int to = toff[kq];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[base[mb] + to];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[0][nb] = wl[nb * 16];
+        }
+        int g1 = 0, cc1 = 0;                                        // (cc, g) of the step being prefetched
+        for (int t = 0; t < nst; t += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (t + h < nst) {
+                    asm volatile("" ::: "memory");
+                    if (++g1 == G) { g1 = 0; ++cc1; }
+                    if (t + h + 1 < nst) {
+                        const int to = toff[g1 * 4 + kq];
+                        const float* xc = xs + cc1 * a.ch + to;
+                        const float* wc = wl + (cc1 * G + g1) * 4 * WS;
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) av[h ^ 1][mb] = xc[base[mb]];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) bv[h ^ 1][nb] = wc[nb * 16];
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][mb], bv[h][nb], acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) commit(c0 + CC);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + LeakyReLU, then through LDS so that the stores are long contiguous runs.  The tile is tz planes of
+    // ty whole rows: in memory, for one cout and one z, ty * so consecutive floats.  A lane holds 4 consecutive linear voxels of
+    // one cout (16-byte LDS write); per cout block the 8 waves then each stream two cout rows out, lane = consecutive voxel.
+    // (Direct stores from the accumulator layout are 4-byte pieces scattered over 16 cout planes: the 1->12 k5 and 12->24 k3
+    // layers of PCPatch48 write 4.2 / 7.3 GB and were store-bound.)
+    constexpr int EV = 512 + 4;                                     // floats per cout row of the epilogue tile
+    float* eb = smem;                                               // [16][EV]; the K loop ended on a barrier
+    const int ovol = so * so * so;
+    const int R = a.ty * so;                                        // floats of one z plane of the tile
+    int zlim = so - z0;                                             // valid planes / rows of a ragged last tile
+    if (zlim > a.tz) zlim = a.tz;
+    int ylim = so - y0;
+    if (ylim > a.ty) ylim = a.ty;
+    const int mlim = zlim * R, rlim = ylim * so;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        {
+            const int co = cob + nb * 16 + j;
+            const float bz = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 v = acc[mb][nb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float t = v[r] + bz; v[r] = t > 0.f ? t : t * a.slope; }
+                *reinterpret_cast<f32x4*>(eb + j * EV + (wave * MB + mb) * 16 + kq * 4) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = wave * 2 + h, co = cob + nb * 16 + col;
+            if (co < a.cout) {                                      // wave-uniform
+                float* o = a.out + ((size_t)nn * a.cout + co) * ovol + ((size_t)z0 * so + y0) * so;
+                const float* src = eb + col * EV;
+                int mr = lane, lz = 0;                              // m = lz * R + mr
+                while (mr >= R) { mr -= R; ++lz; }
+                for (int m = lane; m < mlim; m += 64) {
+                    if (mr < rlim) o[(size_t)lz * so * so + mr] = src[m];
+                    mr += 64;
+                    while (mr >= R) { mr -= R; ++lz; }
+                }
+            }
+        }
+        if (nb + 1 < NB) __syncthreads();
+    }
+}
+
+// tile choice: (tz, ty) output rows with tz*ty*so <= 512 voxels, <= 512 staged rows per chunk, segments <= RF_VL_SEG floats and
+// the chunk within the LDS budget; among those the one that wastes the fewest MFMA slots (ragged last tiles + unfilled m-blocks)
+static bool convv_lds_plan(int n, int cin, int s, int cout, int k, int stride, ConvVLArgs& a, int& cc_out, size_t& lds_out) {
+    const int so = (s - k) / stride + 1;
+    if (so < 8 || k > 5 || s > 64) return false;
+    const int cout16 = rf_round_up(cout, 16);
+    const int G = (k * k * k + 3) / 4;
+    const int nbw = cout16 <= 48 ? cout16 / 16 : (cout16 % 48 == 0 ? 3 : 2);     // cout blocks per workgroup
+    const int CC = cin >= 2 ? 2 : 1;
+    double best = 0.0;
+    for (int tz = 1; tz <= so; ++tz)
+        for (int ty = 1; ty <= so; ++ty) {
+            const int V = tz * ty * so;
+            if (V > 512) continue;
+            const int zi = (tz - 1) * stride + k, yi = (ty - 1) * stride + k;
+            const int rows = CC * zi * yi;
+            if (rows > 512) continue;
+            const int P = 512 / rows < 16 ? 512 / rows : 16;
+            const int seg = (s + P - 1) / P;
+            if (seg > RF_VL_SEG) continue;
+            const int ch = zi * yi * s;
+            const int ws = nbw * 16 + ((nbw * 16) % 32 == 0 ? 16 : 0);
+            size_t lds = ((size_t)CC * ch + (size_t)CC * G * 4 * ws + (size_t)G * 4) * sizeof(float);
+            if (lds < (size_t)16 * (512 + 4) * sizeof(float)) lds = (size_t)16 * (512 + 4) * sizeof(float);     // the epilogue tile
+            if (lds > 72 * 1024) continue;                          // two workgroups per CU
+            if ((size_t)CC * G * 4 * (nbw * 16 / 4) > 1024) continue;   // weight slab: two float4 per thread
+            const int ntz = (so + tz - 1) / tz, nty = (so + ty - 1) / ty;
+            const double eff = (double)so * so * so / ((double)ntz * nty * 512.0);
+            if (eff > best) {
+                best = eff;
+                a.tz = tz; a.ty = ty; a.ntz = ntz; a.nty = nty; a.zi = zi; a.yi = yi; a.ch = ch; a.P = P; a.seg = seg;
+                lds_out = lds;
+            }
+        }
+    if (best < 0.5) return false;
+    a.n = n; a.cin = cin; a.s = s; a.cout = cout; a.cout16 = cout16; a.k = k; a.stride = stride; a.so = so; a.G = G;
+    a.gz = (cout16 + nbw * 16 - 1) / (nbw * 16);
+    cc_out = CC * 10 + nbw;
+    return true;
+}
+
+extern "C" int rf_conv3d_valid_lds_supported(int n, int cin, int s, int cout, int k, int stride) {
+    ConvVLArgs a;
+    int v;
+    size_t lds;
+    return n > 0 && cin > 0 && cout > 0 && k > 0 && stride > 0 && s >= k && convv_lds_plan(n, cin, s, cout, k, stride, a, v, lds) ? 1 : 0;
+}
+
+extern "C" int rf_conv3d_valid_leaky_lds(const float* x, int n, int cin, int s, const float* w_packed, const float* bias, int cout, int k,
+                                         int stride, float slope, float* out, void* stream) {
+    RF_REQUIRE(x && w_packed && out && n > 0 && cin > 0 && cout > 0 && k > 0 && stride > 0 && s >= k, RF_E_INVALID,
+               "rf_conv3d_valid_leaky_lds: bad arguments");
+    ConvVLArgs a;
+    int variant;
+    size_t lds;
+    RF_REQUIRE(convv_lds_plan(n, cin, s, cout, k, stride, a, variant, lds), RF_E_UNSUPPORTED,
+               "rf_conv3d_valid_leaky_lds: shape not taken by the LDS-staged form (ask rf_conv3d_valid_lds_supported; use rf_conv3d_valid_leaky_mfma)");
+    a.x = x; a.wp = w_packed; a.bias = bias; a.out = out; a.slope = slope;
+    const unsigned grid = (unsigned)a.ntz * a.nty * a.gz * n;
+    hipStream_t st = (hipStream_t)stream;
+#define RF_VL_LAUNCH(NB_, CC_)                                                                                                   \
+    do {                                                                                                                         \
+        if (lds > 65536) {                                                                                                       \
+            static RfLdsOptIn opt_in;                                                                                            \
+            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_lds<NB_, CC_>), (int)lds, "rf_conv3d_valid_leaky_lds")) return rc; \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((k_convv_lds<NB_, CC_>), dim3(grid), dim3(512), lds, st, a);                                          \
+    } while (0)
+    switch (variant) {
+        case 11: RF_VL_LAUNCH(1, 1); break;
+        case 12: RF_VL_LAUNCH(2, 1); break;
+        case 13: RF_VL_LAUNCH(3, 1); break;
+        case 21: RF_VL_LAUNCH(1, 2); break;
+        case 22: RF_VL_LAUNCH(2, 2); break;
+        default: RF_VL_LAUNCH(3, 2); break;
+    }
+#undef RF_VL_LAUNCH
+    RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_lds");
+    return RF_OK;
+}

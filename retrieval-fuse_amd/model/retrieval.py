@@ -8,7 +8,8 @@ so ``model.get_retrieval_networks`` (reference model/__init__.py:6-38) keeps wor
   MLP family   (Patch04 :64-84, Patch05 :87-107, Patch04V2 :110-132): rf_linear (fp32 MFMA) with fused ReLU
   conv family  (Patch08 :136-156, Patch12 :364-388, Patch16 :277-303, Patch24 :306-332, Patch24V2 :335-361,
                 Patch32 :4-28, PCPatch32 :187-213, PCPatch48 :217-243, PCPatch64 :247-273):
-                rf_conv3d_valid_leaky_mfma (valid strided conv + bias + LeakyReLU 0.2, fp32 MFMA) then rf_linear for final_layer
+                rf_conv3d_valid_leaky_lds (large layers: LDS-staged) / rf_conv3d_valid_leaky_mfma (small ones: gather form) -- valid
+                strided conv + bias + LeakyReLU 0.2 on the fp32 matrix cores -- then rf_linear for final_layer
 
 The two BatchNorm variants (PatchNorm08 :160-184, PatchNorm32 :31-61) construct and serialise identically but their
 forward is not built: no shipped config selects them.
@@ -90,7 +91,10 @@ class _ConvPatchEncoder(nn.Module):
         x = x.contiguous()
         for layer in self.layers:
             if isinstance(layer, Conv3dParams):
-                x = ops.conv3d_valid_leaky_mfma(x, layer.packed(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
+                if ops.conv_valid_lds_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
+                    x = ops.conv3d_valid_leaky_lds(x, layer.packed_lds(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
+                else:
+                    x = ops.conv3d_valid_leaky_mfma(x, layer.packed(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
         if tuple(x.shape[2:]) != (1, 1, 1):
             raise ValueError(f'{type(self).__name__}: input window does not reduce to 1^3 (got {tuple(x.shape[2:])})')
         x = self.final_layer.apply_to(x.reshape(x.shape[0], x.shape[1]))

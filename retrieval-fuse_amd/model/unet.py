@@ -49,6 +49,7 @@ class Conv3dParams(nn.Module):
         self.reset_parameters()
         self._packed = ops.PackedWeight('conv3' if (kernel_size == 3 and padding == 1) else 'convv')
         self._packed_up = ops.PackedWeight('conv3up')
+        self._packed_lds = ops.PackedWeight('convvl')
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -59,6 +60,10 @@ class Conv3dParams(nn.Module):
 
     def packed(self):
         return self._packed.get(self.weight)
+
+    def packed_lds(self):
+        """operand image of the LDS-staged valid-conv form (patch encoders' large layers)"""
+        return self._packed_lds.get(self.weight)
 
     def packed_up(self, c0):
         """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""

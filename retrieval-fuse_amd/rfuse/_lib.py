@@ -40,6 +40,10 @@ SIGNATURES = {
     'rf_conv3d_valid_leaky_mfma': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
     'rf_convv_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_convv_packed_floats': (c_sz, [c_i, c_i, c_i]),
+    'rf_conv3d_valid_lds_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_valid_leaky_lds': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_convv_lds_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_convv_lds_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_pool_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_k3_gn_relu_pool': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_conv3_up_packed_floats': (c_sz, [c_i, c_i, c_i]),

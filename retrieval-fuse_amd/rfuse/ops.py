@@ -91,7 +91,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -364,6 +364,34 @@ def conv3d_valid_leaky_mfma(x, w_packed, bias, cout, k, stride, slope):
     out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().rf_conv3d_valid_leaky_mfma(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
                                                       stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_mfma')
+    return out
+
+
+def pack_convv_lds_weight(w):
+    _req(w.detach(), 'conv weight')
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    lib = _lib.load()
+    out = torch.empty(lib.rf_convv_lds_packed_floats(cout, cin, k), dtype=torch.float32, device=w.device)
+    _lib.check(lib.rf_convv_lds_pack_weight(_p(w.detach()), cout, cin, k, _p(out), _stream()), 'rf_convv_lds_pack_weight')
+    return out
+
+
+USE_CONVV_LDS = True            # False: every valid-conv layer runs the gather form
+
+
+def conv_valid_lds_supported(x, cout, k, stride):
+    """True when the LDS-staged form (rf_conv3d_valid_leaky_lds) takes this layer (output edge >= 8 and a tile that fits LDS)."""
+    return USE_CONVV_LDS and bool(_lib.load().rf_conv3d_valid_lds_supported(x.shape[0], x.shape[1], x.shape[2], cout, k, stride))
+
+
+def conv3d_valid_leaky_lds(x, w_packed, bias, cout, k, stride, slope):
+    """valid strided conv + bias + LeakyReLU, LDS-staged fp32-MFMA form (w_packed from pack_convv_lds_weight)."""
+    _req(x, 'x')
+    n, cin, s = x.shape[0], x.shape[1], x.shape[2]
+    so = (s - k) // stride + 1
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_lds(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
+                                                     stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_lds')
     return out
 
 

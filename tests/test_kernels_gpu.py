@@ -627,6 +627,25 @@ def test_conv3d_valid_leaky_mfma(ops, spec):
     close(got, ref, 1e-5, 'valid conv (mfma)')
 
 
+@pytest.mark.parametrize('spec', [(3, 1, 48, 12, 5, 1), (2, 12, 44, 24, 3, 1), (2, 24, 42, 48, 3, 2), (3, 48, 20, 48, 3, 2), (2, 1, 32, 8, 5, 1),
+                                  (2, 8, 28, 16, 3, 1), (3, 16, 26, 32, 3, 2), (2, 32, 12, 64, 3, 1), (2, 12, 24, 24, 3, 1), (1, 1, 24, 12, 3, 1),
+                                  (2, 24, 22, 24, 3, 2), (5, 16, 11, 20, 2, 1), (2, 4, 13, 24, 4, 1), (3, 8, 17, 96, 3, 1)])
+def test_conv3d_valid_leaky_lds(ops, spec):
+    """LDS-staged form of the patch encoders' large layers (every layer shape of PCPatch48 / Patch32 / Patch24V2 with an output
+    edge >= 8, plus odd edges, k = 2 / 4, ragged last tiles, cout not a multiple of 16, two cout blocks) vs torch and vs the
+    gather form"""
+    n, cin, s, cout, k, stride = spec
+    gen = torch.Generator().manual_seed(sum(spec) + 2)
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    xd = x.to(DEV)
+    assert ops.conv_valid_lds_supported(xd, cout, k, stride)
+    ref = F.leaky_relu(F.conv3d(x.double(), w.double(), b.double(), stride=stride), 0.2).float()
+    got = ops.conv3d_valid_leaky_lds(xd, ops.pack_convv_lds_weight(w.to(DEV)), b.to(DEV), cout, k, stride, 0.2)
+    close(got, ref, 1e-5, 'valid conv (lds)')
+    gather = ops.conv3d_valid_leaky_mfma(xd, ops.pack_convv_weight(w.to(DEV)), b.to(DEV), cout, k, stride, 0.2)
+    close(got, gather, 1e-5, 'lds form vs gather form')
+
+
 def test_cpu_tensors_raise(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.maxpool2(torch.zeros(1, 1, 2, 2, 2))
