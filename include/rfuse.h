@@ -148,6 +148,25 @@ int rf_conv3d_up_variant(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                             const float* gn_affine, const float* w_packed, int cout, float* out, double* stats, void* stream);
 
+/* ------------------------------------------------------------------------------- backward (training slice, N4) */
+
+/* rf_conv3d_k3_gn_relu with the ReLU optional (relu = 0: plain GroupNorm + conv): the DATA-GRADIENT convolution of the
+ * backward pass is this kernel on dz with the transposed, tap-flipped weight and an identity affine. */
+int rf_conv3d_k3_gn(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                    const float* gn_affine, const float* w_packed, int cout, int relu, float* out, void* stream);
+/* out = dy where y > 0 else 0 (count floats, a multiple of 4): the ReLU of SingleConv 'gcr' (model/unet.py:45) backwards */
+int rf_relu_backward(const float* dy, const float* y, size_t count, float* out, void* stream);
+/* GroupNorm backward (model/unet.py:54-66; torch.nn.GroupNorm semantics, biased variance): x, dxn [n][c][edge^3], gamma [c] ->
+ * dx [n][c][edge^3] and per-(n, c) float64 pieces of dgamma / dbeta (sum them over n). */
+int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, float* dx,
+                   double* dgamma_parts, double* dbeta_parts, void* ws, size_t ws_bytes, void* stream);
+size_t rf_gn_backward_ws_bytes(int n, int c);
+/* Weight gradient of the 3x3x3 conv: dw[co][ci][tap] = sum_{n,v} dz[n][co][v] * GN(x)[n][ci][v + tap - 1] (zero padded), fp32 MFMA
+ * with K = voxels; edge a power of two >= 8.  gn_affine as in the forward. */
+int rf_conv3d_k3_wgrad(const float* x, int cin, int n, int edge, const float* gn_affine, const float* dz, int cout, float* dw, void* ws,
+                       size_t ws_bytes, void* stream);
+size_t rf_conv3d_k3_wgrad_ws_bytes(int cin, int cout, int n, int edge);
+
 /* --------------------------------------------------------------------------------------------- fold / unfold */
 
 /* Unfold3D.forward (model/attention.py:186-188): x [b][c][s^3] -> rows [(b*r^3)][c][e^3], r = s/e, row = ((b*r+px)*r+py)*r+pz */

@@ -42,6 +42,7 @@ struct ConvArgs {
     float* pool_out;
     double2* pool_stats;
     int pool_mode;
+    float floor;       // output clamp from below: 0 = ReLU (the forward layers), -inf = none (rf_conv3d_k3_gn with relu = 0: the dgrad conv)
 };
 
 // Voxel order inside the 8^3 box of the 8-wave x MB 4 tile: m = wave*64 + mb*16 + i -> (z, y, x) such that one lane's
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
                 const int co = cob + nb * 16 + (lane & 15);
                 if (co < a.cout) {
                     f32x4 v = acc[mb][nb];
-                    float4 o = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+                    float4 o = make_float4(fmaxf(v[0], a.floor), fmaxf(v[1], a.floor), fmaxf(v[2], a.floor), fmaxf(v[3], a.floor));
                     *reinterpret_cast<float4*>(a.out + ((size_t)nn * a.cout + co) * vol + off) = o;
                 }
             }
@@ -643,7 +644,8 @@ int rf_conv3_small_launch(const float* src, int cin, int n, int edge, const floa
 
 static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                        const float* gn_affine, const float* w_packed, int cout,
-                       float* out, double* stats, void* stream, float* pool_out = nullptr, double* pool_stats = nullptr, int pool_mode = 0) {
+                       float* out, double* stats, void* stream, float* pool_out = nullptr, double* pool_stats = nullptr, int pool_mode = 0,
+                       bool relu = true) {
     RF_REQUIRE(n > 0 && c0 >= 0 && c1 >= 0 && c0 + c1 > 0 && cout > 0, RF_E_INVALID, "rf_conv3d_k3_gn_relu: bad sizes");
     RF_REQUIRE(rf_is_pow2(edge) && edge <= 128, RF_E_INVALID, "rf_conv3d_k3_gn_relu: edge %d must be a power of two <= 128", edge);
     RF_REQUIRE((c0 == 0 || src0) && (c1 == 0 || src1) && gn_affine && w_packed && (out || pool_mode == 2), RF_E_INVALID,
@@ -656,7 +658,13 @@ static int conv3d_impl(const float* src0, int c0, const float* src1, int c1, int
     a.stats = reinterpret_cast<double2*>(stats);
     a.stats_tiles = (stats || pool_stats) ? rf_conv3d_stats_tiles(c0, c1, n, edge, cout) : 0;
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats); a.pool_mode = pool_mode;
+    a.floor = relu ? 0.f : -INFINITY;
     hipStream_t s = (hipStream_t)stream;
+    if (!relu) {                                          // only the box-tiled kernel carries the clamp switch
+        RF_REQUIRE(!stats && !pool_mode, RF_E_INVALID, "rf_conv3d_k3_gn: no fused statistics / pooling without the ReLU");
+        if (edge >= 8) return conv_use_big(n, edge, a.cout16) ? dispatch_nb<8, 8, 8, 1, TILE_BIG>(a, s) : dispatch_nb<4, 4, 8, 1, TILE_SMALL>(a, s);
+        return edge == 4 ? dispatch_nb<4, 4, 4, 2, TILE_SMALL>(a, s) : dispatch_nb<2, 2, 2, 16, TILE_SMALL>(a, s);
+    }
     if (conv_use_cin1(c0, c1, edge, cout)) return cout == 8 ? launch_cin1<8>(a, s) : launch_cin1<6>(a, s);
     // whole 4^3 / 2^3 volumes: the position-major kernel (conv3d_small.hip) leaves out every zero-padding tap
     if ((!pool_mode || edge == 4) && rf_conv3_small_takes(c0, c1, n, edge, cout))
@@ -674,6 +682,12 @@ extern "C" int rf_conv3d_k3_gn_relu(const float* src0, int c0, const float* src1
                                     const float* gn_affine, const float* w_packed, int cout,
                                     float* out, void* stream) {
     return conv3d_impl(src0, c0, src1, c1, n, edge, gn_affine, w_packed, cout, out, nullptr, stream);
+}
+
+// the same convolution with the ReLU optional: relu = 0 is the data-gradient conv of the backward pass (rfuse/autograd.py)
+extern "C" int rf_conv3d_k3_gn(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                               const float* gn_affine, const float* w_packed, int cout, int relu, float* out, void* stream) {
+    return conv3d_impl(src0, c0, src1, c1, n, edge, gn_affine, w_packed, cout, out, nullptr, stream, nullptr, nullptr, 0, relu != 0);
 }
 
 // fused MaxPool3d(2): only the 8^3-box tiling (edge >= 8, enough boxes, not the cin == 1 kernel) holds whole pooling cells

@@ -73,8 +73,13 @@ class AttentionFeatureEncoder(nn.Module):
         return self._fused.get([self.encoder[i] for i in (0, 2, 4, 6)])
 
     def forward(self, x):
-        ops._no_grad_only(x, self.encoder[0].weight)
         x = x.reshape((x.shape[0], self.n_in))
+        if ops.needs_grad(x, self.encoder[0].weight):
+            # training slice: per-layer rf_linear behind torch.autograd.Function (rfuse/autograd.py)
+            from rfuse import autograd as rf_autograd
+            for i in (0, 2, 4):
+                x = rf_autograd.Linear.apply(x, self.encoder[i].weight, self.encoder[i].bias, ops.ACT_LEAKY, 0.01)
+            return rf_autograd.Linear.apply(x, self.encoder[6].weight, self.encoder[6].bias, ops.ACT_NONE, 0.0)
         if self.fusable():
             return ops.attn_mlp_rows(x.contiguous(), self.packed_fused())
         for i in (0, 2, 4):

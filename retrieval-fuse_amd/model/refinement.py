@@ -88,9 +88,14 @@ class Superresolution08FinalDecoder(nn.Module):
 
     def forward(self, x):
         x = self.network[0](x)
+        if ops.needs_grad(x, self.network[1].weight):
+            # grad mode (training slice, rfuse/autograd.py): the 16 -> 1 pointwise conv + tanh is 0.1 % of the work, torch differentiates it
+            return torch.tanh(torch.nn.functional.conv3d(x, self.network[1].weight, self.network[1].bias))
         return ops.conv1x1_tanh(x, self.network[1].weight, self.network[1].bias)
 
     def forward_df(self, x, target_trunc):
+        if ops.needs_grad(x, self.network[1].weight):
+            return (self.forward(x) + 1.0) * (float(target_trunc) / 2)
         x = self.network[0](x)
         return ops.conv1x1_tanh(x, self.network[1].weight, self.network[1].bias, post_add=1.0, post_mul=float(target_trunc) / 2)
 

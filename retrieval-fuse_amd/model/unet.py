@@ -92,9 +92,13 @@ class SingleConv(nn.Module):
         ``pool``: None -> returns the output; 'also' / 'only' -> returns (output, MaxPool3d(2)(output)) with the pooling
         fused into the conv epilogue where the tiling allows ('only': the caller never reads the full-resolution output, which
         is then not written at all and returned as None)."""
-        ops._no_grad_only(x, upsampled, self.conv.weight)
         gn = self.groupnorm
         cout = self.conv.out_channels
+        if ops.needs_grad(x, upsampled, self.conv.weight, gn.weight, gn.bias):
+            # training slice (SURVEY 8f N4): the same kernels behind torch.autograd.Function, see rfuse/autograd.py
+            from rfuse import autograd as rf_autograd
+            out = rf_autograd.conv_gn_relu(x, upsampled, gn.weight, gn.bias, self.conv.weight, gn.num_groups, gn.eps)
+            return out if pool is None else (out, torch.nn.functional.max_pool3d(out, 2))
         aff = ops.gn_affine(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
         if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
@@ -156,7 +160,12 @@ class Encoder(nn.Module):
     def forward(self, x, prepooled=None, pool=None):
         """``prepooled``: MaxPool3d(2)(x) when the producer already emitted it (fused epilogue); ``pool``: see SingleConv.forward."""
         if self.apply_pooling:
-            x = prepooled if prepooled is not None else ops.maxpool2(x)
+            if prepooled is not None:
+                x = prepooled
+            elif ops.needs_grad(x):
+                x = torch.nn.functional.max_pool3d(x, 2)            # grad mode: torch's max-pool carries the backward
+            else:
+                x = ops.maxpool2(x)
         return self.basic_module(x, pool=pool) if pool is not None else self.basic_module(x)
 
 

@@ -1,0 +1,149 @@
+"""Training slice: ``torch.autograd.Function``s whose forward AND backward run the HIP kernels.
+
+The reference trains THROUGH the drop-in modules (trainer/train_refinement.py:41-43 optimisers over unet_backbone / decoder /
+retrieval_backbone / attention parameters, :295-306 phase hand-over).  Built here:
+
+  ConvGnRelu   y = ReLU(conv3(GroupNorm(x)))   one SingleConv 'gcr' layer (reference model/unet.py:19-76) -- 97 % of the FLOPs
+      forward   rf_gn_stats / rf_gn_from_stats + rf_conv3d_k3_gn_relu*         (the inference kernels)
+      backward  rf_relu_backward -> rf_conv3d_k3_gn (relu = 0) on (dz, W^T with flipped taps)   = data gradient, same MFMA kernel
+                rf_conv3d_k3_wgrad (fp32 MFMA, K = voxels)                                     = weight gradient (edge >= 8)
+                rf_gn_backward                                                                  = dx, dgamma, dbeta
+                4^3 / 2^3 / 1^3 volumes: weight gradient as rf_linear GEMMs on the unfolded input (K split, float64 partial sums)
+  Linear       y = act(x W^T + b)               the layers of AttentionFeatureEncoder (reference model/attention.py:29-46)
+      backward  dx = rf_linear(dpre, W^T-as-weight),  dW = rf_linear(dpre^T, x^T-as-weight) in row chunks summed in float64
+
+torch does the bookkeeping only (transposes / flips / unfolds of operands, the activation mask of Linear, sums over the batch of
+per-sample float64 pieces).  Gradients are checked against float64 autograd of the oracle in tests/test_autograd_gpu.py.
+Not built (modules raise in grad mode): the patch attention proper (scores / softmax / blend), the fused attention MLP, the
+parity-split decoder kernel's own backward (two-source layers are differentiated through a materialised concat), the patch
+encoders (trained by trainer/train_retrieval.py, out of the refinement path).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+
+_p, _stream = ops._p, ops._stream
+
+
+def _ws(dev, nbytes):
+    return ops._workspace(dev, nbytes)
+
+
+def relu_backward(dy, y):
+    out = torch.empty_like(y)
+    _lib.check(_lib.load().rf_relu_backward(_p(dy), _p(y), y.numel(), _p(out), _stream()), 'rf_relu_backward')
+    return out
+
+
+def conv3d_gn(x, aff, w_packed, cout, relu):
+    n, c, edge = x.shape[0], x.shape[1], x.shape[2]
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv3d_k3_gn(_p(x), c, _p(None), 0, n, edge, _p(aff), _p(w_packed), cout, int(relu), _p(out), _stream()), 'rf_conv3d_k3_gn')
+    return out
+
+
+def gn_backward(x, dxn, gamma, groups, eps):
+    n, c, edge = x.shape[0], x.shape[1], x.shape[2]
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dg = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    db = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    ws = _ws(x.device, lib.rf_gn_backward_ws_bytes(n, c))
+    _lib.check(lib.rf_gn_backward(_p(x), _p(dxn), n, c, edge, _p(gamma), groups, eps, _p(dx), _p(dg), _p(db), _p(ws), ws.numel(), _stream()), 'rf_gn_backward')
+    return dx, dg.sum(0).float(), db.sum(0).float()
+
+
+def conv3d_wgrad(x, aff, dz, cout):
+    n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
+    lib = _lib.load()
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    ws = _ws(x.device, lib.rf_conv3d_k3_wgrad_ws_bytes(cin, cout, n, edge))
+    _lib.check(lib.rf_conv3d_k3_wgrad(_p(x), cin, n, edge, _p(aff), _p(dz), cout, _p(dw), _p(ws), ws.numel(), _stream()), 'rf_conv3d_k3_wgrad')
+    return dw
+
+
+def _gemm_tn_f64(a, b, chunk=8192):
+    """a [K, M], b [K, N] float32 -> a^T b [M, N]: rf_linear GEMMs over K chunks (one fp32 MFMA chain per chunk), summed in float64"""
+    acc = torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float64, device=a.device)
+    for k0 in range(0, a.shape[0], chunk):
+        at = a[k0:k0 + chunk].t().contiguous()                      # [M, kc] = the "x" of rf_linear
+        bt = b[k0:k0 + chunk].t().contiguous()                      # [N, kc] = its "weight" [nout, nin]
+        acc += ops.linear(at, ops.pack_linear_weight(bt), None, bt.shape[0]).double()
+    return acc.float()
+
+
+class ConvGnRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, groups, eps):
+        x = x.contiguous()
+        n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
+        cout = weight.shape[0]
+        g = 1 if cin < groups else groups
+        with torch.no_grad():
+            aff = ops.gn_affine(x, None, gamma, beta, g, eps)
+            if edge == 1:
+                y = ops.conv3d_gn_relu(x, None, aff, None, cout, direct_weight=weight.contiguous())
+            else:
+                y = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(weight.contiguous()), cout)
+        ctx.save_for_backward(x, gamma, weight, aff, y)
+        ctx.groups, ctx.eps = g, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, weight, aff, y = ctx.saved_tensors
+        n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
+        cout = weight.shape[0]
+        with torch.no_grad():
+            dz = relu_backward(dy.contiguous(), y) if y.numel() % 4 == 0 else dy * (y > 0)
+            if edge >= 2:
+                wt = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [cin, cout, 3,3,3]: the data-gradient conv's weight
+                ident = torch.zeros((n, cout, 4), dtype=torch.float32, device=x.device)
+                ident[..., 1] = 1.0
+                dxn = conv3d_gn(dz, ident, ops.pack_conv3_weight(wt), cin, relu=False)
+            else:                                                                   # 1^3 volume: only the centre tap touches data
+                dxn = ops.linear(dz.reshape(n, cout), ops.pack_linear_weight(weight[:, :, 1, 1, 1].t().contiguous()), None, cin).reshape(n, cin, 1, 1, 1)
+            if edge >= 8:
+                dw = conv3d_wgrad(x, aff, dz, cout)
+            else:
+                # small volumes: dW = dz^T . im2col(GN(x)) through rf_linear (the operands are re-laid by torch, the products run on MFMA)
+                xn = torch.addcmul(aff[..., 2, None, None, None], x - aff[..., 0, None, None, None], aff[..., 1, None, None, None])
+                cols = F.pad(xn, (1, 1, 1, 1, 1, 1)).unfold(2, 3, 1).unfold(3, 3, 1).unfold(4, 3, 1)       # [n, cin, e,e,e, 3,3,3]
+                cols = cols.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(n * edge ** 3, cin * 27)
+                dzf = dz.permute(0, 2, 3, 4, 1).reshape(n * edge ** 3, cout)
+                dw = _gemm_tn_f64(dzf, cols).reshape(cout, cin, 3, 3, 3)
+            dx, dgamma, dbeta = gn_backward(x, dxn.contiguous(), gamma, ctx.groups, ctx.eps)
+        return dx, dgamma, dbeta, dw, None, None
+
+
+class Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x = x.contiguous()
+        with torch.no_grad():
+            y = ops.linear(x, ops.pack_linear_weight(weight.contiguous()), bias, weight.shape[0], act, slope)
+        ctx.save_for_backward(x, weight, y)
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        with torch.no_grad():
+            if ctx.act == ops.ACT_NONE:
+                dpre = dy.contiguous()
+            else:                                                   # y > 0 <=> pre-activation > 0 for ReLU and LeakyReLU(slope > 0)
+                dpre = torch.where(y > 0, dy, dy * (ctx.slope if ctx.act == ops.ACT_LEAKY else 0.0)).contiguous()
+            dx = ops.linear(dpre, ops.pack_linear_weight(weight.t().contiguous()), None, weight.shape[1])
+            dw = _gemm_tn_f64(dpre, x)
+            db = dpre.double().sum(0).float() if ctx.has_bias else None
+        return dx, dw, db, None, None
+
+
+def conv_gn_relu(x, upsampled, gamma, beta, weight, groups, eps):
+    """grad-mode SingleConv: two-source (decoder) layers are differentiated through a materialised nearest-x2 upsample + concat"""
+    if upsampled is not None:
+        up = F.interpolate(upsampled, scale_factor=2, mode='nearest')
+        x = up if x is None else torch.cat((x, up), dim=1)
+    return ConvGnRelu.apply(x, gamma, beta, weight, groups, eps)

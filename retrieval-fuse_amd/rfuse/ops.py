@@ -58,11 +58,15 @@ def _device_scoped(fn):
     return scoped
 
 
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def _no_grad_only(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+    if needs_grad(*tensors):
         raise NotImplementedError(
-            'rfuse kernels implement inference only; call under torch.no_grad() '
-            '(backward for the custom ops is the "next" row N4 of SURVEY.md section 8f)')
+            'this rfuse op implements inference only; call under torch.no_grad().  Backward exists for the SingleConv layers and '
+            'the attention feature encoders (rfuse/autograd.py, SURVEY.md section 8f row N4), not for this op')
 
 
 _ws_cache = {}

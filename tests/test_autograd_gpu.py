@@ -1,0 +1,135 @@
+"""GPU: the training slice (rfuse/autograd.py) -- gradients of the HIP-backed SingleConv layer, the attention
+feature encoder and a whole retrieval U-Net against float64 autograd of the ORACLE on the same parameters and inputs
+(reference trainer/train_refinement.py:41-43 optimises exactly these parameters)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers
+from oracle import refpath
+from rfuse import configs as rf_configs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    return torch.device(DEV)
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return float((got - ref).abs().max() / max(1e-12, ref.abs().max()))
+
+
+@pytest.mark.parametrize('case', [(3, 8, 0, 16, 16, 8), (2, 16, 0, 8, 32, 8), (5, 6, 0, 8, 12, 6), (4, 32, 0, 4, 64, 8), (6, 64, 0, 2, 64, 8),
+                                  (3, 64, 0, 1, 128, 8), (2, 1, 0, 16, 8, 8), (2, 16, 32, 8, 24, 8), (1, 0, 16, 16, 16, 8)])
+def test_single_conv_gradients_match_float64_oracle(gpu, case):
+    """(n, c0, c1, edge, cout, groups): full-resolution source, optional low-res source (decoder layers), edges 16 .. 1"""
+    from model.unet import SingleConv
+    n, c0, c1, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case))
+    cin = c0 + c1
+    layer = SingleConv(cin, cout, num_groups=groups)
+    with torch.no_grad():
+        layer.groupnorm.weight.copy_(1 + 0.3 * torch.randn(cin, generator=gen))
+        layer.groupnorm.bias.copy_(0.3 * torch.randn(cin, generator=gen))
+    layer.to(gpu)
+    x0 = torch.randn(n, c0, edge, edge, edge, generator=gen).relu() if c0 else None
+    x1 = torch.randn(n, c1, edge // 2, edge // 2, edge // 2, generator=gen).relu() if c1 else None
+    r = torch.randn(n, cout, edge, edge, edge, generator=gen)
+    ins = [t.to(gpu).requires_grad_(True) if t is not None else None for t in (x0, x1)]
+    y = layer(ins[0], ins[1])
+    (y * r.to(gpu)).sum().backward()
+    # float64 oracle
+    sd = {'p.groupnorm.weight': layer.groupnorm.weight.detach().cpu().double().requires_grad_(True),
+          'p.groupnorm.bias': layer.groupnorm.bias.detach().cpu().double().requires_grad_(True),
+          'p.conv.weight': layer.conv.weight.detach().cpu().double().requires_grad_(True)}
+    o0 = x0.double().requires_grad_(True) if c0 else None
+    o1 = x1.double().requires_grad_(True) if c1 else None
+    parts = ([o0] if c0 else []) + ([F.interpolate(o1, scale_factor=2, mode='nearest')] if c1 else [])
+    yo = refpath.single_conv_gcr(torch.cat(parts, 1), sd, 'p', groups)
+    (yo * r.double()).sum().backward()
+    assert rel_err(y, yo) < 1e-5
+    errs = {'dW': rel_err(layer.conv.weight.grad, sd['p.conv.weight'].grad), 'dgamma': rel_err(layer.groupnorm.weight.grad, sd['p.groupnorm.weight'].grad),
+            'dbeta': rel_err(layer.groupnorm.bias.grad, sd['p.groupnorm.bias'].grad)}
+    if c0:
+        errs['dx0'] = rel_err(ins[0].grad, o0.grad)
+    if c1:
+        errs['dx1'] = rel_err(ins[1].grad, o1.grad)
+    print('\n', case, {k: '%.1e' % v for k, v in errs.items()})
+    assert max(errs.values()) < 2e-4, errs
+
+
+def test_attention_feature_encoder_gradients(gpu):
+    from model.attention import AttentionFeatureEncoder
+    gen = torch.Generator().manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = AttentionFeatureEncoder(16, 32, 2).to(gpu)
+    x = torch.randn(700, 128, generator=gen)
+    r = torch.randn(700, 32, generator=gen)
+    xg = x.to(gpu).requires_grad_(True)
+    y = enc(xg)
+    (y * r.to(gpu)).sum().backward()
+    sd = {'t.' + k: v.detach().cpu().double().requires_grad_(True) for k, v in enc.state_dict().items()}
+    xo = x.double().requires_grad_(True)
+    yo = refpath.attention_feature_encoder(xo, sd, 't')
+    (yo * r.double()).sum().backward()
+    assert rel_err(y, yo) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 1e-4
+    for name, p in enc.named_parameters():
+        assert rel_err(p.grad, sd['t.' + name].grad) < 1e-4, name
+
+
+def test_retrieval_backbone_trains_like_the_oracle(gpu):
+    """RetrievalUNetBackbone (12 SingleConv layers incl. max-pools, skip connections and the StepDown decoder) end to end: loss
+    gradients of every parameter and of the input against float64 autograd of the oracle; then one SGD step lowers the loss."""
+    import model
+    cfg = rf_configs.get_config('C1')
+    with contextlib.redirect_stdout(io.StringIO()):
+        rb = model.get_retrieval_backbone(cfg)
+    shapes = {k: tuple(v.shape) for k, v in rb.state_dict().items()}
+    sd = helpers.seeded_sd(shapes, 4242)
+    rb.load_state_dict(sd)
+    rb.to(gpu).train()
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(6, 1, 16, 16, 16, generator=gen)
+    tgt = torch.randn(6, 16, 8, 8, 8, generator=gen)
+    xg = x.to(gpu).requires_grad_(True)
+    loss = ((rb(xg) - tgt.to(gpu)) ** 2).mean()
+    loss.backward()
+    # float64 oracle = the truth; the oracle in fp32 (what the reference trainer computes) shows how far fp32 autograd itself is from
+    # it on this network (ReLU / max-pool routing flips at near-zero activations: ~3e-3 on the worst tensor)
+    def oracle_grads(dt):
+        sdo = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in sd.items()}
+        xo = x.detach().clone().to(dt).requires_grad_(True)
+        lo = ((refpath.retrieval_backbone(xo, sdo, cfg) - tgt.to(dt)) ** 2).mean()
+        lo.backward()
+        return lo, sdo, xo
+    lo, sd64, xo = oracle_grads(torch.float64)
+    _, sd32, xo32 = oracle_grads(torch.float32)
+    assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    worst, dot, n1, n2 = ('', 0.0, 0.0), 0.0, 0.0, 0.0
+    for name, p in rb.named_parameters():
+        e, e32 = rel_err(p.grad, sd64[name].grad), rel_err(sd32[name].grad, sd64[name].grad)
+        if e > worst[1]:
+            worst = (name, e, e32)
+        assert e <= max(1e-2, 10 * e32), (name, e, e32)          # (which units flip at a ReLU / max-pool threshold is luck in both fp32 runs)
+        g, r = p.grad.detach().cpu().double().flatten(), sd64[name].grad.flatten()
+        dot, n1, n2 = dot + float(g @ r), n1 + float(g @ g), n2 + float(r @ r)
+    e_in, e_in32 = rel_err(xg.grad, xo.grad), rel_err(xo32.grad, xo.grad)
+    cos = dot / np.sqrt(n1 * n2)
+    print('\nworst parameter gradient (name, hip vs f64, torch-fp32 vs f64):', worst, ' input gradient %.1e (torch fp32 %.1e)  cosine %.8f' % (e_in, e_in32, cos))
+    assert e_in <= max(1e-2, 10 * e_in32) and cos > 0.99999
+    with torch.no_grad():
+        for p in rb.parameters():
+            p -= 0.05 * p.grad
+    loss2 = ((rb(x.to(gpu)) - tgt.to(gpu)) ** 2).mean()
+    assert loss2.item() < loss.item()

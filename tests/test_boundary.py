@@ -90,8 +90,11 @@ def test_product_path_has_no_cpu_fallback():
     with torch.no_grad():
         with pytest.raises(RuntimeError, match='no CPU fallback'):
             m['decoder'](torch.zeros(1, 16, 32, 32, 32))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m['decoder'](torch.zeros(1, 16, 32, 32, 32))          # grad mode: the autograd functions run the same GPU-only kernels
     with pytest.raises(NotImplementedError, match='inference only'):
-        m['decoder'](torch.zeros(1, 16, 32, 32, 32))          # grad mode + parameters requiring grad
+        # the patch attention proper has no backward (only the SingleConv layers and the feature encoders do)
+        m['patched_attention_block'](torch.zeros(1, 16, 32, 32, 32), torch.zeros(4, 16, 32, 32, 32))
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
