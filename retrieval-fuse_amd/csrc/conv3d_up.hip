@@ -109,7 +109,12 @@ template <int TE, int SPW, int MB, int NB>
 struct UpTile {
     static constexpr int NW = 8, NT = 512;
     static constexpr int L = TE / 2, LH = L + 2, HE = TE + 2;
-    static constexpr int CH0 = HE * HE * HE, CH1 = LH * LH * LH;
+    // x-row stride of the full-res halo box.  T = 8: the 16 lattice points of an A read are 2 floats apart in x and 2 rows apart in y;
+    // with rows of 10 floats they fall on 14 of the 32 ds_read_b32 banks (2-way) and the second channel of the 32-lane group
+    // (stride 1000) lands on the same even banks (3x the conflict-free cycles, SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.43).  Rows of 12
+    // floats spread them over all 16 even banks, an ODD channel stride puts the other channel on the odd banks: conflict-free.
+    static constexpr int HXA = TE == 8 ? 12 : HE;
+    static constexpr int CH0 = HE * HE * HXA + (TE == 8 ? 1 : 0), CH1 = LH * LH * LH;
     static constexpr int XS0 = SPW * 4 * CH0;                          // full-res halo box of a 4-channel chunk
     static constexpr int XS1 = SPW * 8 * CH1;                          // low-res halo box of an 8-channel chunk (x2 buffers)
     static constexpr int XS = ((XS0 > 2 * XS1 ? XS0 : 2 * XS1) + 3) / 4 * 4;
@@ -131,7 +136,7 @@ struct UpTile {
 template <int TE, int SPW, int MB, int NB>
 __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
     using T = UpTile<TE, SPW, MB, NB>;
-    constexpr int L = T::L, LH = T::LH, HE = T::HE, CH0 = T::CH0, CH1 = T::CH1, NCO = T::NCO, NT = T::NT, P = T::P;
+    constexpr int L = T::L, LH = T::LH, HE = T::HE, HXA = T::HXA, CH0 = T::CH0, CH1 = T::CH1, NCO = T::NCO, NT = T::NT, P = T::P;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* wsb = smem + T::XS;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             const int v = mb * 16 + li_a;
             int X, Y, Z, s;
             up_lattice<TE>(v, s, Z, Y, X);
-            aoff0[mb] = (s * 4 + kq_a) * CH0 + ((2 * Z + pz) * HE + (2 * Y + py)) * HE + (2 * X + px);
+            aoff0[mb] = (s * 4 + kq_a) * CH0 + ((2 * Z + pz) * HE + (2 * Y + py)) * HXA + (2 * X + px);
         }
         int boff[NB];
 #pragma unroll
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                         for (int j = 0; j < TE + 2; ++j) v[j] = 0.f;
                     }
-                    float* dst = xs + (s * 4 + c) * CH0 + (hz * HE + hy) * HE;
+                    float* dst = xs + (s * 4 + c) * CH0 + (hz * HE + hy) * HXA;
 #pragma unroll
                     for (int j = 0; j < TE + 2; ++j) dst[j] = v[j];
                 }
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                     asm volatile("" ::: "memory");
                     if (t + 1 < 27) {
                         const int t1 = t + 1;
-                        const int toff = ((t1 / 9) * HE + (t1 / 3) % 3) * HE + t1 % 3;
+                        const int toff = ((t1 / 9) * HE + (t1 / 3) % 3) * HXA + t1 % 3;
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xs[aoff0[mb] + toff];
 #pragma unroll

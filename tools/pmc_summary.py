@@ -18,7 +18,8 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
 pmc_dir = Path(sys.argv[1]) if len(sys.argv) > 1 else REPO / 'gpurun_out' / 'pmc'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r01'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+cfg_name = sys.argv[3] if len(sys.argv) > 3 else 'C2'
 DOMINANT = 'k_conv3_up<8, 1, 4, 4>'
 
 
@@ -57,7 +58,7 @@ def avg(table, key, ctr):
 rows = []
 for key in sq1:
     kern, wgs = key
-    if not (kern.startswith('k_') or 'k_conv3' in kern or 'k_linear' in kern):
+    if not (kern.startswith('k_') or 'k_conv3' in kern or 'k_linear' in kern or 'k_l2' in kern or 'k_convv' in kern):
         continue
     gui = avg(sq1, key, 'GRBM_GUI_ACTIVE')
     cycles = gui / 8.0
@@ -72,9 +73,9 @@ for key in sq1:
     rows.append((cycles * len(sq1[key]['GRBM_GUI_ACTIVE']), kern, wgs, len(sq1[key]['GRBM_GUI_ACTIVE']), cycles, mfma, wait_any, wait_inst, lds_conf, fetch_mb, write_mb))
 rows.sort(reverse=True)
 
-out_csv = REPO / 'profiles' / ('%s_pmc_bench_C2_B32.csv' % tag)
+out_csv = REPO / 'profiles' / ('%s_pmc_bench_%s_B32.csv' % (tag, cfg_name))
 with open(out_csv, 'w') as f:
-    f.write('# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline  (C2, B=32 chunks/step; tools/pmc_conv.sh, summarised by tools/pmc_summary.py)\n')
+    f.write('# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --config %s --steps 2 --warmup 1 --no-cpu-baseline --no-extras  (B=32 chunks/step; tools/pmc_conv.sh, summarised by tools/pmc_summary.py)\n' % cfg_name)
     f.write('# separate passes: {SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE}, {SQ_LDS_* SQ_INSTS_*}, {FETCH_SIZE}, {WRITE_SIZE}\n')
     f.write('# per-launch averages; counters are summed over the 8 XCDs; cycles = GRBM_GUI_ACTIVE/8; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024 SIMDs);\n')
     f.write('# fetch_MB = 2 x FETCH_SIZE KB (gfx950 correction of MI355X_MICROARCH.md, HBM section), write_MB = WRITE_SIZE KB; rows ordered by total cycles\n')
@@ -84,7 +85,7 @@ with open(out_csv, 'w') as f:
 print('wrote', out_csv)
 
 dom = [r for r in rows if r[1] == DOMINANT]
-if dom:
+if dom and cfg_name == 'C2':
     _, kern, wgs, launches, cycles, mfma, wa, wi, lc, fm, wm = max(dom, key=lambda r: r[2])
     n_patches = wgs                                   # one 8^3 box = one patch per workgroup, one cout block
     j = {'kernel': kern, 'batch': n_patches // 256, 'n_patches': n_patches, 'fetch_MB_per_launch': fm, 'write_MB_per_launch': wm,
