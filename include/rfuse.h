@@ -121,6 +121,14 @@ int rf_conv3d_valid_leaky_lds(const float* x, int n, int cin, int s, const float
 int rf_convv_lds_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream);
 size_t rf_convv_lds_packed_floats(int cout, int cin, int k);
 
+/* The same layer on the packed-fp32 VALU for the FIRST layers of the patch encoders (stride 1; 1 -> 8/12 with k = 3/5, 1 -> 16,
+ * 8 -> 16 and 12 -> 24 with k = 3): couts of 12 / 24 waste a quarter of the 16-wide MFMA tiles, the vector unit has the same fp32
+ * peak and no padding.  w_t: the weight as [cin][k^3][cout] (OIDHW permuted to (1,2,3,4,0)): the kernel reads whole cout vectors
+ * through the scalar cache.  rf_conv3d_valid_valu_supported: 1 when this form takes the shape. */
+int rf_conv3d_valid_valu_supported(int n, int cin, int s, int cout, int k, int stride);
+int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
+                               int stride, float slope, float* out, void* stream);
+
 /* rf_conv3d_k3_gn_relu with the encoder's MaxPool3d(2) (model/unet.py:230-253) fused into the epilogue: additionally
  * writes pool_out [n][cout][(edge/2)^3] = maxpool2(out) and, when pool_stats is non-NULL, its (sum, sum of squares)
  * [n][cout][rf_conv3d_stats_tiles(...)][2] for rf_gn_from_stats.  out == NULL: only the pooled tensor is written (an

@@ -512,3 +512,153 @@ extern "C" int rf_conv3d_valid_leaky_lds(const float* x, int n, int cin, int s, 
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_lds");
     return RF_OK;
 }
+
+// ====================================================================================================================
+// VALU form for the FIRST layers of the patch encoders: stride 1, few channels on both sides (1 -> 8/12 with k = 3/5, 8 -> 16 and
+// 12 -> 24 with k = 3).  On the matrix cores these layers pad cout 12 -> 16 / 24 -> 32 (25 % of the MFMA slots) and k^3 to a
+// multiple of 4, and stay below 65 TFLOP/s; packed-fp32 VALU has the same 157 TFLOP/s peak and no padding at all.
+//   * thread = one (y, x) column of TZ = 4 consecutive output voxels, all COUT accumulators in registers (TZ * COUT <= 96 VGPRs);
+//     workgroup = TY whole output rows (TY * so <= 256 columns) x TZ planes of one window;
+//   * per input channel and (dy, dx): the column's TZ + K - 1 input values come from the LDS tile (lane = consecutive x); the K
+//     weight vectors w[dz][dy][dx][0..COUT) are wave-uniform and come through the SCALAR cache into SGPR pairs (s_load_dwordx4;
+//     as LDS broadcasts each of them would cost a full 1-KB data return and the LDS, not the VALU, was the limit), then
+//     K * TZ * COUT / 2 v_pk_fma_f32 with an SGPR-pair operand -- every input read feeds up to K * COUT FMAs;
+//   * channels are staged in chunks of CC <= 4 (input tile [CC][TZ + K - 1][TY + K - 1][s]); weights: the transposed image
+//     [cin][K^3][cout] (a permute of the OIDHW tensor, done by the caller).
+struct ConvVVArgs {
+    const float* x;
+    const float* w;       // [cin][K^3][cout]
+    const float* bias;
+    float* out;
+    int n, cin, cout, s, so, ty, nty, ntz;     // cout: all output channels; a workgroup computes COUT of them (blockIdx.y picks the block)
+    float slope;
+};
+
+typedef float rf_v2 __attribute__((ext_vector_type(2)));
+
+template <int COUT, int K, int CC>
+__global__ __launch_bounds__(256) void k_convv_valu(ConvVVArgs a) {
+    constexpr int TZ = 4, ZI = TZ + K - 1, K3 = K * K * K;
+    static_assert(COUT % 4 == 0, "weight vectors are read as float4");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int s = a.s, so = a.so, YI = a.ty + K - 1;
+    float* xs = smem;                                               // [CC][ZI][YI][s]
+    const int tiles = a.ntz * a.nty;
+    const int tb = blockIdx.x % tiles, nn = blockIdx.x / tiles;
+    const int cob = blockIdx.y * COUT;
+    const int z0 = (tb / a.nty) * TZ, y0 = (tb % a.nty) * a.ty;
+    const int ly = tid / so, lx = tid % so;
+    const bool col_ok = tid < a.ty * so && y0 + ly < so;
+    const size_t ivol = (size_t)s * s * s;
+    const float* xin = a.x + (size_t)nn * a.cin * ivol;
+    const int ch = ZI * YI * s;
+
+    rf_v2 acc[TZ][COUT / 2];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z)
+#pragma unroll
+        for (int c = 0; c < COUT / 2; ++c) acc[z][c] = (rf_v2){0.f, 0.f};
+
+    for (int c0 = 0; c0 < a.cin; c0 += CC) {
+        __syncthreads();                                            // the previous chunk is consumed
+        for (int r = tid; r < CC * ZI * YI; r += 256) {             // input rows (full width): one row per thread and pass
+            const int yy = r % YI, zz = (r / YI) % ZI, cc = r / (YI * ZI);
+            const int iz = z0 + zz, iy = y0 + yy;
+            float* dst = xs + (cc * ZI + zz) * YI * s + yy * s;
+            if (c0 + cc < a.cin && iz < s && iy < s) {
+                const float* src = xin + (size_t)(c0 + cc) * ivol + ((size_t)iz * s + iy) * s;
+                for (int i = 0; i < s; ++i) dst[i] = src[i];
+            } else {
+                for (int i = 0; i < s; ++i) dst[i] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (col_ok) {
+            const int ccn = a.cin - c0 < CC ? a.cin - c0 : CC;
+            for (int cc = 0; cc < ccn; ++cc) {
+#pragma unroll
+                for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < K; ++dx) {
+                        float col[ZI];
+                        const float* xc = xs + cc * ch + (ly + dy) * s + lx + dx;
+#pragma unroll
+                        for (int i = 0; i < ZI; ++i) col[i] = xc[i * YI * s];
+#pragma unroll
+                        for (int dz = 0; dz < K; ++dz) {
+                            const float* wv = a.w + ((size_t)(c0 + cc) * K3 + (dz * K + dy) * K + dx) * a.cout + cob;    // wave-uniform: scalar loads
+#pragma unroll
+                            for (int q = 0; q < COUT / 4; ++q) {
+                                const rf_v2 wa = {wv[4 * q], wv[4 * q + 1]}, wb = {wv[4 * q + 2], wv[4 * q + 3]};
+#pragma unroll
+                                for (int z = 0; z < TZ; ++z) {
+                                    const rf_v2 xv = {col[z + dz], col[z + dz]};
+                                    acc[z][2 * q] = __builtin_elementwise_fma(xv, wa, acc[z][2 * q]);
+                                    acc[z][2 * q + 1] = __builtin_elementwise_fma(xv, wb, acc[z][2 * q + 1]);
+                                }
+                            }
+                        }
+                    }
+            }
+        }
+    }
+    if (!col_ok) return;
+    const size_t ovol = (size_t)so * so * so;
+#pragma unroll
+    for (int c = 0; c < COUT / 2; ++c) {
+        const float b0 = a.bias ? a.bias[cob + 2 * c] : 0.f, b1 = a.bias ? a.bias[cob + 2 * c + 1] : 0.f;
+        float* o0 = a.out + ((size_t)nn * a.cout + cob + 2 * c) * ovol + ((size_t)z0 * so + y0 + ly) * so + lx;
+#pragma unroll
+        for (int z = 0; z < TZ; ++z) {
+            if (z0 + z < so) {
+                const float v0 = acc[z][c][0] + b0, v1 = acc[z][c][1] + b1;
+                o0[(size_t)z * so * so] = v0 > 0.f ? v0 : v0 * a.slope;
+                o0[(size_t)z * so * so + ovol] = v1 > 0.f ? v1 : v1 * a.slope;
+            }
+        }
+    }
+}
+
+static bool convv_valu_takes(int cin, int s, int cout, int k, int stride) {
+    if (stride != 1 || (k != 3 && k != 5) || s > 64 || s - k + 1 < 8) return false;
+    if (k == 5) return cin == 1 && (cout == 8 || cout == 12);
+    return (cin == 1 && (cout == 8 || cout == 12 || cout == 16)) || (cin == 8 && cout == 16) || (cin == 12 && cout == 24);
+}
+
+extern "C" int rf_conv3d_valid_valu_supported(int n, int cin, int s, int cout, int k, int stride) {
+    return n > 0 && convv_valu_takes(cin, s, cout, k, stride) ? 1 : 0;
+}
+
+// x [n][cin][s^3], w_t [cin][k^3][cout] (the OIDHW weight permuted to (1,2,3,4,0)), out [n][cout][so^3]
+extern "C" int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
+                                          int stride, float slope, float* out, void* stream) {
+    const float* w_oidhw = w_t;
+    RF_REQUIRE(x && w_oidhw && out && n > 0, RF_E_INVALID, "rf_conv3d_valid_leaky_valu: bad arguments");
+    RF_REQUIRE(convv_valu_takes(cin, s, cout, k, stride), RF_E_UNSUPPORTED,
+               "rf_conv3d_valid_leaky_valu: shape not taken by the VALU form (ask rf_conv3d_valid_valu_supported)");
+    ConvVVArgs a;
+    a.x = x; a.w = w_oidhw; a.bias = bias; a.out = out; a.n = n; a.cin = cin; a.cout = cout; a.s = s; a.so = s - k + 1; a.slope = slope;
+    a.ty = 256 / a.so;
+    if (a.ty > a.so) a.ty = a.so;
+    a.nty = (a.so + a.ty - 1) / a.ty;
+    a.ntz = (a.so + 3) / 4;
+    const int cc = cin >= 4 ? 4 : 1;
+    const int cpw = cout == 24 ? 12 : cout;                         // couts per workgroup: 24 accumulator columns x TZ leave 2 waves per SIMD, 12 leave 4
+    (void)cpw;
+    const size_t lds = ((size_t)cc * (4 + k - 1) * (a.ty + k - 1) * s) * sizeof(float);
+    RF_REQUIRE(lds <= 64 * 1024, RF_E_UNSUPPORTED, "rf_conv3d_valid_leaky_valu: tile of %zu bytes does not fit LDS", lds);
+    const unsigned grid = (unsigned)a.ntz * a.nty * n;
+    hipStream_t st = (hipStream_t)stream;
+#define RF_VV(COUT_, K_, CC_) hipLaunchKernelGGL((k_convv_valu<COUT_, K_, CC_>), dim3(grid, cout / COUT_), dim3(256), lds, st, a)
+    if (k == 5 && cout == 8) RF_VV(8, 5, 1);
+    else if (k == 5) RF_VV(12, 5, 1);
+    else if (cin == 1 && cout == 8) RF_VV(8, 3, 1);
+    else if (cin == 1 && cout == 12) RF_VV(12, 3, 1);
+    else if (cin == 1) RF_VV(16, 3, 1);
+    else if (cout == 16) RF_VV(16, 3, 4);
+    else RF_VV(12, 3, 4);
+#undef RF_VV
+    RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_valu");
+    return RF_OK;
+}

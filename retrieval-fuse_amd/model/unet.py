@@ -50,6 +50,7 @@ class Conv3dParams(nn.Module):
         self._packed = ops.PackedWeight('conv3' if (kernel_size == 3 and padding == 1) else 'convv')
         self._packed_up = ops.PackedWeight('conv3up')
         self._packed_lds = ops.PackedWeight('convvl')
+        self._packed_valu = ops.PackedWeight('convvv')
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -64,6 +65,10 @@ class Conv3dParams(nn.Module):
     def packed_lds(self):
         """operand image of the LDS-staged valid-conv form (patch encoders' large layers)"""
         return self._packed_lds.get(self.weight)
+
+    def packed_valu(self):
+        """[cin, k,k,k, cout] image of the VALU valid-conv form (patch encoders' first layers)"""
+        return self._packed_valu.get(self.weight)
 
     def packed_up(self, c0):
         """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""

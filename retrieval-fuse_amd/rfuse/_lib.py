@@ -42,6 +42,8 @@ SIGNATURES = {
     'rf_convv_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_valid_lds_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_valid_leaky_lds': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_conv3d_valid_valu_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_valid_leaky_valu': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
     'rf_convv_lds_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_convv_lds_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_pool_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),

@@ -95,7 +95,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'convvl': pack_convv_lds_weight, 'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -396,6 +396,32 @@ def conv3d_valid_leaky_lds(x, w_packed, bias, cout, k, stride, slope):
     out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().rf_conv3d_valid_leaky_lds(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
                                                      stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_lds')
+    return out
+
+
+USE_CONVV_VALU = True           # False: the first layers of the patch encoders stay on the matrix cores
+
+
+def conv_valid_valu_supported(x, cout, k, stride):
+    """True when the packed-fp32 VALU form (rf_conv3d_valid_leaky_valu) takes this layer (first layers of the patch encoders)."""
+    return USE_CONVV_VALU and bool(_lib.load().rf_conv3d_valid_valu_supported(x.shape[0], x.shape[1], x.shape[2], cout, k, stride))
+
+
+def pack_convv_valu_weight(w):
+    """OIDHW -> [cin][k^3][cout] (a permute: the VALU form reads whole cout vectors of a (channel, tap) through the scalar cache)"""
+    _req(w.detach(), 'conv weight')
+    return w.detach().permute(1, 2, 3, 4, 0).contiguous()
+
+
+def conv3d_valid_leaky_valu(x, w_t, bias, stride, slope):
+    """valid stride-1 conv + bias + LeakyReLU on the vector unit (w_t from pack_convv_valu_weight: [cin, k, k, k, cout])."""
+    _req(x, 'x'), _req(w_t, 'w_t')
+    n, cin, s = x.shape[0], x.shape[1], x.shape[2]
+    cout, k = w_t.shape[4], w_t.shape[1]
+    so = (s - k) // stride + 1
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_valu(_p(x), n, cin, s, _p(w_t), _p(bias.detach() if bias is not None else None), cout, k,
+                                                      stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_valu')
     return out
 
 

@@ -646,6 +646,23 @@ def test_conv3d_valid_leaky_lds(ops, spec):
     close(got, gather, 1e-5, 'lds form vs gather form')
 
 
+@pytest.mark.parametrize('spec', [(3, 1, 48, 12, 5), (2, 12, 44, 24, 3), (3, 1, 32, 8, 5), (2, 8, 28, 16, 3), (2, 1, 24, 12, 3), (3, 12, 22, 24, 3),
+                                  (2, 1, 16, 16, 3), (5, 1, 13, 8, 3), (2, 12, 11, 24, 3)])
+def test_conv3d_valid_leaky_valu(ops, spec):
+    """packed-fp32 VALU form of the patch encoders' first layers (PCPatch48 / Patch32 / Patch24V2 / Patch16 shapes, odd edges and
+    ragged last tiles) vs float64 torch and vs the gather-form MFMA kernel"""
+    n, cin, s, cout, k = spec
+    gen = torch.Generator().manual_seed(sum(spec) + 3)
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    xd = x.to(DEV)
+    assert ops.conv_valid_valu_supported(xd, cout, k, 1)
+    ref = F.leaky_relu(F.conv3d(x.double(), w.double(), b.double()), 0.2).float()
+    got = ops.conv3d_valid_leaky_valu(xd, ops.pack_convv_valu_weight(w.to(DEV)), b.to(DEV), 1, 0.2)
+    close(got, ref, 1e-5, 'valid conv (valu)')
+    gather = ops.conv3d_valid_leaky_mfma(xd, ops.pack_convv_weight(w.to(DEV)), b.to(DEV), cout, k, 1, 0.2)
+    close(got, gather, 1e-5, 'valu form vs gather form')
+
+
 def test_cpu_tensors_raise(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.maxpool2(torch.zeros(1, 1, 2, 2, 2))

@@ -57,8 +57,12 @@ for enc, nf, s0, spec in [('PCPatch48 nf=12', 12, 48, ((0, 1, 5, 1), (1, 2, 3, 1
         if ops.conv_valid_lds_supported(x, cout, k, stride):
             wl = ops.pack_convv_lds_weight(w)
             ms2 = timeit(lambda: ops.conv3d_valid_leaky_lds(x, wl, b, cout, k, stride, 0.2))
-        print('%-16s %3d->%-3d k%d s%d  %2d^3->%2d^3  gather %9.3f ms %6.1f TF/s   lds %s' % (enc, cin, cout, k, stride, s, so, ms, flops / ms / 1e9,
-              '%9.3f ms %6.1f TF/s' % (ms2, flops / ms2 / 1e9) if ms2 else '-'))
-        tot += min(ms, ms2) if ms2 else ms
+        ms3 = None
+        if ops.conv_valid_valu_supported(x, cout, k, stride):
+            wt = ops.pack_convv_valu_weight(w)
+            ms3 = timeit(lambda: ops.conv3d_valid_leaky_valu(x, wt, b, stride, 0.2))
+        print('%-16s %3d->%-3d k%d s%d  %2d^3->%2d^3  gather %9.3f ms %6.1f TF/s   lds %s   valu %s' % (enc, cin, cout, k, stride, s, so, ms, flops / ms / 1e9,
+              '%9.3f ms %6.1f TF/s' % (ms2, flops / ms2 / 1e9) if ms2 else '-', '%9.3f ms %6.1f TF/s' % (ms3, flops / ms3 / 1e9) if ms3 else '-'))
+        tot += min(t for t in (ms, ms2, ms3) if t)
         s = so
     print('%-16s total %.3f ms' % (enc, tot))
