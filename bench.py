@@ -198,7 +198,7 @@ def kernel_work(name, a, cfg):
     if name in ('rf_l2_topk', 'rf_l2_topk_keys'):
         nq, dim, n = a[:3]
         return 'mfma', 2.0 * nq * n * dim, 'flop (q.x per pair)'
-    if name == 'rf_conv3d_valid_leaky_mfma':
+    if name in ('rf_conv3d_valid_leaky_mfma', 'rf_conv3d_valid_leaky_lds', 'rf_conv3d_valid_leaky_valu'):
         n, cin, s, cout, k, stride = a[:6]
         so = (s - k) // stride + 1
         return 'mfma', 2.0 * cin * k ** 3 * cout * so ** 3 * n, 'flop'

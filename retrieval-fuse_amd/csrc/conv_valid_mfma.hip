@@ -562,15 +562,39 @@ __global__ __launch_bounds__(256) void k_convv_valu(ConvVVArgs a) {
 
     for (int c0 = 0; c0 < a.cin; c0 += CC) {
         __syncthreads();                                            // the previous chunk is consumed
-        for (int r = tid; r < CC * ZI * YI; r += 256) {             // input rows (full width): one row per thread and pass
-            const int yy = r % YI, zz = (r / YI) % ZI, cc = r / (YI * ZI);
-            const int iz = z0 + zz, iy = y0 + yy;
-            float* dst = xs + (cc * ZI + zz) * YI * s + yy * s;
-            if (c0 + cc < a.cin && iz < s && iy < s) {
-                const float* src = xin + (size_t)(c0 + cc) * ivol + ((size_t)iz * s + iy) * s;
-                for (int i = 0; i < s; ++i) dst[i] = src[i];
-            } else {
-                for (int i = 0; i < s; ++i) dst[i] = 0.f;
+        if ((s & 3) == 0) {
+            // input rows (full width, 16-byte aligned): float4 pieces, all loads of a thread in flight before the first LDS write
+            const int s4 = s >> 2, total4 = CC * ZI * YI * s4;
+            constexpr int PASSES = CC == 1 ? 4 : 10;               // >= ceil(total4 / 256) for every shape convv_valu_takes admits (s <= 64)
+            float4 st[PASSES];
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int i = tid + p * 256;
+                st[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < total4) {
+                    const int r = i / s4, x4 = i - r * s4;
+                    const int yy = r % YI, zz = (r / YI) % ZI, cc = r / (YI * ZI);
+                    const int iz = z0 + zz, iy = y0 + yy;
+                    if (c0 + cc < a.cin && iz < s && iy < s)
+                        st[p] = reinterpret_cast<const float4*>(xin + (size_t)(c0 + cc) * ivol + ((size_t)iz * s + iy) * s)[x4];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int i = tid + p * 256;
+                if (i < total4) reinterpret_cast<float4*>(xs)[i] = st[p];
+            }
+        } else {
+            for (int r = tid; r < CC * ZI * YI; r += 256) {         // odd row lengths: one row per thread and pass
+                const int yy = r % YI, zz = (r / YI) % ZI, cc = r / (YI * ZI);
+                const int iz = z0 + zz, iy = y0 + yy;
+                float* dst = xs + (cc * ZI + zz) * YI * s + yy * s;
+                if (c0 + cc < a.cin && iz < s && iy < s) {
+                    const float* src = xin + (size_t)(c0 + cc) * ivol + ((size_t)iz * s + iy) * s;
+                    for (int i = 0; i < s; ++i) dst[i] = src[i];
+                } else {
+                    for (int i = 0; i < s; ++i) dst[i] = 0.f;
+                }
             }
         }
         __syncthreads();
@@ -644,8 +668,6 @@ extern "C" int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s,
     a.nty = (a.so + a.ty - 1) / a.ty;
     a.ntz = (a.so + 3) / 4;
     const int cc = cin >= 4 ? 4 : 1;
-    const int cpw = cout == 24 ? 12 : cout;                         // couts per workgroup: 24 accumulator columns x TZ leave 2 waves per SIMD, 12 leave 4
-    (void)cpw;
     const size_t lds = ((size_t)cc * (4 + k - 1) * (a.ty + k - 1) * s) * sizeof(float);
     RF_REQUIRE(lds <= 64 * 1024, RF_E_UNSUPPORTED, "rf_conv3d_valid_leaky_valu: tile of %zu bytes does not fit LDS", lds);
     const unsigned grid = (unsigned)a.ntz * a.nty * n;
@@ -657,7 +679,7 @@ extern "C" int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s,
     else if (cin == 1 && cout == 12) RF_VV(12, 3, 1);
     else if (cin == 1) RF_VV(16, 3, 1);
     else if (cout == 16) RF_VV(16, 3, 4);
-    else RF_VV(12, 3, 4);
+    else RF_VV(24, 3, 4);
 #undef RF_VV
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_valu");
     return RF_OK;
