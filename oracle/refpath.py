@@ -155,7 +155,7 @@ def attention_block(x, p, sd, prefix, retrieval_mode, gumbel_noise=None, details
         y_soft = ((logits + gumbel_noise) / 1.0).softmax(dim=-1)                 # torch gumbel_softmax, tau = 1
         index = y_soft.max(dim=-1, keepdim=True)[1]
         y_hard = torch.zeros_like(logits).scatter_(-1, index, 1.0)
-        weights = y_hard - y_soft + y_soft                                       # hard=True forward value
+        weights = y_hard - y_soft.detach() + y_soft                              # hard=True: forward value y_hard, gradient of y_soft (torch's straight-through form)
     else:
         sharpness = (32 * e * e * e) * 4                                         # :105, cf_feat = 32
         weights = torch.softmax(sharpness * scores, dim=1)                       # :106

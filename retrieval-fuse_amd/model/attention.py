@@ -123,11 +123,34 @@ class AttentionBlock(nn.Module):
         p_feat = self.phi(p.contiguous()).reshape((b, -1))
         return ops.l2_normalize_rows_(x_feat), ops.l2_normalize_rows_(p_feat)
 
+    def _forward_autograd(self, x, p, gumbel_noise):
+        """Grad mode (training slice): the two feature encoders run rf_linear behind rfuse.autograd.Linear (the
+        GEMMs are 99 % of this block's work); the per-row rest -- normalise, K scores, switch, softmax / straight-through
+        Gumbel-hard, mix, blend -- is a few elementwise torch ops that autograd differentiates."""
+        b, k = p.shape[0], p.shape[1]
+        xf = nn.functional.normalize(self.theta(x), dim=1)
+        pf = nn.functional.normalize(self.phi(p.reshape((b * k,) + tuple(p.shape[2:]))), dim=1).reshape(b, k, -1)
+        scores = (xf.unsqueeze(1) * pf).sum(dim=2)                                   # [b, K]
+        switch = scores.amax(dim=1, keepdim=True).clamp_min(0.0)
+        if self.retrieval_mode:
+            if gumbel_noise is None:
+                gumbel_noise = self.sample_gumbel(b, k, x.device)
+            soft = torch.softmax(scores * 25.0 + gumbel_noise, dim=1)
+            hard = torch.zeros_like(soft).scatter_(1, soft.argmax(dim=1, keepdim=True), 1.0)
+            weights = hard - soft.detach() + soft                                    # straight-through estimator of gumbel_softmax(hard=True)
+        else:
+            weights = torch.softmax(scores * float((self.cf_feat * self.patch_extent ** 3) * 4), dim=1)
+        mixed = (weights.unsqueeze(2) * p.reshape(b, k, -1)).sum(dim=1)
+        flat = x.reshape(b, -1)
+        return (flat * (1.0 - switch) + mixed * switch).reshape(x.shape)
+
     def forward(self, x, p, gumbel_noise=None, debug=None):
         """x: [B,C,E,E,E]; p: [B,K,C,E,E,E] -> [B,C,E,E,E]; reference :84-113."""
         b, k, c, e = p.shape[0], p.shape[1], p.shape[2], p.shape[3]
         if k != self.K:
             raise ValueError(f'expected K={self.K} retrieved patches per row, got {k} (reference MaxPool1d(K) would window silently)')
+        if ops.needs_grad(x, p, self.theta.encoder[0].weight):
+            return self._forward_autograd(x, p, gumbel_noise)
         x, p = x.contiguous(), p.contiguous()
         x_feat = self.theta(x)
         p_feat = self.phi(p.reshape(b * k, c, e, e, e))
@@ -193,9 +216,24 @@ class PatchedAttentionBlock(nn.Module):
         occupancy_flat = occupancy_.reshape((x_predicted_feat_.shape[0], -1)).ne(0).any(dim=1)
         return x_feat_flat, p_feat_flat, occupancy_flat
 
+    def _forward_autograd(self, x_predicted, x_retrieved, gumbel_noise):
+        """grad mode: unfold / regroup / fold as differentiable views (no kernels), AttentionBlock._forward_autograd in between"""
+        b, c, s = x_predicted.shape[0], x_predicted.shape[1], x_predicted.shape[-1]
+        e, k = self.patch_extent, self.num_nearest_neighbors
+        r = s // e
+
+        def rows(v):                                                    # [n, c, s,s,s] -> [n, r,r,r, c, e,e,e]
+            return v.reshape(v.shape[0], c, r, e, r, e, r, e).permute(0, 2, 4, 6, 1, 3, 5, 7)
+        x_rows = rows(x_predicted).reshape(-1, c, e, e, e)
+        p_rows = rows(x_retrieved).reshape(b, k, r, r, r, c, e, e, e).permute(0, 2, 3, 4, 1, 5, 6, 7, 8).reshape(-1, k, c, e, e, e)
+        out = self.attention_blocks_layer(x_rows, p_rows, gumbel_noise)
+        return out.reshape(b, r, r, r, c, e, e, e).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b, c, s, s, s)
+
     def forward(self, x_predicted, x_retrieved, gumbel_noise=None, debug=None):
         """x_predicted [B,F,S,S,S]; x_retrieved [B*K,F,S,S,S] (folded volumes) -> [B,F,S,S,S]."""
         b, s = x_predicted.shape[0], x_predicted.shape[-1]
+        if ops.needs_grad(x_predicted, x_retrieved, self.attention_blocks_layer.theta.encoder[0].weight):
+            return self._forward_autograd(x_predicted, x_retrieved, gumbel_noise)
         if self.attention_blocks_layer.volume_route_ok():
             return self.attention_blocks_layer.forward_volumes(x_predicted, x_retrieved, s, gumbel_noise, debug)
         x_rows = self.unfold_3d(x_predicted)
@@ -208,6 +246,10 @@ class PatchedAttentionBlock(nn.Module):
         layout [(B*K*q^3), F, t,t,t] (what Fold3D(q, t, F) would consume, trainer/train_refinement.py:37,112): the fold
         is never materialised."""
         b, s = x_predicted.shape[0], x_predicted.shape[-1]
+        if ops.needs_grad(x_predicted, retrieved_patch_features, self.attention_blocks_layer.theta.encoder[0].weight):
+            q, c = s // patch_edge, x_predicted.shape[1]               # fold the patch-major features (Fold3D semantics) as a view
+            vols = retrieved_patch_features.reshape(-1, q, q, q, c, patch_edge, patch_edge, patch_edge).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(-1, c, s, s, s)
+            return self._forward_autograd(x_predicted, vols, gumbel_noise)
         if self.attention_blocks_layer.volume_route_ok():
             return self.attention_blocks_layer.forward_volumes(x_predicted, retrieved_patch_features, patch_edge, gumbel_noise)
         x_rows = self.unfold_3d(x_predicted)
@@ -227,6 +269,9 @@ class Fold3D(nn.Module):
         self.patch_extent = patch_extent
 
     def forward(self, x):
+        if ops.needs_grad(x):                                           # grad mode: the same index map as a differentiable view
+            r, e, c = self.num_patch_x, self.patch_extent, self.nf
+            return x.reshape(-1, r, r, r, c, e, e, e).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(-1, c, r * e, r * e, r * e)
         return ops.fold3d(x.contiguous(), self.num_patch_x, self.patch_extent, self.nf)
 
 
@@ -239,4 +284,7 @@ class Unfold3D(nn.Module):
         self.nf = nf
 
     def forward(self, x):
+        if ops.needs_grad(x):
+            e, c, r = self.patch_extent, x.shape[1], x.shape[2] // self.patch_extent
+            return x.reshape(x.shape[0], c, r, e, r, e, r, e).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(-1, c, e, e, e)
         return ops.unfold3d(x.contiguous(), self.patch_extent)

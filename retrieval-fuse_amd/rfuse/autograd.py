@@ -12,11 +12,14 @@ retrieval_backbone / attention parameters, :295-306 phase hand-over).  Built her
   Linear       y = act(x W^T + b)               the layers of AttentionFeatureEncoder (reference model/attention.py:29-46)
       backward  dx = rf_linear(dpre, W^T-as-weight),  dW = rf_linear(dpre^T, x^T-as-weight) in row chunks summed in float64
 
-torch does the bookkeeping only (transposes / flips / unfolds of operands, the activation mask of Linear, sums over the batch of
-per-sample float64 pieces).  Gradients are checked against float64 autograd of the oracle in tests/test_autograd_gpu.py.
-Not built (modules raise in grad mode): the patch attention proper (scores / softmax / blend), the fused attention MLP, the
-parity-split decoder kernel's own backward (two-source layers are differentiated through a materialised concat), the patch
-encoders (trained by trainer/train_retrieval.py, out of the refinement path).
+torch does the bookkeeping and the light per-row work: transposes / flips / unfolds of operands, the activation mask of Linear,
+sums over the batch of per-sample float64 pieces, max-pool (F.max_pool3d), the 16 -> 1 pointwise conv + tanh of the final decoder,
+fold / unfold as views, and the patch attention's per-row normalise / scores / softmax or straight-through Gumbel-hard / blend
+(model/attention.py:_forward_autograd) -- together < 1 % of the FLOPs.  With that the whole training graph of the reference
+(trainer/train_refinement.py:108-116 forward_full, all four networks trainable = phase 3) runs through the drop-in modules in grad
+mode; loss and every parameter gradient are checked against float64 autograd of the oracle in tests/test_autograd_gpu.py.
+Not built: backward of the fused kernels' fast routes (parity-split decoder conv, fused attention MLP, fused max-pool epilogue --
+grad mode takes the plain routes), the patch encoders (trained by trainer/train_retrieval.py, outside the refinement path).
 """
 import torch
 import torch.nn.functional as F

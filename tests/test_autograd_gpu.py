@@ -133,3 +133,62 @@ def test_retrieval_backbone_trains_like_the_oracle(gpu):
             p -= 0.05 * p.grad
     loss2 = ((rb(x.to(gpu)) - tgt.to(gpu)) ** 2).mean()
     assert loss2.item() < loss.item()
+
+
+@pytest.mark.parametrize('cfg_name', ['C3', 'C1'])
+def test_forward_full_trains_like_the_oracle(gpu, cfg_name):
+    """The reference's training graph (trainer/train_refinement.py:108-116 forward_full -> an L1 loss on df, phase 3: every network
+    trainable) through the drop-in modules in grad mode: loss value and the gradient of EVERY parameter of the four networks
+    against float64 autograd of the oracle.  C3 = softmax attention, C1 = straight-through Gumbel-hard with injected noise."""
+    import model
+    from model.attention import Unfold3D, Fold3D
+    cfg = rf_configs.get_config(cfg_name)
+    _, trunc_t = rf_configs.truncations(cfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mods = {'unet_backbone': model.get_unet_backbone(cfg), 'decoder': model.get_decoder(cfg),
+                'retrieval_backbone': model.get_retrieval_backbone(cfg), 'patched_attention_block': model.get_attention_block(cfg)}
+    sds = {k: helpers.seeded_sd({n: tuple(v.shape) for n, v in m.state_dict().items()}, 7000 + i) for i, (k, m) in enumerate(mods.items())}
+    for k, m in mods.items():
+        m.load_state_dict(sds[k])
+        m.to(gpu).train()
+    gen = torch.Generator().manual_seed(21)
+    K, B = cfg['K'], 1
+    x_in = torch.randn(B, 1, 8, 8, 8, generator=gen)
+    retr = torch.randn(B, K, 64, 64, 64, generator=gen)
+    target = torch.rand(B, 1, 64, 64, 64, generator=gen) * trunc_t
+    noise = -torch.empty(B * 4096, K).exponential_(generator=gen).log() * 4.0 if cfg['attn_retrieval_mode'] else None
+
+    x_back = mods['unet_backbone'](x_in.to(gpu))
+    feats = mods['retrieval_backbone'](Unfold3D(16, 1)(retr.reshape(B * K, 1, 64, 64, 64).to(gpu)))
+    x_retr = Fold3D(4, 8, cfg['nf'])(feats)
+    x_attn = mods['patched_attention_block'](x_back, x_retr, noise.to(gpu) if noise is not None else None)
+    df = (mods['decoder'](x_attn) + 1) * trunc_t / 2
+    loss = (df - target.to(gpu)).abs().mean()
+    loss.backward()
+
+    def oracle(dt):
+        sdo = {k: {n: v.detach().clone().to(dt).requires_grad_(True) for n, v in sd.items()} for k, sd in sds.items()}
+        dfo = refpath.forward_full(sdo, cfg, x_in.to(dt), retr.to(dt), trunc_t, noise.to(dt) if noise is not None else None)
+        lo = (dfo - target.to(dt)).abs().mean()
+        lo.backward()
+        return lo, sdo
+    torch.set_num_threads(16)
+    lo, sd64 = oracle(torch.float64)
+    _, sd32 = oracle(torch.float32)
+    assert abs(loss.item() - lo.item()) < 1e-4 * abs(lo.item())
+    dot = n1 = n2 = 0.0
+    worst = ('', 0.0, 0.0)
+    for k, m in mods.items():
+        for name, p in m.named_parameters():
+            ref = sd64[k][name].grad
+            if ref is None:                                   # sig_scale / sig_shift: serialised but unused (reference model/attention.py:62-63)
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0
+                continue
+            g = p.grad.detach().cpu().double()
+            e, e32 = rel_err(g, ref), rel_err(sd32[k][name].grad, ref)
+            if e > worst[1]:
+                worst = (k + '.' + name, e, e32)
+            dot, n1, n2 = dot + float((g * ref).sum()), n1 + float((g * g).sum()), n2 + float((ref * ref).sum())
+    cos = dot / np.sqrt(n1 * n2)
+    print(f'\n{cfg_name}: loss {loss.item():.6f} (oracle {lo.item():.6f}); worst parameter gradient (hip vs f64, torch-fp32 vs f64): {worst}; cosine {cos:.8f}')
+    assert cos > 0.9999

@@ -92,8 +92,7 @@ def test_product_path_has_no_cpu_fallback():
             m['decoder'](torch.zeros(1, 16, 32, 32, 32))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m['decoder'](torch.zeros(1, 16, 32, 32, 32))          # grad mode: the autograd functions run the same GPU-only kernels
-    with pytest.raises(NotImplementedError, match='inference only'):
-        # the patch attention proper has no backward (only the SingleConv layers and the feature encoders do)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
         m['patched_attention_block'](torch.zeros(1, 16, 32, 32, 32), torch.zeros(4, 16, 32, 32, 32))
 
 
