@@ -17,8 +17,13 @@
 //   A) skip channels (c0): 4-channel chunks, 27 taps on the full-res halo box, weight slab [27][4][NB*16] shared by the
 //      8 waves through LDS (LDS-DMA, double buffered) -- the scheme of conv3d_mfma.hip.
 //   B) upsampled channels (c1): 8-channel chunks, 8 taps on the low-res halo box (double buffered in LDS); every wave
-//      needs its own parity's weights [8 taps][8 ch][NB*16], read once per workgroup: they go global -> registers
-//      directly (one tap ahead), not through LDS.
+//      needs its own parity's weights [8 taps][8 ch][NB*16], read once per workgroup: they stream by LDS-DMA through a
+//      wave-private ring, several k-steps ahead of the MFMAs.  For 8^3 boxes the halo rows of the next chunk are LDS-DMA'd
+//      too (staging area, normalised into the other box buffer mid-chunk): the phase is one software pipeline without a
+//      s_waitcnt vmcnt(0) or a VGPR-staged load in it (see the comment at the phase).
+// All per-lane index arithmetic of the DMAs / row loads is done once per phase, per chunk only scalar bases change: VALU
+// instructions issue through the same port as the MFMAs, and the round-1 form (indices recomputed per piece to save
+// registers) cost 6 % of the kernel.
 // Epilogue: accumulators -> LDS tile [16 cout][box] -> ReLU -> contiguous float4 rows to HBM (the parity split would
 // otherwise leave every lane with stride-2 scalars), GroupNorm statistics of the output for the next layer as in
 // conv3d_mfma.hip (float64, fixed order, per workgroup tile).
@@ -90,6 +95,20 @@ struct UpArgs {
     int stats_tiles;
 };
 
+// s_waitcnt vmcnt(n) for an n that is a constant after unrolling (the instruction takes an immediate)
+__device__ __forceinline__ void rf_wait_vm(int n) {
+#define RF_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        RF_WVM(0) RF_WVM(1) RF_WVM(2) RF_WVM(3) RF_WVM(4) RF_WVM(5) RF_WVM(6) RF_WVM(7) RF_WVM(8) RF_WVM(9) RF_WVM(10) RF_WVM(11) RF_WVM(12)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef RF_WVM
+}
+
+// lane id from nothing (v_mbcnt): a value the register allocator can recompute instead of keeping threadIdx.x alive -- or spilling it --
+// across the MFMA phases
+__device__ __forceinline__ int rf_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 __device__ __forceinline__ unsigned up_xcd_contiguous(unsigned b, unsigned g) {      // see conv3d_mfma.hip
     const unsigned per = g >> 3, rem = g & 7u, k = b & 7u;
     return k * per + (k < rem ? k : rem) + (b >> 3);
@@ -124,7 +143,9 @@ struct UpTile {
     static constexpr int P = SPW * TE * TE * TE;
     static constexpr int EPI = 16 * (P + 1);                           // epilogue tile [16 cout][P + 1]
     static constexpr int MAIN = XS + 2 * WSLAB_PAD;                     // phase A: halo box + two shared weight slabs
-    static constexpr int MAINB = 2 * XS1 + NW * 2 * 16 * NCO;          // phase B: two low-res boxes + per-wave quarter slabs x2
+    static constexpr int RING = 7;                                     // TE == 8: 1-KiB pieces of weights per wave-private ring
+    static constexpr int MAINB = TE == 8 ? 2 * XS1 + NW * RING * 256 + 288 * 6 + 32      // two low-res boxes + rings + row staging
+                                         : 2 * XS1 + NW * 2 * 16 * NCO;                  // two low-res boxes + per-wave quarter slabs x2
     static constexpr int LDS_FLOATS = MAIN > MAINB ? (MAIN > EPI ? MAIN : EPI) : (MAINB > EPI ? MAINB : EPI);
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
     static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
@@ -195,44 +216,66 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
         int boff[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) boff[nb] = kq_a * NCO + ((nb * 16 + li_a + ROT * (kq_a & 1)) % NCO);
-        constexpr int WF4 = T::WSLAB / 4, NPIECE = (WF4 + 63) / 64;
-        auto dma_weights = [&](int cbase, int buf, int lane_) {
+        // Weight slab DMA: 1-KiB pieces of RPP slab rows [tap][ci] x NCO; piece q is rows [q RPP, (q+1) RPP).  Everything that
+        // depends on the lane is computed ONCE (the per-chunk part is a scalar base): the per-piece index arithmetic of the
+        // round-1 form -- a runtime modulo and 64-bit multiplies among it -- ran on the VALU port the MFMAs issue through.
+        constexpr int LPR = NCO / 4, RPP = 64 / LPR;                    // lanes per slab row; slab rows per piece (4, 8, 16)
+        constexpr int NPIECE = (27 * 4 + RPP - 1) / RPP;
+        const int wr_a = lane_a / LPR, wslot_a = (lane_a % LPR) * 4;
+        const int wcol_a = (wslot_a + NCO - ROT * (wr_a & 1)) % NCO;    // slab row parity = piece row parity (RPP is even)
+        int wco_a = cob + wcol_a;
+        if (wco_a >= a.cout16) wco_a = wcol_a % a.cout16;               // block wider than the image: masked at the store
+        const int wtap_a = wr_a >> 2;                                   // tap of this lane's row inside a piece
+        const unsigned walane = 4u * (unsigned)((wtap_a * a.c0_4 + (wr_a & 3)) * a.cout16 + wco_a);   // bytes
+        auto dma_weights = [&](int cbase, int buf) {
             float* dst = wsb + buf * T::WSLAB_PAD;
+            unsigned off = walane;                                      // opaque: SGPR base + 32-bit lane offset addressing
+            asm volatile("" : "+v"(off));
 #pragma unroll
             for (int i = 0; i < (NPIECE + 7) / 8; ++i) {
                 const int q = wave + i * 8;
                 if (q < NPIECE) {
-                    int idx = q * 64 + lane_;
-                    if (idx >= WF4) idx = WF4 - 1;
-                    const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
-                    const int col = (slot + NCO - ROT * (r & 1)) % NCO;
-                    int co = cob + col;
-                    if (co >= a.cout16) co = col % a.cout16;
-                    int ci = cbase + r % 4;
-                    if (ci >= a.c0_4) ci = a.c0_4 - 1;
-                    const float* src = a.wp + ((size_t)(r / 4) * a.c0_4 + ci) * a.cout16 + co;
-                    __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+                    const int tap0 = q * (RPP / 4);
+                    const char* src = reinterpret_cast<const char*>(a.wp + ((size_t)tap0 * a.c0_4 + cbase) * a.cout16);
+                    if (RPP == 4 || tap0 + wtap_a < 27)                 // rows past tap 26 of the last piece are never read
+                        __builtin_amdgcn_global_load_lds((rf_gptr)(src + off), (rf_lptr)(dst + q * 256), 16, 0, 0);
                 }
             }
         };
+        // Halo rows of the chunk: thread r -> row (sample s, chunk channel c, hz, hy) of TE + 2 floats, through registers (they
+        // are normalised on the way into LDS).  Per-lane constants once, per chunk a scalar base.
         constexpr int ROWS = SPW * 4 * HE * HE;
         constexpr int RPT = (ROWS + NT - 1) / NT;
         float xraw[RPT][TE + 2];
         float xce[RPT], xsc[RPT], xsh[RPT];
         const bool has_l = x0 > 0, has_r = x0 + TE < edge;
-        auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
-            hy = r % HE; hz = (r / HE) % HE; c = (r / (HE * HE)) % 4; s = r / (HE * HE * 4);
-            nn = n0 + s; ci = cbase + c; z = z0 + hz - 1; y = y0 + hy - 1;
-            return r < ROWS && nn < a.n && ci < a.c0 && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge;
-        };
-        auto issue_rows = [&](int cbase, int tid_) {
+        unsigned rowoffA[RPT], affoffA[RPT];                            // bytes behind (sample n0, channel cbase) of src0 / the affine table
+        int rowboxA[RPT], rowcA[RPT];                                   // LDS row; chunk channel (>= 1 << 20: zero row, < 0: no row)
+        {
+            int tid_a = tid;
+            asm volatile("" : "+v"(tid_a));
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                int s, c, hz, hy, nn, ci, z, y;
-                if (row_coords(tid_ + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
-                    const size_t si = (size_t)nn * cin + ci;
-                    { const float4 af = a.affine[si]; xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
-                    const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
+                const int r = tid_a + i * NT;
+                const int hy = r % HE, hz = (r / HE) % HE, c = (r / (HE * HE)) % 4, s = r / (HE * HE * 4);
+                const int z = z0 + hz - 1, y = y0 + hy - 1;
+                const bool in = r < ROWS && n0 + s < a.n && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge;
+                rowoffA[i] = in ? 4u * (unsigned)((((s * a.c0 + c) * edge + z) * edge + y) * edge + x0) : 4u * (unsigned)x0;
+                affoffA[i] = in ? 16u * (unsigned)(s * cin + c) : 0u;
+                rowboxA[i] = (s * 4 + c) * CH0 + (hz * HE + hy) * HXA;
+                rowcA[i] = r < ROWS ? (in ? c : (1 << 20)) : -1;
+            }
+        }
+        auto issue_rows = [&](int cbase) {
+            const char* vol0 = reinterpret_cast<const char*>(a.src0 + ((size_t)n0 * a.c0 + cbase) * edge * edge * edge);
+            const char* aff0 = reinterpret_cast<const char*>(a.affine + ((size_t)n0 * cin + cbase));
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                if (rowcA[i] >= 0 && cbase + rowcA[i] < a.c0) {
+                    unsigned ro = rowoffA[i], ao = affoffA[i];
+                    asm volatile("" : "+v"(ro), "+v"(ao));
+                    { const float4 af = *reinterpret_cast<const float4*>(aff0 + ao); xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
+                    const float* row = reinterpret_cast<const float*>(vol0 + ro);
 #pragma unroll
                     for (int q = 0; q < TE / 4; ++q) {
                         const float4 t = reinterpret_cast<const float4*>(row)[q];
@@ -243,15 +286,12 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 }
             }
         };
-        auto commit_rows = [&](int cbase, int tid_) {
+        auto commit_rows = [&](int cbase) {
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int r = tid_ + i * NT;
-                int s, c, hz, hy, nn, ci, z, y;
-                const bool ok = row_coords(r, cbase, s, c, hz, hy, nn, ci, z, y);
-                if (r < ROWS) {
+                if (rowcA[i] >= 0) {
                     float v[TE + 2];
-                    if (ok) {
+                    if (cbase + rowcA[i] < a.c0) {
                         const float ce = xce[i], sc = xsc[i], sh = xsh[i];
 #pragma unroll
                         for (int j = 1; j <= TE; ++j) v[j] = fmaf(xraw[i][j] - ce, sc, sh);
@@ -261,25 +301,23 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                         for (int j = 0; j < TE + 2; ++j) v[j] = 0.f;
                     }
-                    float* dst = xs + (s * 4 + c) * CH0 + (hz * HE + hy) * HXA;
+                    float* dst = xs + rowboxA[i];
 #pragma unroll
                     for (int j = 0; j < TE + 2; ++j) dst[j] = v[j];
                 }
             }
         };
 
-        dma_weights(0, 0, lane);
-        issue_rows(0, tid);
-        commit_rows(0, tid);
+        dma_weights(0, 0);
+        issue_rows(0);
+        commit_rows(0);
         __syncthreads();
         int buf = 0;
         for (int cbase = 0; cbase < a.c0; cbase += 4) {
             const bool more = cbase + 4 < a.c0;
-            int tid_o = tid;                                            // opaque: keeps the row index math inside the loop
-            asm volatile("" : "+v"(tid_o));
             if (more) {
-                issue_rows(cbase + 4, tid_o);
-                dma_weights(cbase + 4, buf ^ 1, tid_o & 63);
+                issue_rows(cbase + 4);
+                dma_weights(cbase + 4, buf ^ 1);
             }
             {
                 const float* ws = wsb + buf * T::WSLAB_PAD;
@@ -291,9 +329,20 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
                     const int cur = t & 1, nxt = cur ^ 1;
-                    // keep the operand reads of later taps out of this step: left alone, hipcc pairs reads of neighbouring
-                    // taps into ds_read2 far ahead of their use and then spills them (and an accumulator) to scratch
-                    asm volatile("" ::: "memory");
+                    // Software pipeline, pinned with scheduling barriers (left alone, hipcc sinks the reads of tap t+1 below the MFMAs
+                    // of tap t and every tap starts with a full LDS round trip): m-block 1 of tap t | reads of tap t+1 | the other
+                    // m-blocks of tap t.  The compiler's s_waitcnt lgkmcnt(0) then lands in front of the first MFMA of tap t+1,
+                    // 3/4 of a tap (~400 cycles) after the reads went out.
+                    auto mfma_mb = [&](int mb) {
+                        // m-block on the first / last z slice of the volume: its dz = -1 / +1 taps read only zero padding
+                        if ((t / 9 == 0 && ((LO >> mb) & 1u)) || (t / 9 == 2 && ((HI >> mb) & 1u))) return;        // compile-time
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_mb(1);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (t + 1 < 27) {
                         const int t1 = t + 1;
                         const int toff = ((t1 / 9) * HE + (t1 / 3) % 3) * HXA + t1 % 3;
@@ -302,28 +351,211 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + t1 * 4 * NCO];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        // m-block on the first / last z slice of the volume: its dz = -1 / +1 taps read only zero padding
-                        if ((t / 9 == 0 && ((LO >> mb) & 1u)) || (t / 9 == 2 && ((HI >> mb) & 1u))) continue;      // compile-time
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
-                    }
+                    for (int mb = 0; mb < MB; ++mb)
+                        if (mb != 1) mfma_mb(mb);
                 }
             }
             __syncthreads();
-            if (more) {
-                int tid_c = tid;
-                asm volatile("" : "+v"(tid_c));
-                commit_rows(cbase + 4, tid_c);
-            }
+            if (more) commit_rows(cbase + 4);
             __syncthreads();
             buf ^= 1;
         }
     }
 
     // ========================================================================== B) upsampled channels, 8 low-res taps
+    if constexpr (TE == 8) {
+        // One 8^3 box (L = 4): low-res halo rows are 4 floats = one 16-byte LDS-DMA unit.  Nothing of the next chunk passes
+        // through VGPRs and no address is recomputed per step (in the round-1 form the halo rows lived in 9 VGPRs across the
+        // MFMA steps -- hipcc spilled them right behind their loads, s_waitcnt vmcnt(0) included -- and every weight DMA redid
+        // ~45 VALU instructions of index arithmetic, quarter-rate multiplies among them, competing with the MFMAs for the
+        // SIMD's issue port):
+        //   * wave w stages channel w of the chunk: lanes 0..35 DMA the 6 x 6 (z, y) rows, their two x-halo floats and the
+        //     channel's GroupNorm triple into a staging area; at mid-chunk the same lanes normalise them into the other box
+        //     buffer (zero padding outside the volume).  The wave that DMAs a row commits it: no barrier in between.
+        //   * this wave's weights [tap][k8][cout16] stream through a wave-private ring of RING 1-KiB pieces (one full-wave DMA
+        //     instruction = GS k-steps of 4 rows x NCO floats), RING - 1 pieces ahead of the MFMAs.  The number of DMA
+        //     instructions between any two points of the loop is static (pieces past the end are re-reads of the last one)
+        //     and vmcnt retires in order, so "piece P+1 has landed" is s_waitcnt vmcnt(RING - 2 [+ RDMA while the chunk's row
+        //     DMAs are younger than that piece]) and "the rows have landed" is vmcnt(pieces issued since).
+        //   * one software pipeline across the whole phase: operand reads of k-step S+1 go out in the middle of k-step S, also
+        //     across the chunk boundary (one LDS-only barrier per chunk, no vmcnt(0) anywhere in the loop).
+        static_assert(L == 4 && LH == 6 && SPW == 1, "TE == 8 tile");
+        constexpr int RING = T::RING, STEP = 4 * NCO;                  // ring pieces per wave; floats per k-step
+        constexpr int GS = 256 / STEP, PPC = 16 / GS;                   // k-steps per piece (1, 2, 4); pieces per chunk
+        constexpr int CS = 8;                                           // the k-step in whose middle the next chunk's rows are committed
+        constexpr int RDMA = 4;                                         // row, left halo, right halo, affine: DMA instructions per chunk
+        float* const stg = smem + 2 * T::XS1 + T::NW * RING * 256;        // [288][4] raw rows | [288] left | [288] right | [8][4] affine
+        float* const stgl = stg + 288 * 4;
+        float* const stgr = stgl + 288;
+        float* const stga = stgr + 288;
+        float* const wslab = smem + 2 * T::XS1 + wave * (RING * 256);
+        const int Z0 = z0 >> 1, Y0 = y0 >> 1, X0 = x0 >> 1;
+        const bool has_l = X0 > 0, has_r = X0 + L < half;
+        const int nstep = (a.c1_8 >> 3) * 16, npiece = (a.c1_8 >> 3) * PPC;
+        const size_t hvol = (size_t)half * half * half;
+
+        const int lane_b = rf_lane();
+        const int kq = lane_b >> 4, li = lane_b & 15;
+        // ---- staging: row (hz, hy) = lane (< 36) of channel `wave`.  Recomputed from an opaque copy of the lane id where it is
+        //      used (once per chunk, ~10 VALU): held across the loop these values get spilled, and a reload is a s_waitcnt vmcnt(0).
+        auto row_of_lane = [&](int l, bool& in, unsigned& off) {
+            const int hz = l / 6, hy = l - hz * 6;
+            const int rz = Z0 + hz - 1, ry = Y0 + hy - 1;
+            in = l < 36 && (unsigned)rz < (unsigned)half && (unsigned)ry < (unsigned)half;
+            // BYTES from the channel's volume (SGPR base + 32-bit lane offset addressing); rows outside the volume read row (0, 0) at
+            // X0 (their -4 / +16 halo reads stay inside the row: the offset is unsigned, a wrap would be +4 GiB)
+            off = 4u * (unsigned)((in ? (rz * half + ry) * half : 0) + X0);
+        };
+        // ---- per-lane constant of the weight DMA: row r = lane / (NCO/4) of the k-step, bank-rotated column
+        const int wr = lane_b / (NCO / 4), wslot = (lane_b % (NCO / 4)) * 4;
+        const int wcol = (wslot + NCO - (16 * (wr & 3)) % NCO) % NCO;
+        int wco = cob + wcol;
+        if (wco >= a.cout16) wco = wcol % a.cout16;                     // block wider than the image: masked at the store
+        const unsigned wlane = 4u * (unsigned)(wr * a.cout16 + wco);    // bytes
+        const float* const wimg = a.wp + (size_t)27 * a.c0_4 * a.cout16 + (size_t)wave * 64 * a.cout16;
+
+        int aoff1[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int v = mb * 16 + li;
+            int X, Y, Z, s;
+            up_lattice<TE>(v, s, Z, Y, X);
+            aoff1[mb] = kq * CH1 + ((Z + pz) * LH + (Y + py)) * LH + (X + px);
+        }
+        int boff1[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) boff1[nb] = kq * NCO + ((nb * 16 + li + 16 * kq) % NCO);
+
+        auto dma_piece = [&](int P, int slot) {                         // image rows [4 GS P, 4 GS (P + 1)) of this parity -> ring slot
+            if (P >= npiece) P = npiece - 1;                            // past the end: keeps the DMA count static, lands in a dead slot
+            const float* src = wimg + ((size_t)(P / PPC) * 512 + (size_t)(P % PPC) * (4 * GS)) * a.cout16;
+            unsigned off = wlane;                                       // opaque: SGPR base + 32-bit lane offset at the instruction, not a
+            asm volatile("" : "+v"(off));                               // hoisted 64-bit address pair per lane
+            __builtin_amdgcn_global_load_lds((rf_gptr)(reinterpret_cast<const char*>(src) + off), (rf_lptr)(wslab + slot * 256), 16, 0, 0);
+        };
+        auto dma_rows = [&](int cbase) {                                // channel cbase + wave -> staging (RDMA instructions)
+            int ci = cbase + wave;
+            if (ci >= a.c1) ci = a.c1 - 1;                              // padded channel: staged, committed as zeros
+            const char* vol1 = reinterpret_cast<const char*>(a.src1 + ((size_t)n0 * a.c1 + ci) * hvol);
+            int l = rf_lane();                                          // opaque: not hoisted out of the loop (and then spilled)
+            asm volatile("" : "+v"(l));
+            bool in;
+            unsigned off;
+            row_of_lane(l, in, off);
+            if (l < 36) {
+                __builtin_amdgcn_global_load_lds((rf_gptr)(vol1 + off), (rf_lptr)(stg + wave * 36 * 4), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((rf_gptr)(vol1 + (off - (has_l ? 4u : 0u))), (rf_lptr)(stgl + wave * 36), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((rf_gptr)(vol1 + (off + (has_r ? 4u * L : 0u))), (rf_lptr)(stgr + wave * 36), 4, 0, 0);
+            }
+            if (l == 0)
+                __builtin_amdgcn_global_load_lds((rf_gptr)(a.affine + ((size_t)n0 * cin + a.c0 + ci)), (rf_lptr)(stga + wave * 4), 16, 0, 0);
+        };
+        auto commit_rows = [&](int cbase, float* box) {                 // staging -> normalised rows of channel `wave`
+            int l = rf_lane();                                          // opaque: not hoisted out of the loop (and then spilled)
+            asm volatile("" : "+v"(l));
+            if (l < 36) {
+                bool in;
+                unsigned off;
+                row_of_lane(l, in, off);
+                const float4 af = *reinterpret_cast<const float4*>(stga + wave * 4);
+                const float4 u = *reinterpret_cast<const float4*>(stg + (wave * 36 + l) * 4);
+                const float ul = stgl[wave * 36 + l], ur = stgr[wave * 36 + l];
+                const bool ok = in && cbase + wave < a.c1;
+                float2 v0, v1, v2;
+                v0.x = ok && has_l ? fmaf(ul - af.x, af.y, af.z) : 0.f;
+                v0.y = ok ? fmaf(u.x - af.x, af.y, af.z) : 0.f;
+                v1.x = ok ? fmaf(u.y - af.x, af.y, af.z) : 0.f;
+                v1.y = ok ? fmaf(u.z - af.x, af.y, af.z) : 0.f;
+                v2.x = ok ? fmaf(u.w - af.x, af.y, af.z) : 0.f;
+                v2.y = ok && has_r ? fmaf(ur - af.x, af.y, af.z) : 0.f;
+                float2* dst = reinterpret_cast<float2*>(box + wave * CH1 + l * LH);
+                dst[0] = v0; dst[1] = v1; dst[2] = v2;
+            }
+        };
+        auto lds_barrier = [&]() {                                      // LDS-only: the weight DMAs in flight stay in flight
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        };
+
+        // ---- prologue: the whole ring in flight, chunk 0 staged and committed
+#pragma unroll
+        for (int i = 0; i < RING; ++i) dma_piece(i, i);
+        dma_rows(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        commit_rows(0, xs);
+        lds_barrier();
+
+        float av[2][MB], bv[2][NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff1[mb]];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[0][nb] = wslab[boff1[nb]];
+        int slot = 0;                                                   // ring slot of the current piece (wave-uniform)
+        int buf = 0;
+        for (int S0 = 0; S0 < nstep; S0 += 16) {
+            const bool more = S0 + 16 < nstep;
+            const int P0 = (S0 >> 4) * PPC;                             // first piece of this chunk
+            const float* xb = xs + buf * T::XS1;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                const int tz = s >> 3;                                  // low-res z tap of this k-step (tap = s >> 1)
+                auto mfma_mb = [&](int mb) {
+                    // low-res row Z-1 of the first lattice plane / Z+1 of the last one is zero padding of the volume
+                    if ((tz == 0 && ((LO >> mb) & 1u)) || (tz == 1 && ((HI >> mb) & 1u))) return;                  // compile-time
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_mb(1);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- middle of k-step S0 + s
+                const bool last_of_piece = s % GS == GS - 1;            // the next k-step reads the next piece; this one's slot is free
+                int nslot = slot;
+                if (last_of_piece) {
+                    // piece P+1 landed?  In flight: pieces P+1 .. P+RING-1, and -- if already issued (s >= 1) and younger than piece
+                    // P+1 -- the RDMA row DMAs of this chunk.  They went out in the middle of k-step 0, behind piece
+                    // P0 + RING (GS == 1; P0 + RING - 1 otherwise).
+                    const int j = s / GS;                               // P = P0 + j
+                    const bool rows_younger = s >= 1 && j + 1 <= (GS == 1 ? RING : RING - 1);
+                    if (more && rows_younger) rf_wait_vm(RING - 2 + RDMA); else rf_wait_vm(RING - 2);
+                    nslot = slot + 1;
+                    if (nslot == RING) nslot = 0;
+                }
+                if (s == 15 && more) lds_barrier();                     // the next chunk's box is complete (committed at s = CS)
+                if (s < 15 || more) {
+                    const float* xn = s < 15 ? xb : xs + (buf ^ 1) * T::XS1;
+                    const int s1 = (s + 1) & 15, t1 = s1 >> 1, k1 = s1 & 1;
+                    const int toff = ((t1 >> 2) * LH + ((t1 >> 1) & 1)) * LH + (t1 & 1) + k1 * 4 * CH1;
+                    const float* wn = wslab + nslot * 256 + (s1 % GS) * STEP;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xn[aoff1[mb] + toff];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = wn[boff1[nb]];
+                }
+                if (last_of_piece) dma_piece(P0 + s / GS + RING, slot); // refill the slot just read to the end
+                if (s == 0 && more) dma_rows((S0 >> 1) + 8);
+                if (s == CS && more) {
+                    int younger = 0;                                    // pieces issued behind the row DMAs so far
+#pragma unroll
+                    for (int q = 1; q <= CS; ++q) younger += q % GS == GS - 1;
+                    rf_wait_vm(younger);
+                    commit_rows((S0 >> 1) + 8, xs + (buf ^ 1) * T::XS1);
+                }
+                slot = nslot;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    if (mb != 1) mfma_mb(mb);
+            }
+            buf ^= 1;
+        }
+        __syncthreads();                                                // every wave is done with the boxes and its ring
+    } else
     {
         constexpr int ROWS = SPW * 8 * LH * LH;                         // rows of LH floats
         constexpr int RPT = (ROWS + NT - 1) / NT;
@@ -446,7 +678,17 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {                        // step = (tap 2q + st/2, k-step st&1)
                     const int cur = st & 1, nxt = cur ^ 1;
-                    asm volatile("" ::: "memory");
+                    const int tz = (2 * q + (st >> 1)) >> 2;             // low-res z tap of this step (compile-time)
+                    auto mfma_mb = [&](int mb) {
+                        // low-res row Z-1 of the first lattice plane / Z+1 of the last one is zero padding of the volume
+                        if ((tz == 0 && ((LO >> mb) & 1u)) || (tz == 1 && ((HI >> mb) & 1u))) return;              // compile-time
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                    };
+                    __builtin_amdgcn_sched_barrier(0);                   // same pipeline as phase A
+                    mfma_mb(1);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (st + 1 < 4) {
                         const int t1 = 2 * q + ((st + 1) >> 1), k1 = (st + 1) & 1;
                         const int toff = ((t1 >> 2) * LH + ((t1 >> 1) & 1)) * LH + (t1 & 1) + k1 * 4 * CH1;
@@ -455,15 +697,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff1[nb] + (st + 1) * 4 * NCO];
                     }
-                    const int tz = (2 * q + (st >> 1)) >> 2;             // low-res z tap of this step (compile-time)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        // low-res row Z-1 of the first lattice plane / Z+1 of the last one is zero padding of the volume
-                        if ((tz == 0 && ((LO >> mb) & 1u)) || (tz == 1 && ((HI >> mb) & 1u))) continue;            // compile-time
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
-                    }
+                    for (int mb = 0; mb < MB; ++mb)
+                        if (mb != 1) mfma_mb(mb);
                 }
             }
             if (more) {
@@ -478,8 +715,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 
     // ===================================================================================================== epilogue
     // accumulators -> LDS [16 cout][P + 1] in memory order of the box -> ReLU'd float4 rows; statistics on the way
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
+    const int lane_e = rf_lane();
+    const int tid_e = wave * 64 + lane_e;
     const int kq = lane_e >> 4, li = lane_e & 15;
     float* eb = smem;
     double* red = reinterpret_cast<double*>(smem);                       // [8 waves][SPW][16 cout][2], used after the stores
@@ -499,7 +736,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             }
         }
         __syncthreads();
-        for (int q = tid; q < 16 * (P / 4); q += NT) {
+        for (int q = tid_e; q < 16 * (P / 4); q += NT) {
             const int col = q / (P / 4), lin = (q % (P / 4)) * 4;
             const int co = cob + nb * 16 + col;
             const int s = lin / TE3, rem = lin % TE3;
@@ -526,7 +763,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                     }
                 sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
                 sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-                if (lane < 16) { red[(wave * 16 + lane) * 2] = sm; red[(wave * 16 + lane) * 2 + 1] = sq; }
+                if (lane_e < 16) { red[(wave * 16 + lane_e) * 2] = sm; red[(wave * 16 + lane_e) * 2 + 1] = sq; }
             } else {
                 // T = 4, four samples: voxel v = mb*16 + 4*kq + r belongs to sample kq (both m-blocks = lattice planes)
                 double sm = 0.0, sq = 0.0;
@@ -541,8 +778,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 red[((wave * SPW + kq) * 16 + li) * 2 + 1] = sq;
             }
             __syncthreads();
-            if (tid < SPW * 16) {
-                const int s = tid / 16, col = tid % 16;
+            if (tid_e < SPW * 16) {
+                const int s = tid_e / 16, col = tid_e % 16;
                 const int co = cob + nb * 16 + col, nn = n0 + s;
                 if (co < a.cout && nn < a.n) {
                     double sm = 0.0, sq = 0.0;
