@@ -154,51 +154,66 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- weight slab of one chunk -> LDS by DMA: piece q (1 KiB = 64 lanes x 16 B) is issued by wave q % NW
-    constexpr int WF4 = T::WSLAB / 4;                      // float4s in a slab
-    constexpr int NPIECE = (WF4 + 63) / 64;
-    auto dma_weights = [&](int cbase, int buf, int lane) {
+    // ---- weight slab of one chunk -> LDS by DMA: piece q (1 KiB = 64 lanes x 16 B = RPP slab rows [tap][channel] x NCO) is issued by
+    // wave q % NW.  Everything that depends on the lane is computed ONCE, per chunk only a scalar base changes: VALU instructions
+    // issue through the same port as the MFMAs, and the round-1 form (~45 VALU per piece -- a runtime modulo and 64-bit multiplies
+    // among them -- recomputed to save registers) cost the 16-cout layers a quarter of their MFMA time.
+    static_assert(CC == 4, "the lane-constant DMA addressing assumes 4-channel chunks (cin4 % CC == 0)");
+    constexpr int LPR = NCO / 4, RPP = 64 / LPR;            // lanes per slab row; slab rows per piece (4, 8, 16)
+    constexpr int NPIECE = (27 * CC + RPP - 1) / RPP;
+    const int wr = lane / LPR, wslot = (lane % LPR) * 4;
+    const int wcol = (wslot + NCO - ROT * (wr & 1)) % NCO;   // logical cout column stored at this slot (slab row parity = piece row parity)
+    int wco = cob + wcol;
+    if (wco >= a.cout16) wco = wcol % a.cout16;              // cout block wider than the packed image: any valid column (masked at store)
+    const unsigned wlane = 4u * (unsigned)(((wr / CC) * a.cin4 + wr % CC) * a.cout16 + wco);     // bytes
+    auto dma_weights = [&](int cbase, int buf) {
         float* dst = wsb + buf * T::WSLAB_PAD;
+        unsigned off = wlane;                                // opaque: SGPR base + 32-bit lane offset addressing at the instruction
+        asm volatile("" : "+v"(off));
 #pragma unroll
         for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
-            const int q = wave + i * NW;                   // wave-uniform
+            const int q = wave + i * NW;                     // wave-uniform
             if (q < NPIECE) {
-                int idx = q * 64 + lane;                   // float4 index inside the slab (LDS image is linear in idx)
-                if (idx >= WF4) idx = WF4 - 1;             // tail lanes of the last piece: harmless duplicate into the pad
-                const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
-                const int col = (slot + NCO - ROT * (r & 1)) % NCO;      // logical cout column stored at this slot
-                int co = cob + col;
-                if (co >= a.cout16) co = col % a.cout16;   // cout block wider than the packed image: any valid column (masked at store)
-                int ci = cbase + r % CC;                  // slab row r = tap*CC + channel
-                if (ci >= a.cin4) ci = a.cin4 - 1;         // chunk reaches past the packed image (cin4 % CC != 0): the matching input rows are zero
-                const float* src = a.wp + ((size_t)(r / CC) * a.cin4 + ci) * a.cout16 + co;
-                __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+                const int tap0 = q * (RPP / CC);
+                const char* src = reinterpret_cast<const char*>(a.wp + ((size_t)tap0 * a.cin4 + cbase) * a.cout16);
+                if (RPP == CC || tap0 + wr / CC < 27)        // rows past tap 26 of the last piece are never read
+                    __builtin_amdgcn_global_load_lds((rf_gptr)(src + off), (rf_lptr)(dst + q * 256), 16, 0, 0);
             }
         }
     };
 
-    // ---- input halo rows: one thread per row (HX = TX + 2 floats), register-staged
+    // ---- input halo rows: one thread per row (HX = TX + 2 floats), register-staged.  Row r -> (sample s, chunk channel c, hz, hy);
+    // the per-row constants once, per chunk a scalar base (the skip-source rows; rows of an upsampled source keep the index math).
     constexpr int ROWS = SPW * CC * T::HZ * HY;
     constexpr int RPT = (ROWS + NT - 1) / NT;
     float xraw[RPT][TX + 2];       // [left halo | TX interior (or TX/2 low-res values) | right halo]
     float xce[RPT], xsc[RPT], xsh[RPT];
     const bool has_l = x0 > 0, has_r = x0 + TX < edge;
+    unsigned rowoff[RPT], affoff[RPT];                     // bytes behind (sample n0, channel cbase) of src0 / of the affine table
+    int rowbox[RPT], rowc[RPT];                            // LDS row; chunk channel (>= 1 << 20: row outside the volume -> zeros, < 0: no row)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = tid + i * NT;
+        const int hy = r % HY, hz = (r / HY) % T::HZ, c = (r / (HY * T::HZ)) % CC, s = r / (HY * T::HZ * CC);
+        const int z = z0 + hz - 1, y = y0 + hy - 1;
+        const bool in = r < ROWS && n0 + s < a.n && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge;
+        rowoff[i] = in ? 4u * (unsigned)((((s * a.c0 + c) * edge + z) * edge + y) * edge + x0) : 0u;
+        affoff[i] = in ? 16u * (unsigned)(s * cin + c) : 0u;
+        rowbox[i] = (s * CC + c) * CH + (hz * HY + hy) * HX;
+        rowc[i] = r < ROWS ? (in ? c : (1 << 20)) : -1;
+    }
 
-    auto row_coords = [&](int r, int cbase, int& s, int& c, int& hz, int& hy, int& nn, int& ci, int& z, int& y) -> bool {
-        hy = r % HY; hz = (r / HY) % T::HZ; c = (r / (HY * T::HZ)) % CC; s = r / (HY * T::HZ * CC);
-        nn = n0 + s; ci = cbase + c; z = z0 + hz - 1; y = y0 + hy - 1;
-        return r < ROWS && nn < a.n && ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge;
-    };
-
-    auto issue_rows = [&](int cbase, int tid) {
+    auto issue_rows = [&](int cbase) {
+        const char* vol0 = reinterpret_cast<const char*>(a.src0 + ((size_t)n0 * a.c0 + cbase) * edge * edge * edge);
+        const char* aff0 = reinterpret_cast<const char*>(a.affine + ((size_t)n0 * cin + cbase));
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            int s, c, hz, hy, nn, ci, z, y;
-            if (row_coords(tid + i * NT, cbase, s, c, hz, hy, nn, ci, z, y)) {
-                const size_t si = (size_t)nn * cin + ci;
-                { const float4 af = a.affine[si]; xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
-                if (ci < a.c0) {
-                    const float* row = a.src0 + ((((size_t)nn * a.c0 + ci) * edge + z) * edge + y) * edge + x0;
+            if (rowc[i] >= 0 && cbase + rowc[i] < cin) {
+                unsigned ro = rowoff[i], ao = affoff[i];
+                asm volatile("" : "+v"(ro), "+v"(ao));
+                { const float4 af = *reinterpret_cast<const float4*>(aff0 + ao); xce[i] = af.x; xsc[i] = af.y; xsh[i] = af.z; }
+                if (cbase + rowc[i] < a.c0) {
+                    const float* row = reinterpret_cast<const float*>(vol0 + ro);
                     if (TX >= 4) {
 #pragma unroll
                         for (int q = 0; q < TX / 4; ++q) {
@@ -213,7 +228,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
                     if (has_r) xraw[i][TX + 1] = row[TX];
                 } else {
                     // nearest x2 upsample: voxel x reads low-res x>>1 -> TX/2 low-res values, expanded at commit time
-                    const float* row = a.src1 + ((((size_t)nn * a.c1 + (ci - a.c0)) * half + (z >> 1)) * half + (y >> 1)) * half + (x0 >> 1);
+                    const int r = tid + i * NT;
+                    const int hy = r % HY, hz = (r / HY) % T::HZ, s = r / (HY * T::HZ * CC);
+                    const int z = z0 + hz - 1, y = y0 + hy - 1;
+                    const float* row = a.src1 + ((((size_t)(n0 + s) * a.c1 + (cbase + rowc[i] - a.c0)) * half + (z >> 1)) * half + (y >> 1)) * half + (x0 >> 1);
                     if (TX == 8) {
                         const float4 t = *reinterpret_cast<const float4*>(row);
                         xraw[i][1] = t.x; xraw[i][2] = t.y; xraw[i][3] = t.z; xraw[i][4] = t.w;
@@ -230,17 +248,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
         }
     };
 
-    auto commit_rows = [&](int cbase, int tid) {
+    auto commit_rows = [&](int cbase) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int r = tid + i * NT;
-            int s, c, hz, hy, nn, ci, z, y;
-            const bool ok = row_coords(r, cbase, s, c, hz, hy, nn, ci, z, y);
-            if (r < ROWS) {
+            if (rowc[i] >= 0) {
                 float v[TX + 2];
-                if (ok) {
+                if (cbase + rowc[i] < cin) {
                     const float ce = xce[i], sc = xsc[i], sh = xsh[i];
-                    if (ci < a.c0) {
+                    if (cbase + rowc[i] < a.c0) {
 #pragma unroll
                         for (int j = 1; j <= TX; ++j) v[j] = fmaf(xraw[i][j] - ce, sc, sh);
                     } else {
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < TX + 2; ++j) v[j] = 0.f;
                 }
-                float* dst = xs + (s * CC + c) * CH + (hz * HY + hy) * HX;
+                float* dst = xs + rowbox[i];
 #pragma unroll
                 for (int j = 0; j < TX + 2; ++j) dst[j] = v[j];
             }
@@ -261,9 +276,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     };
 
     // ---- prologue: chunk 0
-    dma_weights(0, 0, lane);
-    issue_rows(0, tid);
-    commit_rows(0, tid);
+    dma_weights(0, 0);
+    issue_rows(0);
+    commit_rows(0);
     __syncthreads();                                       // also drains the DMA (vmcnt(0) before the barrier)
 
     // K loop + epilogue, instantiated per z-border variant of this wave (see the MFMA loop); barriers match across variants
@@ -272,13 +287,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
     int buf = 0;
     for (int cbase = 0; cbase < cin; cbase += CC) {
         const bool more = cbase + CC < cin;
-        // opaque copy of the thread id: keeps the compiler from hoisting the per-row index math (lane-constant across
-        // chunks) out of the K loop, where it would sit in -- and spill from -- registers the MFMA loop needs
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
         if (more) {
-            if (PFX) issue_rows(cbase + CC, tid_o);        // global loads fly under the MFMA loop ...
-            dma_weights(cbase + CC, buf ^ 1, tid_o & 63);  // ... and so does the next weight slab
+            if (PFX) issue_rows(cbase + CC);               // global loads fly under the MFMA loop ...
+            dma_weights(cbase + CC, buf ^ 1);              // ... and so does the next weight slab
         }
         {
             const float* ws = wsb + buf * T::WSLAB_PAD;
@@ -323,10 +334,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
         }
         __syncthreads();                                   // everyone is done reading xs / ws[buf]; loads + DMA have landed
         if (more) {
-            int tid_c = tid;
-            asm volatile("" : "+v"(tid_c));
-            if (!PFX) issue_rows(cbase + CC, tid_c);
-            commit_rows(cbase + CC, tid_c);
+            if (!PFX) issue_rows(cbase + CC);
+            commit_rows(cbase + CC);
         }
         __syncthreads();
         buf ^= 1;
@@ -518,7 +527,7 @@ static int dispatch_nb(const ConvArgs& a, hipStream_t stream) {
     } else if constexpr (MODE == TILE_BIG) {
         // (16-cout layers: an 8-channel K chunk -- 216 instead of 108 MFMAs per wave between barriers -- measured 3-7 % slower than
         // the 4-channel chunk on every such layer and is not instantiated)
-        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 4>(a, stream);
+        if (a.cout16 <= 16) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 1, 6>(a, stream);   // <= 85 VGPRs: three workgroups per CU
         if (a.cout16 <= 32) return launch_conv3<TZ, TY, TX, SPW, 8, 4, 2, 4>(a, stream);
         return launch_conv3<TZ, TY, TX, SPW, 8, 4, 4, 4>(a, stream);
     } else {
