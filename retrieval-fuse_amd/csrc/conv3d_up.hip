@@ -105,6 +105,18 @@ __device__ __forceinline__ void rf_wait_vm(int n) {
 #undef RF_WVM
 }
 
+// In place: r[m] row c  ->  r[c] row m, rows = the four 16-lane groups of a wave (probed on gfx950, tools/micro/mfma4x4_probe.hip:
+// v_permlane32_swap(a, b) exchanges a.rows{2,3} with b.rows{0,1}; v_permlane16_swap(a, b) exchanges a.row1 <-> b.row0, a.row3 <-> b.row2).
+// Turns the four A operands of v_mfma_f32_16x16x4_f32 (lane = (channel, voxel % 16) per m-block) into the four A operands of
+// v_mfma_f32_4x4x1_16b_f32 (lane = voxel, one register per channel).
+__device__ __forceinline__ void rf_rows4_transpose(float& r0, float& r1, float& r2, float& r3) {
+    auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+    auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+    auto p01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+    auto p23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+    r0 = __uint_as_float(p01[0]); r1 = __uint_as_float(p01[1]); r2 = __uint_as_float(p23[0]); r3 = __uint_as_float(p23[1]);
+}
+
 // lane id from nothing (v_mbcnt): a value the register allocator can recompute instead of keeping threadIdx.x alive -- or spilling it --
 // across the MFMA phases
 __device__ __forceinline__ int rf_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -154,8 +166,16 @@ struct UpTile {
     static_assert((TE == 8 && SPW == 1) || (TE == 4 && SPW == 4), "built tiles: one 8^3 box, or four whole 4^3 samples");
 };
 
-template <int TE, int SPW, int MB, int NB>
+// HALF (NB = 4, 48 < cout <= 56 -- the retrieval backbone's 96 -> 56 conv): couts 48..55 are NOT a fourth, half-empty 16-wide n-block
+// (1/8 of all MFMA cycles multiplying zero columns) but two 4-cout groups on v_mfma_f32_4x4x1_16b_f32: 16 blocks = the wave's 16
+// groups of 4 voxels, A = one register per channel with lane = voxel (rf_rows4_transpose of the four m-blocks' A operands, after
+// their last 16x16x4 use), B = w[channel][48 + 4h + lane % 4], D[reg i][lane 4b + j] = out(voxel 4b + i, cout 48 + 4h + j).
+// Same flop rate, no padding: 8 x 8 cycles instead of 4 x 32 per k-step, and 8 accumulator VGPRs instead of 16.  The z-border
+// skip does not apply to these (an instruction covers all four m-blocks; the skipped taps add exact zeros either way).
+template <int TE, int SPW, int MB, int NB, bool HALF = false>
 __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
+    static_assert(!HALF || (NB == 4 && MB == 4 && TE == 8), "the half n-block form is built for the 8^3 tile with 64-wide slabs");
+    constexpr int NBF = HALF ? NB - 1 : NB;                              // full 16-cout n-blocks
     using T = UpTile<TE, SPW, MB, NB>;
     constexpr int L = T::L, LH = T::LH, HE = T::HE, HXA = T::HXA, CH0 = T::CH0, CH1 = T::CH1, NCO = T::NCO, NT = T::NT, P = T::P;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -192,11 +212,22 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
     // Whole-kernel variants (not a test inside the loop) keep the accumulators in place; barriers match across variants.
     auto run = [&](auto lo_c, auto hi_c) {
     constexpr unsigned LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-    f32x4 acc[MB][NB];
+    f32x4 acc[MB][NBF];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBF; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc4[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};      // HALF: couts 48 + 4h + (lane % 4) of voxels 4 (lane / 4) + i
+    // HALF: the 8 MFMAs of a k-step on couts 48..55; b4[c] = (h = 0, h = 1) weights of channel c.  Destroys a0..a3.
+    auto mfma_half = [&](float& a0, float& a1, float& a2, float& a3, const float2 (&b4)[4]) {
+        rf_rows4_transpose(a0, a1, a2, a3);
+        const float at[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(at[c], b4[c].x, acc4[0], 0, 0, 0);
+            acc4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(at[c], b4[c].y, acc4[1], 0, 0, 0);
+        }
+    };
 
     // ================================================================================= A) skip channels, 27 taps
     if (a.c0 > 0) {
@@ -213,9 +244,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             up_lattice<TE>(v, s, Z, Y, X);
             aoff0[mb] = (s * 4 + kq_a) * CH0 + ((2 * Z + pz) * HE + (2 * Y + py)) * HXA + (2 * X + px);
         }
-        int boff[NB];
+        int boff[NBF];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) boff[nb] = kq_a * NCO + ((nb * 16 + li_a + ROT * (kq_a & 1)) % NCO);
+        for (int nb = 0; nb < NBF; ++nb) boff[nb] = kq_a * NCO + ((nb * 16 + li_a + ROT * (kq_a & 1)) % NCO);
+        const int l4_a = lane_a & 3;                                    // HALF: slab row k = tap*4 + c holds cout 48 + 4h + j at (48 + ROT (c & 1)) % NCO + 4h + j
         // Weight slab DMA: 1-KiB pieces of RPP slab rows [tap][ci] x NCO; piece q is rows [q RPP, (q+1) RPP).  Everything that
         // depends on the lane is computed ONCE (the per-chunk part is a scalar base): the per-piece index arithmetic of the
         // round-1 form -- a runtime modulo and 64-bit multiplies among it -- ran on the VALU port the MFMAs issue through.
@@ -321,11 +353,11 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             }
             {
                 const float* ws = wsb + buf * T::WSLAB_PAD;
-                float av[2][MB], bv[2][NB];
+                float av[2][MB], bv[2][NBF];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff0[mb]];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bv[0][nb] = ws[boff[nb]];
+                for (int nb = 0; nb < NBF; ++nb) bv[0][nb] = ws[boff[nb]];
 #pragma unroll
                 for (int t = 0; t < 27; ++t) {
                     const int cur = t & 1, nxt = cur ^ 1;
@@ -337,7 +369,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                         // m-block on the first / last z slice of the volume: its dz = -1 / +1 taps read only zero padding
                         if ((t / 9 == 0 && ((LO >> mb) & 1u)) || (t / 9 == 2 && ((HI >> mb) & 1u))) return;        // compile-time
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
+                        for (int nb = 0; nb < NBF; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
                     };
                     __builtin_amdgcn_sched_barrier(0);
@@ -349,12 +381,24 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xs[aoff0[mb] + toff];
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = ws[boff[nb] + t1 * 4 * NCO];
+                        for (int nb = 0; nb < NBF; ++nb) bv[nxt][nb] = ws[boff[nb] + t1 * 4 * NCO];
+                    }
+                    float2 b4[4];                                       // HALF: this tap's weights of couts 48..55, used at the end of the step
+                    if constexpr (HALF) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float* w4 = ws + (t * 4 + c) * NCO + (48 + ROT * (c & 1)) % NCO + l4_a;
+                            b4[c] = make_float2(w4[0], w4[4]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         if (mb != 1) mfma_mb(mb);
+                    if constexpr (HALF) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_half(av[cur][0], av[cur][1], av[cur][2], av[cur][3], b4);
+                    }
                 }
             }
             __syncthreads();
@@ -375,9 +419,9 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
         //     channel's GroupNorm triple into a staging area; at mid-chunk the same lanes normalise them into the other box
         //     buffer (zero padding outside the volume).  The wave that DMAs a row commits it: no barrier in between.
         //   * this wave's weights [tap][k8][cout16] stream through a wave-private ring of RING 1-KiB pieces (one full-wave DMA
-        //     instruction = GS k-steps of 4 rows x NCO floats), RING - 1 pieces ahead of the MFMAs.  The number of DMA
+        //     instruction = GS k-steps of 4 rows x NCO floats), RING - 2 pieces ahead of the MFMAs.  The number of DMA
         //     instructions between any two points of the loop is static (pieces past the end are re-reads of the last one)
-        //     and vmcnt retires in order, so "piece P+1 has landed" is s_waitcnt vmcnt(RING - 2 [+ RDMA while the chunk's row
+        //     and vmcnt retires in order, so "piece P+1 has landed" is s_waitcnt vmcnt(RING - 3 [+ RDMA while the chunk's row
         //     DMAs are younger than that piece]) and "the rows have landed" is vmcnt(pieces issued since).
         //   * one software pipeline across the whole phase: operand reads of k-step S+1 go out in the middle of k-step S, also
         //     across the chunk boundary (one LDS-only barrier per chunk, no vmcnt(0) anywhere in the loop).
@@ -424,9 +468,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             up_lattice<TE>(v, s, Z, Y, X);
             aoff1[mb] = kq * CH1 + ((Z + pz) * LH + (Y + py)) * LH + (X + px);
         }
-        int boff1[NB];
+        int boff1[NBF];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) boff1[nb] = kq * NCO + ((nb * 16 + li + 16 * kq) % NCO);
+        for (int nb = 0; nb < NBF; ++nb) boff1[nb] = kq * NCO + ((nb * 16 + li + 16 * kq) % NCO);
+        const int l4_b = lane_b & 3;                                    // HALF: ring row c holds cout 48 + 4h + j at (48 + 16 c) % NCO + 4h + j
 
         auto dma_piece = [&](int P, int slot) {                         // image rows [4 GS P, 4 GS (P + 1)) of this parity -> ring slot
             if (P >= npiece) P = npiece - 1;                            // past the end: keeps the DMA count static, lands in a dead slot
@@ -480,19 +525,19 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         };
 
-        // ---- prologue: the whole ring in flight, chunk 0 staged and committed
+        // ---- prologue: RING - 1 pieces in flight, chunk 0 staged and committed
 #pragma unroll
-        for (int i = 0; i < RING; ++i) dma_piece(i, i);
+        for (int i = 0; i < RING - 1; ++i) dma_piece(i, i);
         dma_rows(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         commit_rows(0, xs);
         lds_barrier();
 
-        float av[2][MB], bv[2][NB];
+        float av[2][MB], bv[2][NBF];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) av[0][mb] = xs[aoff1[mb]];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[0][nb] = wslab[boff1[nb]];
+        for (int nb = 0; nb < NBF; ++nb) bv[0][nb] = wslab[boff1[nb]];
         int slot = 0;                                                   // ring slot of the current piece (wave-uniform)
         int buf = 0;
         for (int S0 = 0; S0 < nstep; S0 += 16) {
@@ -507,22 +552,30 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                     // low-res row Z-1 of the first lattice plane / Z+1 of the last one is zero padding of the volume
                     if ((tz == 0 && ((LO >> mb) & 1u)) || (tz == 1 && ((HI >> mb) & 1u))) return;                  // compile-time
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NBF; ++nb)
                         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
                 };
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_mb(1);
                 __builtin_amdgcn_sched_barrier(0);
+                float2 b4[4];                                           // HALF: this k-step's weights of couts 48..55 (its piece has landed)
+                if constexpr (HALF) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float* w4 = wslab + slot * 256 + (s % GS) * STEP + c * NCO + (48 + 16 * c) % NCO + l4_b;
+                        b4[c] = make_float2(w4[0], w4[4]);
+                    }
+                }
                 // ---- middle of k-step S0 + s
-                const bool last_of_piece = s % GS == GS - 1;            // the next k-step reads the next piece; this one's slot is free
+                const bool last_of_piece = s % GS == GS - 1;            // the next k-step reads the next piece
                 int nslot = slot;
                 if (last_of_piece) {
-                    // piece P+1 landed?  In flight: pieces P+1 .. P+RING-1, and -- if already issued (s >= 1) and younger than piece
+                    // piece P+1 landed?  In flight: pieces P+1 .. P+RING-2, and -- if already issued (s >= 1) and younger than piece
                     // P+1 -- the RDMA row DMAs of this chunk.  They went out in the middle of k-step 0, behind piece
-                    // P0 + RING (GS == 1; P0 + RING - 1 otherwise).
+                    // P0 + RING - 1 (GS == 1; P0 + RING - 2 otherwise).
                     const int j = s / GS;                               // P = P0 + j
-                    const bool rows_younger = s >= 1 && j + 1 <= (GS == 1 ? RING : RING - 1);
-                    if (more && rows_younger) rf_wait_vm(RING - 2 + RDMA); else rf_wait_vm(RING - 2);
+                    const bool rows_younger = s >= 1 && j + 1 <= (GS == 1 ? RING - 1 : RING - 2);
+                    if (more && rows_younger) rf_wait_vm(RING - 3 + RDMA); else rf_wait_vm(RING - 3);
                     nslot = slot + 1;
                     if (nslot == RING) nslot = 0;
                 }
@@ -535,9 +588,15 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) av[nxt][mb] = xn[aoff1[mb] + toff];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bv[nxt][nb] = wn[boff1[nb]];
+                    for (int nb = 0; nb < NBF; ++nb) bv[nxt][nb] = wn[boff1[nb]];
                 }
-                if (last_of_piece) dma_piece(P0 + s / GS + RING, slot); // refill the slot just read to the end
+                if (last_of_piece) {
+                    // refill the slot of the PREVIOUS piece: every read of it has been consumed by an MFMA.  (Reads of the current
+                    // piece -- HALF's b4 of this k-step -- may still be in the LDS queue.)
+                    int fslot = slot - 1;
+                    if (fslot < 0) fslot = RING - 1;
+                    dma_piece(P0 + s / GS + RING - 1, fslot);
+                }
                 if (s == 0 && more) dma_rows((S0 >> 1) + 8);
                 if (s == CS && more) {
                     int younger = 0;                                    // pieces issued behind the row DMAs so far
@@ -551,6 +610,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
                     if (mb != 1) mfma_mb(mb);
+                if constexpr (HALF) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_half(av[cur][0], av[cur][1], av[cur][2], av[cur][3], b4);
+                }
             }
             buf ^= 1;
         }
@@ -723,7 +786,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
     const size_t vol = (size_t)edge * edge * edge;
     constexpr int TE3 = TE * TE * TE;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
+    for (int nb = 0; nb < NBF; ++nb) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -794,6 +857,58 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
             __syncthreads();
         }
     }
+    if constexpr (HALF) {
+        // couts 48..55: acc4[h][i] of lane 4b + j = out(voxel 4b + i of this wave's lattice, cout 48 + 4h + j)
+        const int j4 = lane_e & 3, b4i = lane_e >> 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = b4i * 4 + i;
+                int X, Y, Z, s;
+                up_lattice<TE>(v, s, Z, Y, X);
+                const int lin = ((2 * Z + pz) * TE + (2 * Y + py)) * TE + (2 * X + px);
+                eb[(4 * h + j4) * (P + 1) + lin] = fmaxf(acc4[h][i], 0.f);
+            }
+        __syncthreads();
+        for (int q = tid_e; q < 8 * (P / 4); q += NT) {
+            const int col = q / (P / 4), lin = (q % (P / 4)) * 4;
+            const int co = cob + 48 + col;
+            if (co < a.cout && n0 < a.n) {
+                const float* e = eb + col * (P + 1) + lin;
+                const float4 o = make_float4(e[0], e[1], e[2], e[3]);
+                const int x = lin % TE, y = (lin / TE) % TE, z = lin / (TE * TE);
+                *reinterpret_cast<float4*>(a.out + ((size_t)n0 * a.cout + co) * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x)) = o;
+            }
+        }
+        __syncthreads();
+        if (a.stats) {
+            // registers (4 voxels) -> the 16 lanes that share lane % 4 -> waves, fixed order
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double v = (double)fmaxf(acc4[h][i], 0.f);
+                    sm += v; sq += v * v;
+                }
+#pragma unroll
+                for (int m = 4; m < 64; m <<= 1) { sm += __shfl_xor(sm, m, 64); sq += __shfl_xor(sq, m, 64); }
+                if (lane_e < 4) { red[(wave * 8 + 4 * h + lane_e) * 2] = sm; red[(wave * 8 + 4 * h + lane_e) * 2 + 1] = sq; }
+            }
+            __syncthreads();
+            if (tid_e < 8) {
+                const int co = cob + 48 + tid_e;
+                if (co < a.cout && n0 < a.n) {
+                    double sm = 0.0, sq = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { sm += red[(w * 8 + tid_e) * 2]; sq += red[(w * 8 + tid_e) * 2 + 1]; }
+                    a.stats[((size_t)n0 * a.cout + co) * a.stats_tiles + tile] = make_double2(sm, sq);
+                }
+            }
+            __syncthreads();
+        }
+    }
     };
     using Zc = std::integral_constant<unsigned, 0u>;
     constexpr bool ZSKIP = true;
@@ -802,10 +917,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
     else run(Zc{}, Zc{});
 }
 
-template <int TE, int SPW, int MB, int NB>
+template <int TE, int SPW, int MB, int NB, bool HALF = false>
 static int launch_up(const UpArgs& a, hipStream_t stream) {
     using T = UpTile<TE, SPW, MB, NB>;
-    auto kern = k_conv3_up<TE, SPW, MB, NB>;
+    auto kern = k_conv3_up<TE, SPW, MB, NB, HALF>;
     if (T::LDS_BYTES > 65536) {
         static RfLdsOptIn opt_in;
         if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), (int)T::LDS_BYTES, "rf_conv3d_up_k3_gn_relu")) return rc;
@@ -821,6 +936,9 @@ template <int TE, int SPW, int MB>
 static int dispatch_up(const UpArgs& a, hipStream_t stream) {
     if (a.cout16 <= 16) return launch_up<TE, SPW, MB, 1>(a, stream);
     if (a.cout16 <= 32) return launch_up<TE, SPW, MB, 2>(a, stream);
+    if constexpr (TE == 8) {
+        if (a.cout16 == 64 && a.cout <= 56) return launch_up<TE, SPW, MB, 4, true>(a, stream);   // 3 n-blocks + 8 couts on 4x4x1 MFMAs
+    }
     return launch_up<TE, SPW, MB, 4>(a, stream);
 }
 

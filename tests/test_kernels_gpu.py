@@ -123,6 +123,9 @@ UP_CASES = [
     (530, 0, 16, 8, 16, 8),
     (520, 6, 12, 8, 12, 6),
     (513, 8, 8, 8, 72, 8),
+    # couts 48..55 on the 4x4x1 MFMA form (3 n-blocks + 8): partial group, several boxes per sample (x halos), padded channels
+    (40, 8, 16, 16, 52, 4),
+    (300, 6, 12, 8, 49, 6),
     # many 4^3 samples: the position-major decoder form (conv3d_small.hip, UP instances)
     (4100, 64, 128, 4, 64, 8),
     (4099, 16, 8, 4, 24, 8),
