@@ -392,9 +392,9 @@ def main():
                        'chunks_per_gpu_per_step': B, 'db_patches': n_patches,
                        'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + one RCCL all-gather of the packed top-2K keys' % (world, world)},
             'roofline': {'bound': 'mfma',
-                         'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4> (retrieval backbone decoder conv %d+%d->%d @8^3: '
+                         'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4%s> (retrieval backbone decoder conv %d+%d->%d @8^3: '
                                    '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, z-border padding taps '
-                                   'left out, %d patches)' % (2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
+                                   'left out, %d patches)' % (', couts 48.. on 4x4x1 MFMAs' if 48 < dom_cout <= 56 else '', 2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_file.name if pmc_file else 'none'),
                          'launch_ms': kern_ms,

@@ -20,7 +20,7 @@ REPO = Path(__file__).resolve().parents[1]
 pmc_dir = Path(sys.argv[1]) if len(sys.argv) > 1 else REPO / 'gpurun_out' / 'pmc'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 cfg_name = sys.argv[3] if len(sys.argv) > 3 else 'C2'
-DOMINANT = 'k_conv3_up<8, 1, 4, 4>'
+DOMINANT = 'k_conv3_up<8, 1, 4, 4, true>'
 
 
 def short(name):
