@@ -362,8 +362,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                 for (int t = 0; t < 27; ++t) {
                     const int cur = t & 1, nxt = cur ^ 1;
                     // Software pipeline, pinned with scheduling barriers (left alone, hipcc sinks the reads of tap t+1 below the MFMAs
-                    // of tap t and every tap starts with a full LDS round trip): m-block 1 of tap t | reads of tap t+1 | the other
-                    // m-blocks of tap t.  The compiler's s_waitcnt lgkmcnt(0) then lands in front of the first MFMA of tap t+1,
+                    // of tap t and every tap starts with a full LDS round trip): m-block 1 of tap t | reads of tap t+1 interleaved
+                    // with the other m-blocks of tap t.  The compiler's s_waitcnt lgkmcnt(0) then lands in front of the first MFMA of tap t+1,
                     // 3/4 of a tap (~400 cycles) after the reads went out.
                     auto mfma_mb = [&](int mb) {
                         // m-block on the first / last z slice of the volume: its dz = -1 / +1 taps read only zero padding
@@ -391,10 +391,15 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up(UpArgs a) {
                             b4[c] = make_float2(w4[0], w4[4]);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         if (mb != 1) mfma_mb(mb);
+                    // one LDS read behind every MFMA: the wave's instruction stream stays MFMA-dense while the reads go out (-1 %)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                     if constexpr (HALF) {
                         __builtin_amdgcn_sched_barrier(0);
                         mfma_half(av[cur][0], av[cur][1], av[cur][2], av[cur][3], b4);
