@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
                     const int cur = st & 1, nxt = cur ^ 1;
                     // keep the operand reads of later taps out of this step: left alone, hipcc pairs reads of neighbouring taps
                     // into ds_read2 far ahead of their use (long live ranges: +30..50 VGPRs, spills in the parity-split kernel)
-                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                     if (st + 1 < 27 * KS) {
                         const int t1 = (st + 1) / KS, k1 = (st + 1) % KS;
                         const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 + k1 * 4 * CH;
@@ -328,6 +328,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_conv3_mfma(ConvArgs a) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mb], bv[cur][nb], acc[mb][nb], 0, 0, 0);
+                    }
+                    // the reads of step st+1 go out one behind every MFMA of step st (the wave's instruction stream stays MFMA-dense)
+#pragma unroll
+                    for (int i = 0; i < MB * NB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
             }
