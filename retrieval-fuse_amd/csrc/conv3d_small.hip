@@ -91,23 +91,27 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
     // operand base: [group][position][k][sample]; the position of the input voxel is added as an immediate (+ z of the wave)
     const int abase = (wgrp * P + (E == 4 ? wz * 16 : 0)) * 64 + kq * 16 + li;
 
-    constexpr int WF4 = T::WSLAB / 4, NPIECE = (WF4 + 63) / 64;
-    auto dma_weights = [&](int cbase, int buf, int lane_) {
+    // Weight slab DMA: 1-KiB pieces of RPP slab rows [tap][channel] x NCO.  Per-lane index arithmetic once (it runs on the VALU port
+    // the MFMAs issue through), per chunk and piece a scalar base -- see conv3d_mfma.hip.
+    constexpr int LPR = NCO / 4, RPP = 64 / LPR;                    // lanes per slab row; slab rows per piece (4, 8, 16)
+    constexpr int NPIECE = (27 * 4 + RPP - 1) / RPP;
+    const int wr = lane / LPR, wslot = (lane % LPR) * 4;
+    const int wcol = (wslot + NCO - ROT * (wr & 1)) % NCO;
+    int wco = cob + wcol;
+    if (wco >= a.cout16) wco = wcol % a.cout16;
+    const unsigned wlane = 4u * (unsigned)(((wr >> 2) * a.cin4 + (wr & 3)) * a.cout16 + wco);        // bytes
+    auto dma_weights = [&](int cbase, int buf) {
         float* dst = wsb + buf * T::WSLAB_PAD;
+        unsigned off = wlane;                                       // opaque: SGPR base + 32-bit lane offset addressing
+        asm volatile("" : "+v"(off));
 #pragma unroll
         for (int i = 0; i < (NPIECE + 7) / 8; ++i) {
             const int q = wave + i * 8;
             if (q < NPIECE) {
-                int idx = q * 64 + lane_;
-                if (idx >= WF4) idx = WF4 - 1;
-                const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
-                const int col = (slot + NCO - ROT * (r & 1)) % NCO;
-                int co = cob + col;
-                if (co >= a.cout16) co = col % a.cout16;
-                int ci = cbase + r % 4;
-                if (ci >= a.cin4) ci = a.cin4 - 1;
-                const float* src = a.wp + ((size_t)(r / 4) * a.cin4 + ci) * a.cout16 + co;
-                __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+                const int tap0 = q * (RPP / 4);
+                const char* src = reinterpret_cast<const char*>(a.wp + ((size_t)tap0 * a.cin4 + cbase) * a.cout16);
+                if (RPP == 4 || tap0 + (wr >> 2) < 27)              // rows past tap 26 of the last piece are never read
+                    __builtin_amdgcn_global_load_lds((rf_gptr)(src + off), (rf_lptr)(dst + q * 256), 16, 0, 0);
             }
         }
     };
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
             for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         if (a.cin > 0) {
-            dma_weights(0, 0, lane);
+            dma_weights(0, 0);
             issue_rows(0);
             commit_rows(0);
         }
@@ -161,9 +165,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
             const bool more = cbase + 4 < a.cin;
             if (more) {
                 issue_rows(cbase + 4);
-                int lane_o = lane;
-                asm volatile("" : "+v"(lane_o));
-                dma_weights(cbase + 4, buf ^ 1, lane_o);
+                dma_weights(cbase + 4, buf ^ 1);
             }
             const float* ws = wsb + buf * T::WSLAB_PAD;
 #pragma unroll
@@ -202,20 +204,22 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
             float* bsl = smem + T::XLOW;                             // [2][(parity*8 + tap)*4 + k][NCO]
             constexpr int BROT = NCO == 32 ? 16 : 0;                 // rows k, k+2 of a B read would share banks at NCO = 32
             constexpr int BF4 = T::BSLAB / 4, BPIECE = BF4 / 64;
-            auto dma_b = [&](int c4, int bufb, int lane_) {          // c4: 4-channel chunk of c1
+            // slab row r = (parity*8 + tap)*4 + k; piece q = rows [q RPP, (q+1) RPP): lane part once, scalar base per chunk and piece
+            const int bw = lane / LPR;                               // row of this lane inside a piece
+            const int bcol = ((lane % LPR) * 4 + NCO - BROT * ((bw >> 1) & 1)) % NCO;
+            int bco = cob + bcol;
+            if (bco >= a.cout16) bco = bcol % a.cout16;
+            const unsigned blane = 4u * (unsigned)(((bw >> 2) * 8 + (bw & 3)) * a.cout16 + bco);          // bytes
+            auto dma_b = [&](int c4, int bufb) {                     // c4: 4-channel chunk of c1
                 float* dst = bsl + bufb * T::BSLAB;
+                unsigned off = blane;
+                asm volatile("" : "+v"(off));
 #pragma unroll
                 for (int i = 0; i < (BPIECE + 7) / 8; ++i) {
                     const int q = wave + i * 8;
                     if (q < BPIECE) {
-                        const int idx = q * 64 + lane_;
-                        const int r = idx / (NCO / 4), slot = (idx % (NCO / 4)) * 4;
-                        const int col = (slot + NCO - BROT * ((r >> 1) & 1)) % NCO;
-                        int co = cob + col;
-                        if (co >= a.cout16) co = col % a.cout16;
-                        const int k = r & 3, pt = r >> 2;            // pt = parity*8 + tap
-                        const float* src = a.wp1 + ((((size_t)(c4 >> 1) * 64 + pt) * 8) + (c4 & 1) * 4 + k) * a.cout16 + co;
-                        __builtin_amdgcn_global_load_lds((rf_gptr)src, (rf_lptr)(dst + q * 256), 16, 0, 0);
+                        const char* src = reinterpret_cast<const char*>(a.wp1 + ((((size_t)(c4 >> 1) * 64 + q * (RPP / 4)) * 8) + (c4 & 1) * 4) * a.cout16);
+                        __builtin_amdgcn_global_load_lds((rf_gptr)(src + off), (rf_lptr)(dst + q * 256), 16, 0, 0);
                     }
                 }
             };
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bboff[nb] = kq * NCO + ((nb * 16 + li + BROT * ((kq >> 1) & 1)) % NCO);
             const int pz = wz & 1;                                   // z parity of this wave's slice (run time inside ZC == 1)
-            dma_b(0, 0, lane);
+            dma_b(0, 0);
             issue_low(0);
             commit_low(0, 0);
             __syncthreads();
@@ -256,9 +260,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_small(SmallArgs a) {
                 const bool more = c4 + 1 < nchunk;
                 if (more) {
                     issue_low(c4 + 1);
-                    int lane_o = lane;
-                    asm volatile("" : "+v"(lane_o));
-                    dma_b(c4 + 1, bufb ^ 1, lane_o);
+                    dma_b(c4 + 1, bufb ^ 1);
                 }
                 const float* xl = xlow + bufb * 512 + kq * 16 + li;
                 const float* wb = bsl + bufb * T::BSLAB + pz * (4 * 8 * 4 * NCO);
