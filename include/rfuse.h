@@ -197,6 +197,12 @@ size_t rf_linear_packed_floats(int nout, int nin);
 int rf_linear(const float* x, int rows, int nin, const float* w_packed, const float* bias, int nout,
               int act, float slope, float* y, void* stream);
 
+/* Weight gradient of a Linear layer: dw[M][N] = sum_k a[k][M] * b[k][N] with a = dL/d(pre-activation) [K rows][M = nout] and
+ * b = the layer's input [K rows][N = nin] (training slice; the reference trains these layers in trainer/train_refinement.py:108-116).
+ * Split-K fp32 MFMA, slices summed in float64 in a fixed order (deterministic).  ws: rf_linear_wgrad_ws_bytes(K, M, N). */
+int rf_linear_wgrad(const float* a, const float* b, int K, int M, int N, float* dw, void* ws, size_t ws_bytes, void* stream);
+size_t rf_linear_wgrad_ws_bytes(int K, int M, int N);
+
 /* x[rows][dim] /= max(||x||_2, eps) in place: F.normalize (util/retrieval.py:66, model/attention.py:92-93) */
 int rf_l2_normalize_rows(float* x, int rows, int dim, float eps, void* stream);
 

@@ -134,6 +134,116 @@ extern "C" int rf_linear(const float* x, int rows, int nin, const float* w_packe
     return RF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- weight gradient
+// dW[m][n] = sum_k a[k][m] * b[k][n]: the weight gradient of a Linear layer (a = dL/d(pre-activation) [K rows][M = nout],
+// b = the layer input [K rows][N = nin]; rfuse/autograd.py, reference trainer/train_refinement.py:108-116 trains through these).
+// K is the row count of the batch (10^4..10^6), M and N are layer widths (<= 512): a split-K GEMM.  Both operands are already in
+// MFMA operand order -- lane l of an A read takes a[k0 + l/16][m0 + l%16], of a B read b[k0 + l/16][n0 + l%16], i.e. 16 consecutive
+// floats of 4 consecutive rows -- so they go global -> VGPR -> MFMA directly, no LDS.  A workgroup owns a 32 x 64 tile of dW and one
+// K slice; its 4 waves interleave the slice's k-steps, reduce through LDS, and write an fp32 partial; k_linear_wgrad_reduce sums the
+// slices in float64 in a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ a, const float* __restrict__ b, int K, int M, int N, int kslice,
+                                                     float* __restrict__ partial) {
+    constexpr int MB = 2, NB = 4, U = 4;                            // k-steps in flight per wave
+    __shared__ float red[3][32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int kbeg = blockIdx.z * kslice, kend = min(K, kbeg + kslice);
+    const int kq = lane >> 4, li = lane & 15;
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool mok[MB], nok[NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) mok[mb] = m0 + mb * 16 + li < M;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) nok[nb] = n0 + nb * 16 + li < N;
+    for (int k0 = kbeg + wave * 4 * U; k0 < kend; k0 += 16 * U) {
+        float av[U][MB], bv[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 4 + kq;
+            const bool kok = k < kend;
+            const float* ar = a + (size_t)k * M + m0 + li;
+            const float* br = b + (size_t)k * N + n0 + li;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[u][mb] = (kok && mok[mb]) ? ar[mb * 16] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[u][nb] = (kok && nok[nb]) ? br[nb * 16] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mb], bv[u][nb], acc[mb][nb], 0, 0, 0);
+    }
+    // D rows 4*kq + r (m), column li (n): waves 1..3 -> LDS, wave 0 adds them in wave order
+    if (wave > 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][(mb * 16 + kq * 4 + r) * 64 + nb * 16 + li] = acc[mb][nb][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = partial + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = mb * 16 + kq * 4 + r, nl = nb * 16 + li;
+                    const float v = ((acc[mb][nb][r] + red[0][ml * 64 + nl]) + red[1][ml * 64 + nl]) + red[2][ml * 64 + nl];
+                    if (m0 + ml < M && n0 + nl < N) out[(size_t)(m0 + ml) * N + n0 + nl] = v;
+                }
+    }
+}
+
+__global__ void k_linear_wgrad_reduce(const float* __restrict__ partial, int slices, size_t mn, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int z = 0; z < slices; ++z) s += (double)partial[(size_t)z * mn + i];
+        out[i] = (float)s;
+    }
+}
+
+static void linear_wgrad_plan(int K, int M, int N, int& slices, int& kslice) {
+    const int tiles = ((M + 31) / 32) * ((N + 63) / 64);
+    int want = (1024 + tiles - 1) / tiles;                           // ~4 workgroups per CU
+    const int maxs = (K + 255) / 256;                               // at least 256 rows (16 k-steps per wave) per slice
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    kslice = ((K + want - 1) / want + 15) / 16 * 16;
+    slices = (K + kslice - 1) / kslice;
+}
+
+extern "C" size_t rf_linear_wgrad_ws_bytes(int K, int M, int N) {
+    int slices, kslice;
+    linear_wgrad_plan(K, M, N, slices, kslice);
+    return (size_t)slices * M * N * sizeof(float);
+}
+
+extern "C" int rf_linear_wgrad(const float* a, const float* b, int K, int M, int N, float* dw, void* ws, size_t ws_bytes, void* stream) {
+    RF_REQUIRE(a && b && dw && ws && K > 0 && M > 0 && N > 0, RF_E_INVALID, "rf_linear_wgrad: bad arguments");
+    RF_REQUIRE(ws_bytes >= rf_linear_wgrad_ws_bytes(K, M, N), RF_E_INVALID, "rf_linear_wgrad: workspace of %zu bytes is too small", ws_bytes);
+    int slices, kslice;
+    linear_wgrad_plan(K, M, N, slices, kslice);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_linear_wgrad, dim3((M + 31) / 32, (N + 63) / 64, slices), dim3(256), 0, s, a, b, K, M, N, kslice, static_cast<float*>(ws));
+    RF_CHECK_LAUNCH("rf_linear_wgrad");
+    const size_t mn = (size_t)M * N;
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(ws), slices, mn, dw);
+    RF_CHECK_LAUNCH("rf_linear_wgrad(reduce)");
+    return RF_OK;
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void k_l2norm_rows(float* __restrict__ x, int rows, int dim, float eps) {
     const int lane = threadIdx.x & 63;

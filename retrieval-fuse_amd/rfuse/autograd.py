@@ -8,7 +8,7 @@ retrieval_backbone / attention parameters, :295-306 phase hand-over).  Built her
       backward  rf_relu_backward -> rf_conv3d_k3_gn (relu = 0) on (dz, W^T with flipped taps)   = data gradient, same MFMA kernel
                 rf_conv3d_k3_wgrad (fp32 MFMA, K = voxels)                                     = weight gradient (edge >= 8)
                 rf_gn_backward                                                                  = dx, dgamma, dbeta
-                4^3 / 2^3 / 1^3 volumes: weight gradient as rf_linear GEMMs on the unfolded input (K split, float64 partial sums)
+                4^3 / 2^3 / 1^3 volumes: weight gradient as a split-K MFMA GEMM (rf_linear_wgrad) on the unfolded input, float64 slice sum
   Linear       y = act(x W^T + b)               the layers of AttentionFeatureEncoder (reference model/attention.py:29-46)
       backward  dx = rf_linear(dpre, W^T-as-weight),  dW = rf_linear(dpre^T, x^T-as-weight) in row chunks summed in float64
 
@@ -66,16 +66,6 @@ def conv3d_wgrad(x, aff, dz, cout):
     return dw
 
 
-def _gemm_tn_f64(a, b, chunk=8192):
-    """a [K, M], b [K, N] float32 -> a^T b [M, N]: rf_linear GEMMs over K chunks (one fp32 MFMA chain per chunk), summed in float64"""
-    acc = torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float64, device=a.device)
-    for k0 in range(0, a.shape[0], chunk):
-        at = a[k0:k0 + chunk].t().contiguous()                      # [M, kc] = the "x" of rf_linear
-        bt = b[k0:k0 + chunk].t().contiguous()                      # [N, kc] = its "weight" [nout, nin]
-        acc += ops.linear(at, ops.pack_linear_weight(bt), None, bt.shape[0]).double()
-    return acc.float()
-
-
 class ConvGnRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, weight, groups, eps):
@@ -110,12 +100,12 @@ class ConvGnRelu(torch.autograd.Function):
             if edge >= 8:
                 dw = conv3d_wgrad(x, aff, dz, cout)
             else:
-                # small volumes: dW = dz^T . im2col(GN(x)) through rf_linear (the operands are re-laid by torch, the products run on MFMA)
+                # small volumes: dW = dz^T . im2col(GN(x)) through rf_linear (the operands are re-laid by torch, the products run on rf_linear_wgrad's split-K MFMA GEMM)
                 xn = torch.addcmul(aff[..., 2, None, None, None], x - aff[..., 0, None, None, None], aff[..., 1, None, None, None])
                 cols = F.pad(xn, (1, 1, 1, 1, 1, 1)).unfold(2, 3, 1).unfold(3, 3, 1).unfold(4, 3, 1)       # [n, cin, e,e,e, 3,3,3]
                 cols = cols.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(n * edge ** 3, cin * 27)
                 dzf = dz.permute(0, 2, 3, 4, 1).reshape(n * edge ** 3, cout)
-                dw = _gemm_tn_f64(dzf, cols).reshape(cout, cin, 3, 3, 3)
+                dw = ops.linear_wgrad(dzf.contiguous(), cols.contiguous()).reshape(cout, cin, 3, 3, 3)
             dx, dgamma, dbeta = gn_backward(x, dxn.contiguous(), gamma, ctx.groups, ctx.eps)
         return dx, dgamma, dbeta, dw, None, None
 
@@ -139,7 +129,7 @@ class Linear(torch.autograd.Function):
             else:                                                   # y > 0 <=> pre-activation > 0 for ReLU and LeakyReLU(slope > 0)
                 dpre = torch.where(y > 0, dy, dy * (ctx.slope if ctx.act == ops.ACT_LEAKY else 0.0)).contiguous()
             dx = ops.linear(dpre, ops.pack_linear_weight(weight.t().contiguous()), None, weight.shape[1])
-            dw = _gemm_tn_f64(dpre, x)
+            dw = ops.linear_wgrad(dpre, x)
             db = dpre.double().sum(0).float() if ctx.has_bias else None
         return dx, dw, db, None, None
 

@@ -479,6 +479,20 @@ def linear(x, w_packed, bias, nout, act=ACT_NONE, slope=0.0):
     return y
 
 
+def linear_wgrad(a, b):
+    """a [K, M], b [K, N] -> a^T b [M, N] (split-K MFMA GEMM, float64 slice sum): the weight gradient of a Linear layer"""
+    _req(a, 'a'), _req(b, 'b')
+    if a.shape[0] != b.shape[0]:
+        raise ValueError('linear_wgrad: row counts differ (%d vs %d)' % (a.shape[0], b.shape[0]))
+    k, m, n = a.shape[0], a.shape[1], b.shape[1]
+    lib = _lib.load()
+    nbytes = lib.rf_linear_wgrad_ws_bytes(k, m, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    dw = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _lib.check(lib.rf_linear_wgrad(_p(a), _p(b), k, m, n, _p(dw), _p(ws), nbytes, _stream()), 'rf_linear_wgrad')
+    return dw
+
+
 def l2_normalize_rows_(x, eps=1e-12):
     _req(x, 'x')
     _lib.check(_lib.load().rf_l2_normalize_rows(_p(x), x.shape[0], x.shape[1], eps, _stream()), 'rf_l2_normalize_rows')

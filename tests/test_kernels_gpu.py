@@ -702,3 +702,17 @@ def test_fused_groupnorm_statistics_match_recomputed(ops, case):
     y.mul_(2.0)                                                            # in-place edit invalidates the attached statistics
     stale = ops.gn_affine(y, None, g2, b2, groups)
     same_affine(stale, ops.gn_affine(y.clone(), None, g2, b2, groups), 'stale stats must not be used')
+
+
+@pytest.mark.parametrize('case', [(65536, 128, 128), (4096, 32, 128), (1000, 56, 50), (300, 7, 513), (16, 128, 128), (70000, 512, 256)])
+def test_linear_wgrad_split_k_gemm(ops, case):
+    """rf_linear_wgrad: dW = a^T b over K rows (the Linear layers' weight gradient, rfuse/autograd.py) vs float64; ragged M / N / K,
+    K smaller than one slice, and run-to-run bit-identical (fixed-order float64 slice sum, no atomics)."""
+    k, m, n = case
+    gen = torch.Generator().manual_seed(k + m + n)
+    a, b = rnd(gen, k, m).to(DEV), rnd(gen, k, n).to(DEV)
+    got = ops.linear_wgrad(a, b)
+    want = a.double().t() @ b.double()
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= 2e-6 * scale * max(1.0, (k / 4096) ** 0.5)
+    assert torch.equal(got, ops.linear_wgrad(a, b))
