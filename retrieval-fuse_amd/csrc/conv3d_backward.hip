@@ -40,7 +40,16 @@ __global__ __launch_bounds__(256) void k_gnb_reduce(const float* __restrict__ x,
     const float* xg = x + ((size_t)nn * C + (size_t)g * cpg) * vol;
     const size_t glen = (size_t)cpg * vol;
     double s = 0.0, q = 0.0;
-    for (size_t i = tid; i < glen; i += 256) { const double v = xg[i]; s += v; q += v * v; }
+    if ((vol & 3) == 0) {                                           // 16-byte loads (every volume but 1^3)
+        const float4* xg4 = reinterpret_cast<const float4*>(xg);
+        for (size_t i = tid; i < glen / 4; i += 256) {
+            const float4 t = xg4[i];
+            const double v0 = t.x, v1 = t.y, v2 = t.z, v3 = t.w;
+            s += (v0 + v1) + (v2 + v3); q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        }
+    } else {
+        for (size_t i = tid; i < glen; i += 256) { const double v = xg[i]; s += v; q += v * v; }
+    }
     s = wave_sum(s); q = wave_sum(q);
     if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
     __syncthreads();
@@ -54,7 +63,19 @@ __global__ __launch_bounds__(256) void k_gnb_reduce(const float* __restrict__ x,
     const float* xc = x + (size_t)nc * vol;
     const float* dc = dxn + (size_t)nc * vol;
     double a1 = 0.0, a2 = 0.0;
-    for (size_t i = tid; i < vol; i += 256) { const double d = dc[i]; a1 += d; a2 += d * ((double)xc[i] - mean) * rstd; }
+    if ((vol & 3) == 0) {
+        const float4* xc4 = reinterpret_cast<const float4*>(xc);
+        const float4* dc4 = reinterpret_cast<const float4*>(dc);
+        for (size_t i = tid; i < vol / 4; i += 256) {
+            const float4 xv = xc4[i], dv = dc4[i];
+            const double d0 = dv.x, d1 = dv.y, d2 = dv.z, d3 = dv.w;
+            a1 += (d0 + d1) + (d2 + d3);
+            a2 += (d0 * (((double)xv.x - mean) * rstd) + d1 * (((double)xv.y - mean) * rstd)) +
+                  (d2 * (((double)xv.z - mean) * rstd) + d3 * (((double)xv.w - mean) * rstd));
+        }
+    } else {
+        for (size_t i = tid; i < vol; i += 256) { const double d = dc[i]; a1 += d; a2 += d * ((double)xc[i] - mean) * rstd; }
+    }
     a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane == 0) { red[wave * 2] = a1; red[wave * 2 + 1] = a2; }
     __syncthreads();
@@ -84,9 +105,24 @@ __global__ __launch_bounds__(256) void k_gnb_apply(const float* __restrict__ x, 
     const float* xc = x + (size_t)nc * vol;
     const float* dc = dxn + (size_t)nc * vol;
     float* o = dx + (size_t)nc * vol;
-    for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < vol; i += (size_t)gridDim.y * 256) {
-        const double xh = ((double)xc[i] - mo.x) * mo.y;
-        o[i] = (float)(k0 * (double)dc[i] - k1 - xh * k2);
+    if ((vol & 3) == 0) {
+        const float4* xc4 = reinterpret_cast<const float4*>(xc);
+        const float4* dc4 = reinterpret_cast<const float4*>(dc);
+        float4* o4 = reinterpret_cast<float4*>(o);
+        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < vol / 4; i += (size_t)gridDim.y * 256) {
+            const float4 xv = xc4[i], dv = dc4[i];
+            float4 r;
+            r.x = (float)(k0 * (double)dv.x - k1 - (((double)xv.x - mo.x) * mo.y) * k2);
+            r.y = (float)(k0 * (double)dv.y - k1 - (((double)xv.y - mo.x) * mo.y) * k2);
+            r.z = (float)(k0 * (double)dv.z - k1 - (((double)xv.z - mo.x) * mo.y) * k2);
+            r.w = (float)(k0 * (double)dv.w - k1 - (((double)xv.w - mo.x) * mo.y) * k2);
+            o4[i] = r;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < vol; i += (size_t)gridDim.y * 256) {
+            const double xh = ((double)xc[i] - mo.x) * mo.y;
+            o[i] = (float)(k0 * (double)dc[i] - k1 - xh * k2);
+        }
     }
 }
 
@@ -104,7 +140,7 @@ extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, in
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_gnb_reduce, dim3(n * c), dim3(256), 0, s, x, dxn, c, cpg, vol, (double)eps, moments, dbeta_parts, dgamma_parts);
     RF_CHECK_LAUNCH("rf_gn_backward(reduce)");
-    const unsigned gy = (unsigned)((vol + 4095) / 4096);
+    const unsigned gy = (unsigned)((vol / 4 + 1023) / 1024);          // 1024 float4 per workgroup
     hipLaunchKernelGGL(k_gnb_apply, dim3(n * c, gy < 1 ? 1 : gy), dim3(256), 0, s, x, dxn, gamma, c, cpg, vol, moments, dbeta_parts, dgamma_parts, dx);
     RF_CHECK_LAUNCH("rf_gn_backward(apply)");
     return RF_OK;
