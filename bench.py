@@ -421,7 +421,7 @@ def main():
             'config': {'workload': '%s: %s super-res/recon ->064, synthetic chunks, K=%d, DB=%d patches (exact L2 top-%d), '
                                    'random-init weights' % (args.config, cfg['dataset_train']['dataset_name'], K, n_patches, 2 * K),
                        'chunks_per_gpu_per_step': B, 'db_patches': n_patches,
-                       'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way + one RCCL all-gather of the packed top-2K keys' % (world, world)},
+                       'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way: RCCL all-gather of the queries + all-to-all of the packed top-2K keys' % (world, world)},
             'roofline': {'bound': 'mfma',
                          'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4%s> (retrieval backbone decoder conv %d+%d->%d @8^3: '
                                    '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, z-border padding taps '
@@ -438,9 +438,9 @@ def main():
         if collective_events:
             q_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in collective_events]))
             k_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in collective_events]))
-            out['collectives'] = {'rccl_ranks': world, 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_gather_keys_ms': k_ms,
-                                  'keys_bytes_per_rank': world * B * 64 * 2 * K * 8,
-                                  'note': 'HIP events on the issuing stream around each all_gather_into_tensor (includes waiting for the slowest rank)'}
+            out['collectives'] = {'rccl_ranks': world, 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_to_all_keys_ms': k_ms,
+                                  'keys_bytes_received_per_rank': world * B * 64 * 2 * K * 8,
+                                  'note': 'HIP events on the issuing stream around each collective (includes waiting for the slowest rank)'}
         state = None
         if world == 1 and not args.no_extras:
             state = {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}

@@ -9,7 +9,7 @@ util/retrieval.py:21-26,45).  On the device it is kept as structure-of-arrays:
   volumes     float32 [S][64][64][64]                        replicated scene chunks the 16^3 boxes point into
 
 Sharding: rank g scans rows [g*N/W, (g+1)*N/W) for ALL queries and the per-shard top-2K
-(dist, global row id) lists are exchanged with one all-gather and merged -- the only collective on the path.
+(dist, global row id) lists are exchanged with one all-to-all (each rank receives the candidates of its own queries) and merged.
 The voxel store is replicated (1 M patches = 15 625 chunks = 16.4 GB fp32, trivial against 288 GB), so no payload
 exchange is needed.
 """
@@ -48,8 +48,10 @@ def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings
 
       1. all-gather the queries (every shard must see every query)                              [W * nq, 64] float32
       2. local_topk_keys(all_queries) -> packed 64-bit keys (dist bits << 32 | GLOBAL row id, -1 = none) over this rank's rows
-      3. ONE all-gather of the candidate keys                                                  [W, W * nq, k2] int64
-      4. merge_keys(parts restricted to this rank's own queries) -> (dist [nq, k2], idx [nq, k2])
+      3. ONE all-to-all of the candidate keys: rank r receives, from every shard, the candidates of ITS nq queries  [W, nq, k2] int64
+         (an all-gather would move W times as much -- every rank's candidates for every rank's queries -- to use 1/W of it;
+         xGMI is point-to-point, an all-to-all of W-1 messages of nq * k2 * 8 bytes is its natural pattern)
+      4. merge_keys(the W candidate lists of this rank's own queries) -> (dist [nq, k2], idx [nq, k2])
 
     The unsigned order of the keys is the (distance, row id) order, so the merge of W shard lists equals a single scan
     bit for bit.  ``timings``: optional list; (start, end) CUDA event pairs of the two collectives are appended."""
@@ -68,16 +70,15 @@ def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings
     dist.all_gather_into_tensor(q_all, q_local, group=group)
     if ev:
         ev[1].record()
-    keys = local_topk_keys(q_all).contiguous()                                  # [W*nq, k2] int64
-    flat = torch.empty((world * keys.shape[0], keys.shape[1]), dtype=keys.dtype, device=keys.device)      # rank-major concatenation
+    keys = local_topk_keys(q_all).contiguous()                                  # [W*nq, k2] int64: rows [r*nq, (r+1)*nq) = rank r's queries
+    recv = torch.empty_like(keys)                                               # [W, nq, k2]: part w = shard w's candidates for MY queries
     if ev:
         ev[2].record()
-    dist.all_gather_into_tensor(flat, keys, group=group)
+    dist.all_to_all_single(recv, keys, group=group)
     if ev:
         ev[3].record()
         timings.append((ev[0], ev[1], ev[2], ev[3]))
-    mine = flat.view(world, keys.shape[0], keys.shape[1])[:, rank * nq:(rank + 1) * nq].contiguous()
-    return merge_keys(mine)
+    return merge_keys(recv.view(world, nq, keys.shape[1]))
 
 
 class HipSearchBackend:
@@ -164,7 +165,7 @@ class PatchDatabase:
         numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes."""
         emb = torch.as_tensor(emb)
         self.backend = backend
-        self.collective_events = None    # bench.py: a list to collect (start, end) event pairs of the two all-gathers
+        self.collective_events = None    # bench.py: a list to collect (start, end) event pairs of the two collectives
         self.n_rows = emb.shape[0]
         self.dim = emb.shape[1]
         self.rank, self.world, self.group = rank, world, group

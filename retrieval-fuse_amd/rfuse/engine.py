@@ -5,7 +5,7 @@ This is the build's own runner for the data flow of ``RefinementTrainingModule.f
 retrieval (util/retrieval.py ``--mode map`` / ``--mode compose``, :222-248) done online on the device:
 
    raw input chunk  --rf_query_windows-->  query windows --fenc_input + normalise-->  unit embeddings        (A11, A16)
-                    --rf_l2_topk (+ all-gather + rf_topk_merge when the DB is sharded)-->  top-2K             (A12)
+                    --rf_l2_topk (+ all-gather of the queries, all-to-all of the keys, rf_topk_merge when the DB is sharded)-->  top-2K             (A12)
                     --rf_demote_same_scene-->  top-K (scene, box)                                             (A13)
                     --rf_gather_patches-->  K*64 retrieved 16^3 patches per chunk, normalised, already in the
                                            Unfold3D(16,1) row layout                                          (A15, A16, A4)
