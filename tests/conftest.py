@@ -24,3 +24,28 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return REPO / 'tests' / 'golden'
+
+
+@pytest.fixture(autouse=True)
+def poison_gpu_memory(request):
+    """Before every GPU test: fill the caching allocator's free memory with NaN bit patterns, so that `torch.empty` workspaces and
+    outputs start as garbage, not as the zeros a fresh process usually sees -- a kernel that reads something it never wrote then
+    fails every time instead of once in a blue moon (when the VRAM still holds another process's data)."""
+    if 'gpu' not in request.keywords:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        blocks = []
+        try:
+            for _ in range(6):                                          # 6 x 256 MiB: more than any test's working set of fresh blocks
+                blocks.append(torch.full((64 * 1024 * 1024,), float('nan'), dtype=torch.float32, device='cuda:0'))
+            for _ in range(256):                                        # the allocator's small-block pool (requests <= 1 MiB) is separate
+                blocks.append(torch.full((256 * 1024 - 64,), float('nan'), dtype=torch.float32, device='cuda:0'))
+        except RuntimeError:
+            pass
+        del blocks                                                      # back to the allocator's cache, contents intact
+        from rfuse import _lib
+        _lib.check(_lib.load().rf_debug_poison_lds(None), 'rf_debug_poison_lds')       # and NaNs in the LDS of every CU
+        torch.cuda.synchronize()
+    yield
