@@ -159,6 +159,20 @@ int rf_conv3d_up_variant(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                             const float* gn_affine, const float* w_packed, int cout, float* out, double* stats, void* stream);
 
+/* The same decoder-form convolution on the F16 matrix cores by OPERAND SPLITTING (csrc/conv3d_up_split.hip): every fp32 operand
+ * is carried as two f16 numbers h = f16(x), l = f16((x - h) * 2^11); a*b ~ ah*bh + (ah*bl + al*bh) / 2^11 with exact f16 x f16
+ * products, fp32 accumulation in two separate accumulators, combined once.  Same inputs, outputs, statistics layout (one tile per
+ * sample) and arithmetic contract as rf_conv3d_up_k3_gn_relu -- measured rounding error against float64 is half that of the
+ * fp32 MFMA chain (tools/micro/split_probe.hip) at three 16-cycle MFMAs per 8192 multiply-adds instead of eight 32-cycle ones.
+ * Takes whole 8^3 samples (edge == 8, n >= 256), c0 and c1 in multiples of 8, c1 <= 64, 33..64 couts
+ * (rf_conv3d_up_split_supported).  Weight image: rf_conv3_up_split_pack_weight -> rf_conv3_up_split_packed_bytes bytes
+ * (f16 fragment order, pre-sums in float64 and split from the float64 value). */
+size_t rf_conv3_up_split_packed_bytes(int cout, int c0, int c1);
+int rf_conv3_up_split_pack_weight(const float* w_oidhw, int cout, int c0, int c1, void* w_packed, void* stream);
+int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int cout);
+int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
+                                  const float* gn_affine, const void* w_packed, int cout, float* out, double* stats, void* stream);
+
 /* ------------------------------------------------------------------------------- backward (training slice, N4) */
 
 /* rf_conv3d_k3_gn_relu with the ReLU optional (relu = 0: plain GroupNorm + conv): the DATA-GRADIENT convolution of the

@@ -1,0 +1,372 @@
+// rf_conv3d_up_split_k3_gn_relu: the decoder form of SingleConv 'gcr' (reference model/unet.py:19-76 with the nearest x2 upsample +
+// concat of :297-308 / :354-360) on whole 8^3 samples -- the same arithmetic contract as rf_conv3d_up_k3_gn_relu (conv3d_up.hip:
+// upsampled channels convolved in LOW resolution with 8 pre-summed taps per output parity), evaluated on the F16 matrix cores by
+// OPERAND SPLITTING instead of on v_mfma_f32_16x16x4_f32:
+//
+//     every fp32 operand x is carried as two f16 numbers   h = f16(x),  l = f16((x - h) * 2^11)       (x - h is exact in fp32)
+//     so that x = h + l / 2^11 up to 2^-22 |x|, and        a * b  ~  ah * bh  +  (ah * bl + al * bh) / 2^11  (al * bl: 2^-22 relative, dropped).
+//     An f16 x f16 product is exact in fp32.  v_mfma_f32_16x16x32_f16 accumulates in fp32; the ah*bh sums and the cross sums go to
+//     SEPARATE accumulators (hi, lo) and meet once, in the epilogue:  out = hi + lo / 2^11.
+//
+// Three f16 MFMAs (16 cycles each for 16x16x32) replace eight fp32 MFMAs (32 cycles each for 16x16x4): 5.3x the multiply-add rate of the
+// fp32 matrix path at -- measured, tools/micro/split_probe.hip -- HALF its rounding error against float64 (K = 216 ... 5184: rms 1.2e-8
+// vs 2.5e-8 of sum|a b|, max 9.7e-8 vs 3.1e-7): the fp32 MFMA is a sequential fmaf chain with one rounding per product, the f16 MFMA
+// rounds once per 32 products, and the 2^-22 representation error of the operands is random per element and does not accumulate.
+// Activations are scaled by 2^-4 and weights by 2^4 before the split (exact): f16 overflows at 65504, so a GroupNorm output would have to
+// exceed 1e6 to saturate (it is clamped, never inf), while small values lose nothing (whatever h drops, l carries).
+//
+// Work split (as conv3d_up.hip): one workgroup of 8 waves per sample, WAVE w OWNS OUTPUT PARITY w = (pz,py,px): its 4 m-blocks are the
+// four z planes of that parity's 4^3 lattice (m-block row r = (Y,X) = (r >> 2, r & 3)), all couts (NB n-blocks of 16) -> 16 output tiles,
+// 2 accumulator sets.  K order: an MFMA k-step is 4 TAPS x 8 CHANNELS -- lane group g = lane >> 4 supplies tap 4s + g, its 8 halves are 8
+// consecutive channels of one voxel -- so the LDS image of the input is [8-channel group][voxel of the halo box] in 16-byte slots and every
+// A operand is ONE ds_read_b128 at (voxel + tap offset):
+//   A) skip channels: per 8-channel chunk 7 k-steps (27 taps + one zero-weight dummy) on the full-res halo box [10][10][10], double
+//      buffered: the next chunk's 8 values per voxel are loaded into registers before the chunk's MFMAs and normalised + split + written
+//      to the other buffer after them (thread = voxel; one barrier per chunk);
+//   B) upsampled channels: per 8-channel chunk 2 k-steps (tz = 0 / 1, lane group = (ty,tx)) on the low-res halo box [6][6][6] of the
+//      chunk, all chunks staged once at kernel start (wave = channel group).
+// B operands (weights) are stored in HBM in fragment order (rf_conv3_up_split_pack_weight: [k-step][n-block][h|l][lane][8 halves], the
+// phase-B part once per parity), stay L2-resident (1.25 MB for 32+64->56) and go global -> VGPR with one 16-byte load per fragment, one
+// k-step ahead of their MFMAs (register double buffer).  A operands are read just in time per m-block (two m-blocks of registers).
+// Epilogue: accumulators -> ReLU -> LDS tile [cout][8^3] -> contiguous float4 rows; GroupNorm statistics of the output (float64, fixed
+// order) for the next layer.
+#include "common.h"
+#include <type_traits>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int US_SY = 12, US_SZ = 120, US_ASLOTS = 1208;        // full-res halo box, slot(z,y,x) = z*120 + y*12 + x (x, y, z in 0..9)
+constexpr int US_BY = 6, US_BZ = 36, US_BSLOTS = 216;           // low-res halo box, slot(Z,Y,X) = Z*36 + Y*6 + X
+constexpr int US_A_PLANE = US_ASLOTS * 16;                       // bytes of one (h or l) plane of a phase-A buffer
+constexpr int US_A_BUF = 2 * US_A_PLANE;
+constexpr int US_B_OFF = 2 * US_A_BUF;
+constexpr int US_B_PLANE = US_BSLOTS * 16;
+constexpr int US_MAX_CGB = 8;                                    // low-res channel groups that fit (c1 <= 64)
+constexpr int US_LDS_BYTES = US_B_OFF + US_MAX_CGB * 2 * US_B_PLANE;      // 132,608
+constexpr int US_E_STRIDE = 516;                                 // epilogue tile row (floats)
+constexpr float US_ACT_SCALE = 1.0f / 16, US_W_SCALE = 16.0f, US_LO = 2048.0f;
+static_assert(64 * US_E_STRIDE * 4 <= US_LDS_BYTES, "epilogue tile must fit");
+}   // namespace
+
+// ------------------------------------------------------------------------------------------------------------ weight image
+// in 16-byte units (8 halves): A region [c0/8][7 steps][NB][h|l][64 lanes]  ++  B region [8 parities][c1/8][2 steps][NB][h|l][64]  ++ one
+// step of zeros (the last step's prefetch lands there).  Lane l of a fragment: cout = nb*16 + (l & 15), tap group g = l >> 4.
+static inline size_t us_steps(int c0, int c1) { return (size_t)(c0 / 8) * 7 + (size_t)8 * (c1 / 8) * 2 + 1; }
+
+extern "C" size_t rf_conv3_up_split_packed_bytes(int cout, int c0, int c1) {
+    return us_steps(c0, c1) * (size_t)(rf_round_up(cout, 16) / 16) * 2 * 64 * 16;
+}
+
+__global__ void k_conv3_up_split_pack(const float* __restrict__ w, int cout, int c0, int c1, int nb_count, h8* __restrict__ wp, size_t total) {
+    const int cin = c0 + c1;
+    const size_t nA = (size_t)(c0 / 8) * 7 * nb_count * 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), piece = (int)((i >> 6) & 1);
+        const size_t f = i >> 7;
+        const int nb = (int)(f % nb_count);
+        const size_t st = f / nb_count;
+        const int co = nb * 16 + (lane & 15), g = lane >> 4;
+        h8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double v = 0.0;
+            if (i < nA) {
+                const int s = (int)(st % 7), ca = (int)(st / 7), tap = 4 * s + g, ci = ca * 8 + j;
+                if (tap < 27 && co < cout) v = (double)w[((size_t)co * cin + ci) * 27 + tap];
+            } else {
+                const size_t sb = st - (size_t)(c0 / 8) * 7;
+                const int nB = c1 / 8;
+                if (sb < (size_t)8 * nB * 2 && co < cout) {
+                    const int s = (int)(sb % 2), cb = (int)((sb / 2) % nB), ph = (int)(sb / ((size_t)2 * nB));
+                    const int ci = c0 + cb * 8 + j;
+                    // per axis: parity 0: low-res tap 0 <- {0}, tap 1 <- {1,2};  parity 1: tap 0 <- {0,1}, tap 1 <- {2}   (conv3d_up.hip)
+                    const int pz = ph >> 2, py = (ph >> 1) & 1, px = ph & 1, tz = s, ty = g >> 1, tx = g & 1;
+                    const int z_lo = tz == 0 ? 0 : (pz ? 2 : 1), z_hi = tz == 0 ? (pz ? 1 : 0) : 2;
+                    const int y_lo = ty == 0 ? 0 : (py ? 2 : 1), y_hi = ty == 0 ? (py ? 1 : 0) : 2;
+                    const int x_lo = tx == 0 ? 0 : (px ? 2 : 1), x_hi = tx == 0 ? (px ? 1 : 0) : 2;
+                    const float* wk = w + ((size_t)co * cin + ci) * 27;
+                    for (int dz = z_lo; dz <= z_hi; ++dz)
+                        for (int dy = y_lo; dy <= y_hi; ++dy)
+                            for (int dx = x_lo; dx <= x_hi; ++dx) v += (double)wk[(dz * 3 + dy) * 3 + dx];      // float64 sum, split from it
+                }
+            }
+            v *= (double)US_W_SCALE;
+            v = v > 65504.0 ? 65504.0 : (v < -65504.0 ? -65504.0 : v);
+            const _Float16 h = (_Float16)(float)v;
+            out[j] = piece == 0 ? h : (_Float16)(float)((v - (double)(float)h) * (double)US_LO);
+        }
+        wp[i] = out;
+    }
+}
+
+extern "C" int rf_conv3_up_split_pack_weight(const float* w_oidhw, int cout, int c0, int c1, void* w_packed, void* stream) {
+    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && c0 >= 0 && c1 > 0 && c0 % 8 == 0 && c1 % 8 == 0, RF_E_INVALID,
+               "rf_conv3_up_split_pack_weight: needs c0 and c1 in multiples of 8 (got %d, %d)", c0, c1);
+    const size_t total = rf_conv3_up_split_packed_bytes(cout, c0, c1) / 16;
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_conv3_up_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, c0, c1,
+                       rf_round_up(cout, 16) / 16, reinterpret_cast<h8*>(w_packed), total);
+    RF_CHECK_LAUNCH("rf_conv3_up_split_pack_weight");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------- kernel
+struct UpSplitArgs {
+    const float* src0;
+    const float* src1;
+    const float4* affine;   // GroupNorm per (sample, input channel): (center, scale, shift, -) -> y = (x - center) * scale + shift
+    const h8* wp;
+    float* out;
+    double2* stats;         // optional [n][cout][1]
+    int c0, c1, n, cout;
+};
+
+// 8 normalised channel values of one voxel -> the two f16 pieces (scaled by 2^-4; saturating, never inf)
+__device__ __forceinline__ void us_split8(const float (&y)[8], h8& h, h8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = __builtin_amdgcn_fmed3f(y[j] * US_ACT_SCALE, -65504.f, 65504.f);
+        const _Float16 hh = (_Float16)v;
+        h[j] = hh;
+        l[j] = (_Float16)((v - (float)hh) * US_LO);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void us_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], const h8& ah, const h8& al, const h8 (&bh)[NB], const h8 (&bl)[NB]) {
+    // three passes over the n-blocks: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int n = 0; n < NB; ++n) hi[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], hi[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], lo[n], 0, 0, 0);
+}
+
+template <int NB>
+__global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    const int n = blockIdx.x;
+    const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3;
+    const float4* __restrict__ aff = a.affine + (size_t)n * cin;
+
+    // ---- zero the halo boxes (the padding slots are never written again)
+    for (int i = tid; i < US_LDS_BYTES / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // ---- stage: all low-res channel groups (wave = group, lane = low-res voxel), the first skip chunk (thread = voxel)
+    for (int cg = wave; cg < nB; cg += 8) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 af = aff[c0 + cg * 8 + j];
+            y[j] = fmaf(a.src1[((size_t)n * c1 + cg * 8 + j) * 64 + lane] - af.x, af.y, af.z);
+        }
+        h8 h, l;
+        us_split8(y, h, l);
+        const int slot = ((lane >> 4) + 1) * US_BZ + (((lane >> 2) & 3) + 1) * US_BY + (lane & 3) + 1;
+        unsigned char* p = lds + US_B_OFF + cg * 2 * US_B_PLANE + slot * 16;
+        *reinterpret_cast<h8*>(p) = h;
+        *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
+    }
+    const int vslot = ((tid >> 6) + 1) * US_SZ + (((tid >> 3) & 7) + 1) * US_SY + (tid & 7) + 1;     // this thread's voxel in the full-res halo box
+    const float* __restrict__ s0 = a.src0 + (size_t)n * c0 * 512 + tid;
+    auto stage_store = [&](const float (&x)[8], int ca) {           // ca: chunk slot; past the last chunk: harmless re-staging of the last one
+        float y[8];
+        const int cc = ca < nA ? ca : nA - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 af = aff[cc * 8 + j];
+            y[j] = fmaf(x[j] - af.x, af.y, af.z);
+        }
+        h8 h, l;
+        us_split8(y, h, l);
+        unsigned char* p = lds + (ca & 1) * US_A_BUF + vslot * 16;
+        *reinterpret_cast<h8*>(p) = h;
+        *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
+    };
+    if (nA > 0) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)j * 512];
+        stage_store(x, 0);
+    }
+
+    // ---- per-lane operand addressing
+    const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
+    const int abase = ((pz + 1) * US_SZ + (2 * rj + py + 1) * US_SY + (2 * ri + px + 1)) * 16;      // bytes; + 2 m SZ per m-block, + tap offset
+    int atap[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int t = 4 * s + g < 27 ? 4 * s + g : 26;                                                 // the dummy tap (zero weights) reads tap 26's voxel
+        atap[s] = ((t / 9 - 1) * US_SZ + ((t / 3) % 3 - 1) * US_SY + (t % 3 - 1)) * 16;
+    }
+    const int bbase = (pz * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;        // + (m + tz) BZ
+
+    f32x4 hi[4][NB], lo[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    constexpr int STEP_U4 = NB * 2 * 64;                               // 16-byte fragments rows per k-step of the weight image
+    const h8* __restrict__ wB = a.wp + (size_t)nA * 7 * STEP_U4 + (size_t)wave * nB * 2 * STEP_U4 + lane;      // this parity's phase-B stream
+    const h8* __restrict__ wn = nA > 0 ? a.wp + lane : wB;                                                         // next k-step to fetch
+    h8 b0h[NB], b0l[NB], b1h[NB], b1l[NB];
+    auto load_b = [&](h8 (&bh)[NB], h8 (&bl)[NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bh[nb] = wn[(nb * 2) * 64];
+            bl[nb] = wn[(nb * 2 + 1) * 64];
+        }
+        wn += STEP_U4;
+    };
+    load_b(b0h, b0l);
+
+    h8 ah[2], al[2];
+    __syncthreads();
+
+    // one k-step: the next step's B fragments are requested first (a full step ahead of their use), `xload` (phase A, first step of a chunk)
+    // requests the next chunk's raw voxels BEHIND them -- vmcnt retires in order, so the wait for the next step's weights must not have
+    // the HBM loads in front of it; A operands of m-block m+1 are fetched under the MFMAs of m-block m, `pre`: the NEXT step's m-block 0.
+    // The sched_barriers pin this order (hipcc otherwise sinks every load to just before its first use).
+    auto kstep = [&](auto has_pre, auto&& xload, const unsigned char* ap, const unsigned char* pre, int mstride, int lplane, const h8 (&bh)[NB], const h8 (&bl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
+        load_b(nh, nl);
+        xload();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m < 3) {
+                ah[(m + 1) & 1] = *reinterpret_cast<const h8*>(ap + (m + 1) * mstride);
+                al[(m + 1) & 1] = *reinterpret_cast<const h8*>(ap + (m + 1) * mstride + lplane);
+            } else if constexpr (decltype(has_pre)::value) {
+                ah[0] = *reinterpret_cast<const h8*>(pre);
+                al[0] = *reinterpret_cast<const h8*>(pre + lplane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            us_mfma_block<NB>(hi[m], lo[m], ah[m & 1], al[m & 1], bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto no_x = [] {};
+
+    // ---- phase A: skip channels.  No branch inside a chunk (hipcc's s_waitcnt insertion assumes the worst at every join): the last chunk
+    // re-loads its own channels and stages them into the idle buffer.
+    auto chunk_a = [&](int ca, h8 (&ch)[NB], h8 (&cl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
+        float x[8];
+        const bool more = ca + 1 < nA;
+        const int cx = more ? ca + 1 : ca;
+        auto xload = [&] {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(cx * 8 + j) * 512];
+        };
+        const unsigned char* buf = lds + (ca & 1) * US_A_BUF + abase;
+        ah[0] = *reinterpret_cast<const h8*>(buf + atap[0]);
+        al[0] = *reinterpret_cast<const h8*>(buf + atap[0] + US_A_PLANE);
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            if (s == 6) wn = more ? wn : wB;                            // the last phase-A step fetches the first phase-B step
+            const unsigned char* ap = buf + atap[s];
+            if (s == 0) kstep(std::true_type{}, xload, ap, buf + atap[s + 1], 2 * US_SZ * 16, US_A_PLANE, ch, cl, nh, nl);
+            else if (s == 6) kstep(std::false_type{}, no_x, ap, ap, 2 * US_SZ * 16, US_A_PLANE, ch, cl, nh, nl);
+            else if (s & 1) kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], 2 * US_SZ * 16, US_A_PLANE, nh, nl, ch, cl);
+            else kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], 2 * US_SZ * 16, US_A_PLANE, ch, cl, nh, nl);
+        }
+        stage_store(x, ca + 1);
+        __syncthreads();
+    };
+    for (int ca = 0; ca < nA; ca += 2) {
+        chunk_a(ca, b0h, b0l, b1h, b1l);                                 // 7 steps: the fetched step ends up in b1
+        if (ca + 1 < nA) chunk_a(ca + 1, b1h, b1l, b0h, b0l);
+        else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { b0h[nb] = b1h[nb]; b0l[nb] = b1l[nb]; }
+        }
+    }
+
+    // ---- phase B: upsampled channels in low resolution
+    {
+        const unsigned char* bb = lds + US_B_OFF + bbase;
+        ah[0] = *reinterpret_cast<const h8*>(bb);
+        al[0] = *reinterpret_cast<const h8*>(bb + US_B_PLANE);
+        for (int cb = 0; cb < nB; ++cb) {
+            const unsigned char* ap = bb + cb * 2 * US_B_PLANE;
+            kstep(std::true_type{}, no_x, ap, ap + US_BZ * 16, US_BZ * 16, US_B_PLANE, b0h, b0l, b1h, b1l);                                   // tz = 0
+            kstep(std::true_type{}, no_x, ap + US_BZ * 16, cb + 1 < nB ? ap + 2 * US_B_PLANE : ap, US_BZ * 16, US_B_PLANE, b1h, b1l, b0h, b0l);   // tz = 1
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: out = relu(hi + lo / 2^11) -> LDS tile [cout][z][y][x] -> float4 rows
+    float* e = reinterpret_cast<float*>(lds);
+    {
+        const int col = lane & 15, yj = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lin = (2 * m + pz) * 64 + (2 * yj + py) * 8 + 2 * r + px;
+                    e[(nb * 16 + col) * US_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
+                }
+    }
+    __syncthreads();
+    const int cout = a.cout;
+    float* __restrict__ o = a.out + (size_t)n * cout * 512;
+    for (int q = tid; q < cout * 128; q += 512) {
+        const int co = q >> 7, l4 = q & 127;
+        *reinterpret_cast<float4*>(o + (size_t)co * 512 + l4 * 4) = *reinterpret_cast<const float4*>(e + co * US_E_STRIDE + l4 * 4);
+    }
+    if (a.stats) {
+        // per cout: eight threads sum 64 values each (float64), then the eight partial sums in a fixed order
+        const int co = tid >> 3, part = tid & 7;
+        double sm = 0.0, sq = 0.0;
+        if (co < cout) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(e + co * US_E_STRIDE + (part * 16 + i) * 4);
+                sm += (double)v.x; sq += (double)v.x * v.x;
+                sm += (double)v.y; sq += (double)v.y * v.y;
+                sm += (double)v.z; sq += (double)v.z * v.z;
+                sm += (double)v.w; sq += (double)v.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
+        if (part == 0 && co < cout) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------- host
+extern "C" int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int cout) {
+    if (edge != 8 || n < 256 || c0 < 0 || c1 <= 0 || c0 % 8 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0) return 0;
+    const int nb = rf_round_up(cout, 16) / 16;
+    return nb == 3 || nb == 4;
+}
+
+template <int NB>
+static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
+    auto kern = k_conv3_up_split<NB>;
+    static RfLdsOptIn opt_in;
+    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), US_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.n), dim3(512), US_LDS_BYTES, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
+    return RF_OK;
+}
+
+extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
+                                              const void* w_packed, int cout, float* out, double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256), c0 and c1 in multiples of 8, c1 <= 64, 33..64 couts (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               c0, c1, n, edge, cout);
+    RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu: null pointer");
+    UpSplitArgs a;
+    a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
+    a.out = out; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    return rf_round_up(cout, 16) == 48 ? launch_up_split<3>(a, (hipStream_t)stream) : launch_up_split<4>(a, (hipStream_t)stream);
+}

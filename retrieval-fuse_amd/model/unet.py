@@ -49,6 +49,7 @@ class Conv3dParams(nn.Module):
         self.reset_parameters()
         self._packed = ops.PackedWeight('conv3' if (kernel_size == 3 and padding == 1) else 'convv')
         self._packed_up = ops.PackedWeight('conv3up')
+        self._packed_up_split = ops.PackedWeight('conv3ups')
         self._packed_lds = ops.PackedWeight('convvl')
         self._packed_valu = ops.PackedWeight('convvv')
 
@@ -73,6 +74,10 @@ class Conv3dParams(nn.Module):
     def packed_up(self, c0):
         """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""
         return self._packed_up.get(self.weight, c0)
+
+    def packed_up_split(self, c0):
+        """f16 fragment image of the split-operand decoder form (csrc/conv3d_up_split.hip)"""
+        return self._packed_up_split.get(self.weight, c0)
 
     def extra_repr(self):
         return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
@@ -110,6 +115,9 @@ class SingleConv(nn.Module):
             return ops.conv3d_gn_relu_pool(x, None, aff, self.conv.packed(), cout, keep_full=(pool == 'also'))
         if _direct or edge == 1:
             out = ops.conv3d_gn_relu(x, upsampled, aff, None, cout, direct_weight=self.conv.weight)
+        elif ops.conv_up_split_supported(x, upsampled, cout):
+            c0 = x.shape[1] if x is not None else 0
+            out = ops.conv3d_up_split_gn_relu(x, upsampled, aff, self.conv.packed_up_split(c0), cout)
         elif ops.conv_up_supported(x, upsampled, cout):
             c0 = x.shape[1] if x is not None else 0
             out = ops.conv3d_up_gn_relu(x, upsampled, aff, self.conv.packed_up(c0), cout)

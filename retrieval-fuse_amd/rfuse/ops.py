@@ -95,7 +95,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -309,6 +309,59 @@ def conv3d_up_gn_relu(src0, src1, aff, w_up_packed, cout):
     if stats is not None:
         out._rf_stats = (stats, tiles, out._version)
     return out
+
+
+# Arithmetic of the heavy convolutions that have a split-operand form (csrc/conv3d_up_split.hip): 'split' = fp32 operands carried as
+# two f16 pieces on the F16 matrix cores (exact products, fp32 accumulation; measured closer to float64 than the fp32 MFMA chain),
+# 'fp32' = v_mfma_f32_16x16x4_f32 everywhere.  An API switch, not an environment variable.
+CONV_ARITH = 'split'
+
+
+def pack_conv3_up_split_weight(w, c0):
+    """f16 fragment-order weight image of the split-operand decoder conv (pre-sums in float64, split from the float64 value)."""
+    _req(w.detach(), 'conv weight')
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3, 3) or not 0 <= c0 < cin:
+        raise ValueError('pack_conv3_up_split_weight: expected an OIDHW 3x3x3 weight and 0 <= c0 < cin, got %s, c0=%d' % (tuple(w.shape), c0))
+    lib = _lib.load()
+    out = torch.empty(lib.rf_conv3_up_split_packed_bytes(cout, c0, cin - c0), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.rf_conv3_up_split_pack_weight(_p(w.detach()), cout, c0, cin - c0, _p(out), _stream()), 'rf_conv3_up_split_pack_weight')
+    return out
+
+
+def conv_up_split_supported(src0, src1, cout):
+    """True when the split-operand decoder kernel (rf_conv3d_up_split_k3_gn_relu) takes this (skip, low-res) pair and is switched on."""
+    if src1 is None or not USE_CONV_UP or CONV_ARITH != 'split':
+        return False
+    n, c0, c1, edge = _src_dims(src0, src1)
+    return bool(_lib.load().rf_conv3d_up_split_supported(c0, c1, n, edge, cout))
+
+
+def conv3d_up_split_gn_relu(src0, src1, aff, w_split_packed, cout):
+    """conv3d_up_gn_relu on the F16 matrix cores by operand splitting (whole 8^3 samples)."""
+    n, c0, c1, edge = _src_dims(src0, src1)
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=_check_affine(aff, n, c0 + c1))
+    lib = _lib.load()
+    stats = torch.empty((n, cout, 1, 2), dtype=torch.float64, device=out.device) if USE_FUSED_STATS else None
+    timed = conv_event_filter is not None and conv_event_filter(c0 + c1, cout, edge, n)
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.rf_conv3d_up_split_k3_gn_relu(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(w_split_packed), cout, _p(out),
+                                                 _p(stats), _stream()), 'rf_conv3d_up_split_k3_gn_relu')
+    if timed:
+        ev1.record()
+        conv_events.append((ev0, ev1, conv_up_split_issued_flops(c0, c1, n, edge, cout)))
+    if stats is not None:
+        out._rf_stats = (stats, 1, out._version)
+    return out
+
+
+def conv_up_split_issued_flops(c0, c1, n, edge, cout):
+    """f16 multiply-adds (x2 = flop) rf_conv3d_up_split_k3_gn_relu ISSUES: three MFMAs per k-step of 32, k-steps = 7 per 8 skip
+    channels (28 tap slots for 27 taps) + 2 per 8 upsampled channels, on round_up(cout, 16) columns."""
+    ksteps = (c0 // 8) * 7 + (c1 // 8) * 2
+    return 2.0 * 3 * ksteps * 32 * (-(-cout // 16) * 16) * edge ** 3 * n
 
 
 def conv_up_issued_flops(c0, c1, n, edge, cout):

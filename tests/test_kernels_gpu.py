@@ -166,6 +166,70 @@ def test_conv3d_up_parity_split_decoder_kernel(ops, case):
     same_affine(fused, plain, 'scale from fused stats')
 
 
+SPLIT_UP_CASES = [
+    # (n, c0, c1, edge, cout, groups): shapes rf_conv3d_up_split_supported accepts (whole 8^3 samples, channels in eights, 33..64 couts)
+    (256, 32, 64, 8, 56, 8),    # retrieval backbone dec1 of C1-C4 (the dominant launch): 4 + 8 chunks, NB 4 with 8 padded couts
+    (300, 24, 48, 8, 42, 6),    # the same layer at nf = 12 (C5): odd number of skip chunks, NB 3
+    (257, 0, 16, 8, 64, 8),     # no skip source
+    (260, 8, 8, 8, 33, 4),      # one chunk each
+    (515, 40, 64, 8, 64, 8),    # five skip chunks, full couts
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_UP_CASES)
+def test_conv3d_up_split_operand_kernel(ops, case):
+    """rf_conv3d_up_split_k3_gn_relu (fp32 operands as two f16 pieces on the F16 matrix cores, hi/lo fp32 accumulators) vs float64
+    torch on the materialised upsample + concat (model/unet.py:297-308, 19-76) and vs the fp32-MFMA decoder kernel: the same bar as
+    that kernel, AND no further from the float64 result than it (the split form is the more accurate one); fused statistics too."""
+    n, c0, c1, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case) + 7)
+    src0 = rnd(gen, n, c0, edge, edge, edge).relu_() if c0 else None
+    src1 = rnd(gen, n, c1, edge // 2, edge // 2, edge // 2).relu_()
+    cin = c0 + c1
+    gamma, beta = 1 + 0.2 * rnd(gen, cin), 0.2 * rnd(gen, cin)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin))
+    d0 = src0.to(DEV) if src0 is not None else None
+    d1 = src1.to(DEV)
+    assert ops.conv_up_split_supported(d0, d1, cout)
+    aff = ops.gn_affine(d0, d1, gamma.to(DEV), beta.to(DEV), groups)
+    wd = w.to(DEV)
+    got = ops.conv3d_up_split_gn_relu(d0, d1, aff, ops.pack_conv3_up_split_weight(wd, c0), cout)
+    fp32 = ops.conv3d_up_gn_relu(d0, d1, aff, ops.pack_conv3_up_weight(wd, c0), cout)
+    close(got, fp32, 1e-5, 'split-operand vs fp32-MFMA decoder kernel')
+    e_split, e_fp32 = [], []
+    for sl in (slice(0, min(n, 24)), slice(max(0, n - 5), n)):       # float64 reference on slices (CPU time)
+        ref = ref_gcr(src0[sl].double() if c0 else None, src1[sl].double(), gamma.double(), beta.double(), groups, w.double())
+        close(got[sl], ref.float(), 1e-5, 'split-operand vs float64 torch')
+        e_split.append((got[sl].cpu().double() - ref).flatten())
+        e_fp32.append((fp32[sl].cpu().double() - ref).flatten())
+    e_split, e_fp32 = torch.cat(e_split), torch.cat(e_fp32)
+    rms_s, rms_f = e_split.pow(2).mean().sqrt().item(), e_fp32.pow(2).mean().sqrt().item()
+    print(f'\n{case}: error vs float64  split rms {rms_s:.3e} max {e_split.abs().max().item():.3e} | fp32 MFMA rms {rms_f:.3e} max {e_fp32.abs().max().item():.3e}')
+    assert rms_s <= 1.05 * rms_f and e_split.abs().max().item() <= 1.25 * e_fp32.abs().max().item()
+    g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+    g = groups if cout % groups == 0 else 1
+    assert getattr(got, '_rf_stats', None) is not None
+    fused = ops.gn_affine(got, None, g2, b2, g)
+    plain = ops.gn_affine(got.clone(), None, g2, b2, g)
+    same_affine(fused, plain, 'scale from fused stats')
+
+
+def test_conv3d_up_split_saturates_instead_of_overflowing(ops):
+    """activations beyond the f16 range of the split (|GroupNorm output| > 65504 * 16) saturate; nothing becomes inf / nan"""
+    n, c0, c1, cout = 256, 8, 8, 40
+    gen = torch.Generator().manual_seed(5)
+    d0 = rnd(gen, n, c0, 8, 8, 8).to(DEV)
+    d1 = rnd(gen, n, c1, 4, 4, 4).to(DEV)
+    aff = torch.zeros(n, c0 + c1, 4, device=DEV)
+    aff[..., 1] = 1.0
+    aff[0, :, 1] = 1e7                                                # sample 0: far out of range
+    w = rnd(gen, cout, c0 + c1, 3, 3, 3, scale=0.05).to(DEV)
+    got = ops.conv3d_up_split_gn_relu(d0, d1, aff, ops.pack_conv3_up_split_weight(w, c0), cout)
+    assert torch.isfinite(got).all()
+    fp32 = ops.conv3d_up_gn_relu(d0, d1, aff, ops.pack_conv3_up_weight(w, c0), cout)
+    close(got[1:], fp32[1:], 1e-5, 'in-range samples unaffected')
+
+
 @pytest.mark.parametrize('case', [(300, 8, 16, 16, 8), (1100, 16, 8, 32, 8), (2, 16, 64, 16, 8), (130, 6, 16, 12, 6), (520, 16, 8, 72, 8),
                                   (4100, 32, 4, 64, 8), (2100, 16, 4, 16, 8), (2050, 6, 4, 12, 6)])
 def test_conv_with_fused_maxpool_epilogue(ops, case):
