@@ -1,0 +1,279 @@
+// rf_conv3d_split_k3_gn_relu: SingleConv 'gcr' (reference model/unet.py:19-76: GroupNorm -> 3x3x3 conv, pad 1, no bias -> ReLU) on 8^3
+// output boxes -- the arithmetic contract and the outputs (ReLU'd volume, GroupNorm statistics, fused MaxPool3d(2)) of
+// rf_conv3d_k3_gn_relu[_stats|_pool] (conv3d_mfma.hip), evaluated on the F16 matrix cores by OPERAND SPLITTING:
+//     x = h + l / 2^11,  h = f16(x),  l = f16((x - h) * 2^11);   a*b ~ ah*bh + (ah*bl + al*bh) / 2^11,   exact f16 x f16 products,
+//     fp32 accumulation in two separate accumulators (hi, lo), combined once in the epilogue
+// (see conv3d_up_split.hip for the numerics: half the rounding error of the fp32 MFMA chain at 5.3x its multiply-add rate).
+//
+// GEMM view: M = the 512 voxels of a box (8 waves x 4 m-blocks, voxel order = BoxOrder of conv_box.h so that the epilogue -- shared with
+// the fp32 kernel -- finds whole float4 rows and pooling cells in a lane), N = cout (NB = 1 or 2 n-blocks), K = cin * 27 walked in
+// chunks of 8 input channels, 7 k-steps each: an MFMA k-step (k = 32) is 4 TAPS x 8 CHANNELS -- lane group g = lane >> 4 supplies tap
+// 4s + g (tap 27 is a zero-weight dummy), its 8 halves are the chunk's 8 channels of one voxel.  The LDS image of a chunk is the halo
+// box [10][10][10] in 16-byte slots (8 channels of a voxel), one plane for h and one for l, so an A operand is one ds_read_b128 at
+// (voxel + tap offset).  Two chunk buffers: the next chunk's raw voxels (two halo voxels per thread, 8 channels each) are requested
+// before the MFMAs of the current chunk and normalised + split + written to the other buffer after them; one barrier per chunk.
+// B operands (weights): f16 fragment image from rf_conv3_split_pack_weight ([chunk][k-step][n-block][h|l][lane][8 halves]), L2-resident,
+// global -> VGPR one k-step ahead.  Register use is small (NB 1: 32 accumulator VGPRs), two workgroups per CU.
+#include "common.h"
+#include "conv_box.h"
+#include <type_traits>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int CS_SY = 10, CS_SZ = 100, CS_SLOTS = 1000;         // halo box, slot(z,y,x) = z*100 + y*10 + x
+constexpr int CS_PLANE = CS_SLOTS * 16;                          // bytes of one (h or l) plane
+constexpr int CS_BUF = 2 * CS_PLANE;
+constexpr int CS_LDS_BYTES = 2 * CS_BUF;                         // 64,000
+constexpr float CS_ACT_SCALE = 1.0f / 16, CS_W_SCALE = 16.0f, CS_LO = 2048.0f;
+}   // namespace
+
+// ------------------------------------------------------------------------------------------------------------ weight image
+extern "C" size_t rf_conv3_split_packed_bytes(int cout, int cin) {
+    return ((size_t)(cin / 8) * 7 + 1) * (size_t)(rf_round_up(cout, 16) / 16) * 2 * 64 * 16;
+}
+
+__global__ void k_conv3_split_pack(const float* __restrict__ w, int cout, int cin, int nb_count, h8* __restrict__ wp, size_t total) {
+    const size_t nreal = (size_t)(cin / 8) * 7 * nb_count * 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), piece = (int)((i >> 6) & 1);
+        const size_t f = i >> 7;
+        const int nb = (int)(f % nb_count);
+        const size_t st = f / nb_count;
+        const int co = nb * 16 + (lane & 15), g = lane >> 4;
+        const int s = (int)(st % 7), ca = (int)(st / 7), tap = 4 * s + g;
+        h8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double v = 0.0;
+            if (i < nreal && tap < 27 && co < cout) v = (double)w[((size_t)co * cin + ca * 8 + j) * 27 + tap];
+            v *= (double)CS_W_SCALE;
+            v = v > 65504.0 ? 65504.0 : (v < -65504.0 ? -65504.0 : v);
+            const _Float16 h = (_Float16)(float)v;
+            out[j] = piece == 0 ? h : (_Float16)(float)((v - (double)(float)h) * (double)CS_LO);
+        }
+        wp[i] = out;
+    }
+}
+
+extern "C" int rf_conv3_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream) {
+    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && cin > 0 && cin % 8 == 0, RF_E_INVALID,
+               "rf_conv3_split_pack_weight: needs cin in multiples of 8 (got %d)", cin);
+    const size_t total = rf_conv3_split_packed_bytes(cout, cin) / 16;
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_conv3_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin,
+                       rf_round_up(cout, 16) / 16, reinterpret_cast<h8*>(w_packed), total);
+    RF_CHECK_LAUNCH("rf_conv3_split_pack_weight");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------- kernel
+__device__ __forceinline__ void cs_split8(const float (&y)[8], h8& h, h8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = __builtin_amdgcn_fmed3f(y[j] * CS_ACT_SCALE, -65504.f, 65504.f);
+        const _Float16 hh = (_Float16)v;
+        h[j] = hh;
+        l[j] = (_Float16)((v - (float)hh) * CS_LO);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], const h8& ah, const h8& al, const h8 (&bh)[NB], const h8 (&bl)[NB]) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) hi[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], hi[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], lo[n], 0, 0, 0);
+}
+
+template <int NB, int WPS>
+__global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int edge = a.edge, cin = a.c0, nC = cin >> 3;
+    const size_t vol = (size_t)edge * edge * edge;
+
+    const unsigned lblock = rf_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tpe = edge >> 3;
+    int t = (int)lblock;
+    const int x0 = (t % tpe) * 8; t /= tpe;
+    const int y0 = (t % tpe) * 8; t /= tpe;
+    const int z0 = (t % tpe) * 8; t /= tpe;
+    const int n0 = t;
+    const int cob = blockIdx.y * (NB * 16);
+    const float4* __restrict__ aff = a.affine + (size_t)n0 * cin;
+
+    // ---- staging: thread t owns halo voxels t and t + 512 (the second only for t < 488)
+    int voff[2];
+    bool vin[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int v = tid + r * 512;
+        const int hx = v % 10, hy = (v / 10) % 10, hz = v / 100;
+        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+        vin[r] = v < CS_SLOTS && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge;
+        voff[r] = vin[r] ? (z * edge + y) * edge + x : 0;
+    }
+    const float* __restrict__ s0 = a.src0 + (size_t)n0 * cin * vol;
+    auto stage_load = [&](float (&x)[2][8], int ca) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[r][j] = s0[(size_t)(ca * 8 + j) * vol + voff[r]];
+    };
+    auto stage_store = [&](const float (&x)[2][8], int ca, int buf) {      // zeros outside the volume (the padding of the NORMALISED tensor)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 af = aff[ca * 8 + j];
+                y[j] = vin[r] ? fmaf(x[r][j] - af.x, af.y, af.z) : 0.f;
+            }
+            h8 h, l;
+            cs_split8(y, h, l);
+            if (r == 0 || tid < CS_SLOTS - 512) {
+                unsigned char* p = lds + buf * CS_BUF + (tid + r * 512) * 16;
+                *reinterpret_cast<h8*>(p) = h;
+                *reinterpret_cast<h8*>(p + CS_PLANE) = l;
+            }
+        }
+    };
+    {
+        float x[2][8];
+        stage_load(x, 0);
+        stage_store(x, 0, 0);
+    }
+
+    // ---- per-lane operand addressing (BoxOrder: x = i & 7, y = 4 (wave & 1) + 2 (mb >> 1) + (i >> 3), z = 2 (wave >> 1) + (mb & 1))
+    const int g = lane >> 4, ri = lane & 15;
+    const int abase = ((2 * (wave >> 1) + 1) * CS_SZ + (4 * (wave & 1) + (ri >> 3) + 1) * CS_SY + (ri & 7) + 1) * 16;
+    int atap[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int tp = 4 * s + g < 27 ? 4 * s + g : 26;
+        atap[s] = ((tp / 9 - 1) * CS_SZ + ((tp / 3) % 3 - 1) * CS_SY + (tp % 3 - 1)) * 16;
+    }
+
+    f32x4 hi[4][NB], lo[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nbt = a.cout16 >> 4;                                        // n-blocks of the weight image
+    const h8* __restrict__ wn = reinterpret_cast<const h8*>(a.wp) + (size_t)blockIdx.y * NB * 128 + lane;      // next k-step to fetch
+    const int wstep = nbt * 128;
+    h8 b0h[NB], b0l[NB], b1h[NB], b1l[NB];
+    auto load_b = [&](h8 (&bh)[NB], h8 (&bl)[NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            bh[nb] = wn[(nb * 2) * 64];
+            bl[nb] = wn[(nb * 2 + 1) * 64];
+        }
+        wn += wstep;
+    };
+    load_b(b0h, b0l);
+    h8 ah[2], al[2];
+    __syncthreads();
+
+    // one k-step (see conv3d_up_split.hip): next step's B fragments first, then (first step of a chunk) the next chunk's raw voxels BEHIND
+    // them (vmcnt retires in order), A operands of m-block m+1 under the MFMAs of m-block m; sched_barriers pin the order
+    auto kstep = [&](auto has_pre, auto&& xload, const unsigned char* ap, const unsigned char* pre, const h8 (&bh)[NB], const h8 (&bl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
+        load_b(nh, nl);
+        xload();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            constexpr int MOFF[4] = {0, CS_SZ * 16, 2 * CS_SY * 16, (CS_SZ + 2 * CS_SY) * 16};
+            if (m < 3) {
+                ah[(m + 1) & 1] = *reinterpret_cast<const h8*>(ap + MOFF[(m + 1) & 3]);
+                al[(m + 1) & 1] = *reinterpret_cast<const h8*>(ap + MOFF[(m + 1) & 3] + CS_PLANE);
+            } else if constexpr (decltype(has_pre)::value) {
+                ah[0] = *reinterpret_cast<const h8*>(pre);
+                al[0] = *reinterpret_cast<const h8*>(pre + CS_PLANE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cs_mfma_block<NB>(hi[m], lo[m], ah[m & 1], al[m & 1], bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto no_x = [] {};
+
+    // no branch inside a chunk (hipcc's s_waitcnt insertion assumes the worst at every join): the last chunk re-loads its own channels
+    // and stages them into the idle buffer
+    auto chunk = [&](int ca, h8 (&ch)[NB], h8 (&cl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
+        float x[2][8];
+        const int cx = ca + 1 < nC ? ca + 1 : ca;
+        auto xload = [&] { stage_load(x, cx); };
+        const unsigned char* buf = lds + (ca & 1) * CS_BUF + abase;
+        ah[0] = *reinterpret_cast<const h8*>(buf + atap[0]);
+        al[0] = *reinterpret_cast<const h8*>(buf + atap[0] + CS_PLANE);
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const unsigned char* ap = buf + atap[s];
+            if (s == 0) kstep(std::true_type{}, xload, ap, buf + atap[s + 1], ch, cl, nh, nl);
+            else if (s == 6) kstep(std::false_type{}, no_x, ap, ap, ch, cl, nh, nl);
+            else if (s & 1) kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], nh, nl, ch, cl);
+            else kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], ch, cl, nh, nl);
+        }
+        stage_store(x, cx, (ca + 1) & 1);
+        __syncthreads();
+    };
+    for (int ca = 0; ca < nC; ca += 2) {
+        chunk(ca, b0h, b0l, b1h, b1l);
+        if (ca + 1 < nC) chunk(ca + 1, b1h, b1l, b0h, b0l);
+    }
+
+    // ---- epilogue (shared with the fp32 kernel): acc = hi + lo / 2^11
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nb][r] = fmaf(lo[m][nb][r], 1.0f / CS_LO, hi[m][nb][r]);
+    conv_box_epilogue<8, 8, 8, 1, 8, 4, NB, (size_t)CS_LDS_BYTES>(a, acc, reinterpret_cast<float*>(lds), tid, lane, wave, n0, z0, y0, x0, cob, lblock);
+}
+
+// -------------------------------------------------------------------------------------------------------------------- host
+extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout) {
+    if (c1 != 0 || c0 < 8 || c0 % 8 || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
+    const int cout16 = rf_round_up(cout, 16);
+    return cout16 <= 32 && rf_conv_use_big(n, edge, cout16);
+}
+
+template <int NB, int WPS>
+static int launch_split(const ConvArgs& a, hipStream_t stream) {
+    auto kern = k_conv3_split<NB, WPS>;
+    const unsigned gx = (unsigned)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), CS_LDS_BYTES, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
+    return RF_OK;
+}
+
+extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
+                                           float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_supported(cin, 0, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_k3_gn_relu: takes cin in multiples of 8, up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
+               cin, n, edge, cout);
+    RF_REQUIRE(src && gn_affine && w_packed && (out || pool_out), RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: null pointer");
+    RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: statistics of an output that is not written");
+    RF_REQUIRE(pool_out || !pool_stats, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: pooled statistics without a pooled output");
+    ConvArgs a;
+    a.src0 = src; a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const float*>(w_packed); a.out = out;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = rf_round_up(cout, 16);
+    a.stats = reinterpret_cast<double2*>(stats);
+    a.stats_tiles = (stats || pool_stats) ? (edge / 8) * (edge / 8) * (edge / 8) : 0;
+    a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
+    a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
+    a.floor = 0.f;
+    // 32 couts run as two 16-cout workgroups per box (grid.y = 2).  A 2-n-block instance (158 VGPRs, one workgroup per CU) was 15 % faster
+    // on its own but left room for other kernels' waves on its SIMDs, and fp32 kernels of the other stream that shared a SIMD with it
+    // returned results that differed from their solo results (measured: tools/scratch notes in DESIGN); the 16-cout instance fills the
+    // register file with its own four waves per SIMD.
+    return launch_split<1, 4>(a, (hipStream_t)stream);
+}

@@ -50,6 +50,7 @@ class Conv3dParams(nn.Module):
         self._packed = ops.PackedWeight('conv3' if (kernel_size == 3 and padding == 1) else 'convv')
         self._packed_up = ops.PackedWeight('conv3up')
         self._packed_up_split = ops.PackedWeight('conv3ups')
+        self._packed_split = ops.PackedWeight('conv3s')
         self._packed_lds = ops.PackedWeight('convvl')
         self._packed_valu = ops.PackedWeight('convvv')
 
@@ -74,6 +75,10 @@ class Conv3dParams(nn.Module):
     def packed_up(self, c0):
         """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""
         return self._packed_up.get(self.weight, c0)
+
+    def packed_split(self):
+        """f16 fragment image of the split-operand box conv (csrc/conv3d_split.hip)"""
+        return self._packed_split.get(self.weight)
 
     def packed_up_split(self, c0):
         """f16 fragment image of the split-operand decoder form (csrc/conv3d_up_split.hip)"""
@@ -111,6 +116,8 @@ class SingleConv(nn.Module):
             return out if pool is None else (out, torch.nn.functional.max_pool3d(out, 2))
         aff = ops.gn_affine(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
+        if upsampled is None and not _direct and ops.conv_split_supported(x, None, cout):
+            return ops.conv3d_split_gn_relu(x, aff, self.conv.packed_split(), cout, pool=pool)
         if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
             return ops.conv3d_gn_relu_pool(x, None, aff, self.conv.packed(), cout, keep_full=(pool == 'also'))
         if _direct or edge == 1:

@@ -95,7 +95,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -315,6 +315,61 @@ def conv3d_up_gn_relu(src0, src1, aff, w_up_packed, cout):
 # two f16 pieces on the F16 matrix cores (exact products, fp32 accumulation; measured closer to float64 than the fp32 MFMA chain),
 # 'fp32' = v_mfma_f32_16x16x4_f32 everywhere.  An API switch, not an environment variable.
 CONV_ARITH = 'split'
+
+
+def pack_conv3_split_weight(w):
+    """f16 fragment-order weight image of the split-operand box conv (csrc/conv3d_split.hip)."""
+    _req(w.detach(), 'conv weight')
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3, 3) or cin % 8:
+        raise ValueError('pack_conv3_split_weight: expected an OIDHW 3x3x3 weight with cin in multiples of 8, got %s' % (tuple(w.shape),))
+    lib = _lib.load()
+    out = torch.empty(lib.rf_conv3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.rf_conv3_split_pack_weight(_p(w.detach()), cout, cin, _p(out), _stream()), 'rf_conv3_split_pack_weight')
+    return out
+
+
+def conv_split_supported(src0, src1, cout):
+    """True when the split-operand box kernel (rf_conv3d_split_k3_gn_relu) takes this source and is switched on."""
+    if src1 is not None or src0 is None or CONV_ARITH != 'split':
+        return False
+    n, c0, c1, edge = _src_dims(src0, src1)
+    return bool(_lib.load().rf_conv3d_split_supported(c0, c1, n, edge, cout))
+
+
+def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
+    """ReLU(conv3(GN(src))) on the F16 matrix cores by operand splitting.  pool: None -> out; 'also' -> (out, maxpool2(out));
+    'only' -> (None, maxpool2(out)) with the full-resolution tensor never written.  Statistics of what is written ride along."""
+    n, cin, _, edge = _src_dims(src, None)
+    dev = _check_affine(aff, n, cin)
+    lib = _lib.load()
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if pool != 'only' else None
+    pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev) if pool is not None else None
+    tiles = (edge // 8) ** 3
+    stats = pstats = None
+    if USE_FUSED_STATS:
+        stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if out is not None else None
+        pstats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if pooled is not None else None
+    timed = conv_event_filter is not None and conv_event_filter(cin, cout, edge, n)
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.rf_conv3d_split_k3_gn_relu(_p(src), cin, n, edge, _p(aff), _p(w_split_packed), cout, _p(out), _p(stats), _p(pooled), _p(pstats),
+                                              _stream()), 'rf_conv3d_split_k3_gn_relu')
+    if timed:
+        ev1.record()
+        conv_events.append((ev0, ev1, conv_split_issued_flops(cin, n, edge, cout)))
+    if stats is not None:
+        out._rf_stats = (stats, tiles, out._version)
+    if pstats is not None:
+        pooled._rf_stats = (pstats, tiles, pooled._version)
+    return out if pool is None else (out, pooled)
+
+
+def conv_split_issued_flops(cin, n, edge, cout):
+    """f16 flop rf_conv3d_split_k3_gn_relu ISSUES: three MFMAs per k-step of 32, 7 k-steps (28 tap slots) per 8 input channels, on
+    round_up(cout, 16) columns."""
+    return 2.0 * 3 * (cin // 8) * 7 * 32 * (-(-cout // 16) * 16) * edge ** 3 * n
 
 
 def pack_conv3_up_split_weight(w, c0):

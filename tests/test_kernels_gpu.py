@@ -166,6 +166,89 @@ def test_conv3d_up_parity_split_decoder_kernel(ops, case):
     same_affine(fused, plain, 'scale from fused stats')
 
 
+SPLIT_BOX_CASES = [
+    # (n, cin, edge, cout, groups): shapes rf_conv3d_split_supported accepts (cin in eights, <= 32 couts, >= 1024 boxes of 8^3)
+    (1030, 8, 8, 16, 8),       # one chunk, whole 8^3 volumes (zero-padding halo), ragged sample count
+    (130, 8, 16, 16, 8),       # retrieval backbone enc0 second conv: 8 boxes per sample, halos from the neighbouring boxes
+    (1100, 16, 8, 32, 8),      # NB 2, two chunks
+    (1025, 56, 8, 16, 8),      # seven chunks (odd), GroupNorm groups of 7 channels
+    (3, 16, 64, 16, 8),        # final decoder: 512 boxes per sample
+    (1040, 24, 8, 12, 6),      # nf = 12 family: cout < 16
+    (33, 32, 32, 24, 8),
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_BOX_CASES)
+def test_conv3d_split_operand_box_kernel(ops, case):
+    """rf_conv3d_split_k3_gn_relu (conv3d_split.hip) vs float64 torch (model/unet.py:19-76) and vs the fp32-MFMA box kernel: same bar, no
+    further from float64 than it; the fused MaxPool3d(2) outputs equal the stand-alone pool of its own output bit for bit; statistics."""
+    n, cin, edge, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case) + 11)
+    src = rnd(gen, n, cin, edge, edge, edge).relu_()
+    gamma, beta = 1 + 0.2 * rnd(gen, cin), 0.2 * rnd(gen, cin)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * cin))
+    x = src.to(DEV)
+    assert ops.conv_split_supported(x, None, cout)
+    aff = ops.gn_affine(x, None, gamma.to(DEV), beta.to(DEV), groups)
+    wd = w.to(DEV)
+    ws = ops.pack_conv3_split_weight(wd)
+    got = ops.conv3d_split_gn_relu(x, aff, ws, cout)
+    fp32 = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(wd), cout)
+    close(got, fp32, 1e-5, 'split-operand vs fp32-MFMA box kernel')
+    nref = max(1, min(n, 16384 // edge ** 3 * 2))
+    e_split, e_fp32 = [], []
+    for sl in (slice(0, nref), slice(max(0, n - 3), n)):
+        ref = ref_gcr(src[sl].double(), None, gamma.double(), beta.double(), groups, w.double())
+        close(got[sl], ref.float(), 1e-5, 'split-operand vs float64 torch')
+        e_split.append((got[sl].cpu().double() - ref).flatten())
+        e_fp32.append((fp32[sl].cpu().double() - ref).flatten())
+    e_split, e_fp32 = torch.cat(e_split), torch.cat(e_fp32)
+    rms_s, rms_f = e_split.pow(2).mean().sqrt().item(), e_fp32.pow(2).mean().sqrt().item()
+    print(f'\n{case}: error vs float64  split rms {rms_s:.3e} max {e_split.abs().max().item():.3e} | fp32 MFMA rms {rms_f:.3e} max {e_fp32.abs().max().item():.3e}')
+    assert rms_s <= 1.05 * rms_f and e_split.abs().max().item() <= 1.25 * e_fp32.abs().max().item()
+    want_pool = ops.maxpool2(got)
+    full, pooled = ops.conv3d_split_gn_relu(x, aff, ws, cout, pool='also')
+    assert torch.equal(full, got) and torch.equal(pooled, want_pool)
+    none, pooled_only = ops.conv3d_split_gn_relu(x, aff, ws, cout, pool='only')
+    assert none is None and torch.equal(pooled_only, want_pool)
+    g = groups if cout % groups == 0 else 1
+    g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+    for t in (got, pooled, pooled_only, full):
+        assert getattr(t, '_rf_stats', None) is not None
+        same_affine(ops.gn_affine(t, None, g2, b2, g), ops.gn_affine(t.clone(), None, g2, b2, g), 'scale from fused stats')
+
+
+@pytest.mark.parametrize('cout', [16, 32])
+def test_split_box_kernel_leaves_concurrent_kernels_alone(ops, cout):
+    """Two-stream regression (the engine runs the U-Net backbone on a side stream): small fp32 convs on a second stream must return
+    their solo results bit for bit while split-operand box convs run on the main stream.  A 2-n-block instance of the box kernel
+    (158 VGPRs, room for foreign waves on its SIMDs) made co-resident fp32 kernels return different bits; 32 couts now run as two
+    16-cout workgroups."""
+    gen = torch.Generator().manual_seed(3)
+    x = rnd(gen, 2048, 16, 8, 8, 8).relu_().to(DEV)
+    aff = ops.gn_affine(x, None, torch.ones(16, device=DEV), torch.zeros(16, device=DEV), 8)
+    ws = ops.pack_conv3_split_weight(rnd(gen, cout, 16, 3, 3, 3, scale=0.05).to(DEV))
+    xs = rnd(gen, 8, 32, 16, 16, 16).relu_().to(DEV)
+    affs = ops.gn_affine(xs, None, torch.ones(32, device=DEV), torch.zeros(32, device=DEV), 8)
+    wps = ops.pack_conv3_weight(rnd(gen, 32, 32, 3, 3, 3, scale=0.05).to(DEV))
+    solo = ops.conv3d_gn_relu(xs, None, affs, wps, 32).clone()
+    main_ref = ops.conv3d_split_gn_relu(x, aff, ws, cout).clone()
+    side = torch.cuda.Stream(DEV)
+    torch.cuda.synchronize()
+    wrong = 0
+    for _ in range(6):
+        outs = []
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(30):
+                outs.append(ops.conv3d_gn_relu(xs, None, affs, wps, 32))
+        for _ in range(6):
+            o = ops.conv3d_split_gn_relu(x, aff, ws, cout)
+        torch.cuda.synchronize()
+        wrong += sum(0 if torch.equal(v, solo) else 1 for v in outs) + (0 if torch.equal(o, main_ref) else 1)
+    assert wrong == 0, f'{wrong} launches returned different bits when run concurrently'
+
+
 SPLIT_UP_CASES = [
     # (n, c0, c1, edge, cout, groups): shapes rf_conv3d_up_split_supported accepts (whole 8^3 samples, channels in eights, 33..64 couts)
     (256, 32, 64, 8, 56, 8),    # retrieval backbone dec1 of C1-C4 (the dominant launch): 4 + 8 chunks, NB 4 with 8 padded couts

@@ -7,13 +7,13 @@ sys.path[:0] = [str(REPO / 'retrieval-fuse_amd')]
 from rfuse import ops
 
 dev = torch.device('cuda:0')
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 # (name, n, c0, c1, edge, cout)
 LAYERS = [('rb enc0 1->8 @16', 256 * B, 1, 0, 16, 8), ('rb enc0 8->16 @16', 256 * B, 8, 0, 16, 16), ('rb enc1 16->16 @8', 256 * B, 16, 0, 8, 16),
           ('rb enc1 16->32 @8', 256 * B, 16, 0, 8, 32), ('rb enc2 32->64 @4', 256 * B, 32, 0, 4, 64), ('rb enc3 64->128 @2', 256 * B, 64, 0, 2, 128),
           ('rb dec0 192->64 @4', 256 * B, 64, 128, 4, 64), ('rb dec1 96->56 @8', 256 * B, 32, 64, 8, 56), ('rb dec1 56->16 @8', 256 * B, 56, 0, 8, 16),
           ('dec 16->16 @64', B, 0, 16, 64, 16), ('dec 16->16 @64 (2)', B, 16, 0, 64, 16), ('unet 32->16 @32', B, 0, 32, 32, 16)]
-print('%-22s %9s %9s %9s' % ('layer', 'us', 'TFLOP/s', 'GB/s'))
+print('%-22s %9s %9s %9s | %9s %9s %8s' % ('layer', 'us', 'TFLOP/s', 'GB/s', 'split us', 'TF/s eq', 'f16 pipe'))
 for name, n, c0, c1, edge, cout in LAYERS:
     s0 = torch.rand(n, c0, edge, edge, edge, device=dev) if c0 else None
     s1 = torch.rand(n, c1, edge // 2, edge // 2, edge // 2, device=dev) if c1 else None
@@ -34,4 +34,17 @@ for name, n, c0, c1, edge, cout in LAYERS:
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 2 * 27 * cin * cout * edge ** 3 * n
     byts = 4 * (n * edge ** 3 * (c0 + cout) + (n * (edge // 2) ** 3 * c1 if c1 else 0))
-    print('%-22s %9.1f %9.1f %9.0f' % (name, us, flops / us / 1e6, byts / us / 1e3))
+    line = '%-22s %9.1f %9.1f %9.0f' % (name, us, flops / us / 1e6, byts / us / 1e3)
+    if ops.conv_split_supported(s0, s1, cout):
+        ws = ops.pack_conv3_split_weight(w)
+        for _ in range(3):
+            ops.conv3d_split_gn_relu(s0, aff, ws, cout)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.conv3d_split_gn_relu(s0, aff, ws, cout)
+        e1.record()
+        torch.cuda.synchronize()
+        us2 = e0.elapsed_time(e1) * 1e3 / reps
+        line += ' | %9.1f %9.1f %7.1f%%' % (us2, flops / us2 / 1e6, 100 * ops.conv_split_issued_flops(cin, n, edge, cout) / us2 / 1e6 / 2516)
+    print(line)
