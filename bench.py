@@ -41,6 +41,7 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA (= packed-fp32 vector) peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0              # HBM3E, same guide
+F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16/bf16 MFMA peak, same guide ("~2.5 PF dense"; 16x the fp32 MFMA rate)
 
 
 def parse():
@@ -189,6 +190,16 @@ def kernel_work(name, a, cfg):
         c0, c1, n, edge, cout = a[:5]
         from rfuse import ops
         return 'mfma', ops.conv_up_issued_flops(c0, c1, n, edge, cout), 'flop ISSUED (decoder form, 8 pre-summed taps for the upsampled channels, minus the skipped padding taps)'
+    if name == 'rf_conv3d_up_split_k3_gn_relu':
+        c0, c1, n, edge, cout = a[:5]
+        from rfuse import ops
+        return 'mfma-f16', ops.conv_up_split_issued_flops(c0, c1, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; decoder form; 28 tap slots per 27 taps, couts padded to 16); '
+                                                                                  'fp32-equivalent %.1f GFLOP' % (2.0 * (27 * c0 + 8 * c1) * cout * edge ** 3 * n / 1e9))
+    if name == 'rf_conv3d_split_k3_gn_relu':
+        cin, n, edge, cout = a[:4]
+        from rfuse import ops
+        return 'mfma-f16', ops.conv_split_issued_flops(cin, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; 28 tap slots per 27 taps, couts padded to 16); '
+                                                                            'fp32-equivalent %.1f GFLOP' % (2.0 * 27 * cin * cout * edge ** 3 * n / 1e9))
     if name in ('rf_attn_mlp_volume',):
         b, kv, c, s, t = a[:5]
         return 'mfma', b * kv * (s // 2) ** 3 * 2.0 * (c * 8 * 128 + 2 * 128 * 128 + 128 * 32), 'flop'
@@ -253,9 +264,10 @@ def kernel_table(eng, raw_dev, cfg, steps=3, top=5):
         w = kernel_work(name, ints, cfg)
         if w:
             bound, work, unit = w
-            if bound == 'mfma':
+            if bound in ('mfma', 'mfma-f16'):
+                peak = F16_MFMA_PEAK_TFLOPS if bound == 'mfma-f16' else FP32_MFMA_PEAK_TFLOPS
                 ach = work / (per_launch * 1e-3) / 1e12
-                row.update(bound='mfma', achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / FP32_MFMA_PEAK_TFLOPS, work=unit)
+                row.update(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, work=unit)
             else:
                 ach = work / (per_launch * 1e-3) / 1e9
                 row.update(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, work='algorithmic ' + unit)
@@ -364,11 +376,10 @@ def main():
     raws = np.stack([synthetic.make_chunk(10_000 + rank * B + b, cfg)['input_raw'] for b in range(B)])
     raw_dev = torch.from_numpy(raws).to(device)
 
-    # dominant kernel: the 96->56 (nf=16) first conv of the retrieval backbone's last decoder, n = B*K*64 patches of 8^3
-    # (32 skip channels at 8^3 + 64 channels upsampled from 4^3: the parity-split kernel rf_conv3d_up_k3_gn_relu)
+    # roofline: HIP events around every heavy conv launch of the timed region (the retrieval backbone's n = B*K*64 patch launches and the
+    # final decoder's 64^3 layers, on their launch stream); the DOMINANT kernel = the launch with the largest mean duration
     nf = cfg['nf']
-    dom_cin, dom_cout = 6 * nf, (6 * nf + nf) // 2
-    ops.conv_event_filter = lambda cin, cout, edge, n: cin == dom_cin and cout == dom_cout and edge == 8 and n == B * K * 64
+    ops.conv_event_filter = lambda cin, cout, edge, n: n >= B * K * 64 or edge == 64
 
     def barrier():
         if world > 1 or force_dist:
@@ -396,9 +407,13 @@ def main():
 
     ev = list(ops.conv_events)
     ops.conv_event_filter = None
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev])) if ev else float('nan')
-    kern_flops = ev[0][2] if ev else 0.0
-    achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if ev else float('nan')
+    by_launch = {}
+    for e0, e1, fl, label in ev:
+        by_launch.setdefault(label, []).append((e0.elapsed_time(e1), fl))
+    dom_label, dom = max(by_launch.items(), key=lambda kv: np.mean([t for t, _ in kv[1]])) if by_launch else (None, [])
+    kern_ms = float(np.mean([t for t, _ in dom])) if dom else float('nan')
+    kern_flops = dom[0][1] if dom else 0.0
+    achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if dom else float('nan')
 
     # every rank computes its own recall (collective-free for world == 1; with shards the search itself is a collective)
     recall = None
@@ -408,31 +423,43 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         # HBM traffic of the dominant kernel: OFFLINE PMC (separate rocprofv3 --pmc passes of this same command, FETCH_SIZE x2
-        # gfx950 correction + WRITE_SIZE, summary committed under profiles/), scaled per patch to this launch; None when no
-        # summary is committed for this config family
+        # gfx950 correction + WRITE_SIZE, summary committed under profiles/), scaled per sample to this launch; None when the
+        # committed summary is of another kernel
         traffic = None
-        pmc_file = next((f for f in (REPO / 'profiles' / 'r02_dominant_kernel.json', REPO / 'profiles' / 'r01_dominant_kernel.json') if f.exists()), None)
-        if pmc_file is not None and args.config in ('C1', 'C2', 'C3'):
-            traffic = json.loads(pmc_file.read_text())['traffic_bytes_per_patch'] * B * K * 64
+        pmc_file = REPO / 'profiles' / 'r02_dominant_kernel.json'
+        pmc = json.loads(pmc_file.read_text()) if pmc_file.exists() else None
+        roof = None
+        if dom_label is not None:
+            entry, arith, (c0_, c1_, n_, edge_, cout_) = dom_label
+            peak = F16_MFMA_PEAK_TFLOPS if arith == 'f16 split' else FP32_MFMA_PEAK_TFLOPS
+            useful = 2.0 * (27 * c0_ + (8 if 'up' in entry else 27) * c1_) * cout_ * edge_ ** 3 * n_       # multiply-adds of the layer in the form the kernel evaluates
+            if pmc is not None and pmc.get('entry') == entry and pmc.get('shape') == [c0_, c1_, edge_, cout_]:
+                traffic = pmc['traffic_bytes_per_sample'] * n_
+            src_bytes = 4.0 * n_ * (c0_ * edge_ ** 3 + (c1_ * (edge_ // 2) ** 3 if 'up' in entry else c1_ * edge_ ** 3) + cout_ * edge_ ** 3)
+            roof = {'bound': 'mfma',
+                    'kernel': '%s: %d+%d -> %d channels @%d^3 x %d samples, %s' % (entry, c0_, c1_, cout_, edge_, n_,
+                              'fp32 operands as two f16 pieces on v_mfma_f32_16x16x32_f16 (3 MFMAs per product tile, exact products, hi/lo fp32 accumulators)'
+                              if arith == 'f16 split' else 'v_mfma_f32_16x16x4_f32'),
+                    'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                    'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_file.name if traffic is not None else 'no summary of this kernel committed'),
+                    'launch_ms': kern_ms,
+                    'flops_per_launch': kern_flops,          # flop ISSUED on the matrix pipe of `peak` (f16 split: 3 f16 MFMAs per product tile, 28 tap slots per 27 taps, couts padded to 16)
+                    'fp32_equivalent_flops_per_launch': useful,
+                    'fp32_equivalent_tflops': useful / (kern_ms * 1e-3) / 1e12,
+                    'algorithmic_bytes_per_launch': src_bytes,
+                    'heavy_launches_ms': {'%s %s' % (lab[0], list(lab[2])): float(np.mean([t for t, _ in v])) for lab, v in sorted(by_launch.items(), key=lambda kv: -np.mean([t for t, _ in kv[1]]))}}
         out = {
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'arithmetic': 'fp32 tensors and fp32 accumulation throughout; the heavy 3x3x3 convolutions multiply on the F16 matrix cores with every fp32 operand '
+                          'carried as two f16 pieces (x = h + l / 2^11, exact f16 x f16 products, separate hi / lo fp32 accumulators): measured error against '
+                          'float64 is lower than that of the fp32 MFMA chain (tests/test_kernels_gpu.py, tools/micro/split_probe.hip)' if ops.CONV_ARITH == 'split' else 'fp32 (v_mfma_f32_16x16x4_f32)',
             'config': {'workload': '%s: %s super-res/recon ->064, synthetic chunks, K=%d, DB=%d patches (exact L2 top-%d), '
                                    'random-init weights' % (args.config, cfg['dataset_train']['dataset_name'], K, n_patches, 2 * K),
                        'chunks_per_gpu_per_step': B, 'db_patches': n_patches,
                        'parallelism': 'chunk-parallel replicas x%d, DB embedding matrix sharded %d-way: RCCL all-gather of the queries + all-to-all of the packed top-2K keys' % (world, world)},
-            'roofline': {'bound': 'mfma',
-                         'kernel': 'k_conv3_up<8^3 box, 8 waves = 8 output parities, MB4, NB4%s> (retrieval backbone decoder conv %d+%d->%d @8^3: '
-                                   '%d skip channels x 27 taps + %d upsampled channels x 8 pre-summed low-res taps, z-border padding taps '
-                                   'left out, %d patches)' % (', couts 48.. on 4x4x1 MFMAs' if 48 < dom_cout <= 56 else '', 2 * nf, 4 * nf, dom_cout, 2 * nf, 4 * nf, B * K * 64),
-                         'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_file.name if pmc_file else 'none'),
-                         'launch_ms': kern_ms,
-                         'flops_per_launch': kern_flops,          # multiply-adds ISSUED (decoder form minus the skipped zero-padding taps)
-                         'decoder_form_flops_per_launch': 2.0 * (27 * 2 * nf + 8 * 4 * nf) * dom_cout * 512 * B * K * 64,
-                         'direct_form_flops_per_launch': 2.0 * 27 * dom_cin * dom_cout * 512 * B * K * 64,
-                         'algorithmic_bytes_per_launch': 4.0 * B * K * 64 * (2 * nf * 512 + 4 * nf * 64 + dom_cout * 512)},
+            'roofline': roof,
             'recall_at_k': recall,
         }
         if collective_events:

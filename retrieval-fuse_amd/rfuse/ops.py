@@ -208,7 +208,7 @@ def _conv_launch(lib, src0, c0, src1, c1, n, edge, aff, w_packed, cout, out):
 
 # bench.py hook: time selected conv launches with HIP events recorded on the launch stream
 conv_event_filter = None        # callable(cin, cout, edge, n) -> bool
-conv_events = []                # [(start_event, end_event, flops)]
+conv_events = []                # [(start_event, end_event, flop issued, label)]; label = (entry point, arithmetic, (c0, c1, n, edge, cout))
 
 
 def conv3d_gn_relu(src0, src1, aff, w_packed, cout, direct_weight=None):
@@ -222,7 +222,7 @@ def conv3d_gn_relu(src0, src1, aff, w_packed, cout, direct_weight=None):
         ev0.record()
         _conv_launch(lib, src0, c0, src1, c1, n, edge, aff, w_packed, cout, out)
         ev1.record()
-        conv_events.append((ev0, ev1, 2.0 * 27 * (c0 + c1) * cout * edge ** 3 * n))
+        conv_events.append((ev0, ev1, 2.0 * 27 * (c0 + c1) * cout * edge ** 3 * n, ('rf_conv3d_k3_gn_relu', 'fp32 MFMA', (c0, c1, n, edge, cout))))
         return out
     if direct_weight is not None:
         _lib.check(lib.rf_conv3d_k3_gn_relu_direct(_p(src0), c0, _p(src1), c1, n, edge, _p(aff), _p(direct_weight.detach()),
@@ -305,7 +305,7 @@ def conv3d_up_gn_relu(src0, src1, aff, w_up_packed, cout):
                                            _p(stats), _stream()), 'rf_conv3d_up_k3_gn_relu')
     if timed:
         ev1.record()
-        conv_events.append((ev0, ev1, conv_up_issued_flops(c0, c1, n, edge, cout)))
+        conv_events.append((ev0, ev1, conv_up_issued_flops(c0, c1, n, edge, cout), ('rf_conv3d_up_k3_gn_relu', 'fp32 MFMA', (c0, c1, n, edge, cout))))
     if stats is not None:
         out._rf_stats = (stats, tiles, out._version)
     return out
@@ -358,7 +358,7 @@ def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
                                               _stream()), 'rf_conv3d_split_k3_gn_relu')
     if timed:
         ev1.record()
-        conv_events.append((ev0, ev1, conv_split_issued_flops(cin, n, edge, cout)))
+        conv_events.append((ev0, ev1, conv_split_issued_flops(cin, n, edge, cout), ('rf_conv3d_split_k3_gn_relu', 'f16 split', (cin, 0, n, edge, cout))))
     if stats is not None:
         out._rf_stats = (stats, tiles, out._version)
     if pstats is not None:
@@ -406,7 +406,7 @@ def conv3d_up_split_gn_relu(src0, src1, aff, w_split_packed, cout):
                                                  _p(stats), _stream()), 'rf_conv3d_up_split_k3_gn_relu')
     if timed:
         ev1.record()
-        conv_events.append((ev0, ev1, conv_up_split_issued_flops(c0, c1, n, edge, cout)))
+        conv_events.append((ev0, ev1, conv_up_split_issued_flops(c0, c1, n, edge, cout), ('rf_conv3d_up_split_k3_gn_relu', 'f16 split', (c0, c1, n, edge, cout))))
     if stats is not None:
         out._rf_stats = (stats, 1, out._version)
     return out

@@ -20,7 +20,7 @@ REPO = Path(__file__).resolve().parents[1]
 pmc_dir = Path(sys.argv[1]) if len(sys.argv) > 1 else REPO / 'gpurun_out' / 'pmc'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 cfg_name = sys.argv[3] if len(sys.argv) > 3 else 'C2'
-DOMINANT = 'k_conv3_up<8, 1, 4, 4, true>'
+DOMINANT = 'k_conv3_up_split<4>'          # rf_conv3d_up_split_k3_gn_relu 32+64->56 @8^3 (C1-C4); one 8^3 sample per workgroup
 
 
 def short(name):
@@ -58,7 +58,7 @@ def avg(table, key, ctr):
 rows = []
 for key in sq1:
     kern, wgs = key
-    if not (kern.startswith('k_') or 'k_conv3' in kern or 'k_linear' in kern or 'k_l2' in kern or 'k_convv' in kern):
+    if not (kern.startswith('k_') or 'k_conv3' in kern or 'k_conv3_split' in kern or 'k_linear' in kern or 'k_l2' in kern or 'k_convv' in kern):
         continue
     gui = avg(sq1, key, 'GRBM_GUI_ACTIVE')
     cycles = gui / 8.0
@@ -88,8 +88,9 @@ dom = [r for r in rows if r[1] == DOMINANT]
 if dom and cfg_name == 'C2':
     _, kern, wgs, launches, cycles, mfma, wa, wi, lc, fm, wm = max(dom, key=lambda r: r[2])
     n_patches = wgs                                   # one 8^3 box = one patch per workgroup, one cout block
-    j = {'kernel': kern, 'batch': n_patches // 256, 'n_patches': n_patches, 'fetch_MB_per_launch': fm, 'write_MB_per_launch': wm,
-         'traffic_bytes_per_patch': (fm + wm) * 1e6 / n_patches, 'mfma_busy_pct': mfma, 'cycles_per_launch': cycles,
+    j = {'kernel': kern, 'entry': 'rf_conv3d_up_split_k3_gn_relu', 'shape': [32, 64, 8, 56], 'batch': n_patches // 256, 'n_patches': n_patches,
+         'fetch_MB_per_launch': fm, 'write_MB_per_launch': wm,
+         'traffic_bytes_per_sample': (fm + wm) * 1e6 / n_patches, 'mfma_busy_pct': mfma, 'cycles_per_launch': cycles,
          'source': 'profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)' % out_csv.name}
     (REPO / 'profiles' / ('%s_dominant_kernel.json' % tag)).write_text(json.dumps(j, indent=1))
     print(json.dumps(j, indent=1))
