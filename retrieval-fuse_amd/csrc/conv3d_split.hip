@@ -88,7 +88,8 @@ __device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
     for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], lo[n], 0, 0, 0);
 }
 
-template <int NB, int WPS>
+// ONE: the layer has a single 8-channel chunk (no prefetch of a next chunk, one chunk buffer)
+template <int NB, int WPS, bool ONE>
 __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -206,9 +207,9 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     // no branch inside a chunk (hipcc's s_waitcnt insertion assumes the worst at every join): the last chunk re-loads its own channels
     // and stages them into the idle buffer
     auto chunk = [&](int ca, h8 (&ch)[NB], h8 (&cl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
-        float x[2][8];
+        float x[ONE ? 1 : 2][8];
         const int cx = ca + 1 < nC ? ca + 1 : ca;
-        auto xload = [&] { stage_load(x, cx); };
+        auto xload = [&] { if constexpr (!ONE) stage_load(x, cx); };
         const unsigned char* buf = lds + (ca & 1) * CS_BUF + abase;
         ah[0] = *reinterpret_cast<const h8*>(buf + atap[0]);
         al[0] = *reinterpret_cast<const h8*>(buf + atap[0] + CS_PLANE);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
             else if (s & 1) kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], nh, nl, ch, cl);
             else kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], ch, cl, nh, nl);
         }
-        stage_store(x, cx, (ca + 1) & 1);
+        if constexpr (!ONE) stage_store(x, cx, (ca + 1) & 1);
         __syncthreads();
     };
     for (int ca = 0; ca < nC; ca += 2) {
@@ -246,11 +247,11 @@ extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int co
     return cout16 <= 32 && rf_conv_use_big(n, edge, cout16);
 }
 
-template <int NB, int WPS>
+template <int NB, int WPS, bool ONE>
 static int launch_split(const ConvArgs& a, hipStream_t stream) {
-    auto kern = k_conv3_split<NB, WPS>;
+    auto kern = k_conv3_split<NB, WPS, ONE>;
     const unsigned gx = (unsigned)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
-    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), CS_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), ONE ? CS_BUF : CS_LDS_BYTES, stream, a);
     RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
     return RF_OK;
 }
@@ -275,5 +276,8 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     // on its own but left room for other kernels' waves on its SIMDs, and fp32 kernels of the other stream that shared a SIMD with it
     // returned results that differed from their solo results (measured: tools/scratch notes in DESIGN); the 16-cout instance fills the
     // register file with its own four waves per SIMD.
-    return launch_split<1, 4>(a, (hipStream_t)stream);
+    // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
+    // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and
+    // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
+    return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
 }

@@ -218,16 +218,16 @@ def test_conv3d_split_operand_box_kernel(ops, case):
         same_affine(ops.gn_affine(t, None, g2, b2, g), ops.gn_affine(t.clone(), None, g2, b2, g), 'scale from fused stats')
 
 
-@pytest.mark.parametrize('cout', [16, 32])
-def test_split_box_kernel_leaves_concurrent_kernels_alone(ops, cout):
+@pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (8, 16)])
+def test_split_box_kernel_leaves_concurrent_kernels_alone(ops, cin, cout):
     """Two-stream regression (the engine runs the U-Net backbone on a side stream): small fp32 convs on a second stream must return
     their solo results bit for bit while split-operand box convs run on the main stream.  A 2-n-block instance of the box kernel
     (158 VGPRs, room for foreign waves on its SIMDs) made co-resident fp32 kernels return different bits; 32 couts now run as two
-    16-cout workgroups."""
+    16-cout workgroups.  (cin = 8 is the single-chunk instance: 80 VGPRs, six waves per SIMD.)"""
     gen = torch.Generator().manual_seed(3)
-    x = rnd(gen, 2048, 16, 8, 8, 8).relu_().to(DEV)
-    aff = ops.gn_affine(x, None, torch.ones(16, device=DEV), torch.zeros(16, device=DEV), 8)
-    ws = ops.pack_conv3_split_weight(rnd(gen, cout, 16, 3, 3, 3, scale=0.05).to(DEV))
+    x = rnd(gen, 2048, cin, 8, 8, 8).relu_().to(DEV)
+    aff = ops.gn_affine(x, None, torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV), 8)
+    ws = ops.pack_conv3_split_weight(rnd(gen, cout, cin, 3, 3, 3, scale=0.05).to(DEV))
     xs = rnd(gen, 8, 32, 16, 16, 16).relu_().to(DEV)
     affs = ops.gn_affine(xs, None, torch.ones(32, device=DEV), torch.zeros(32, device=DEV), 8)
     wps = ops.pack_conv3_weight(rnd(gen, 32, 32, 3, 3, 3, scale=0.05).to(DEV))
