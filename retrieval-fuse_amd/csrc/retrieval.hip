@@ -59,6 +59,8 @@ extern "C" int rf_query_windows(const float* raw, int b, int s, int ps, int ctx,
 //                                                the 64 contiguous bytes lane (row, g) loads are the dims {4m + g} = the g-th
 //                                                summation chain of the exact distance (see rf_exact_dist below)
 //   hd       [n32]                               (1 - 2^-15) * |row|^2 / 2, +inf for the padding rows (they never pass the filter)
+//   rows16   [n32][64] f16                       the rows rounded to f16, natural dim order: A operands of the f16-filtered scan
+//   hd16     [n32]                               (1 - 2^-9) * |row|^2 / 2; -inf for a row with a component beyond the f16 range (always re-checked)
 #define RF_DIM 64
 #define RF_EPS_FILTER 3.0517578125e-05f            // 2^-15, see the error bound at k_l2_topk_mfma
 
@@ -66,7 +68,7 @@ static inline size_t rf_blocked_floats(int64_t n) { return (size_t)((n + 63) / 6
 static inline int64_t rf_rows32(int64_t n) { return (n + 31) / 32 * 32; }
 
 __global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, long long n, float* __restrict__ blocked, float* __restrict__ rows,
-                                                 float* __restrict__ hd) {
+                                                 float* __restrict__ hd, _Float16* __restrict__ rows16, float* __restrict__ hd16) {
     const long long nblk = (n + 63) / 64, n32 = (n + 31) / 32 * 32;
     const size_t total = (size_t)nblk * RF_DIM * 64;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -78,21 +80,29 @@ __global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, 
         const long long row = (long long)(i / RF_DIM);
         const int p = (int)(i % RF_DIM), g = p >> 4, m = p & 15;
         rows[i] = row < n ? emb[(size_t)row * RF_DIM + 4 * m + g] : 0.f;
+        {   // a row with a component beyond the f16 range is all zeros here and has hd16 = -inf: it passes the filter and is re-checked exactly
+            bool fits = row < n;
+            if (fits)
+                for (int d = 0; d < RF_DIM; ++d) fits = fits && fabsf(emb[(size_t)row * RF_DIM + d]) < 6.0e4f;
+            rows16[i] = (_Float16)(fits ? emb[(size_t)row * RF_DIM + p] : 0.f);
+        }
     }
     for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < n32; row += (long long)gridDim.x * blockDim.x) {
-        float h = INFINITY;
+        float h = INFINITY, h16 = INFINITY;
         if (row < n) {
-            double nd = 0.0;
-            for (int d = 0; d < RF_DIM; ++d) { const double v = emb[(size_t)row * RF_DIM + d]; nd += v * v; }
+            double nd = 0.0, big = 0.0;
+            for (int d = 0; d < RF_DIM; ++d) { const double v = emb[(size_t)row * RF_DIM + d]; nd += v * v; big = fmax(big, fabs(v)); }
             h = (float)((1.0 - (double)RF_EPS_FILTER) * 0.5 * nd);
+            h16 = big < 6.0e4 ? (float)((1.0 - 1.953125e-03) * 0.5 * nd) : -INFINITY;
         }
         hd[row] = h;
+        hd16[row] = h16;
     }
 }
 
 extern "C" size_t rf_db_packed_floats(int64_t n, int dim) {
     (void)dim;
-    return rf_blocked_floats(n) + (size_t)rf_rows32(n) * RF_DIM + (size_t)rf_rows32(n);
+    return rf_blocked_floats(n) + (size_t)rf_rows32(n) * RF_DIM + (size_t)rf_rows32(n) + (size_t)rf_rows32(n) * (RF_DIM / 2) + (size_t)rf_rows32(n);
 }
 
 extern "C" int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float* packed, void* stream) {
@@ -100,8 +110,10 @@ extern "C" int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float
     RF_REQUIRE(dim == RF_DIM, RF_E_UNSUPPORTED, "rf_db_pack_embeddings: embedding dim %d (only 64, the latent_dim of every shipped config)", dim);
     float* rows = packed + rf_blocked_floats(n);
     float* hd = rows + (size_t)rf_rows32(n) * RF_DIM;
+    _Float16* rows16 = reinterpret_cast<_Float16*>(hd + rf_rows32(n));
+    float* hd16 = reinterpret_cast<float*>(rows16 + (size_t)rf_rows32(n) * RF_DIM);
     const size_t want = (rf_blocked_floats(n) + 255) / 256;
-    hipLaunchKernelGGL(k_db_pack, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, emb, (long long)n, packed, rows, hd);
+    hipLaunchKernelGGL(k_db_pack, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, emb, (long long)n, packed, rows, hd, rows16, hd16);
     RF_CHECK_LAUNCH("rf_db_pack_embeddings");
     return RF_OK;
 }
@@ -409,6 +421,205 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma(const float* __restrict
     }
 }
 
+// The same scan with the FILTER on the F16 matrix cores: q.x of f16-rounded rows and queries, 2 x v_mfma_f32_16x16x32_f16 per 16 x 16 tile
+// instead of 16 x v_mfma_f32_16x16x4_f32 (a sixteenth of the matrix-pipe cycles, half the bytes per row).  The filter only has to BOUND the
+// exact distance: |q~.x~ - q.x| <= (2 * 2^-11 + 2^-22) sum|q_d x_d| <= 2^-10 |q||x| <= 2^-11 (|q|^2 + |x|^2), plus 64 * 2^-24 of fp32
+// accumulation and the f16 subnormal floor (3e-8 per component); a pair whose exact distance is below T has
+//   s' = q~.x~ - (1-eps)|x|^2/2  >=  (|q|^2+|x|^2)(1/2 - 4.93e-4) - T/2 - (1-eps)|x|^2/2  >=  (1-eps)|q|^2/2 - T/2 = a_q
+// as soon as eps >= 9.9e-4; eps = 2^-9.  Rows or queries with a component beyond the f16 range get hd = -inf / a_q = -inf (always
+// re-checked).  Pairs that pass are re-evaluated with THE exact distance from the fp32 rows (fetched for that tile only), so the lists
+// are bit-identical to the other scans'.
+#define RF_EPS_FILTER16 1.953125e-03f              // 2^-9
+typedef _Float16 rf_h8 __attribute__((ext_vector_type(8)));
+template <int K2>
+__global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restrict__ q, int nq, const float* __restrict__ rows_img,
+                                                         const _Float16* __restrict__ rows16, const float* __restrict__ hd, long long n, unsigned row_base, int rows_per_slice,
+                                                         const float* __restrict__ t0, int t0_stride, u64* __restrict__ parts) {
+    __shared__ u64 s_lists[4][64 * K2];
+    __shared__ float s_aq[4][64], s_hq[4][64], s_t0[4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x;
+    const int q0 = (blockIdx.y * 4 + wave) * 64;                     // this wave's 64 queries
+    if (q0 >= nq) return;                                            // no barrier in this kernel: a wave may leave
+    const long long n32 = (n + 31) / 32 * 32;
+    const long long r_lo = (long long)slice * rows_per_slice;        // multiple of 64
+    long long r_hi = r_lo + rows_per_slice;
+    if (r_hi > n32) r_hi = n32;
+    u64* lists = s_lists[wave];
+    float* aqs = s_aq[wave];
+    float* hqs = s_hq[wave];
+    float* t0s = s_t0[wave];
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---------------------------------------------------------------- lists start empty, thresholds from the sample pass
+    // t0[q] = k2-th best exact distance among the shard's first rows (rf_l2_topk's sample pass, VALU scan): an upper bound of
+    // the final k2-th distance (+inf when the sample holds fewer than k2 rows).
+    for (int ql = lane; ql < 64; ql += 64) {
+        const int qi = q0 + ql;
+        float hq = 0.f, a = INFINITY;                                // a query that does not exist: nothing passes
+        if (qi < nq) {
+            const float* qp = q + (size_t)qi * RF_DIM;
+            float nqn = 0.f, big = 0.f;
+#pragma unroll
+            for (int d = 0; d < RF_DIM; ++d) { nqn = fmaf(qp[d], qp[d], nqn); big = fmaxf(big, fabsf(qp[d])); }
+            hq = big < 6.0e4f ? (1.f - RF_EPS_FILTER16) * 0.5f * nqn : -INFINITY;     // beyond the f16 range: everything is re-checked
+            const float t = t0[(size_t)qi * t0_stride];
+            a = hq - 0.5f * t;                                       // t = +inf (sample smaller than k2): -inf, everything passes
+        }
+        hqs[ql] = hq;
+        aqs[ql] = a;
+        t0s[ql] = qi < nq ? t0[(size_t)qi * t0_stride] : 0.f;
+    }
+    for (int i = lane; i < 64 * K2; i += 64) lists[i] = RF_KEY_NONE;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---------------------------------------------------------------- the filtered scan
+    float b[4][16];                                                  // B operands: b[nb][j] = dim 4j + g of query q0 + nb*16 + n
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int qi = q0 + nb * 16 + li;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[nb][j] = qi < nq ? q[(size_t)qi * RF_DIM + 4 * j + lg] : 0.f;
+    }
+    rf_h8 bq[4][2];                                                  // the filter's B operands: k = 32 t + 8 lg + j of query q0 + nb*16 + li, as f16
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int qi = q0 + nb * 16 + li;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bq[nb][t][j] = (_Float16)(qi < nq && hqs[nb * 16 + li] != -INFINITY ? q[(size_t)qi * RF_DIM + 32 * t + 8 * lg + j] : 0.f);   // out-of-range query: zeros, a_q = -inf
+    }
+    float aq[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
+
+    auto load_tile = [&](long long row0, rf_h8 (&a16)[2][2], f32x4 (&h)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const rf_h8* rp = reinterpret_cast<const rf_h8*>(rows16 + (size_t)(row0 + mb * 16 + li) * RF_DIM + 8 * lg);
+            a16[mb][0] = rp[0];
+            a16[mb][1] = rp[4];                                       // + 32 halves
+            const float4 t = *reinterpret_cast<const float4*>(hd + row0 + mb * 16 + 4 * lg);
+            h[mb] = (f32x4){-t.x, -t.y, -t.z, -t.w};
+        }
+    };
+    // the fp32 rows of a tile, fetched only when some pair passed the filter (the exact re-check reads them)
+    auto load_exact = [&](long long row0, float (&a)[2][16]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float4* rp = reinterpret_cast<const float4*>(rows_img + (size_t)(row0 + mb * 16 + li) * RF_DIM + 16 * lg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float4 t = rp[k]; a[mb][4 * k] = t.x; a[mb][4 * k + 1] = t.y; a[mb][4 * k + 2] = t.z; a[mb][4 * k + 3] = t.w; }
+        }
+    };
+
+    auto scan_tile = [&](long long row0, const rf_h8 (&a16)[2][2], const f32x4 (&h)[2]) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = h[mb];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mb][t], bq[nb][t], acc[mb][nb], 0, 0, 0);
+        // does ANY pair of the tile pass?  per accumulator register one v_cmp whose lane mask is OR-ed on the scalar unit
+        unsigned long long anyhit = 0ull;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) anyhit |= __ballot(acc[mb][nb][i] >= aq[nb]);
+        if (anyhit == 0ull) return;
+        unsigned m = 0u;                                              // bit (mb*4 + nb)*4 + i: D row 4*lg + i of m-block mb, query column li of n-block nb
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m |= (acc[mb][nb][i] >= aq[nb] ? 1u : 0u) << ((mb * 4 + nb) * 4 + i);
+        // ---- some pair passed the filter: fetch the tile's fp32 rows, exact re-check from registers
+        float a[2][16];
+        load_exact(row0, a);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const unsigned m4 = (m >> ((mb * 4 + nb) * 4)) & 15u;
+                unsigned long long bal = __ballot(m4 != 0u);
+                while (bal) {
+                    const int src = __ffsll((long long)bal) - 1;     // lane (n_, g_) of the D tile
+                    bal &= bal - 1;
+                    unsigned mi = __builtin_amdgcn_readlane(m4, src);
+                    const int n_ = src & 15, g_ = src >> 4;
+                    const int ql = nb * 16 + n_;
+                    while (mi) {
+                        const int i = __ffs((int)mi) - 1;
+                        mi &= mi - 1;
+                        const int r = 4 * g_ + i;                     // row of the m-block
+                        const long long row = row0 + mb * 16 + r;
+                        if (row >= n) continue;
+                        // chain g of THE exact distance on lane (r, g): the query chunk comes from lane (n_, g)
+                        float P = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float qv = __shfl(b[nb][j], n_ + (lane & 48), 64);
+                            const float t = qv - a[mb][j];
+                            P = fmaf(t, t, P);
+                        }
+                        const unsigned Pb = __float_as_uint(P);        // readlane moves 32-bit patterns
+                        const float c0 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r)), c1 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 16));
+                        const float c2 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 32)), c3 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 48));
+                        const float dist = (c0 + c2) + (c1 + c3);
+                        const u64 key = make_key(dist, row_base + (unsigned)row);
+                        u64 e = lane < K2 ? lists[ql * K2 + lane] : RF_KEY_NONE;
+                        const unsigned wlo = __builtin_amdgcn_readlane((unsigned)(e & 0xffffffffu), K2 - 1);
+                        const unsigned whi = __builtin_amdgcn_readlane((unsigned)(e >> 32), K2 - 1);
+                        if (key < (((u64)whi << 32) | wlo) && dist <= t0s[ql]) {          // (<=: the sample's own k2-th row must get in)
+                            list_insert<K2>(e, lane, key);
+                            if (lane < K2) lists[ql * K2 + lane] = e;
+                            if (lane == K2 - 1) {                    // T = min(sample bound, the list's k2-th distance once it is full)
+                                const float tl = e == RF_KEY_NONE ? INFINITY : __uint_as_float((unsigned)(e >> 32));
+                                aqs[ql] = hqs[ql] - 0.5f * fminf(tl, t0s[ql]);
+                            }
+                        }
+                    }
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
+    };
+
+    rf_h8 a0[2][2], a1[2][2];
+    f32x4 h0[2], h1[2];
+    long long row0 = r_lo;
+    if (row0 < r_hi) load_tile(row0, a0, h0);
+    while (row0 < r_hi) {
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, h1);
+        scan_tile(row0, a0, h0);
+        row0 += 32;
+        if (row0 >= r_hi) break;
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a0, h0);
+        scan_tile(row0, a1, h1);
+        row0 += 32;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // publish: parts[slice][q][K2]
+    for (int ql = 0; ql < 64; ++ql) {
+        const int qi = q0 + ql;
+        if (qi < nq && lane < K2) parts[((size_t)slice * nq + qi) * K2 + lane] = lists[ql * K2 + lane];
+    }
+}
+
 // bitonic sort of up to CAP keys per query in LDS; the first k2 are the answer (as (dist, idx) pairs and / or packed keys)
 template <int CAP>
 __global__ __launch_bounds__(256) void k_merge_keys(const u64* __restrict__ parts, int nparts, int nq, int width, int k2,
@@ -472,7 +683,7 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
     RF_REQUIRE(q && db_packed && (out_keys || (out_dist && out_idx)) && ws && nq > 0 && n > 0, RF_E_INVALID, "rf_l2_topk: bad arguments");
     RF_REQUIRE(dim == RF_DIM, RF_E_UNSUPPORTED, "rf_l2_topk: embedding dim %d (only 64, the latent_dim of every shipped config)", dim);
     RF_REQUIRE(k2 >= 1 && k2 <= 16, RF_E_UNSUPPORTED, "rf_l2_topk: k2=%d outside 1..16", k2);
-    RF_REQUIRE(algo >= 0 && algo <= 2, RF_E_INVALID, "rf_l2_topk: algo %d (0 auto, 1 VALU scan, 2 MFMA-filtered scan)", algo);
+    RF_REQUIRE(algo >= 0 && algo <= 3, RF_E_INVALID, "rf_l2_topk: algo %d (0 auto, 1 VALU scan, 2 fp32-MFMA-filtered scan, 3 f16-MFMA-filtered scan)", algo);
     RF_REQUIRE(row_base >= 0 && row_base + n <= 0xFFFFFFFELL, RF_E_UNSUPPORTED, "rf_l2_topk: global row ids must fit 32 bits");
     RF_REQUIRE(ws_bytes >= rf_l2_topk_ws_bytes(nq, n, k2), RF_E_WORKSPACE, "rf_l2_topk: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -480,7 +691,8 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
     const int k2p = k2 <= 8 ? 8 : 16;
     u64* parts = (u64*)ws;
     int slices;
-    const bool mfma = algo == 2 || (algo == 0 && use_mfma_scan(nq, n));
+    const bool mfma = algo == 2 || algo == 3 || (algo == 0 && use_mfma_scan(nq, n));
+    const bool f16_filter = algo != 2;
     if (mfma) {
         // one wave per (slice, 64 queries); two waves per SIMD on 256 CUs = 2048 waves; at least 128 rows per list, at most 64 lists
         const int qgroups = (nq + 63) / 64, qtiles = (qgroups + 3) / 4;
@@ -504,7 +716,12 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         int rc = topk_impl(q, nq, dim, db_packed, sample, row_base, k2p, 1, t_dist, t_idx, nullptr, ws, ws_bytes, stream);
         if (rc != RF_OK) return rc;
         const float* t0 = t_dist + (k2 - 1);                         // the k2-th best of query qi: t0[qi * k2p]
-        if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+        const _Float16* rows16 = reinterpret_cast<const _Float16*>(hd + rf_rows32(n));
+        const float* hd16 = reinterpret_cast<const float*>(rows16 + (size_t)rf_rows32(n) * RF_DIM);
+        if (f16_filter) {
+            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+        } else if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         else hipLaunchKernelGGL(k_l2_topk_mfma<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         RF_CHECK_LAUNCH("rf_l2_topk(mfma scan)");
     } else {

@@ -739,7 +739,7 @@ def db_pack_embeddings(emb):
     return out
 
 
-TOPK_AUTO, TOPK_VALU_SCAN, TOPK_MFMA_SCAN = 0, 1, 2
+TOPK_AUTO, TOPK_VALU_SCAN, TOPK_MFMA_SCAN, TOPK_MFMA16_SCAN = 0, 1, 2, 3      # 2: fp32-MFMA filter, 3: f16-MFMA filter (what AUTO takes for big shards)
 
 
 def l2_topk(q, db_packed, n, row_base, k2, algo=TOPK_AUTO):

@@ -607,10 +607,10 @@ def check_topk(idx_got, dist_got, q, emb, k2, row_base=0):
     return exact / (nq * n_valid)
 
 
-@pytest.mark.parametrize('algo', [1, 2])
+@pytest.mark.parametrize('algo', [1, 2, 3])
 @pytest.mark.parametrize('n,nq,k2', [(1000, 64, 8), (50_001, 128, 8), (4097, 70, 16), (5, 3, 8), (64, 1, 8), (131, 300, 8)])
 def test_l2_topk(ops, n, nq, k2, algo):
-    """both scans (1 = VALU, every pair exact; 2 = MFMA dot-product filter + exact re-check) against the float64 oracle"""
+    """the scans (1 = VALU, every pair exact; 2 / 3 = fp32- / f16-MFMA dot-product filter + exact re-check) against the float64 oracle"""
     rng = np.random.default_rng(n + nq)
     emb = rng.standard_normal((n, 64)).astype(np.float32)
     emb /= np.linalg.norm(emb, axis=1, keepdims=True)
@@ -631,17 +631,22 @@ def test_l2_topk(ops, n, nq, k2, algo):
         assert row[0] == 4 and row[1] == 9
 
 
+@pytest.mark.parametrize('mfma_algo', [2, 3])
 @pytest.mark.parametrize('n,nq,k2,kind', [(20_000, 200, 8, 'unit'), (70_001, 64, 16, 'unit'), (30_000, 100, 8, 'dups'), (9_000, 130, 8, 'big'),
-                                          (300_000, 512, 8, 'unit')])
-def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind):
+                                          (300_000, 512, 8, 'unit'), (12_000, 90, 8, 'huge')])
+def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind, mfma_algo):
     """The matrix-core dot product only FILTERS; every survivor is re-evaluated with the one exact distance of the path, so the
     MFMA scan must return the same bits (distances and row ids) as the VALU scan that evaluates every pair exactly -- on unit
     vectors, on a database full of duplicate rows (ties at the list threshold, lower row id wins), and on rows of very
-    different norms (the filter margin scales with |q|^2 + |x|^2).  Also through the packed-key outputs."""
+    different norms (the filter margin scales with |q|^2 + |x|^2; 'huge': some rows and queries beyond the f16 range, which the
+    f16 filter (algo 3) must hand to the exact re-check unfiltered).  Also through the packed-key outputs."""
     rng = np.random.default_rng(n + nq)
     emb = rng.standard_normal((n, 64)).astype(np.float32)
     q = rng.standard_normal((nq, 64)).astype(np.float32)
-    if kind != 'big':
+    if kind == 'huge':
+        emb *= (10.0 ** rng.uniform(0, 5.5, size=(n, 1))).astype(np.float32)
+        q *= (10.0 ** rng.uniform(2, 5.5, size=(nq, 1))).astype(np.float32)
+    elif kind != 'big':
         emb /= np.linalg.norm(emb, axis=1, keepdims=True)
         q /= np.linalg.norm(q, axis=1, keepdims=True)
     else:
@@ -655,10 +660,10 @@ def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind):
     qd = torch.from_numpy(q).to(DEV)
     packed = ops.db_pack_embeddings(torch.from_numpy(emb).to(DEV))
     d1, i1 = ops.l2_topk(qd, packed, n, 1000, k2, ops.TOPK_VALU_SCAN)
-    d2, i2 = ops.l2_topk(qd, packed, n, 1000, k2, ops.TOPK_MFMA_SCAN)
+    d2, i2 = ops.l2_topk(qd, packed, n, 1000, k2, mfma_algo)
     assert torch.equal(i1, i2), f'{(i1 != i2).sum().item()} row ids differ'
     assert torch.equal(d1, d2)
-    keys = ops.l2_topk_keys(qd, packed, n, 1000, k2, ops.TOPK_MFMA_SCAN)
+    keys = ops.l2_topk_keys(qd, packed, n, 1000, k2, mfma_algo)
     assert torch.equal(keys & 0xffffffff, i1) and torch.equal((keys >> 32).to(torch.int32).view(torch.float32), d1)
     dm, im = ops.topk_merge_keys(keys[None].contiguous())
     assert torch.equal(im, i1) and torch.equal(dm, d1)
@@ -667,7 +672,7 @@ def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind):
         assert i1[0].cpu().tolist() == dup_rows.tolist()         # ties resolved towards the lower row id
 
 
-@pytest.mark.parametrize('algo', [1, 2])
+@pytest.mark.parametrize('algo', [1, 2, 3])
 def test_sharded_topk_merge_equals_single_scan(ops, algo):
     rng = np.random.default_rng(1)
     n, nq, k2, shards = 10_000, 96, 8, 4
@@ -681,7 +686,7 @@ def test_sharded_topk_merge_equals_single_scan(ops, algo):
     for r in range(shards):
         lo, hi = shard_bounds(n, r, shards)
         packed = ops.db_pack_embeddings(torch.from_numpy(emb[lo:hi]).to(DEV))
-        d, i = ops.l2_topk(qd, packed, hi - lo, lo, k2, 3 - algo)        # the shards with the OTHER scan: same bits
+        d, i = ops.l2_topk(qd, packed, hi - lo, lo, k2, {1: 3, 2: 1, 3: 2}[algo])        # the shards with ANOTHER scan: same bits
         ds.append(d), is_.append(i), ks.append(ops.l2_topk_keys(qd, packed, hi - lo, lo, k2, algo))
     md, mi = ops.topk_merge(torch.stack(ds), torch.stack(is_))
     assert torch.equal(mi, full_i) and torch.equal(md, full_d)

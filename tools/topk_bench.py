@@ -14,7 +14,7 @@ for n in (12_500, 50_000, 125_000, 250_000, 1_000_000):
     emb = torch.randn(n, 64, generator=g, device=dev); emb /= emb.norm(dim=1, keepdim=True)
     packed = ops.db_pack_embeddings(emb)
     out = {}
-    for algo in (1, 2):
+    for algo in (1, 2, 3):
         for _ in range(2):
             r = ops.l2_topk(q, packed, n, 0, 8, algo)
         torch.cuda.synchronize()
@@ -24,7 +24,7 @@ for n in (12_500, 50_000, 125_000, 250_000, 1_000_000):
             r = ops.l2_topk(q, packed, n, 0, 8, algo)
         e1.record(); torch.cuda.synchronize()
         out[algo] = (e0.elapsed_time(e1) / 5, r)
-    same = torch.equal(out[1][1][1], out[2][1][1]) and torch.equal(out[1][1][0], out[2][1][0])
+    same = all(torch.equal(out[1][1][1], out[a][1][1]) and torch.equal(out[1][1][0], out[a][1][0]) for a in (2, 3))
     pairs = nq * n
-    print('n=%8d nq=%d  VALU scan %.3f ms (%.1f Gpair/s)   MFMA scan %.3f ms (%.1f Gpair/s, %.1f TF/s of q.x)  identical=%s'
-          % (n, nq, out[1][0], pairs / out[1][0] / 1e6, out[2][0], pairs / out[2][0] / 1e6, pairs * 128 / out[2][0] / 1e9, same))
+    print('n=%8d nq=%d  VALU scan %.3f ms (%.1f Gpair/s)   fp32-MFMA filter %.3f ms (%.1f TF/s of q.x)   f16-MFMA filter %.3f ms (%.1f Gpair/s)  identical=%s'
+          % (n, nq, out[1][0], pairs / out[1][0] / 1e6, out[2][0], pairs * 128 / out[2][0] / 1e9, out[3][0], pairs / out[3][0] / 1e6, same))
