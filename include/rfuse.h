@@ -287,8 +287,9 @@ int rf_query_windows(const float* raw, int b, int s, int ps, int ctx, float pad_
                      float* out, void* stream);
 
 /* Database embedding image for the scans: emb [n][dim] row-major (dim = 64) -> rf_db_packed_floats(n, dim) floats holding
- * the blocked view [ceil(n/64)][dim][64] of the VALU scan, the chunk-permuted row view [n32][64] of the MFMA-filtered scan and
- * its per-row half norms [n32] (n32 = n rounded up to 32; padding rows can never be returned).
+ * the blocked view [ceil(n/64)][dim][64] of the VALU scan, the chunk-permuted row view [n32][64] of the MFMA-filtered scans and
+ * its per-row half norms [n32], the rows rounded to f16 [n32][64] and their half norms [n32] for the f16 filter (n32 = n rounded up
+ * to 32; padding rows can never be returned).
  * DB rows: util/retrieval.py:32,39-45 (columns 7..70). */
 int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float* packed, void* stream);
 size_t rf_db_packed_floats(int64_t n, int dim);
@@ -296,9 +297,9 @@ size_t rf_db_packed_floats(int64_t n, int dim);
 /* Exact squared-L2 top-k2 of q[nq][dim] against one DB shard (packed image of `n` rows whose global row ids start
  * at row_base): stands where the reference calls FLANN nn_index(feats, 2K) (util/retrieval.py:92).
  * dist = sum_d (q_d - x_d)^2 in fp32 (four fixed FMA chains, the same bits on every code path), ascending, ties -> lower
- * global row id.  algo: 0 = pick by shard size, 1 = VALU scan (every pair evaluated exactly), 2 = MFMA-filtered scan (fp32
- * matrix-core dot products discard the pairs that provably cannot enter a list, the rest is evaluated exactly): both return
- * the same bits.
+ * global row id.  algo: 0 = pick by shard size, 1 = VALU scan (every pair evaluated exactly), 2 / 3 = MFMA-filtered scan
+ * (matrix-core dot products -- 2: fp32 inputs, 3: inputs rounded to f16 with a wider margin -- discard the pairs that provably
+ * cannot enter a list, the rest is evaluated exactly in fp32): all return the same bits.
  * out_dist [nq][k2] float32, out_idx [nq][k2] int64 (global ids); missing candidates (n < k2): dist=+inf, idx=-1. */
 int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
                float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream);
