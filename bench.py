@@ -200,6 +200,9 @@ def kernel_work(name, a, cfg):
         from rfuse import ops
         return 'mfma-f16', ops.conv_split_issued_flops(cin, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; 28 tap slots per 27 taps, couts padded to 16); '
                                                                             'fp32-equivalent %.1f GFLOP' % (2.0 * 27 * cin * cout * edge ** 3 * n / 1e9))
+    if name == 'rf_attn_mlp_split_volume':
+        b, kv, c, s, t = a[:5]
+        return 'mfma-f16', b * kv * (s // 2) ** 3 * 2.0 * 3 * (-(-c * 8 // 32) * 32 * 128 + 2 * 128 * 128 + 128 * 32), 'f16 flop ISSUED (operand splitting: 3 MFMAs per product tile)'
     if name in ('rf_attn_mlp_volume',):
         b, kv, c, s, t = a[:5]
         return 'mfma', b * kv * (s // 2) ** 3 * 2.0 * (c * 8 * 128 + 2 * 128 * 128 + 128 * 32), 'flop'

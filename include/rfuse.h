@@ -268,6 +268,15 @@ int rf_attn_gather_retrieved(const float* src, int src_layout, int b, int k, int
  *   mode (as rf_attn_fuse) -> weights[rows][k], switches[rows], optional scores_out[rows][k].
  * rf_attn_blend: out[b][c][s^3] = x*(1-switch[row]) + (sum_k weights[row][k]*retrieved_k)*switch[row], row = the
  *   attention patch of the voxel; `retrieved` in the same patch-major / volume layout as rf_attn_mlp_volume's src.   */
+/* Split-operand form of the same encoder (F16 matrix cores, every fp32 operand as two f16 pieces, exact products, hi / lo fp32
+ * accumulators: csrc/attention_fused.hip): rf_attn_mlp_split_pack writes the f16 fragment image of the four weight matrices
+ * (rf_attn_mlp_split_packed_floats floats); rf_attn_mlp_split_rows / _volume take it next to the fp32 image (biases are read from
+ * that one) and return the same rows, closer to float64 than the fp32 MFMA form. */
+size_t rf_attn_mlp_split_packed_floats(int n_in);
+int rf_attn_mlp_split_pack(const float* w1, const float* w2, const float* w3, const float* w4, int n_in, float* packed_split, void* stream);
+int rf_attn_mlp_split_rows(const float* x, int rows, int n_in, const float* packed, const float* packed_split, float* out, void* stream);
+int rf_attn_mlp_split_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, const float* packed_split,
+                             float* out, void* stream);
 size_t rf_attn_mlp_packed_floats(int n_in);
 int rf_attn_mlp_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                      const float* w4, const float* b4, int n_in, float* packed, void* stream);

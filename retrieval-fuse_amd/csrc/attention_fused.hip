@@ -90,6 +90,7 @@ extern "C" int rf_attn_mlp_pack(const float* w1, const float* b1, const float* w
 struct AmArgs {
     const float* src;
     const float* img;
+    const float* img2;     // split-operand image (rf_attn_mlp_split_pack) or NULL: fp32 MFMA form
     float* out;            // [out rows][32]
     int mode;              // 0: src = rows [nrows][n_in]; 1: src = volumes / patch-major features, e = 2
     int nrows, n_in, ntiles;
@@ -226,33 +227,243 @@ __global__ __launch_bounds__(AM_WAVES * 64) void k_attn_mlp(AmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused MLP, split-operand form
+// The same encoder on the F16 matrix cores with every fp32 operand carried as two f16 pieces (x = h + l / 2^11, exact products, hi / lo
+// fp32 accumulators: csrc/conv3d_up_split.hip has the numerics).  A k-step of v_mfma_f32_16x16x32_f16 is 32 input features; lane group
+// g supplies 8 of them and holds, after a layer, 4 features of every 16-feature output block -- so k-step t is made of the output
+// blocks 2t and 2t+1 (contraction order k <-> {16*(2t) + 4g + r, 16*(2t+1) + 4g + r}), the weight image is packed in that order, and
+// the activations again never leave registers: bias, LeakyReLU and the split run on the D registers in place.
+typedef _Float16 am_h8 __attribute__((ext_vector_type(8)));
+#define AMS_ACT 0.0625f
+#define AMS_W 16.0f
+#define AMS_LO 2048.0f
+
+// split image, in 16-byte fragments rows of 64 lanes: layer L at ams_layer_off(L): [t][ib][h|l][lane]
+static __host__ __device__ inline int ams_steps(int n_in, int layer) { return layer == 0 ? (n_in / 16 + 1) / 2 : 4; }
+static __host__ __device__ inline int ams_ibn(int layer) { return layer == 3 ? AM_OUT / 16 : AM_HID / 16; }
+static __host__ __device__ inline size_t ams_layer_off(int n_in, int layer) {       // in floats (256 floats = one fragment row)
+    size_t o = 0;
+    for (int l = 0; l < layer; ++l) o += (size_t)ams_steps(n_in, l) * ams_ibn(l) * 2 * 256;
+    return o;
+}
+extern "C" size_t rf_attn_mlp_split_packed_floats(int n_in) { return ams_layer_off(n_in, 4); }
+
+struct AmsPackArgs {
+    const float* w[4];
+    float* img;
+    int n_in;
+};
+
+__global__ void k_attn_mlp_split_pack(AmsPackArgs a) {
+    const size_t total = ams_layer_off(a.n_in, 4) / 4;              // 16-byte entries
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int layer = 0;
+        while (layer < 3 && i * 4 >= ams_layer_off(a.n_in, layer + 1)) ++layer;
+        const size_t li = i - ams_layer_off(a.n_in, layer) / 4;
+        const int nin = layer == 0 ? a.n_in : AM_HID, ibn = ams_ibn(layer);
+        const int lane = (int)(li & 63), piece = (int)((li >> 6) & 1);
+        const int ib = (int)((li >> 7) % ibn), t = (int)((li >> 7) / ibn);
+        const int feat = ib * 16 + (lane & 15), g = lane >> 4;
+        am_h8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * (2 * t + (j >> 2)) + 4 * g + (j & 3);
+            double v = k < nin ? (double)a.w[layer][(size_t)feat * nin + k] * (double)AMS_W : 0.0;
+            v = v > 65504.0 ? 65504.0 : (v < -65504.0 ? -65504.0 : v);
+            const _Float16 h = (_Float16)(float)v;
+            out[j] = piece == 0 ? h : (_Float16)(float)((v - (double)(float)h) * (double)AMS_LO);
+        }
+        reinterpret_cast<am_h8*>(a.img)[i] = out;
+    }
+}
+
+extern "C" int rf_attn_mlp_split_pack(const float* w1, const float* w2, const float* w3, const float* w4, int n_in, float* packed, void* stream) {
+    RF_REQUIRE(w1 && w2 && w3 && w4 && packed, RF_E_INVALID, "rf_attn_mlp_split_pack: null pointer");
+    RF_REQUIRE(n_in >= 16 && n_in <= AM_HID && n_in % 16 == 0, RF_E_UNSUPPORTED, "rf_attn_mlp_split_pack: n_in %d must be a multiple of 16 in 16..128", n_in);
+    AmsPackArgs a;
+    a.w[0] = w1; a.w[1] = w2; a.w[2] = w3; a.w[3] = w4; a.img = packed; a.n_in = n_in;
+    hipLaunchKernelGGL(k_attn_mlp_split_pack, dim3(256), dim3(256), 0, (hipStream_t)stream, a);
+    RF_CHECK_LAUNCH("rf_attn_mlp_split_pack");
+    return RF_OK;
+}
+
+// 4 activation values (one D register quartet) -> 4 halves of the h and of the l piece, at positions o..o+3
+__device__ __forceinline__ void ams_split4(const f32x4& v, am_h8& h, am_h8& l, int o) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = __builtin_amdgcn_fmed3f(v[e] * AMS_ACT, -65504.f, 65504.f);
+        const _Float16 hh = (_Float16)x;
+        h[o + e] = hh;
+        l[o + e] = (_Float16)((x - (float)hh) * AMS_LO);
+    }
+}
+
+// one layer, transposed: hi/lo[ib] = W[ib-block][k-step t] . (bh, bl)[t]; weight fragments from LDS, one (t, ib) pair ahead
+template <int IB>
+__device__ __forceinline__ void ams_layer(const float* wbuf, int tn, const am_h8 (&bh)[4], const am_h8 (&bl)[4], f32x4 (&hi)[8], f32x4 (&lo)[8], int lane) {
+    const am_h8* wv = reinterpret_cast<const am_h8*>(wbuf) + lane;
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) { hi[ib] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[ib] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    am_h8 wh[2], wl[2];
+    wh[0] = wv[0]; wl[0] = wv[64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < tn) {                                                  // uniform
+#pragma unroll
+            for (int ib = 0; ib < IB; ++ib) {
+                const int st = t * IB + ib, cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < 4 * IB) { wh[nxt] = wv[(st + 1) * 128]; wl[nxt] = wv[(st + 1) * 128 + 64]; }
+                hi[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cur], bh[t], hi[ib], 0, 0, 0);
+                lo[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cur], bl[t], lo[ib], 0, 0, 0);
+                lo[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cur], bh[t], lo[ib], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(AM_WAVES * 64) void k_attn_mlp_split(AmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // two weight buffers of AM_BUF_FLOATS
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int kb0 = a.n_in >> 4, t0n = (kb0 + 1) >> 1;
+
+    // a.img: the fp32 image (biases are read from it); a.img2: the split image
+    auto dma_layer = [&](int layer) {
+        const int npiece = ams_steps(a.n_in, layer) * ams_ibn(layer) * 2;
+        const float* src = a.img2 + ams_layer_off(a.n_in, layer);
+        float* dst = smem + (layer & 1) * AM_BUF_FLOATS;
+        for (int q = wave; q < npiece; q += AM_WAVES)
+            __builtin_amdgcn_global_load_lds((rf_gptr)(src + q * 256 + lane * 4), (rf_lptr)(dst + q * 256), 16, 0, 0);
+    };
+    const float4* bias4 = reinterpret_cast<const float4*>(a.img + am_layer_off(a.n_in, 4));     // [layer][32 float4s]
+
+    dma_layer(0);
+    const int nwt = (a.ntiles + AM_WAVES - 1) / AM_WAVES;             // workgroup tiles of 16 waves x 16 rows
+    for (int wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
+        const int rt = wt * AM_WAVES + wave;
+        const bool live = rt < a.ntiles;
+        int row = rt * 16 + j;
+        if (row >= a.nrows) row = a.nrows - 1;                        // clamp: computed, never stored
+        if (row < 0) row = 0;
+        size_t orow = (size_t)row;
+        am_h8 bh[4], bl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { bh[t] = (am_h8){0, 0, 0, 0, 0, 0, 0, 0}; bl[t] = bh[t]; }
+        if (a.mode == 0) {
+            const float* p = a.src + (size_t)row * a.n_in + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb < kb0) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + kb * 16);
+                    ams_split4((f32x4){v.x, v.y, v.z, v.w}, bh[kb >> 1], bl[kb >> 1], 4 * (kb & 1));
+                }
+            }
+        } else {
+            const int r = a.s >> 1, t = a.t, q = a.s / t;
+            const int r3 = r * r * r;
+            const int vol = row / r3, prow = row - vol * r3;
+            const int p2 = prow % r, p1 = (prow / r) % r, p0 = prow / (r * r);
+            const int bb = vol / a.kv, k = vol - bb * a.kv;
+            orow = ((size_t)bb * r3 + prow) * a.kv + k;
+            const int d0 = 2 * p0 + (g & 1), d1 = 2 * p1, d2 = 2 * p2;
+            const size_t t3 = (size_t)t * t * t;
+            const size_t patch = (((size_t)vol * q + d0 / t) * q + d1 / t) * q + d2 / t;
+            const float* p = a.src + (patch * a.c + (g >> 1)) * t3 + ((size_t)(d0 % t) * t + (d1 % t)) * t + (d2 % t);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb < kb0) {                                        // features 16kb+4g+r: channel 2kb+(g>>1), e0 = g&1, (e1,e2) = r
+                    const float2 lo2 = *reinterpret_cast<const float2*>(p + (size_t)(2 * kb) * t3);
+                    const float2 hi2 = *reinterpret_cast<const float2*>(p + (size_t)(2 * kb) * t3 + t);
+                    ams_split4((f32x4){lo2.x, lo2.y, hi2.x, hi2.y}, bh[kb >> 1], bl[kb >> 1], 4 * (kb & 1));
+                }
+            }
+        }
+
+        f32x4 hi[8], lo[8];
+#pragma unroll
+        for (int layer = 0; layer < 4; ++layer) {
+            __syncthreads();                                          // weights of `layer` landed; everyone left layer-1's buffer
+            if (layer < 3) dma_layer(layer + 1);
+            else if (wt + (int)gridDim.x < nwt) dma_layer(0);
+            const float* wbuf = smem + (layer & 1) * AM_BUF_FLOATS;
+            if (layer < 3) {
+                ams_layer<8>(wbuf, layer == 0 ? t0n : 4, bh, bl, hi, lo, lane);
+#pragma unroll
+                for (int ib = 0; ib < 8; ++ib) {                       // bias + LeakyReLU(0.01) + split: the next layer's B operands
+                    const float4 bz = bias4[layer * 32 + ib * 4 + g];
+                    f32x4 v;
+                    v[0] = fmaf(lo[ib][0], 1.0f / AMS_LO, hi[ib][0]) + bz.x; v[1] = fmaf(lo[ib][1], 1.0f / AMS_LO, hi[ib][1]) + bz.y;
+                    v[2] = fmaf(lo[ib][2], 1.0f / AMS_LO, hi[ib][2]) + bz.z; v[3] = fmaf(lo[ib][3], 1.0f / AMS_LO, hi[ib][3]) + bz.w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
+                    ams_split4(v, bh[ib >> 1], bl[ib >> 1], 4 * (ib & 1));
+                }
+            } else {
+                ams_layer<2>(wbuf, 4, bh, bl, hi, lo, lane);
+                if (live && rt * 16 + j < a.nrows) {
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        const float4 bz = bias4[3 * 32 + ib * 4 + g];
+                        const float4 o = make_float4(fmaf(lo[ib][0], 1.0f / AMS_LO, hi[ib][0]) + bz.x, fmaf(lo[ib][1], 1.0f / AMS_LO, hi[ib][1]) + bz.y,
+                                                     fmaf(lo[ib][2], 1.0f / AMS_LO, hi[ib][2]) + bz.z, fmaf(lo[ib][3], 1.0f / AMS_LO, hi[ib][3]) + bz.w);
+                        *reinterpret_cast<float4*>(a.out + orow * AM_OUT + ib * 16 + 4 * g) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 static int am_launch(const AmArgs& a, hipStream_t st) {
     const int lds = 2 * AM_BUF_FLOATS * (int)sizeof(float);
     static RfLdsOptIn opt_in;
     if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_attn_mlp), lds, "rf_attn_mlp")) return rc;
     const int nwt = (a.ntiles + AM_WAVES - 1) / AM_WAVES;
-    hipLaunchKernelGGL(k_attn_mlp, dim3(nwt < 256 ? nwt : 256), dim3(AM_WAVES * 64), lds, st, a);
+    if (a.img2) {
+        static RfLdsOptIn opt_in2;
+        if (int rc = opt_in2.ensure(reinterpret_cast<const void*>(k_attn_mlp_split), lds, "rf_attn_mlp")) return rc;
+        hipLaunchKernelGGL(k_attn_mlp_split, dim3(nwt < 256 ? nwt : 256), dim3(AM_WAVES * 64), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(k_attn_mlp, dim3(nwt < 256 ? nwt : 256), dim3(AM_WAVES * 64), lds, st, a);
+    }
     RF_CHECK_LAUNCH("rf_attn_mlp");
     return RF_OK;
 }
 
+static int am_rows(const float* x, int rows, int n_in, const float* packed, const float* packed_split, float* out, void* stream);
 extern "C" int rf_attn_mlp_rows(const float* x, int rows, int n_in, const float* packed, float* out, void* stream) {
+    return am_rows(x, rows, n_in, packed, nullptr, out, stream);
+}
+extern "C" int rf_attn_mlp_split_rows(const float* x, int rows, int n_in, const float* packed, const float* packed_split, float* out, void* stream) {
+    RF_REQUIRE(packed_split, RF_E_INVALID, "rf_attn_mlp_split_rows: null split image");
+    return am_rows(x, rows, n_in, packed, packed_split, out, stream);
+}
+static int am_rows(const float* x, int rows, int n_in, const float* packed, const float* packed_split, float* out, void* stream) {
     RF_REQUIRE(x && packed && out && rows > 0, RF_E_INVALID, "rf_attn_mlp_rows: bad arguments");
     RF_REQUIRE(n_in >= 16 && n_in <= AM_HID && n_in % 16 == 0, RF_E_UNSUPPORTED, "rf_attn_mlp_rows: n_in %d must be a multiple of 16 in 16..128", n_in);
     AmArgs a;
-    a.src = x; a.img = packed; a.out = out; a.mode = 0; a.nrows = rows; a.n_in = n_in; a.ntiles = (rows + 15) / 16;
+    a.src = x; a.img = packed; a.img2 = packed_split; a.out = out; a.mode = 0; a.nrows = rows; a.n_in = n_in; a.ntiles = (rows + 15) / 16;
     a.kv = 1; a.c = 0; a.s = 0; a.t = 0;
     return am_launch(a, (hipStream_t)stream);
 }
 
+static int am_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, const float* packed_split, float* out, void* stream);
 extern "C" int rf_attn_mlp_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, float* out, void* stream) {
+    return am_volume(src, b, kv, c, s, t, packed, nullptr, out, stream);
+}
+extern "C" int rf_attn_mlp_split_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, const float* packed_split, float* out, void* stream) {
+    RF_REQUIRE(packed_split, RF_E_INVALID, "rf_attn_mlp_split_volume: null split image");
+    return am_volume(src, b, kv, c, s, t, packed, packed_split, out, stream);
+}
+static int am_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, const float* packed_split, float* out, void* stream) {
     RF_REQUIRE(src && packed && out && b > 0 && kv > 0 && c > 0 && s > 0 && t > 0, RF_E_INVALID, "rf_attn_mlp_volume: bad arguments");
     RF_REQUIRE(s % 2 == 0 && t % 2 == 0 && s % t == 0, RF_E_INVALID, "rf_attn_mlp_volume: edges s=%d t=%d must be even and t | s", s, t);
     RF_REQUIRE(c % 2 == 0 && c * 8 <= AM_HID, RF_E_UNSUPPORTED, "rf_attn_mlp_volume: %d channels (need an even count <= 16)", c);
     const long long rows = (long long)b * kv * (s / 2) * (s / 2) * (s / 2);
     RF_REQUIRE(rows < (1ll << 31) - 16, RF_E_UNSUPPORTED, "rf_attn_mlp_volume: too many rows");
     AmArgs a;
-    a.src = src; a.img = packed; a.out = out; a.mode = 1; a.nrows = (int)rows; a.n_in = c * 8; a.ntiles = (int)((rows + 15) / 16);
+    a.src = src; a.img = packed; a.img2 = packed_split; a.out = out; a.mode = 1; a.nrows = (int)rows; a.n_in = c * 8; a.ntiles = (int)((rows + 15) / 16);
     a.kv = kv; a.c = c; a.s = s; a.t = t;
     return am_launch(a, (hipStream_t)stream);
 }

@@ -82,6 +82,10 @@ SIGNATURES = {
     'rf_attn_mlp_packed_floats': (c_sz, [c_i]),
     'rf_attn_mlp_pack': (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
     'rf_attn_mlp_rows': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_p]),
+    'rf_attn_mlp_split_packed_floats': (c_sz, [c_i]),
+    'rf_attn_mlp_split_pack': (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_p]),
+    'rf_attn_mlp_split_rows': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
+    'rf_attn_mlp_split_volume': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
     'rf_attn_mlp_volume': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_p]),
     'rf_attn_weights': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_p]),
     'rf_attn_blend': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),

@@ -657,7 +657,8 @@ class PackedAttnMLP:
 
 
 def pack_attn_mlp(params):
-    """[w0, b0, w1, b1, w2, b2, w3, b3] of Linear(n_in,128) x (128,128) x (128,128) x (128,32) -> the fused kernel's operand image."""
+    """[w0, b0, w1, b1, w2, b2, w3, b3] of Linear(n_in,128) x (128,128) x (128,128) x (128,32) -> the fused kernel's operand images:
+    (fp32 MFMA image incl. biases, split-operand f16 image)."""
     for t in params:
         _req(t.detach(), 'attention MLP parameter')
     n_in = params[0].shape[1]
@@ -668,15 +669,21 @@ def pack_attn_mlp(params):
     lib = _lib.load()
     out = torch.empty(lib.rf_attn_mlp_packed_floats(n_in), dtype=torch.float32, device=params[0].device)
     _lib.check(lib.rf_attn_mlp_pack(*[_p(t.detach()) for t in params], n_in, _p(out), _stream()), 'rf_attn_mlp_pack')
-    return out
+    split = torch.empty(lib.rf_attn_mlp_split_packed_floats(n_in), dtype=torch.float32, device=params[0].device)
+    _lib.check(lib.rf_attn_mlp_split_pack(*[_p(t.detach()) for t in params[0::2]], n_in, _p(split), _stream()), 'rf_attn_mlp_split_pack')
+    return out, split
 
 
 def attn_mlp_rows(x, packed):
-    """x [rows, n_in] -> [rows, 32] through the fused 4-layer encoder."""
+    """x [rows, n_in] -> [rows, 32] through the fused 4-layer encoder (split-operand form unless CONV_ARITH == 'fp32')."""
     _req(x, 'x')
     rows, n_in = x.shape
     out = torch.empty((rows, 32), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rf_attn_mlp_rows(_p(x), rows, n_in, _p(packed), _p(out), _stream()), 'rf_attn_mlp_rows')
+    img, split = packed
+    if CONV_ARITH == 'split':
+        _lib.check(_lib.load().rf_attn_mlp_split_rows(_p(x), rows, n_in, _p(img), _p(split), _p(out), _stream()), 'rf_attn_mlp_split_rows')
+    else:
+        _lib.check(_lib.load().rf_attn_mlp_rows(_p(x), rows, n_in, _p(img), _p(out), _stream()), 'rf_attn_mlp_rows')
     return out
 
 
@@ -688,7 +695,11 @@ def attn_mlp_volume(src, b, kv, c, s, t, packed):
         raise ValueError('attn_mlp_volume: %d values are not %d volumes of [%d,%d^3]' % (src.numel(), b * kv, c, s))
     r = s // 2
     out = torch.empty((b * r * r * r * kv, 32), dtype=torch.float32, device=src.device)
-    _lib.check(_lib.load().rf_attn_mlp_volume(_p(src), b, kv, c, s, t, _p(packed), _p(out), _stream()), 'rf_attn_mlp_volume')
+    img, split = packed
+    if CONV_ARITH == 'split':
+        _lib.check(_lib.load().rf_attn_mlp_split_volume(_p(src), b, kv, c, s, t, _p(img), _p(split), _p(out), _stream()), 'rf_attn_mlp_split_volume')
+    else:
+        _lib.check(_lib.load().rf_attn_mlp_volume(_p(src), b, kv, c, s, t, _p(img), _p(out), _stream()), 'rf_attn_mlp_volume')
     return out
 
 

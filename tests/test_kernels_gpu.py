@@ -497,14 +497,24 @@ def test_attn_mlp_rows_matches_float64(ops, rows, c):
         if i < 6:
             h = F.leaky_relu(h, 0.01)
     with torch.no_grad():
-        got = enc(x.to(DEV))
+        got = enc(x.to(DEV))                                       # the split-operand form (ops.CONV_ARITH == 'split')
+        ops.CONV_ARITH = 'fp32'
+        try:
+            got32 = enc(x.to(DEV))
+        finally:
+            ops.CONV_ARITH = 'split'
         ops.USE_FUSED_ATTN_MLP = False
         try:
             layered = enc(x.to(DEV))
         finally:
             ops.USE_FUSED_ATTN_MLP = True
-    close(got, h.float(), 2e-6, 'fused MLP')
+    close(got, h.float(), 2e-6, 'fused MLP, split-operand form')
+    close(got32, h.float(), 2e-6, 'fused MLP, fp32 MFMA form')
     close(got, layered, 2e-6, 'fused vs per-layer rf_linear')
+    e_s = (got.cpu().double() - h).pow(2).mean().sqrt().item()
+    e_f = (got32.cpu().double() - h).pow(2).mean().sqrt().item()
+    print(f'\nrows {rows} c {c}: rms error vs float64  split {e_s:.3e} | fp32 MFMA {e_f:.3e}')
+    assert e_s <= 1.05 * e_f + 1e-9
 
 
 @pytest.mark.parametrize('b,kv,c,s,t', [(2, 1, 16, 32, 32), (2, 4, 16, 32, 8), (1, 8, 12, 32, 8), (3, 2, 4, 8, 4), (1, 1, 2, 4, 2)])
