@@ -124,6 +124,17 @@ int rf_conv3d_valid_leaky_lds(const float* x, int n, int cin, int s, const float
 int rf_convv_lds_pack_weight(const float* w_oidhw, int cout, int cin, int k, float* w_packed, void* stream);
 size_t rf_convv_lds_packed_floats(int cout, int cin, int k);
 
+/* The same layer on the F16 matrix cores by operand splitting (x = h + l/2^11, three f16 MFMAs per product block, fp32
+ * accumulation; closer to float64 than the fp32 MFMA chain): the large layers with cin a multiple of 4 (PCPatch48's 12 -> 24 k3
+ * @44^3, 24 -> 48 k3 s2 @42^3, 48 -> 48 k3 s2 @20^3, model/retrieval.py:222-228; Patch32's, :9-15).  K is walked in pieces of
+ * (tap, 4 channels); the tile / chunk plan depends on (cin, s, cout, k, stride) only and the weight image is packed for it:
+ * rf_convv_split_packed_bytes is 0 when the form does not take the layer. */
+int rf_conv3d_valid_split_supported(int n, int cin, int s, int cout, int k, int stride);
+int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
+                                int stride, float slope, float* out, void* stream);
+int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int cin, int k, int s, int stride, void* w_packed, void* stream);
+size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, int stride);
+
 /* The same layer on the packed-fp32 VALU for the FIRST layers of the patch encoders (stride 1; 1 -> 8/12 with k = 3/5, 1 -> 16,
  * 8 -> 16 and 12 -> 24 with k = 3): couts of 12 / 24 waste a quarter of the 16-wide MFMA tiles, the vector unit has the same fp32
  * peak and no padding.  w_t: the weight as [cin][k^3][cout] (OIDHW permuted to (1,2,3,4,0)): the kernel reads whole cout vectors

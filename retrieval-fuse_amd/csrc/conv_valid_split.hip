@@ -1,0 +1,344 @@
+// rf_conv3d_valid_leaky_split: valid (no padding) strided Conv3d + bias + LeakyReLU of the conv patch encoders (reference
+// model/retrieval.py:4-28 Patch32, :217-243 PCPatch48; the layers rf_conv3d_valid_leaky_lds takes) on the F16 matrix cores by
+// OPERAND SPLITTING (conv3d_up_split.hip has the numerics):
+//     x = h + l / 2^11,  h = f16(x),  l = f16((x - h) * 2^11);   a*b ~ ah*bh + (ah*bl + al*bh) / 2^11,   exact f16 x f16 products,
+//     fp32 accumulation in two accumulators (hi, lo), combined once in the epilogue.
+//
+// GEMM view: M = output voxels of a tile (tz x ty whole output rows of one window, linear index, 4 waves x 4 m-blocks = 256), N = cout
+// (NB <= 3 n-blocks per workgroup), K = k^3 * cin walked in PIECES: a piece is (tap, group of 4 input channels); an MFMA k-step (k = 32)
+// is 8 pieces, lane group g = lane >> 4 supplies pieces 8q + 2g and 8q + 2g + 1.  The encoders' channel counts are multiples of 4, not
+// of 8 (PCPatch48: 12, 24, 48, 96), and with 4-channel pieces in flat order a 12-channel layer needs 11 k-steps where 8-channel slots
+// would need 14.  LDS image of a chunk of `cgc` channel groups: [group][input position] in 8-byte slots (4 channels of one input voxel),
+// one plane for h, one for l; positions are the tile's (tz-1)*stride + k input planes of (ty-1)*stride + k whole input rows.  An A
+// operand is four ds_read_b64 at (output corner + piece offset), the piece offsets of a k-step come from a table in LDS.
+// Staging: 4 channel planes -> one item (position, group) per thread step, scaled, clamped and split on the way in; no LDS double
+// buffer -- two or three workgroups per CU overlap one's staging with the other's MFMAs.
+// B operands (weights): f16 fragment image from rf_convv_split_pack_weight ([chunk][k-step][n-block][h|l][lane][8 halves]), L2-resident,
+// global -> VGPR one k-step ahead (across chunk boundaries too).
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr float VS_ACT_SCALE = 1.0f / 16, VS_W_SCALE = 16.0f, VS_LO = 2048.0f;
+constexpr int VS_NT = 256, VS_MB = 4, VS_M = 256;               // threads, m-blocks per wave, output voxels per tile
+constexpr int VS_EV = VS_M + 4;                                 // floats per cout row of the epilogue tile
+constexpr size_t VS_LDS_MAX = 78 * 1024;                        // two workgroups per CU
+}   // namespace
+
+struct ConvVSArgs {
+    const float* x;
+    const h8* wp;
+    const float* bias;
+    float* out;
+    int n, cin, s, cout, k, stride, so;
+    float slope;
+    int tz, ty, ntz, nty, gz;      // output rows per tile, tiles per dim, groups of NB cout blocks
+    int zi, yi, npos;              // staged input planes / rows per plane, positions per channel group (zi * yi * s)
+    int cgc, nchunk, ksteps;       // 4-channel groups per chunk, chunks, k-steps per chunk
+    int nbt;                       // n-blocks of the weight image (cout16 / 16)
+};
+
+// tile and chunk choice; depends on the layer only (not on n): the weight image is packed for it
+static bool convv_split_plan(int cin, int s, int cout, int k, int stride, ConvVSArgs& a, int& nb_out, size_t& lds_out) {
+    if (cin <= 0 || cout <= 0 || k < 2 || k > 5 || stride < 1 || stride > 2 || s < k || s > 64 || (cin & 3)) return false;
+    const int so = (s - k) / stride + 1;
+    if (so < 6) return false;
+    const int cout16 = rf_round_up(cout, 16);
+    const int nbw = cout16 <= 48 ? cout16 / 16 : (cout16 % 48 == 0 ? 3 : 2);
+    const int k3 = k * k * k, cgt = cin / 4;
+    double best = 0.0;
+    for (int tz = 1; tz <= so; ++tz)
+        for (int ty = 1; ty <= so; ++ty) {
+            const int V = tz * ty * so;
+            if (V > VS_M) continue;
+            const int zi = (tz - 1) * stride + k, yi = (ty - 1) * stride + k;
+            const int npos = zi * yi * s;
+            const int ntz = (so + tz - 1) / tz, nty = (so + ty - 1) / ty;
+            const double tile_eff = (double)so * so * so / ((double)ntz * nty * VS_M);
+            for (int cgc = 1; cgc <= cgt; ++cgc) {
+                if (cgt % cgc) continue;
+                const int ksteps = (k3 * cgc + 7) / 8;
+                size_t lds = (size_t)2 * cgc * npos * 8 + (size_t)ksteps * 8 * 4 + (size_t)cgc * zi * yi * 4;
+                if (lds > VS_LDS_MAX) continue;
+                if (lds < (size_t)16 * VS_EV * 4) lds = (size_t)16 * VS_EV * 4;
+                const double eff = tile_eff * (double)(k3 * cgc) / (8.0 * ksteps);
+                if (eff > best + 1e-9) {
+                    best = eff;
+                    a.tz = tz; a.ty = ty; a.ntz = ntz; a.nty = nty; a.zi = zi; a.yi = yi; a.npos = npos;
+                    a.cgc = cgc; a.nchunk = cgt / cgc; a.ksteps = ksteps;
+                    lds_out = lds;
+                }
+            }
+        }
+    if (best < 0.55) return false;
+    a.cin = cin; a.s = s; a.cout = cout; a.k = k; a.stride = stride; a.so = so;
+    a.nbt = cout16 / 16;
+    a.gz = (a.nbt + nbw - 1) / nbw;
+    nb_out = nbw;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------ weight image
+extern "C" size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, int stride) {
+    ConvVSArgs a;
+    int nb;
+    size_t lds;
+    if (!convv_split_plan(cin, s, cout, k, stride, a, nb, lds)) return 0;
+    // two k-steps of slack: the kernel's one-ahead B prefetch (NB blocks from the last group's first block) never leaves the image
+    return ((size_t)a.nchunk * a.ksteps + 2) * (size_t)a.nbt * 2 * 64 * 16;
+}
+
+__global__ void k_convv_split_pack(const float* __restrict__ w, int cout, int cin, int k3, int cgc, int ksteps, int nbt, size_t nreal,
+                                   h8* __restrict__ wp, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
+        const size_t f = i >> 7;
+        const int nb = (int)(f % nbt);
+        const size_t st = f / nbt;
+        const int q = (int)(st % ksteps), chunk = (int)(st / ksteps);
+        const int co = nb * 16 + (lane & 15), g = lane >> 4;
+        h8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = 8 * q + 2 * g + (j >> 2);
+            double v = 0.0;
+            if (i < nreal && p < k3 * cgc && co < cout) {
+                const int tap = p / cgc, ci = (chunk * cgc + p % cgc) * 4 + (j & 3);
+                v = (double)w[((size_t)co * cin + ci) * k3 + tap];
+            }
+            v *= (double)VS_W_SCALE;
+            v = v > 65504.0 ? 65504.0 : (v < -65504.0 ? -65504.0 : v);
+            const _Float16 h = (_Float16)(float)v;
+            out[j] = part == 0 ? h : (_Float16)(float)((v - (double)(float)h) * (double)VS_LO);
+        }
+        wp[i] = out;
+    }
+}
+
+extern "C" int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int cin, int k, int s, int stride, void* w_packed, void* stream) {
+    RF_REQUIRE(w_oidhw && w_packed, RF_E_INVALID, "rf_convv_split_pack_weight: null pointer");
+    ConvVSArgs a;
+    int nb;
+    size_t lds;
+    RF_REQUIRE(convv_split_plan(cin, s, cout, k, stride, a, nb, lds), RF_E_UNSUPPORTED,
+               "rf_convv_split_pack_weight: layer not taken by the split form (ask rf_conv3d_valid_split_supported)");
+    const size_t total = rf_convv_split_packed_bytes(cout, cin, k, s, stride) / 16;
+    const size_t nreal = (size_t)a.nchunk * a.ksteps * a.nbt * 128;
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_convv_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin,
+                       k * k * k, a.cgc, a.ksteps, a.nbt, nreal, reinterpret_cast<h8*>(w_packed), total);
+    RF_CHECK_LAUNCH("rf_convv_split_pack_weight");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------- kernel
+template <int NB>
+__global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
+    constexpr int NT = VS_NT, MB = VS_MB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int so = a.so, s = a.s, st = a.stride;
+    const int plane = a.cgc * a.npos * 8;                           // bytes of the h plane (l plane follows)
+    int* poff = reinterpret_cast<int*>(lds + 2 * plane);            // [ksteps * 8] byte offset of a piece in the h plane
+    int* rowsrc = poff + a.ksteps * 8;                              // [cgc * zi * yi] float offset of a staged row (< 0: outside the volume)
+
+    // XCD-aware 1-D grid as in k_convv_lds: an XCD walks whole windows (tiles fastest, then cout block groups)
+    const unsigned total = gridDim.x, per = total >> 3, rem = total & 7u, xk = blockIdx.x & 7u;
+    const unsigned lb = xk * per + (xk < rem ? xk : rem) + (blockIdx.x >> 3);
+    const unsigned tiles = (unsigned)(a.ntz * a.nty);
+    const unsigned tb = lb % tiles, zb = (lb / tiles) % (unsigned)a.gz;
+    const int nn = (int)(lb / (tiles * (unsigned)a.gz));
+    const int z0 = (int)(tb / (unsigned)a.nty) * a.tz, y0 = (int)(tb % (unsigned)a.nty) * a.ty;
+    const int nb0 = (int)zb * NB;                                   // first n-block of this workgroup
+    const int V = a.tz * a.ty * so;
+    const size_t ivol = (size_t)s * s * s;
+
+    // this lane's output voxels: m-block (wave*MB + mb), voxel j -> byte offset of its input corner in a plane
+    int base[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        int m = (wave * MB + mb) * 16 + j;
+        if (m >= V) m = 0;                                          // computed, never stored
+        const int x = m % so, r = m / so, ly = r % a.ty, lz = r / a.ty;
+        base[mb] = (((lz * st) * a.yi + ly * st) * s + x * st) * 8;
+    }
+    {
+        const int k = a.k, k3 = k * k * k, np = k3 * a.cgc;
+        for (int p = tid; p < a.ksteps * 8; p += NT) {
+            int off = 0;                                            // zero-weight pad pieces read position 0 (always staged, finite)
+            if (p < np) {
+                const int tap = p / a.cgc, cg = p - tap * a.cgc;
+                off = (cg * a.npos + ((tap / (k * k)) * a.yi + (tap / k) % k) * s + tap % k) * 8;
+            }
+            poff[p] = off;
+        }
+        const int rows_g = a.zi * a.yi;
+        for (int r = tid; r < a.cgc * rows_g; r += NT) {
+            const int cg = r / rows_g, rr = r - cg * rows_g;
+            const int iz = z0 * st + rr / a.yi, iy = y0 * st + rr % a.yi;
+            rowsrc[r] = (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
+        }
+    }
+    const float* xin = a.x + (size_t)nn * a.cin * ivol;
+    const int items = a.cgc * a.npos;
+    const int step_r = NT / s, step_x = NT - step_r * s;            // item index advances by NT: (row, x) += (step_r, step_x) with carry
+    const int row0 = tid / s, x0 = tid - row0 * s;
+
+    f32x4 hi[MB][NB], lo[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const h8* wl = a.wp + (size_t)nb0 * 128 + lane;
+    const size_t wstep = (size_t)a.nbt * 128;                       // h8 per k-step of the image
+    h8 bh[NB], bl[NB], nh[NB], nl[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { bh[nb] = wl[nb * 128]; bl[nb] = wl[nb * 128 + 64]; }
+
+    for (int c = 0; c < a.nchunk; ++c) {
+        __syncthreads();                                            // tables written / everyone left the previous chunk
+        {
+            const float* xc = xin + (size_t)c * a.cgc * 4 * ivol;
+            int row = row0, ix = x0;
+            for (int i = tid; i < items; i += NT) {
+                const int ro = rowsrc[row];
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ro >= 0) {
+                    const float* src = xc + ro + ix;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = src[(size_t)e * ivol];
+                }
+                h4 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = __builtin_amdgcn_fmed3f(v[e] * VS_ACT_SCALE, -65504.f, 65504.f);
+                    const _Float16 h = (_Float16)t;
+                    hh[e] = h;
+                    ll[e] = (_Float16)((t - (float)h) * VS_LO);
+                }
+                *reinterpret_cast<h4*>(lds + i * 8) = hh;
+                *reinterpret_cast<h4*>(lds + plane + i * 8) = ll;
+                row += step_r; ix += step_x;
+                if (ix >= s) { ix -= s; ++row; }
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < a.ksteps; ++q) {
+            {   // next k-step's weights (the image has one k-step of slack behind the last one)
+                const h8* wn = wl + ((size_t)c * a.ksteps + q + 1) * wstep;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { nh[nb] = wn[nb * 128]; nl[nb] = wn[nb * 128 + 64]; }
+            }
+            const int2 po = *reinterpret_cast<const int2*>(poff + q * 8 + 2 * g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const unsigned char* p0 = lds + base[mb] + po.x;
+                const unsigned char* p1 = lds + base[mb] + po.y;
+                const h4 a0 = *reinterpret_cast<const h4*>(p0), a1 = *reinterpret_cast<const h4*>(p1);
+                const h4 c0 = *reinterpret_cast<const h4*>(p0 + plane), c1 = *reinterpret_cast<const h4*>(p1 + plane);
+                const h8 ah = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const h8 al = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) hi[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nb], hi[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) lo[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nb], lo[mb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) lo[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nb], lo[mb][nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
+        }
+    }
+    __syncthreads();                                                // the chunk image is dead: the epilogue tile aliases it
+
+    // ---- epilogue (as k_convv_lds): hi + lo / 2^11 (activation and weight scales cancel), bias, LeakyReLU; through LDS so that the
+    // stores are long contiguous runs -- per cout block the 4 waves each stream four cout rows out, lane = consecutive voxel
+    static_assert(VS_ACT_SCALE * VS_W_SCALE == 1.0f, "epilogue assumes the operand scales cancel");
+    float* eb = reinterpret_cast<float*>(lds);                      // [16][VS_EV]
+    const int ovol = so * so * so;
+    const int R = a.ty * so;                                        // floats of one z plane of the tile
+    int zlim = so - z0;
+    if (zlim > a.tz) zlim = a.tz;
+    int ylim = so - y0;
+    if (ylim > a.ty) ylim = a.ty;
+    const int mlim = zlim * R, rlim = ylim * so;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        {
+            const int co = (nb0 + nb) * 16 + j;
+            const float bz = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = fmaf(lo[mb][nb][r], 1.0f / VS_LO, hi[mb][nb][r]) + bz;
+                    v[r] = t > 0.f ? t : t * a.slope;
+                }
+                *reinterpret_cast<f32x4*>(eb + j * VS_EV + (wave * MB + mb) * 16 + g * 4) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int col = wave * 4 + h, co = (nb0 + nb) * 16 + col;
+            if (co < a.cout) {                                      // wave-uniform
+                float* o = a.out + ((size_t)nn * a.cout + co) * ovol + ((size_t)z0 * so + y0) * so;
+                const float* src = eb + col * VS_EV;
+                int mr = lane, lz = 0;                              // m = lz * R + mr
+                while (mr >= R) { mr -= R; ++lz; }
+                for (int m = lane; m < mlim; m += 64) {
+                    if (mr < rlim) o[(size_t)lz * so * so + mr] = src[m];
+                    mr += 64;
+                    while (mr >= R) { mr -= R; ++lz; }
+                }
+            }
+        }
+        if (nb + 1 < NB) __syncthreads();
+    }
+}
+
+extern "C" int rf_conv3d_valid_split_supported(int n, int cin, int s, int cout, int k, int stride) {
+    ConvVSArgs a;
+    int nb;
+    size_t lds;
+    return n > 0 && convv_split_plan(cin, s, cout, k, stride, a, nb, lds) ? 1 : 0;
+}
+
+// x [n][cin][s^3], w_packed from rf_convv_split_pack_weight for the same (cout, cin, k, s, stride), out [n][cout][so^3]
+extern "C" int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
+                                           int stride, float slope, float* out, void* stream) {
+    RF_REQUIRE(x && w_packed && out && n > 0, RF_E_INVALID, "rf_conv3d_valid_leaky_split: bad arguments");
+    ConvVSArgs a;
+    int nbw;
+    size_t lds;
+    RF_REQUIRE(convv_split_plan(cin, s, cout, k, stride, a, nbw, lds), RF_E_UNSUPPORTED,
+               "rf_conv3d_valid_leaky_split: layer not taken by the split form (ask rf_conv3d_valid_split_supported)");
+    a.n = n; a.x = x; a.wp = reinterpret_cast<const h8*>(w_packed); a.bias = bias; a.out = out; a.slope = slope;
+    const size_t grid64 = (size_t)a.ntz * a.nty * a.gz * n;
+    RF_REQUIRE(grid64 < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_split: too many tiles (%zu)", grid64);
+    const unsigned grid = (unsigned)grid64;
+    hipStream_t st = (hipStream_t)stream;
+#define RF_VS_LAUNCH(NB_)                                                                                                        \
+    do {                                                                                                                         \
+        if (lds > 65536) {                                                                                                       \
+            static RfLdsOptIn opt_in;                                                                                            \
+            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split<NB_>), (int)VS_LDS_MAX, "rf_conv3d_valid_leaky_split")) return rc; \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((k_convv_split<NB_>), dim3(grid), dim3(VS_NT), lds, st, a);                                           \
+    } while (0)
+    switch (nbw) {
+        case 1: RF_VS_LAUNCH(1); break;
+        case 2: RF_VS_LAUNCH(2); break;
+        default: RF_VS_LAUNCH(3); break;
+    }
+#undef RF_VS_LAUNCH
+    RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_split");
+    return RF_OK;
+}

@@ -92,7 +92,10 @@ class _ConvPatchEncoder(nn.Module):
         x = x.contiguous()
         for layer in self.layers:
             if isinstance(layer, Conv3dParams):
-                if ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
+                if ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
+                    x = ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size,
+                                                     layer.stride, 0.2)
+                elif ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
                     x = ops.conv3d_valid_leaky_valu(x, layer.packed_valu(), layer.bias, layer.stride, 0.2)
                 elif ops.conv_valid_lds_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
                     x = ops.conv3d_valid_leaky_lds(x, layer.packed_lds(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)

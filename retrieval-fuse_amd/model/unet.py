@@ -53,6 +53,7 @@ class Conv3dParams(nn.Module):
         self._packed_split = ops.PackedWeight('conv3s')
         self._packed_lds = ops.PackedWeight('convvl')
         self._packed_valu = ops.PackedWeight('convvv')
+        self._packed_vsplit = ops.PackedWeight('convvs')
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -71,6 +72,10 @@ class Conv3dParams(nn.Module):
     def packed_valu(self):
         """[cin, k,k,k, cout] image of the VALU valid-conv form (patch encoders' first layers)"""
         return self._packed_valu.get(self.weight)
+
+    def packed_valid_split(self, s):
+        """f16 fragment image of the split-operand valid-conv form for input edge s (csrc/conv_valid_split.hip)"""
+        return self._packed_vsplit.get(self.weight, s, self.stride)
 
     def packed_up(self, c0):
         """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""

@@ -46,6 +46,10 @@ SIGNATURES = {
     'rf_conv3d_valid_leaky_valu': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
     'rf_convv_lds_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_convv_lds_packed_floats': (c_sz, [c_i, c_i, c_i]),
+    'rf_conv3d_valid_split_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_valid_leaky_split': (c_i, [c_fp, c_i, c_i, c_i, c_p, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_convv_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'rf_convv_split_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_pool_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_k3_gn_relu_pool': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_conv3_up_packed_floats': (c_sz, [c_i, c_i, c_i]),

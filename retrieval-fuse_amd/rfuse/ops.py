@@ -95,7 +95,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight, 'convvs': pack_convv_split_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -504,6 +504,35 @@ def conv3d_valid_leaky_lds(x, w_packed, bias, cout, k, stride, slope):
     out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().rf_conv3d_valid_leaky_lds(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
                                                      stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_lds')
+    return out
+
+
+def pack_convv_split_weight(w, s, stride):
+    """f16 fragment image of the split-operand valid conv for input edge s (the tile / chunk plan depends on the layer's input size)"""
+    _req(w.detach(), 'conv weight')
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    lib = _lib.load()
+    nbytes = lib.rf_convv_split_packed_bytes(cout, cin, k, s, stride)
+    if nbytes == 0:
+        raise ValueError('pack_convv_split_weight: layer %s @%d^3 stride %d is not taken by the split form' % (tuple(w.shape), s, stride))
+    out = torch.empty(nbytes // 2, dtype=torch.float16, device=w.device)
+    _lib.check(lib.rf_convv_split_pack_weight(_p(w.detach()), cout, cin, k, s, stride, _p(out), _stream()), 'rf_convv_split_pack_weight')
+    return out
+
+
+def conv_valid_split_supported(x, cout, k, stride):
+    """True when the split-operand F16-MFMA form (rf_conv3d_valid_leaky_split) takes this layer and CONV_ARITH selects it."""
+    return CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_valid_split_supported(x.shape[0], x.shape[1], x.shape[2], cout, k, stride))
+
+
+def conv3d_valid_leaky_split(x, w_packed, bias, cout, k, stride, slope):
+    """valid strided conv + bias + LeakyReLU on the F16 matrix cores by operand splitting (w_packed from pack_convv_split_weight)."""
+    _req(x, 'x')
+    n, cin, s = x.shape[0], x.shape[1], x.shape[2]
+    so = (s - k) // stride + 1
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_split(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
+                                                       stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_split')
     return out
 
 

@@ -828,6 +828,41 @@ def test_conv3d_valid_leaky_valu(ops, spec):
     close(got, gather, 1e-5, 'valu form vs gather form')
 
 
+@pytest.mark.parametrize('spec', [(2, 12, 44, 24, 3, 1), (2, 24, 42, 48, 3, 2), (3, 48, 20, 48, 3, 2), (2, 8, 28, 16, 3, 1), (3, 16, 26, 32, 3, 2),
+                                  (2, 32, 12, 64, 3, 1), (2, 12, 24, 24, 3, 1), (2, 24, 22, 24, 3, 2), (5, 16, 11, 20, 2, 1), (2, 4, 13, 24, 4, 1),
+                                  (3, 8, 17, 96, 3, 1), (1, 4, 16, 8, 5, 1), (2, 20, 15, 40, 3, 1)])
+def test_conv3d_valid_leaky_split(ops, spec):
+    """split-operand F16-MFMA form of the patch encoders' large layers (PCPatch48 / Patch32 / Patch24V2 shapes with cin a multiple
+    of 4, plus odd edges, k = 2 / 4 / 5, ragged last tiles, several chunks, cout not a multiple of 16, two cout-block groups) vs
+    float64 torch: no further from it than the fp32-MFMA LDS form"""
+    n, cin, s, cout, k, stride = spec
+    gen = torch.Generator().manual_seed(sum(spec) + 4)
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    xd = x.to(DEV)
+    assert ops.conv_valid_split_supported(xd, cout, k, stride)
+    ref = F.leaky_relu(F.conv3d(x.double(), w.double(), b.double(), stride=stride), 0.2)
+    got = ops.conv3d_valid_leaky_split(xd, ops.pack_convv_split_weight(w.to(DEV), s, stride), b.to(DEV), cout, k, stride, 0.2)
+    close(got, ref.float(), 1e-5, 'valid conv (split)')
+    if ops.conv_valid_lds_supported(xd, cout, k, stride):
+        fp32 = ops.conv3d_valid_leaky_lds(xd, ops.pack_convv_lds_weight(w.to(DEV)), b.to(DEV), cout, k, stride, 0.2)
+    else:
+        fp32 = ops.conv3d_valid_leaky_mfma(xd, ops.pack_convv_weight(w.to(DEV)), b.to(DEV), cout, k, stride, 0.2)
+    e_split, e_fp32 = (got.cpu().double() - ref).abs(), (fp32.cpu().double() - ref).abs()
+    print(f'valid split {spec}: rms {e_split.pow(2).mean().sqrt():.3e} (fp32 form {e_fp32.pow(2).mean().sqrt():.3e}), '
+          f'max {e_split.max():.3e} ({e_fp32.max():.3e})')
+    assert e_split.pow(2).mean().sqrt() <= 1.05 * e_fp32.pow(2).mean().sqrt()
+    assert e_split.max() <= 1.25 * e_fp32.max()
+
+
+def test_conv3d_valid_split_saturates_instead_of_overflowing(ops):
+    """activations beyond the f16 range (|x|/16 > 65504) are clamped, not turned into inf / NaN"""
+    gen = torch.Generator().manual_seed(77)
+    x, w, b = rnd(gen, 1, 8, 12, 12, 12), rnd(gen, 16, 8, 3, 3, 3, scale=0.05), rnd(gen, 16)
+    x[0, 3, 5, 5, 5] = 3.0e6
+    got = ops.conv3d_valid_leaky_split(x.to(DEV), ops.pack_convv_split_weight(w.to(DEV), 12, 1), b.to(DEV), 16, 3, 1, 0.2)
+    assert torch.isfinite(got).all()
+
+
 def test_cpu_tensors_raise(ops):
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.maxpool2(torch.zeros(1, 1, 2, 2, 2))
