@@ -25,6 +25,7 @@ constexpr float VS_ACT_SCALE = 1.0f / 16, VS_W_SCALE = 16.0f, VS_LO = 2048.0f;
 constexpr int VS_NT = 256, VS_MB = 4, VS_M = 256;               // threads, m-blocks per wave, output voxels per tile
 constexpr int VS_EV = VS_M + 4;                                 // floats per cout row of the epilogue tile
 constexpr size_t VS_LDS_MAX = 78 * 1024;                        // two workgroups per CU
+constexpr int VS_SB = 6;                                        // staging items (4 channels each) in flight per thread
 }   // namespace
 
 struct ConvVSArgs {
@@ -38,6 +39,7 @@ struct ConvVSArgs {
     int zi, yi, npos;              // staged input planes / rows per plane, positions per channel group (zi * yi * s)
     int cgc, nchunk, ksteps;       // 4-channel groups per chunk, chunks, k-steps per chunk
     int nbt;                       // n-blocks of the weight image (cout16 / 16)
+    int hdr;                       // ints of the image's table header, a multiple of 4
 };
 
 // tile and chunk choice; depends on the layer only (not on n): the weight image is packed for it
@@ -62,9 +64,9 @@ static bool convv_split_plan(int cin, int s, int cout, int k, int stride, ConvVS
                 const int ksteps = (k3 * cgc + 7) / 8;
                 size_t lds = (size_t)2 * cgc * npos * 8 + (size_t)ksteps * 8 * 4 + (size_t)cgc * zi * yi * 4;
                 if (lds > VS_LDS_MAX) continue;
-                if (lds < (size_t)16 * VS_EV * 4) lds = (size_t)16 * VS_EV * 4;
+                if (lds < (size_t)16 * VS_EV * 4) lds = (size_t)16 * VS_EV * 4;     // the epilogue tile aliases the image
                 const double eff = tile_eff * (double)(k3 * cgc) / (8.0 * ksteps);
-                if (eff > best + 1e-9) {
+                if (eff > best + 1e-9 || (eff > best - 1e-9 && npos < a.npos)) {    // ties: the smaller staged tile
                     best = eff;
                     a.tz = tz; a.ty = ty; a.ntz = ntz; a.nty = nty; a.zi = zi; a.yi = yi; a.npos = npos;
                     a.cgc = cgc; a.nchunk = cgt / cgc; a.ksteps = ksteps;
@@ -76,6 +78,7 @@ static bool convv_split_plan(int cin, int s, int cout, int k, int stride, ConvVS
     a.cin = cin; a.s = s; a.cout = cout; a.k = k; a.stride = stride; a.so = so;
     a.nbt = cout16 / 16;
     a.gz = (a.nbt + nbw - 1) / nbw;
+    a.hdr = rf_round_up(a.ksteps * 8 + 3 * VS_M, 4);
     nb_out = nbw;
     return true;
 }
@@ -87,7 +90,36 @@ extern "C" size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, i
     size_t lds;
     if (!convv_split_plan(cin, s, cout, k, stride, a, nb, lds)) return 0;
     // two k-steps of slack: the kernel's one-ahead B prefetch (NB blocks from the last group's first block) never leaves the image
-    return ((size_t)a.nchunk * a.ksteps + 2) * (size_t)a.nbt * 2 * 64 * 16;
+    return (size_t)a.hdr * 4 + ((size_t)a.nchunk * a.ksteps + 2) * (size_t)a.nbt * 2 * 64 * 16;
+}
+
+// image header: the tables every workgroup needs and that depend on the layer only --
+//   [ksteps * 8] byte offset of piece p in the h plane (zero-weight pad pieces: 0, a position that is always staged);
+//   [VS_M]       byte offset of the input corner of tile voxel m in a plane (m >= tile size: 0 -- computed, never stored);
+//   [VS_M]       offset of tile voxel m in the output window relative to the tile's first voxel (m >= tile size: -1);
+//   [VS_M]       (lz << 8) | ly of tile voxel m (ragged last tiles)
+__global__ void k_convv_split_header(ConvVSArgs a, int* __restrict__ hdr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int np = a.ksteps * 8;
+    if (i < np) {
+        const int k = a.k;
+        int off = 0;
+        if (i < k * k * k * a.cgc) {
+            const int tap = i / a.cgc, cg = i - tap * a.cgc;
+            off = (cg * a.npos + ((tap / (k * k)) * a.yi + (tap / k) % k) * a.s + tap % k) * 8;
+        }
+        hdr[i] = off;
+    } else if (i < np + 3 * VS_M) {
+        const int which = (i - np) / VS_M, m0 = (i - np) % VS_M;
+        const bool in = m0 < a.tz * a.ty * a.so;
+        const int m = in ? m0 : 0;
+        const int x = m % a.so, r = m / a.so, ly = r % a.ty, lz = r / a.ty;
+        if (which == 0) hdr[i] = (((lz * a.stride) * a.yi + ly * a.stride) * a.s + x * a.stride) * 8;
+        else if (which == 1) hdr[i] = in ? (lz * a.so + ly) * a.so + x : -1;
+        else hdr[i] = (lz << 8) | ly;
+    } else if (i < a.hdr) {
+        hdr[i] = 0;
+    }
 }
 
 __global__ void k_convv_split_pack(const float* __restrict__ w, int cout, int cin, int k3, int cgc, int ksteps, int nbt, size_t nreal,
@@ -124,19 +156,25 @@ extern "C" int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int ci
     size_t lds;
     RF_REQUIRE(convv_split_plan(cin, s, cout, k, stride, a, nb, lds), RF_E_UNSUPPORTED,
                "rf_convv_split_pack_weight: layer not taken by the split form (ask rf_conv3d_valid_split_supported)");
-    const size_t total = rf_convv_split_packed_bytes(cout, cin, k, s, stride) / 16;
+    const size_t total = (rf_convv_split_packed_bytes(cout, cin, k, s, stride) - (size_t)a.hdr * 4) / 16;
+    hipLaunchKernelGGL(k_convv_split_header, dim3((unsigned)((a.hdr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, reinterpret_cast<int*>(w_packed));
     const size_t nreal = (size_t)a.nchunk * a.ksteps * a.nbt * 128;
     const size_t want = (total + 255) / 256;
     hipLaunchKernelGGL(k_convv_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin,
-                       k * k * k, a.cgc, a.ksteps, a.nbt, nreal, reinterpret_cast<h8*>(w_packed), total);
+                       k * k * k, a.cgc, a.ksteps, a.nbt, nreal, reinterpret_cast<h8*>(w_packed) + a.hdr / 4, total);
     RF_CHECK_LAUNCH("rf_convv_split_pack_weight");
     return RF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------- kernel
-template <int NB>
-__global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
-    constexpr int NT = VS_NT, MB = VS_MB;
+// workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence: it also waits for the epilogue's global
+// stores, and on gfx9 loads and stores retire through one in-order counter (vmcnt) -- any wait for a load requested after a store waits
+// for the store's acknowledgement too.  The epilogue therefore requests nothing: bias values are loaded before the MFMAs.
+__device__ __forceinline__ void vs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NB, int WPE>
+__global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
+    constexpr int NT = VS_NT, MB = VS_MB, SB = VS_SB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,7 +182,9 @@ __global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
     const int so = a.so, s = a.s, st = a.stride;
     const int plane = a.cgc * a.npos * 8;                           // bytes of the h plane (l plane follows)
     int* poff = reinterpret_cast<int*>(lds + 2 * plane);            // [ksteps * 8] byte offset of a piece in the h plane
-    int* rowsrc = poff + a.ksteps * 8;                              // [cgc * zi * yi] float offset of a staged row (< 0: outside the volume)
+    int* rowsrc = poff + a.ksteps * 8;                              // [nrows] float offset of a staged row (< 0: outside the volume)
+    const int nrows = a.cgc * a.zi * a.yi;
+    const size_t ivol = (size_t)s * s * s;
 
     // XCD-aware 1-D grid as in k_convv_lds: an XCD walks whole windows (tiles fastest, then cout block groups)
     const unsigned total = gridDim.x, per = total >> 3, rem = total & 7u, xk = blockIdx.x & 7u;
@@ -154,36 +194,28 @@ __global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
     const int nn = (int)(lb / (tiles * (unsigned)a.gz));
     const int z0 = (int)(tb / (unsigned)a.nty) * a.tz, y0 = (int)(tb % (unsigned)a.nty) * a.ty;
     const int nb0 = (int)zb * NB;                                   // first n-block of this workgroup
-    const int V = a.tz * a.ty * so;
-    const size_t ivol = (size_t)s * s * s;
 
-    // this lane's output voxels: m-block (wave*MB + mb), voxel j -> byte offset of its input corner in a plane
-    int base[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        int m = (wave * MB + mb) * 16 + j;
-        if (m >= V) m = 0;                                          // computed, never stored
-        const int x = m % so, r = m / so, ly = r % a.ty, lz = r / a.ty;
-        base[mb] = (((lz * st) * a.yi + ly * st) * s + x * st) * 8;
-    }
+    // tables from the image header; the staged rows of this tile
+    const int* hdr = reinterpret_cast<const int*>(a.wp);
+    for (int p = tid; p < a.ksteps * 8; p += NT) poff[p] = hdr[p];
     {
-        const int k = a.k, k3 = k * k * k, np = k3 * a.cgc;
-        for (int p = tid; p < a.ksteps * 8; p += NT) {
-            int off = 0;                                            // zero-weight pad pieces read position 0 (always staged, finite)
-            if (p < np) {
-                const int tap = p / a.cgc, cg = p - tap * a.cgc;
-                off = (cg * a.npos + ((tap / (k * k)) * a.yi + (tap / k) % k) * s + tap % k) * 8;
-            }
-            poff[p] = off;
-        }
         const int rows_g = a.zi * a.yi;
-        for (int r = tid; r < a.cgc * rows_g; r += NT) {
+        for (int r = tid; r < nrows; r += NT) {
             const int cg = r / rows_g, rr = r - cg * rows_g;
             const int iz = z0 * st + rr / a.yi, iy = y0 * st + rr % a.yi;
             rowsrc[r] = (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
         }
     }
-    const float* xin = a.x + (size_t)nn * a.cin * ivol;
+    int base[MB];                                                   // byte offset of the input corner of voxel (m-block, j) in a plane
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) base[mb] = hdr[a.ksteps * 8 + (wave * MB + mb) * 16 + j];
+    float bz[NB];                                                   // before any store (see vs_lds_barrier)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int co = (nb0 + nb) * 16 + j;
+        bz[nb] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
+
     const int items = a.cgc * a.npos;
     const int step_r = NT / s, step_x = NT - step_r * s;            // item index advances by NT: (row, x) += (step_r, step_x) with carry
     const int row0 = tid / s, x0 = tid - row0 * s;
@@ -194,7 +226,7 @@ __global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { hi[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    const h8* wl = a.wp + (size_t)nb0 * 128 + lane;
+    const h8* wl = a.wp + a.hdr / 4 + (size_t)nb0 * 128 + lane;
     const size_t wstep = (size_t)a.nbt * 128;                       // h8 per k-step of the image
     h8 bh[NB], bl[NB], nh[NB], nl[NB];
 #pragma unroll
@@ -203,33 +235,50 @@ __global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
     for (int c = 0; c < a.nchunk; ++c) {
         __syncthreads();                                            // tables written / everyone left the previous chunk
         {
-            const float* xc = xin + (size_t)c * a.cgc * 4 * ivol;
+            // scalar base + 32-bit lane offset loads, SB items (4 channels each) in flight per thread, no branches around the loads:
+            // items outside the volume / the chunk read the channel's first value and are zeroed by their scale
+            const char* xc = reinterpret_cast<const char*>(a.x + ((size_t)nn * a.cin + (size_t)c * a.cgc * 4) * ivol);
             int row = row0, ix = x0;
-            for (int i = tid; i < items; i += NT) {
-                const int ro = rowsrc[row];
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (ro >= 0) {
-                    const float* src = xc + ro + ix;
+            for (int i = tid; i < items; i += SB * NT) {
+                float v[SB][4];
+                unsigned off[SB];
+                unsigned real = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = src[(size_t)e * ivol];
+                for (int b = 0; b < SB; ++b) {
+                    const int ro = rowsrc[row < nrows ? row : nrows - 1];
+                    const bool ok = ro >= 0 && i + b * NT < items;
+                    off[b] = ok ? (unsigned)(ro + ix) * 4u : 0u;
+                    real |= (ok ? 1u : 0u) << b;
+                    row += step_r; ix += step_x;
+                    if (ix >= s) { ix -= s; ++row; }
                 }
-                h4 hh, ll;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = __builtin_amdgcn_fmed3f(v[e] * VS_ACT_SCALE, -65504.f, 65504.f);
-                    const _Float16 h = (_Float16)t;
-                    hh[e] = h;
-                    ll[e] = (_Float16)((t - (float)h) * VS_LO);
+                for (int b = 0; b < SB; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[b][e] = *reinterpret_cast<const float*>(xc + (size_t)e * 4 * ivol + off[b]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < SB; ++b) {
+                    const float sc = (real >> b) & 1u ? VS_ACT_SCALE : 0.f;
+                    h4 hh, ll;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = __builtin_amdgcn_fmed3f(v[b][e] * sc, -65504.f, 65504.f);
+                        const _Float16 h = (_Float16)t;
+                        hh[e] = h;
+                        ll[e] = (_Float16)((t - (float)h) * VS_LO);
+                    }
+                    const int idx = i + b * NT;
+                    if (idx < items) {
+                        *reinterpret_cast<h4*>(lds + idx * 8) = hh;
+                        *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
+                    }
                 }
-                *reinterpret_cast<h4*>(lds + i * 8) = hh;
-                *reinterpret_cast<h4*>(lds + plane + i * 8) = ll;
-                row += step_r; ix += step_x;
-                if (ix >= s) { ix -= s; ++row; }
             }
         }
         __syncthreads();
         for (int q = 0; q < a.ksteps; ++q) {
-            {   // next k-step's weights (the image has one k-step of slack behind the last one)
+            {   // next k-step's weights (the image has two k-steps of slack behind the last one)
                 const h8* wn = wl + ((size_t)c * a.ksteps + q + 1) * wstep;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) { nh[nb] = wn[nb * 128]; nl[nb] = wn[nb * 128 + 64]; }
@@ -257,50 +306,46 @@ __global__ __launch_bounds__(VS_NT, 2) void k_convv_split(ConvVSArgs a) {
     }
     __syncthreads();                                                // the chunk image is dead: the epilogue tile aliases it
 
-    // ---- epilogue (as k_convv_lds): hi + lo / 2^11 (activation and weight scales cancel), bias, LeakyReLU; through LDS so that the
-    // stores are long contiguous runs -- per cout block the 4 waves each stream four cout rows out, lane = consecutive voxel
+    // ---- epilogue: hi + lo / 2^11 (activation and weight scales cancel), bias, LeakyReLU; through LDS so that the stores are long
+    // contiguous runs -- per cout block the 4 waves each stream four cout rows out, lane = consecutive voxel of the tile
     static_assert(VS_ACT_SCALE * VS_W_SCALE == 1.0f, "epilogue assumes the operand scales cancel");
     float* eb = reinterpret_cast<float*>(lds);                      // [16][VS_EV]
+    int eoff[4], ezy[4];                                            // voxel m = lane + 64 i -> offset in the output window, (lz << 8) | ly
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { eoff[i] = hdr[a.ksteps * 8 + VS_M + lane + 64 * i]; ezy[i] = hdr[a.ksteps * 8 + 2 * VS_M + lane + 64 * i]; }
     const int ovol = so * so * so;
-    const int R = a.ty * so;                                        // floats of one z plane of the tile
     int zlim = so - z0;
     if (zlim > a.tz) zlim = a.tz;
     int ylim = so - y0;
     if (ylim > a.ty) ylim = a.ty;
-    const int mlim = zlim * R, rlim = ylim * so;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (!((ezy[i] >> 8) < zlim && (ezy[i] & 255) < ylim)) eoff[i] = -1;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        {
-            const int co = (nb0 + nb) * 16 + j;
-            const float bz = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                f32x4 v;
+        for (int mb = 0; mb < MB; ++mb) {
+            f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t = fmaf(lo[mb][nb][r], 1.0f / VS_LO, hi[mb][nb][r]) + bz;
-                    v[r] = t > 0.f ? t : t * a.slope;
-                }
-                *reinterpret_cast<f32x4*>(eb + j * VS_EV + (wave * MB + mb) * 16 + g * 4) = v;
+            for (int r = 0; r < 4; ++r) {
+                const float t = fmaf(lo[mb][nb][r], 1.0f / VS_LO, hi[mb][nb][r]) + bz[nb];
+                v[r] = t > 0.f ? t : t * a.slope;
             }
+            *reinterpret_cast<f32x4*>(eb + j * VS_EV + (wave * MB + mb) * 16 + g * 4) = v;
         }
-        __syncthreads();
+        vs_lds_barrier();
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int col = wave * 4 + h, co = (nb0 + nb) * 16 + col;
             if (co < a.cout) {                                      // wave-uniform
                 float* o = a.out + ((size_t)nn * a.cout + co) * ovol + ((size_t)z0 * so + y0) * so;
-                const float* src = eb + col * VS_EV;
-                int mr = lane, lz = 0;                              // m = lz * R + mr
-                while (mr >= R) { mr -= R; ++lz; }
-                for (int m = lane; m < mlim; m += 64) {
-                    if (mr < rlim) o[(size_t)lz * so * so + mr] = src[m];
-                    mr += 64;
-                    while (mr >= R) { mr -= R; ++lz; }
-                }
+                const float* src = eb + col * VS_EV + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (eoff[i] >= 0) o[eoff[i]] = src[64 * i];
             }
         }
-        if (nb + 1 < NB) __syncthreads();
+        if (nb + 1 < NB) vs_lds_barrier();                          // the next block's writers wait for these readers; the stores stay in flight
     }
 }
 
@@ -325,18 +370,18 @@ extern "C" int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s
     RF_REQUIRE(grid64 < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_split: too many tiles (%zu)", grid64);
     const unsigned grid = (unsigned)grid64;
     hipStream_t st = (hipStream_t)stream;
-#define RF_VS_LAUNCH(NB_)                                                                                                        \
+#define RF_VS_LAUNCH(NB_, WPE_)                                                                                                  \
     do {                                                                                                                         \
         if (lds > 65536) {                                                                                                       \
             static RfLdsOptIn opt_in;                                                                                            \
-            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split<NB_>), (int)VS_LDS_MAX, "rf_conv3d_valid_leaky_split")) return rc; \
+            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split<NB_, WPE_>), (int)VS_LDS_MAX, "rf_conv3d_valid_leaky_split")) return rc; \
         }                                                                                                                        \
-        hipLaunchKernelGGL((k_convv_split<NB_>), dim3(grid), dim3(VS_NT), lds, st, a);                                           \
+        hipLaunchKernelGGL((k_convv_split<NB_, WPE_>), dim3(grid), dim3(VS_NT), lds, st, a);                                     \
     } while (0)
     switch (nbw) {
-        case 1: RF_VS_LAUNCH(1); break;
-        case 2: RF_VS_LAUNCH(2); break;
-        default: RF_VS_LAUNCH(3); break;
+        case 1: RF_VS_LAUNCH(1, 3); break;
+        case 2: RF_VS_LAUNCH(2, 3); break;
+        default: RF_VS_LAUNCH(3, 2); break;
     }
 #undef RF_VS_LAUNCH
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_split");
