@@ -25,7 +25,7 @@ constexpr float VS_ACT_SCALE = 1.0f / 16, VS_W_SCALE = 16.0f, VS_LO = 2048.0f;
 constexpr int VS_NT = 256, VS_MB = 4, VS_M = 256;               // threads, m-blocks per wave, output voxels per tile
 constexpr int VS_EV = VS_M + 4;                                 // floats per cout row of the epilogue tile
 constexpr size_t VS_LDS_MAX = 78 * 1024;                        // two workgroups per CU
-constexpr int VS_SB = 6;                                        // staging items (4 channels each) in flight per thread
+constexpr int VS_SB = 11;                                       // staging items (4 channels each) in flight per thread
 }   // namespace
 
 struct ConvVSArgs {
@@ -209,6 +209,9 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     int base[MB];                                                   // byte offset of the input corner of voxel (m-block, j) in a plane
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) base[mb] = hdr[a.ksteps * 8 + (wave * MB + mb) * 16 + j];
+    int eoff[4], ezy[4];                                            // epilogue: voxel m = lane + 64 i -> offset in the output window, (lz << 8) | ly
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { eoff[i] = hdr[a.ksteps * 8 + VS_M + lane + 64 * i]; ezy[i] = hdr[a.ksteps * 8 + 2 * VS_M + lane + 64 * i]; }
     float bz[NB];                                                   // before any store (see vs_lds_barrier)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     for (int nb = 0; nb < NB; ++nb) { bh[nb] = wl[nb * 128]; bl[nb] = wl[nb * 128 + 64]; }
 
     for (int c = 0; c < a.nchunk; ++c) {
-        __syncthreads();                                            // tables written / everyone left the previous chunk
+        vs_lds_barrier();                                           // tables written / everyone left the previous chunk
         {
             // scalar base + 32-bit lane offset loads, SB items (4 channels each) in flight per thread, no branches around the loads:
             // items outside the volume / the chunk read the channel's first value and are zeroed by their scale
@@ -276,14 +279,15 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
                 }
             }
         }
-        __syncthreads();
+        vs_lds_barrier();
+        int2 po = *reinterpret_cast<const int2*>(poff + 2 * g);
         for (int q = 0; q < a.ksteps; ++q) {
             {   // next k-step's weights (the image has two k-steps of slack behind the last one)
                 const h8* wn = wl + ((size_t)c * a.ksteps + q + 1) * wstep;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) { nh[nb] = wn[nb * 128]; nl[nb] = wn[nb * 128 + 64]; }
             }
-            const int2 po = *reinterpret_cast<const int2*>(poff + q * 8 + 2 * g);
+            const int2 pn = *reinterpret_cast<const int2*>(poff + (q + 1 < a.ksteps ? q + 1 : q) * 8 + 2 * g);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -302,17 +306,15 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
+            po = pn;
         }
     }
-    __syncthreads();                                                // the chunk image is dead: the epilogue tile aliases it
+    vs_lds_barrier();                                               // the chunk image is dead: the epilogue tile aliases it
 
     // ---- epilogue: hi + lo / 2^11 (activation and weight scales cancel), bias, LeakyReLU; through LDS so that the stores are long
     // contiguous runs -- per cout block the 4 waves each stream four cout rows out, lane = consecutive voxel of the tile
     static_assert(VS_ACT_SCALE * VS_W_SCALE == 1.0f, "epilogue assumes the operand scales cancel");
     float* eb = reinterpret_cast<float*>(lds);                      // [16][VS_EV]
-    int eoff[4], ezy[4];                                            // voxel m = lane + 64 i -> offset in the output window, (lz << 8) | ly
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { eoff[i] = hdr[a.ksteps * 8 + VS_M + lane + 64 * i]; ezy[i] = hdr[a.ksteps * 8 + 2 * VS_M + lane + 64 * i]; }
     const int ovol = so * so * so;
     int zlim = so - z0;
     if (zlim > a.tz) zlim = a.tz;

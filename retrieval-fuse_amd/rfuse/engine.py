@@ -80,13 +80,14 @@ class RefinementEngine:
 
     @_on_engine_device
     @torch.no_grad()
-    def retrieve(self, input_raw, query_scene=None, patch_mask=None):
+    def retrieve(self, input_raw, query_scene=None, patch_mask=None, q=None):
         """-> (patches [(B*K*64),1,16,16,16] normalised, meta [B*64,K,7]).
         ``patch_mask`` [B,64] bool: the dataset's query-side occupancy filter (reference dataset/patched_scene_dataset.py:28-32).
         Patches it drops (False) are never looked up and keep the truncation value in all K retrieved volumes
-        (util/retrieval.py:148,151)."""
+        (util/retrieval.py:148,151).  ``q``: the query embeddings if the caller already has them."""
         d = self.config['dataset_train']
-        q = self.embed_queries(input_raw)
+        if q is None:
+            q = self.embed_queries(input_raw)
         keep = patch_mask.reshape(-1).contiguous() if patch_mask is not None else None
         meta, _, _ = self.database.retrieve(q, self.K, query_scene, keep)
         patches = ops.gather_patches(self.database.volumes, meta, input_raw.shape[0], self.K, self.target_trunc, 1.0,
@@ -100,6 +101,11 @@ class RefinementEngine:
         d = self.config['dataset_train']
         s = input_raw.shape[-1]
         return ops.query_windows(input_raw, s, 0, 0.0, d['input_mean'], d['input_std']).reshape(input_raw.shape[0], 1, s, s, s)
+
+    def _encoder_runs_alone(self, input_raw):
+        g = self.config['query_geometry']
+        uses = getattr(self.fenc_input, 'uses_split_valid_convs', None)
+        return bool(uses and not self.serial and uses(g['patch_size_input'] + 2 * g['patch_context_input'], input_raw.device))
 
     def _fork_backbone(self, x_in):
         """Launch the U-Net backbone on a second HIP stream: it depends only on the input chunk, is made of small
@@ -143,18 +149,23 @@ class RefinementEngine:
         ``use_feature_cache=True`` (needs ``database.build_feature_cache``) fetches the retrieval-backbone features of the
         retrieved database rows from HBM instead of recomputing them -- an optional serving mode that skips 87 % of the
         FLOPs; results agree with the full path to GroupNorm-statistics rounding."""
+        # The split-operand valid convs of the large-window patch encoders (PCPatch48 ...) must not share a SIMD with fp32-MFMA kernels
+        # of another stream (DESIGN 4.7, "two-stream hazard": the co-resident kernel's results move by a few ulp): such an encoder
+        # runs before the backbone is forked.  Its launches fill the GPU anyway, there was nothing to overlap.
+        q = self.embed_queries(input_raw) if self._encoder_runs_alone(input_raw) else None
         x_back, side = self._fork_backbone(self.normalise_input(input_raw))
+        if q is None:
+            q = self.embed_queries(input_raw)
         if use_feature_cache:
             if self.database.feature_cache is None:
                 raise RuntimeError('use_feature_cache=True needs database.build_feature_cache(retrieval_backbone, config) first')
             b = input_raw.shape[0]
-            q = self.embed_queries(input_raw)
             keep = patch_mask.reshape(-1).contiguous() if patch_mask is not None else None
             _, _, idx = self.database.retrieve(q, self.K, query_scene, keep)                # [B*64, K] database row ids; -1 (none) gathers the sentinel row
             order = idx.reshape(b, 64, self.K).permute(0, 2, 1).reshape(-1).contiguous()     # (b, k, slot): the patch-major order
             feats = ops.gather_rows(self.database.feature_cache, order)
         else:
-            patches, _ = self.retrieve(input_raw, query_scene, patch_mask)
+            patches, _ = self.retrieve(input_raw, query_scene, patch_mask, q=q)
             feats = self.retrieval_backbone(patches)
         torch.cuda.current_stream(self.device).wait_stream(side)
         return self._attend_and_decode(x_back, feats, gumbel_noise)

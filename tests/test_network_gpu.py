@@ -255,6 +255,33 @@ def test_engine_fast_routes_match_plain_routes_at_bench_sizes(gpu, cfg_name, B):
         assert err <= tol
 
 
+@pytest.mark.parametrize('cfg_name,B', [('C1', 8), ('C5', 4)])
+def test_engine_two_stream_schedule_is_bit_equal_to_serial(gpu, cfg_name, B):
+    """The backbone runs on a second stream beside the retrieval path.  Kernels of the two streams share SIMDs, and split-operand kernels
+    with more than 128 VGPRs were seen to move a co-resident fp32-MFMA kernel's results by a few ulp: the engine's schedule
+    keeps those apart (the large-window patch encoder runs before the fork), so both schedules must give the same bits."""
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config(cfg_name)
+    db = synthetic.make_database(6, cfg, 64 * 30)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {}
+    for name, m in eng.modules().items():
+        sds[name] = helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 91 + len(name))
+    eng.load_state_dicts(sds)
+    raws = np.stack([synthetic.make_chunk(5000 + b, cfg)['input_raw'] for b in range(B)])
+    x = torch.from_numpy(raws).to(gpu)
+    noise = None
+    if cfg['attn_retrieval_mode']:
+        rows = B * cfg['attn_num_patch'] ** 3
+        noise = (-torch.empty(rows, cfg['K']).exponential_(generator=torch.Generator().manual_seed(2)).log()).to(gpu)
+    eng.serial = True
+    ref = eng.refine(x, gumbel_noise=noise).clone()
+    eng.serial = False
+    for _ in range(3):
+        assert torch.equal(eng.refine(x, gumbel_noise=noise), ref)
+
+
 @pytest.mark.parametrize('name', ['feat_C1', 'feat_C5'])
 def test_get_features_matches_reference_golden(gpu, name):
     """A8: PatchedAttentionBlock.get_features as forward_full calls it (reference trainer/train_refinement.py:113-119,
