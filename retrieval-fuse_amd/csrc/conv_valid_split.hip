@@ -62,7 +62,9 @@ static bool convv_split_plan(int cin, int s, int cout, int k, int stride, ConvVS
             for (int cgc = 1; cgc <= cgt; ++cgc) {
                 if (cgt % cgc) continue;
                 const int ksteps = (k3 * cgc + 7) / 8;
-                size_t lds = (size_t)2 * cgc * npos * 8 + (size_t)ksteps * 8 * 4 + (size_t)cgc * zi * yi * 4;
+                if (ksteps > 64) continue;                          // piece table: two entries per thread
+                const int items_pad = rf_round_up(cgc * npos, VS_SB * VS_NT);       // the staging loop writes whole batches
+                size_t lds = (size_t)2 * items_pad * 8 + (size_t)ksteps * 8 * 4 + (size_t)(items_pad / s + 2) * 4;
                 if (lds > VS_LDS_MAX) continue;
                 if (lds < (size_t)16 * VS_EV * 4) lds = (size_t)16 * VS_EV * 4;     // the epilogue tile aliases the image
                 const double eff = tile_eff * (double)(k3 * cgc) / (8.0 * ksteps);
@@ -180,10 +182,12 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int so = a.so, s = a.s, st = a.stride;
-    const int plane = a.cgc * a.npos * 8;                           // bytes of the h plane (l plane follows)
+    const int items = a.cgc * a.npos;
+    const int items_pad = (items + SB * NT - 1) / (SB * NT) * (SB * NT);    // the staging loop writes whole batches (pad slots: never read)
+    const int plane = items_pad * 8;                                // bytes of the h plane (l plane follows)
     int* poff = reinterpret_cast<int*>(lds + 2 * plane);            // [ksteps * 8] byte offset of a piece in the h plane
-    int* rowsrc = poff + a.ksteps * 8;                              // [nrows] float offset of a staged row (< 0: outside the volume)
-    const int nrows = a.cgc * a.zi * a.yi;
+    int* rowsrc = poff + a.ksteps * 8;                              // [rows_pad] float offset of a staged row (< 0: outside the volume / the chunk)
+    const int nrows = a.cgc * a.zi * a.yi, rows_pad = items_pad / s + 2;
     const size_t ivol = (size_t)s * s * s;
 
     // XCD-aware 1-D grid as in k_convv_lds: an XCD walks whole windows (tiles fastest, then cout block groups)
@@ -197,13 +201,17 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
 
     // tables from the image header; the staged rows of this tile
     const int* hdr = reinterpret_cast<const int*>(a.wp);
-    for (int p = tid; p < a.ksteps * 8; p += NT) poff[p] = hdr[p];
+    int pv[2];                                                      // piece offsets: requested now, written to LDS behind the staging loop
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pv[h] = tid + h * NT < a.ksteps * 8 ? hdr[tid + h * NT] : 0;
     {
         const int rows_g = a.zi * a.yi;
-        for (int r = tid; r < nrows; r += NT) {
-            const int cg = r / rows_g, rr = r - cg * rows_g;
-            const int iz = z0 * st + rr / a.yi, iy = y0 * st + rr % a.yi;
-            rowsrc[r] = (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
+        const float inv_g = 1.0f / (float)rows_g, inv_y = 1.0f / (float)a.yi;     // r < 2^16: (r + 0.5) * (1 / d) truncates to r / d
+        for (int r = tid; r < rows_pad; r += NT) {
+            const int cg = (int)(((float)r + 0.5f) * inv_g), rr = r - cg * rows_g;
+            const int rz = (int)(((float)rr + 0.5f) * inv_y), ry = rr - rz * a.yi;
+            const int iz = z0 * st + rz, iy = y0 * st + ry;
+            rowsrc[r] = (r < nrows && iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
         }
     }
     int base[MB];                                                   // byte offset of the input corner of voxel (m-block, j) in a plane
@@ -219,7 +227,6 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
         bz[nb] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
 
-    const int items = a.cgc * a.npos;
     const int step_r = NT / s, step_x = NT - step_r * s;            // item index advances by NT: (row, x) += (step_r, step_x) with carry
     const int row0 = tid / s, x0 = tid - row0 * s;
 
@@ -248,8 +255,8 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
                 unsigned real = 0;
 #pragma unroll
                 for (int b = 0; b < SB; ++b) {
-                    const int ro = rowsrc[row < nrows ? row : nrows - 1];
-                    const bool ok = ro >= 0 && i + b * NT < items;
+                    const int ro = rowsrc[row];
+                    const bool ok = ro >= 0;
                     off[b] = ok ? (unsigned)(ro + ix) * 4u : 0u;
                     real |= (ok ? 1u : 0u) << b;
                     row += step_r; ix += step_x;
@@ -272,12 +279,15 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
                         ll[e] = (_Float16)((t - (float)h) * VS_LO);
                     }
                     const int idx = i + b * NT;
-                    if (idx < items) {
-                        *reinterpret_cast<h4*>(lds + idx * 8) = hh;
-                        *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
-                    }
+                    *reinterpret_cast<h4*>(lds + idx * 8) = hh;
+                    *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
                 }
             }
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (tid + h * NT < a.ksteps * 8) poff[tid + h * NT] = pv[h];
         }
         vs_lds_barrier();
         int2 po = *reinterpret_cast<const int2*>(poff + 2 * g);
