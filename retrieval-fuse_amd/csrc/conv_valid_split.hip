@@ -16,6 +16,7 @@
 // B operands (weights): f16 fragment image from rf_convv_split_pack_weight ([chunk][k-step][n-block][h|l][lane][8 halves]), L2-resident,
 // global -> VGPR one k-step ahead (across chunk boundaries too).
 #include "common.h"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
 
     // tables from the image header; the staged rows of this tile
     const int* hdr = reinterpret_cast<const int*>(a.wp);
+    const bool ragged = z0 * st + a.zi > s || y0 * st + a.yi > s;   // uniform
     int pv[2];                                                      // piece offsets: requested now, written to LDS behind the staging loop
 #pragma unroll
     for (int h = 0; h < 2; ++h) pv[h] = tid + h * NT < a.ksteps * 8 ? hdr[tid + h * NT] : 0;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             const int cg = (int)(((float)r + 0.5f) * inv_g), rr = r - cg * rows_g;
             const int rz = (int)(((float)rr + 0.5f) * inv_y), ry = rr - rz * a.yi;
             const int iz = z0 * st + rz, iy = y0 * st + ry;
-            rowsrc[r] = (r < nrows && iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
+            rowsrc[r] = r >= nrows ? 0 : (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
         }
     }
     int base[MB];                                                   // byte offset of the input corner of voxel (m-block, j) in a plane
@@ -245,44 +247,53 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     for (int c = 0; c < a.nchunk; ++c) {
         vs_lds_barrier();                                           // tables written / everyone left the previous chunk
         {
-            // scalar base + 32-bit lane offset loads, SB items (4 channels each) in flight per thread, no branches around the loads:
-            // items outside the volume / the chunk read the channel's first value and are zeroed by their scale
+            // SB items (4 channels each) in flight per thread, no branches around the loads.  Rows of a ragged last tile that lie outside
+            // the volume (table entry < 0) read the channel's first value and are zeroed by their scale; tiles without such rows (nearly
+            // all) take the path without that bookkeeping.  Pad slots behind the last item hold whatever the first row holds: never read.
             const char* xc = reinterpret_cast<const char*>(a.x + ((size_t)nn * a.cin + (size_t)c * a.cgc * 4) * ivol);
-            int row = row0, ix = x0;
-            for (int i = tid; i < items; i += SB * NT) {
-                float v[SB][4];
-                unsigned off[SB];
-                unsigned real = 0;
+            auto stage = [&](auto ragged_tag) {
+                constexpr bool RAGGED = decltype(ragged_tag)::value;
+                int row = row0, ix = x0;
+                for (int i = tid; i < items; i += SB * NT) {
+                    float v[SB][4];
+                    unsigned off[SB];
+                    unsigned real = 0;
 #pragma unroll
-                for (int b = 0; b < SB; ++b) {
-                    const int ro = rowsrc[row];
-                    const bool ok = ro >= 0;
-                    off[b] = ok ? (unsigned)(ro + ix) * 4u : 0u;
-                    real |= (ok ? 1u : 0u) << b;
-                    row += step_r; ix += step_x;
-                    if (ix >= s) { ix -= s; ++row; }
-                }
-#pragma unroll
-                for (int b = 0; b < SB; ++b)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[b][e] = *reinterpret_cast<const float*>(xc + (size_t)e * 4 * ivol + off[b]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int b = 0; b < SB; ++b) {
-                    const float sc = (real >> b) & 1u ? VS_ACT_SCALE : 0.f;
-                    h4 hh, ll;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = __builtin_amdgcn_fmed3f(v[b][e] * sc, -65504.f, 65504.f);
-                        const _Float16 h = (_Float16)t;
-                        hh[e] = h;
-                        ll[e] = (_Float16)((t - (float)h) * VS_LO);
+                    for (int b = 0; b < SB; ++b) {
+                        const int ro = rowsrc[row];
+                        if constexpr (RAGGED) {
+                            off[b] = ro >= 0 ? (unsigned)(ro + ix) * 4u : 0u;
+                            real |= (ro >= 0 ? 1u : 0u) << b;
+                        } else {
+                            off[b] = (unsigned)(ro + ix) * 4u;
+                        }
+                        row += step_r; ix += step_x;
+                        if (ix >= s) { ix -= s; ++row; }
                     }
-                    const int idx = i + b * NT;
-                    *reinterpret_cast<h4*>(lds + idx * 8) = hh;
-                    *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
+#pragma unroll
+                    for (int b = 0; b < SB; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[b][e] = *reinterpret_cast<const float*>(xc + (size_t)e * 4 * ivol + off[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) {
+                        const float sc = (!RAGGED || ((real >> b) & 1u)) ? VS_ACT_SCALE : 0.f;
+                        h4 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __builtin_amdgcn_fmed3f(v[b][e] * sc, -65504.f, 65504.f);
+                            const _Float16 h = (_Float16)t;
+                            hh[e] = h;
+                            ll[e] = (_Float16)fmaf(-VS_LO, (float)h, t * VS_LO);     // (t - h) * 2^11, exact either way; one v_fma_mix_f32
+                        }
+                        const int idx = i + b * NT;
+                        *reinterpret_cast<h4*>(lds + idx * 8) = hh;
+                        *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
+                    }
                 }
-            }
+            };
+            if (ragged) stage(std::true_type{});
+            else stage(std::false_type{});
         }
         if (c == 0) {
 #pragma unroll
