@@ -193,7 +193,8 @@ int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, 
 /* rf_conv3d_k3_gn_relu / _stats / _pool on the F16 matrix cores by operand splitting (csrc/conv3d_split.hip; arithmetic as
  * rf_conv3d_up_split_k3_gn_relu above), 8^3 output boxes, one full-resolution source.  out / stats / pool_out / pool_stats as in
  * rf_conv3d_k3_gn_relu_pool (pool_out NULL: no pooling; out NULL: pooled tensor only); statistics tiles per sample: (edge/8)^3 =
- * rf_conv3d_stats_tiles of the same shape.  Takes cin in multiples of 8, up to 32 couts, edge >= 8, and enough boxes
+ * rf_conv3d_stats_tiles of the same shape.  Takes cin >= 8 (channel counts between multiples of 8 are padded with zero slots and
+ * taken when at least 3/4 of the slots are real: 12, 20, 28, 42 ...), up to 32 couts, edge >= 8, and enough boxes
  * (rf_conv3d_split_supported).  Weight image: rf_conv3_split_pack_weight -> rf_conv3_split_packed_bytes bytes. */
 size_t rf_conv3_split_packed_bytes(int cout, int cin);
 int rf_conv3_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream);

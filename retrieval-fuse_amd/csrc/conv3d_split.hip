@@ -30,11 +30,11 @@ constexpr float CS_ACT_SCALE = 1.0f / 16, CS_W_SCALE = 16.0f, CS_LO = 2048.0f;
 
 // ------------------------------------------------------------------------------------------------------------ weight image
 extern "C" size_t rf_conv3_split_packed_bytes(int cout, int cin) {
-    return ((size_t)(cin / 8) * 7 + 1) * (size_t)(rf_round_up(cout, 16) / 16) * 2 * 64 * 16;
+    return ((size_t)((cin + 7) / 8) * 7 + 1) * (size_t)(rf_round_up(cout, 16) / 16) * 2 * 64 * 16;
 }
 
 __global__ void k_conv3_split_pack(const float* __restrict__ w, int cout, int cin, int nb_count, h8* __restrict__ wp, size_t total) {
-    const size_t nreal = (size_t)(cin / 8) * 7 * nb_count * 128;
+    const size_t nreal = (size_t)((cin + 7) / 8) * 7 * nb_count * 128;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63), piece = (int)((i >> 6) & 1);
         const size_t f = i >> 7;
@@ -46,7 +46,7 @@ __global__ void k_conv3_split_pack(const float* __restrict__ w, int cout, int ci
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             double v = 0.0;
-            if (i < nreal && tap < 27 && co < cout) v = (double)w[((size_t)co * cin + ca * 8 + j) * 27 + tap];
+            if (i < nreal && tap < 27 && co < cout && ca * 8 + j < cin) v = (double)w[((size_t)co * cin + ca * 8 + j) * 27 + tap];   // channels past cin: zero
             v *= (double)CS_W_SCALE;
             v = v > 65504.0 ? 65504.0 : (v < -65504.0 ? -65504.0 : v);
             const _Float16 h = (_Float16)(float)v;
@@ -57,8 +57,7 @@ __global__ void k_conv3_split_pack(const float* __restrict__ w, int cout, int ci
 }
 
 extern "C" int rf_conv3_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream) {
-    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && cin > 0 && cin % 8 == 0, RF_E_INVALID,
-               "rf_conv3_split_pack_weight: needs cin in multiples of 8 (got %d)", cin);
+    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && cin > 0, RF_E_INVALID, "rf_conv3_split_pack_weight: bad arguments");
     const size_t total = rf_conv3_split_packed_bytes(cout, cin) / 16;
     const size_t want = (total + 255) / 256;
     hipLaunchKernelGGL(k_conv3_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin,
@@ -89,12 +88,14 @@ __device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
 }
 
 // ONE: the layer has a single 8-channel chunk (no prefetch of a next chunk, one chunk buffer)
-template <int NB, int WPS, bool ONE>
+// PADC: cin is not a multiple of 8 -- the last chunk's missing channels are staged as zeros (they re-read channel cin-1 with a zero affine
+// triple; their weights are zero too)
+template <int NB, int WPS, bool ONE, bool PADC>
 __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int edge = a.edge, cin = a.c0, nC = cin >> 3;
+    const int edge = a.edge, cin = a.c0, nC = (cin + 7) >> 3;
     const size_t vol = (size_t)edge * edge * edge;
 
     const unsigned lblock = rf_xcd_contiguous(blockIdx.x, gridDim.x);
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     const int n0 = t;
     const int cob = blockIdx.y * (NB * 16);
     const float4* __restrict__ aff = a.affine + (size_t)n0 * cin;
+    auto chan = [&](int c) { return PADC ? (c < cin ? c : cin - 1) : c; };                     // uniform
+    auto triple = [&](int c) { return (!PADC || c < cin) ? aff[c] : make_float4(0.f, 0.f, 0.f, 0.f); };
 
     // ---- staging: thread t owns halo voxels t and t + 512 (the second only for t < 488)
     int voff[2];
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[r][j] = s0[(size_t)(ca * 8 + j) * vol + voff[r]];
+            for (int j = 0; j < 8; ++j) x[r][j] = s0[(size_t)chan(ca * 8 + j) * vol + voff[r]];
     };
     auto stage_store = [&](const float (&x)[2][8], int ca, int buf) {      // zeros outside the volume (the padding of the NORMALISED tensor)
 #pragma unroll
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
             float y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float4 af = aff[ca * 8 + j];
+                const float4 af = triple(ca * 8 + j);
                 y[j] = vin[r] ? fmaf(x[r][j] - af.x, af.y, af.z) : 0.f;
             }
             h8 h, l;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
         float4 afn[ONE ? 1 : 8];
         if constexpr (!ONE) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) afn[j] = aff[cx * 8 + j];         // uniform: scalar loads, before the k-steps' LDS traffic
+            for (int j = 0; j < 8; ++j) afn[j] = triple(cx * 8 + j);      // uniform: scalar loads, before the k-steps' LDS traffic
         }
         auto xload = [&] { if constexpr (!ONE) stage_load(x, cx); };
         auto no_hook = [](int) {};
@@ -275,14 +278,15 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
 
 // -------------------------------------------------------------------------------------------------------------------- host
 extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout) {
-    if (c1 != 0 || c0 < 8 || c0 % 8 || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
+    // channel counts that are not multiples of 8 are padded up with zero channels: taken when at least 3/4 of the slots are real (12, 20, 28, 42 ...)
+    if (c1 != 0 || c0 < 8 || 4 * c0 < 3 * rf_round_up(c0, 8) || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
     const int cout16 = rf_round_up(cout, 16);
     return cout16 <= 32 && rf_conv_use_big(n, edge, cout16);
 }
 
-template <int NB, int WPS, bool ONE>
+template <int NB, int WPS, bool ONE, bool PADC = false>
 static int launch_split(const ConvArgs& a, hipStream_t stream) {
-    auto kern = k_conv3_split<NB, WPS, ONE>;
+    auto kern = k_conv3_split<NB, WPS, ONE, PADC>;
     const unsigned gx = (unsigned)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), ONE ? CS_BUF : CS_LDS_BYTES, stream, a);
     RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
@@ -292,7 +296,7 @@ static int launch_split(const ConvArgs& a, hipStream_t stream) {
 extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                            float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
     RF_REQUIRE(rf_conv3d_split_supported(cin, 0, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_split_k3_gn_relu: takes cin in multiples of 8, up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_split_k3_gn_relu: takes cin >= 8 (at least 3/4 of the next multiple of 8), up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
                cin, n, edge, cout);
     RF_REQUIRE(src && gn_affine && w_packed && (out || pool_out), RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: null pointer");
     RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: statistics of an output that is not written");
@@ -312,5 +316,6 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
     // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and
     // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
+    if (cin % 8) return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
 }

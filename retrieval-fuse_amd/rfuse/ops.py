@@ -321,8 +321,8 @@ def pack_conv3_split_weight(w):
     """f16 fragment-order weight image of the split-operand box conv (csrc/conv3d_split.hip)."""
     _req(w.detach(), 'conv weight')
     cout, cin = w.shape[0], w.shape[1]
-    if tuple(w.shape[2:]) != (3, 3, 3) or cin % 8:
-        raise ValueError('pack_conv3_split_weight: expected an OIDHW 3x3x3 weight with cin in multiples of 8, got %s' % (tuple(w.shape),))
+    if tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError('pack_conv3_split_weight: expected an OIDHW 3x3x3 weight, got %s' % (tuple(w.shape),))
     lib = _lib.load()
     out = torch.empty(lib.rf_conv3_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
     _lib.check(lib.rf_conv3_split_pack_weight(_p(w.detach()), cout, cin, _p(out), _stream()), 'rf_conv3_split_pack_weight')
@@ -369,7 +369,7 @@ def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
 def conv_split_issued_flops(cin, n, edge, cout):
     """f16 flop rf_conv3d_split_k3_gn_relu ISSUES: three MFMAs per k-step of 32, 7 k-steps (28 tap slots) per 8 input channels, on
     round_up(cout, 16) columns."""
-    return 2.0 * 3 * (cin // 8) * 7 * 32 * (-(-cout // 16) * 16) * edge ** 3 * n
+    return 2.0 * 3 * -(-cin // 8) * 7 * 32 * (-(-cout // 16) * 16) * edge ** 3 * n
 
 
 def pack_conv3_up_split_weight(w, c0):

@@ -175,6 +175,10 @@ SPLIT_BOX_CASES = [
     (3, 16, 64, 16, 8),        # final decoder: 512 boxes per sample
     (1040, 24, 8, 12, 6),      # nf = 12 family: cout < 16
     (33, 32, 32, 24, 8),
+    (1040, 12, 8, 12, 6),      # cin not a multiple of 8: the last chunk's missing channels are zero slots (nf = 12: C5's U-Net)
+    (1030, 42, 8, 12, 6),      # 42 -> 48 slots, six chunks
+    (3, 12, 64, 12, 6),        # C5's final decoder
+    (140, 20, 16, 24, 4),
 ]
 
 
