@@ -170,11 +170,9 @@ extern "C" int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int ci
 }
 
 // ------------------------------------------------------------------------------------------------------------------- kernel
-// workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence: it also waits for the epilogue's global
-// stores, and on gfx9 loads and stores retire through one in-order counter (vmcnt) -- any wait for a load requested after a store waits
-// for the store's acknowledgement too.  The epilogue therefore requests nothing: bias values are loaded before the MFMAs.
-__device__ __forceinline__ void vs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
+// On gfx9 loads and stores retire through ONE in-order counter (vmcnt): a wait for any load that was requested after a store also waits
+// for that store's acknowledgement from L2.  The epilogue therefore requests nothing -- bias values and the store tables are loaded before
+// the MFMAs, nothing may spill (a reload is a scratch load) -- and its stores stay in flight while the workgroup retires.
 template <int NB, int WPE>
 __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     constexpr int NT = VS_NT, MB = VS_MB, SB = VS_SB;
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     int eoff[4], ezy[4];                                            // epilogue: voxel m = lane + 64 i -> offset in the output window, (lz << 8) | ly
 #pragma unroll
     for (int i = 0; i < 4; ++i) { eoff[i] = hdr[a.ksteps * 8 + VS_M + lane + 64 * i]; ezy[i] = hdr[a.ksteps * 8 + 2 * VS_M + lane + 64 * i]; }
-    float bz[NB];                                                   // before any store (see vs_lds_barrier)
+    float bz[NB];                                                   // before any store (see above)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int co = (nb0 + nb) * 16 + j;
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     for (int nb = 0; nb < NB; ++nb) { bh[nb] = wl[nb * 128]; bl[nb] = wl[nb * 128 + 64]; }
 
     for (int c = 0; c < a.nchunk; ++c) {
-        vs_lds_barrier();                                           // tables written / everyone left the previous chunk
+        __syncthreads();                                           // tables written / everyone left the previous chunk
         {
             // SB items (4 channels each) in flight per thread, no branches around the loads.  Rows of a ragged last tile that lie outside
             // the volume (table entry < 0) read the channel's first value and are zeroed by their scale; tiles without such rows (nearly
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             for (int h = 0; h < 2; ++h)
                 if (tid + h * NT < a.ksteps * 8) poff[tid + h * NT] = pv[h];
         }
-        vs_lds_barrier();
+        __syncthreads();
         int2 po = *reinterpret_cast<const int2*>(poff + 2 * g);
         for (int q = 0; q < a.ksteps; ++q) {
             {   // next k-step's weights (the image has two k-steps of slack behind the last one)
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             po = pn;
         }
     }
-    vs_lds_barrier();                                               // the chunk image is dead: the epilogue tile aliases it
+    __syncthreads();                                               // the chunk image is dead: the epilogue tile aliases it
 
     // ---- epilogue: hi + lo / 2^11 (activation and weight scales cancel), bias, LeakyReLU; through LDS so that the stores are long
     // contiguous runs -- per cout block the 4 waves each stream four cout rows out, lane = consecutive voxel of the tile
@@ -356,7 +354,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             }
             *reinterpret_cast<f32x4*>(eb + j * VS_EV + (wave * MB + mb) * 16 + g * 4) = v;
         }
-        vs_lds_barrier();
+        __syncthreads();
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int col = wave * 4 + h, co = (nb0 + nb) * 16 + col;
@@ -368,7 +366,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
                     if (eoff[i] >= 0) o[eoff[i]] = src[64 * i];
             }
         }
-        if (nb + 1 < NB) vs_lds_barrier();                          // the next block's writers wait for these readers; the stores stay in flight
+        if (nb + 1 < NB) __syncthreads();                          // the next block's writers wait for these readers; the stores stay in flight
     }
 }
 
