@@ -377,21 +377,46 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
     for (int i = tid; i < 27 * 8; i += 256) wl[i] = (i % 8) < COUT ? a.wp[(size_t)(i / 8) * a.cin4 * a.cout16 + (i % 8)] : 0.f;   // packed [tap][ci=0][co]
     const float4 af = a.affine[nn];
     const float* src = a.src0 + (size_t)nn * edge * edge * edge;
-    for (int i = tid; i < HZ * HY * HX; i += 256) {
-        const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
-        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-        float v = 0.f;
-        if ((unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge)
-            v = fmaf(src[((size_t)z * edge + y) * edge + x] - af.x, af.y, af.z);
-        xs[i] = v;
+    const int x = tid % TX, y = tid / TX;
+    {
+        // halo tile: a thread loads its own (y, x) column, HZ values, and the first 2 (TY + TX + 2) threads one ring element per plane -- no
+        // div / mod chains (they were a quarter of the kernel's VALU instructions), all loads of a thread in flight at once (the rolled loop
+        // waited for each before it asked for the next).  Out-of-volume slots read the tile's first voxel and are zeroed afterwards.
+        constexpr int RING = 2 * (TY + TX + 2);
+        static_assert(RING <= 256, "one ring element per thread and plane");
+        int ry, rx;                                                  // ring element of this thread (tid < RING): halo-plane coordinates
+        if (tid < HX) { ry = 0; rx = tid; }
+        else if (tid < 2 * HX) { ry = HY - 1; rx = tid - HX; }
+        else { const int r = tid - 2 * HX; ry = 1 + (r >> 1); rx = (r & 1) * (HX - 1); }
+        const size_t first = ((size_t)z0 * edge + y0) * edge + x0;
+        float raw[HZ], rraw[HZ];
+        bool in[HZ], rin[HZ];
+#pragma unroll
+        for (int hz = 0; hz < HZ; ++hz) {
+            const int z = z0 + hz - 1;
+            const bool zin = (unsigned)z < (unsigned)edge;
+            in[hz] = zin;
+            raw[hz] = src[zin ? ((size_t)z * edge + (y0 + y)) * edge + (x0 + x) : first];
+            const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+            rin[hz] = tid < RING && zin && (unsigned)gy < (unsigned)edge && (unsigned)gx < (unsigned)edge;
+            rraw[hz] = src[rin[hz] ? ((size_t)z * edge + gy) * edge + gx : first];
+        }
+#pragma unroll
+        for (int hz = 0; hz < HZ; ++hz) {
+            xs[(hz * HY + y + 1) * HX + x + 1] = in[hz] ? fmaf(raw[hz] - af.x, af.y, af.z) : 0.f;
+            if (tid < RING) xs[(hz * HY + ry) * HX + rx] = rin[hz] ? fmaf(rraw[hz] - af.x, af.y, af.z) : 0.f;
+        }
     }
     __syncthreads();
-    const int x = tid % TX, y = tid / TX;
-    float acc[TZ][COUT];
+    // cout PAIRS per accumulator register pair: v_pk_fma_f32 (two fp32 FMAs per lane and issue -- the 157 TFLOP/s vector peak is the packed
+    // rate); per output the taps are still accumulated one by one in (dy, dx, dz) order, each with a single rounding
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int CP = (COUT + 1) / 2;
+    f32x2 acc2[TZ][CP];
 #pragma unroll
     for (int z = 0; z < TZ; ++z)
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[z][co] = 0.f;
+        for (int cp = 0; cp < CP; ++cp) acc2[z][cp] = (f32x2){0.f, 0.f};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -403,13 +428,20 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
             for (int dz = 0; dz < 3; ++dz) {
                 const float4 w0 = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8);
                 const float4 w1 = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8 + 4);
-                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                const f32x2 wv[4] = {(f32x2){w0.x, w0.y}, (f32x2){w0.z, w0.w}, (f32x2){w1.x, w1.y}, (f32x2){w1.z, w1.w}};
 #pragma unroll
-                for (int z = 0; z < TZ; ++z)
+                for (int z = 0; z < TZ; ++z) {
+                    const f32x2 c2 = (f32x2){col[z + dz], col[z + dz]};
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co) acc[z][co] = fmaf(col[z + dz], wv[co], acc[z][co]);
+                    for (int cp = 0; cp < CP; ++cp) acc2[z][cp] = __builtin_elementwise_fma(c2, wv[cp], acc2[z][cp]);
+                }
             }
         }
+    float acc[TZ][COUT];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[z][co] = acc2[z][co >> 1][co & 1];
     const size_t vol = (size_t)edge * edge * edge;
 #pragma unroll
     for (int z = 0; z < TZ; ++z) {
@@ -418,23 +450,44 @@ __global__ __launch_bounds__(256) void k_conv3_cin1(ConvArgs a) {
         for (int co = 0; co < COUT; ++co) o[co * vol] = fmaxf(acc[z][co], 0.f);
     }
     if (a.stats) {
-        __shared__ double red[4 * 8 * 2];
+        // per (wave, cout) sums of the ReLU'd outputs in float64.  The 16 values of a lane (sum and sum of squares of 8 couts) are reduced over
+        // the wave by recursive halving: at step k a lane keeps half of its values and hands the other half to lane ^ (1 << k) -- 17 value
+        // exchanges instead of 16 x 6 (the per-value butterflies were a quarter of the kernel's instructions); fixed order, no atomics
+        __shared__ double red[4 * 16];
         const int lane = tid & 63, wave = tid >> 6;
+        double v[16];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) {
+        for (int co = 0; co < 8; ++co) {
             double sm = 0.0, sq = 0.0;
+            if (co < COUT) {
 #pragma unroll
-            for (int z = 0; z < TZ; ++z) {
-                const double v = (double)fmaxf(acc[z][co], 0.f);
-                sm += v; sq += v * v;
+                for (int z = 0; z < TZ; ++z) {
+                    const double t = (double)fmaxf(acc[z][co], 0.f);
+                    sm += t; sq += t * t;
+                }
             }
-            sm = wave_sum(sm); sq = wave_sum(sq);
-            if (lane == 0) { red[(wave * 8 + co) * 2] = sm; red[(wave * 8 + co) * 2 + 1] = sq; }
+            v[2 * co] = sm; v[2 * co + 1] = sq;
         }
+        auto halve = [&](auto kc) {
+            constexpr int K = decltype(kc)::value, C = 8 >> K;
+            const bool up = (lane >> K) & 1;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const double send = up ? v[i] : v[i + C], keep = up ? v[i + C] : v[i];
+                v[i] = keep + __shfl_xor(send, 1 << K, 64);
+            }
+        };
+        halve(std::integral_constant<int, 0>{});
+        halve(std::integral_constant<int, 1>{});
+        halve(std::integral_constant<int, 2>{});
+        halve(std::integral_constant<int, 3>{});
+        v[0] += __shfl_xor(v[0], 16, 64);
+        v[0] += __shfl_xor(v[0], 32, 64);
+        if (lane < 16) red[wave * 16 + ((lane & 1) * 8 + ((lane >> 1) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1))] = v[0];
         __syncthreads();
         if (tid < COUT) {
             double sm = 0.0, sq = 0.0;
-            for (int w = 0; w < 4; ++w) { sm += red[(w * 8 + tid) * 2]; sq += red[(w * 8 + tid) * 2 + 1]; }
+            for (int w = 0; w < 4; ++w) { sm += red[w * 16 + 2 * tid]; sq += red[w * 16 + 2 * tid + 1]; }
             const int tile = (int)(lblock % (tx * ty * tz));
             a.stats[((size_t)nn * COUT + tid) * a.stats_tiles + tile] = make_double2(sm, sq);
         }
