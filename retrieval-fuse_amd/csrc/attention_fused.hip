@@ -294,7 +294,7 @@ __device__ __forceinline__ void ams_split4(const f32x4& v, am_h8& h, am_h8& l, i
         const float x = __builtin_amdgcn_fmed3f(v[e] * AMS_ACT, -65504.f, 65504.f);
         const _Float16 hh = (_Float16)x;
         h[o + e] = hh;
-        l[o + e] = (_Float16)((x - (float)hh) * AMS_LO);
+        l[o + e] = (_Float16)fmaf(-AMS_LO, (float)hh, x * AMS_LO);      // (x - h) * 2^11: exact either way, one v_fma_mix instead of cvt + sub + mul
     }
 }
 

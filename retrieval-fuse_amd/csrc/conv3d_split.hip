@@ -73,7 +73,7 @@ __device__ __forceinline__ void cs_split8(const float (&y)[8], h8& h, h8& l) {
         const float v = __builtin_amdgcn_fmed3f(y[j] * CS_ACT_SCALE, -65504.f, 65504.f);
         const _Float16 hh = (_Float16)v;
         h[j] = hh;
-        l[j] = (_Float16)((v - (float)hh) * CS_LO);
+        l[j] = (_Float16)fmaf(-CS_LO, (float)hh, v * CS_LO);          // (v - h) * 2^11: exact either way, one v_fma_mix instead of cvt + sub + mul
     }
 }
 
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
                     const float v = __builtin_amdgcn_fmed3f(y * CS_ACT_SCALE, -65504.f, 65504.f);
                     const _Float16 hh = (_Float16)v;
                     hq[r][j] = hh;
-                    lq[r][j] = (_Float16)((v - (float)hh) * CS_LO);
+                    lq[r][j] = (_Float16)fmaf(-CS_LO, (float)hh, v * CS_LO);
                 }
             };
             if (s == 0) kstep(std::true_type{}, xload, no_hook, ap, buf + atap[s + 1], ch, cl, nh, nl);

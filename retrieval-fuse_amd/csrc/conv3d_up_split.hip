@@ -129,7 +129,7 @@ __device__ __forceinline__ void us_split8(const float (&y)[8], h8& h, h8& l) {
         const float v = __builtin_amdgcn_fmed3f(y[j] * US_ACT_SCALE, -65504.f, 65504.f);
         const _Float16 hh = (_Float16)v;
         h[j] = hh;
-        l[j] = (_Float16)((v - (float)hh) * US_LO);
+        l[j] = (_Float16)fmaf(-US_LO, (float)hh, v * US_LO);          // (v - h) * 2^11: exact either way, one v_fma_mix instead of cvt + sub + mul
     }
 }
 
