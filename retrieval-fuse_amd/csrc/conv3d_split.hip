@@ -276,8 +276,115 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     conv_box_epilogue<8, 8, 8, 1, 8, 4, NB, (size_t)CS_LDS_BYTES>(a, acc, reinterpret_cast<float*>(lds), tid, lane, wave, n0, z0, y0, x0, cob, lblock);
 }
 
+// ---------------------------------------------------------------------------------------------------------- 4^3 volumes
+// The same layer on whole 4^3 samples (the retrieval backbone's third level, n = B*K*64 patches): 8 samples per workgroup, wave w = sample
+// w, m-block = one z-plane (16 voxels), so the accumulator tiles are in the plain (sample, z, y, x) order of conv_box.h and its epilogue
+// applies.  LDS image: 8 halo cubes of 6^3 16-byte slots (8 channels of a voxel), h and l plane; the ring of every cube is the zero padding
+// of the normalised tensor and is written once.  A thread stages ONE voxel per chunk (8 channel loads, requested before the previous
+// chunk's MFMAs), so the staging is a tenth of the 8^3 box kernel's per MFMA.  42 % of the (voxel, tap) pairs of a 4^3 volume read
+// padding: the position-major fp32 kernel (conv3d_small.hip) issues none of them, this one issues them as zeros except where a whole
+// (z-plane, k-step) is padding -- at 3 x 16 cycles per k-step against 8 x 32 that still leaves the F16 pipe 2.5x ahead.
+namespace {
+constexpr int S4_SLOTS = 8 * 216;
+constexpr int S4_PLANE = S4_SLOTS * 16;                          // 27,648 bytes
+constexpr int S4_LDS_BYTES = 2 * S4_PLANE;                       // 55,296: one chunk image; two workgroups per CU
+}   // namespace
+
+__global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // the wave's allocation is pinned at 128 VGPRs: four waves per SIMD then fill the register file and no wave of another stream's fp32-MFMA
+    // kernel can share the SIMD with this kernel's F16 MFMAs
+    asm volatile("" ::: "v127");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cin = a.c0, nC = cin >> 3;
+    const unsigned lblock = rf_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int n0 = (int)lblock * 8;
+    const int cob = blockIdx.y * 16;
+    const int ns = n0 + wave < a.n ? n0 + wave : a.n - 1;         // ragged last group: re-reads the last sample, the epilogue masks its stores
+    const float4* __restrict__ aff = a.affine + (size_t)ns * cin;
+    const float* __restrict__ s0 = a.src0 + (size_t)ns * cin * 64 + lane;             // this thread's voxel (z, y, x) = (lane >> 4, (lane >> 2) & 3, lane & 3)
+    unsigned char* const myslot = lds + (wave * 216 + ((lane >> 4) + 1) * 36 + (((lane >> 2) & 3) + 1) * 6 + (lane & 3) + 1) * 16;
+
+    auto stage_load = [&](float (&x)[8], int ca) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(ca * 8 + j) * 64];
+    };
+    auto stage_store = [&](const float (&x)[8], int ca) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 af = aff[ca * 8 + j];                      // wave-uniform: scalar loads
+            y[j] = fmaf(x[j] - af.x, af.y, af.z);
+        }
+        h8 h, l;
+        cs_split8(y, h, l);
+        *reinterpret_cast<h8*>(myslot) = h;
+        *reinterpret_cast<h8*>(myslot + S4_PLANE) = l;
+    };
+
+    float xr[8];
+    stage_load(xr, 0);
+    for (int i = tid; i < S4_LDS_BYTES / 16; i += 512) *reinterpret_cast<float4*>(lds + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // operand addressing: row i of m-block m = voxel (z = m, y = i >> 2, x = i & 3) of sample `wave`; lane group g supplies tap 4 s + g
+    const int g = lane >> 4, ri = lane & 15;
+    const unsigned char* const abase = lds + (wave * 216 + 36 + ((ri >> 2) + 1) * 6 + (ri & 3) + 1) * 16;
+    int atap[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int tp = 4 * s + g < 27 ? 4 * s + g : 26;             // tap 27: zero weights
+        atap[s] = ((tp / 9 - 1) * 36 + ((tp / 3) % 3 - 1) * 6 + (tp % 3 - 1)) * 16;
+    }
+    f32x4 hi[4][1], lo[4][1];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { hi[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int nbt = a.cout16 >> 4;
+    const h8* __restrict__ wn = reinterpret_cast<const h8*>(a.wp) + (size_t)blockIdx.y * 128 + lane;       // next k-step to fetch
+    const int wstep = nbt * 128;
+    h8 bh[1], bl[1], nh[1], nl[1];
+    bh[0] = wn[0]; bl[0] = wn[64];
+    wn += wstep;
+    __syncthreads();                                                // the zero fill is complete
+    stage_store(xr, 0);
+    __syncthreads();
+
+    for (int ca = 0; ca < nC; ++ca) {
+        const bool more = ca + 1 < nC;
+        if (more) stage_load(xr, ca + 1);                           // lands under this chunk's MFMAs
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            nh[0] = wn[0]; nl[0] = wn[64];                          // next k-step's weights (the image has one k-step of slack)
+            wn += wstep;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if ((m == 0 && s < 2) || (m == 3 && s >= 5)) continue;      // every tap of the k-step reads the plane below / above the volume: zeros
+                const h8 ah = *reinterpret_cast<const h8*>(abase + m * 576 + atap[s]);
+                const h8 al = *reinterpret_cast<const h8*>(abase + m * 576 + atap[s] + S4_PLANE);
+                cs_mfma_block<1>(hi[m], lo[m], ah, al, bh, bl);
+            }
+            bh[0] = nh[0]; bl[0] = nl[0];
+        }
+        __syncthreads();                                            // everyone left the image
+        if (more) {
+            stage_store(xr, ca + 1);
+            __syncthreads();
+        }
+    }
+
+    f32x4 acc[4][1];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][0][r] = fmaf(lo[m][0][r], 1.0f / CS_LO, hi[m][0][r]);
+    conv_box_epilogue<4, 4, 4, 8, 8, 4, 1, (size_t)S4_LDS_BYTES>(a, acc, reinterpret_cast<float*>(lds), tid, lane, wave, n0, 0, 0, 0, cob, lblock);
+}
+
 // -------------------------------------------------------------------------------------------------------------------- host
 extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout) {
+    // whole 4^3 samples (8 per workgroup, k_conv3_split_s4): cin in eights, any cout (16 per workgroup), enough samples to fill the chip
+    if (edge == 4) return c1 == 0 && c0 >= 8 && c0 % 8 == 0 && n >= 1024 && cout > 0;
     // channel counts that are not multiples of 8 are padded up with zero channels: taken when at least 3/4 of the slots are real (12, 20, 28, 42 ...)
     if (c1 != 0 || c0 < 8 || 4 * c0 < 3 * rf_round_up(c0, 8) || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
     const int cout16 = rf_round_up(cout, 16);
@@ -305,7 +412,7 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     a.src0 = src; a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const float*>(w_packed); a.out = out;
     a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = rf_round_up(cout, 16);
     a.stats = reinterpret_cast<double2*>(stats);
-    a.stats_tiles = (stats || pool_stats) ? (edge / 8) * (edge / 8) * (edge / 8) : 0;
+    a.stats_tiles = (stats || pool_stats) ? (edge == 4 ? 1 : (edge / 8) * (edge / 8) * (edge / 8)) : 0;
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
     a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
     a.floor = 0.f;
@@ -316,6 +423,12 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
     // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and
     // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
+    if (edge == 4) {
+        RF_REQUIRE(!pool_out, RF_E_UNSUPPORTED, "rf_conv3d_split_k3_gn_relu: the 4^3 form has no fused max-pool (pool its output with rf_maxpool3d_2_stats)");
+        hipLaunchKernelGGL(k_conv3_split_s4, dim3((unsigned)((n + 7) / 8), (unsigned)(a.cout16 / 16)), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
+        return RF_OK;
+    }
     if (cin % 8) return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
 }

@@ -341,11 +341,14 @@ def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
     """ReLU(conv3(GN(src))) on the F16 matrix cores by operand splitting.  pool: None -> out; 'also' -> (out, maxpool2(out));
     'only' -> (None, maxpool2(out)) with the full-resolution tensor never written.  Statistics of what is written ride along."""
     n, cin, _, edge = _src_dims(src, None)
+    if edge == 4 and pool is not None:                             # the 4^3 form has no fused max-pool: pool its output (statistics ride along)
+        out = conv3d_split_gn_relu(src, aff, w_split_packed, cout)
+        return (out if pool == 'also' else None), maxpool2(out)
     dev = _check_affine(aff, n, cin)
     lib = _lib.load()
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if pool != 'only' else None
     pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev) if pool is not None else None
-    tiles = (edge // 8) ** 3
+    tiles = max(1, (edge // 8) ** 3)
     stats = pstats = None
     if USE_FUSED_STATS:
         stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if out is not None else None
