@@ -342,8 +342,219 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- 4^3 volumes
+// The decoder form on whole 4^3 samples (retrieval backbone dec0: 64 skip channels @4^3 + 128 channels upsampled from 2^3 -> 64): 8 samples
+// per workgroup, wave = output parity (pz, py, px) as above, m-block m = the parity class (8 voxels each) of samples 2m and 2m + 1, 16 couts
+// per workgroup (grid.y).  Phase A (skip channels, 27 taps): 8 halo cubes of 6^3 slots, one voxel staged per thread and chunk.  Phase B
+// (upsampled channels, the 8 pre-summed low-res taps of the weight image's B region): 8 halo cubes of 4^3 slots per chunk, four chunks
+// staged at a time into the same LDS (the phase-A image is dead by then).  Epilogue through an LDS tile [cout][sample][64] as above.
+namespace {
+constexpr int U4_ASLOTS = 8 * 216, U4_A_PLANE = U4_ASLOTS * 16;           // 27,648
+constexpr int U4_BSLOTS = 8 * 64, U4_B_PLANE = U4_BSLOTS * 16;            // 8,192 per chunk and piece
+constexpr int U4_BG = 4;                                                  // phase-B chunks staged together
+constexpr int U4_E_STRIDE = 516;
+constexpr int U4_LDS_BYTES = 32 * U4_E_STRIDE * 4;                        // 66,048 (epilogue tile) >= 2 * U4_A_PLANE, >= U4_BG * 2 * U4_B_PLANE
+static_assert(2 * U4_A_PLANE <= U4_LDS_BYTES && U4_BG * 2 * U4_B_PLANE <= U4_LDS_BYTES, "images must fit the epilogue tile's LDS");
+}   // namespace
+
+// PRE: weight fragments one k-step ahead in a second register set
+template <int NB, bool PRE>
+__global__ __launch_bounds__(512, 4) void k_conv3_up_split_s4(UpSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    asm volatile("" ::: "v127");                                    // allocation pinned at 128 VGPRs: four waves per SIMD fill the register file
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3;
+    const int n0 = blockIdx.x * 8;
+    const int nbt = (a.cout + 15) >> 4, nb0 = blockIdx.y * NB;
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    const int g = lane >> 4, ri = lane & 15;
+
+    auto zero_lds = [&](int bytes) {
+        for (int i = tid; i < bytes / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    };
+
+    f32x4 hi[4][NB], lo[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // weight fragments: A region [chunk][7 steps][nbt][h|l][64], B region of this parity [chunk][2 steps][nbt][h|l][64]; one k-step ahead
+    const int wstep = nbt * 128;
+    const h8* const wA = a.wp + (size_t)nb0 * 128 + lane;
+    const h8* const wB = wA + ((size_t)nA * 7 + (size_t)wave * nB * 2) * wstep;
+    const int TA = nA * 7;
+    auto wptr = [&](int t) { return t < TA ? wA + (size_t)t * wstep : wB + (size_t)(t - TA) * wstep; };   // t == TA + TB: the next parity's region / the slack step
+    h8 bh[NB], bl[NB], nh[NB], nl[NB];
+    auto load_b = [&](int t, h8 (&h)[NB], h8 (&l)[NB]) {
+        const h8* p = wptr(t);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { h[nb] = p[nb * 128]; l[nb] = p[nb * 128 + 64]; }
+    };
+    load_b(0, bh, bl);
+    int t = 0;                                                      // k-step counter over both phases
+
+    // ---------------------------------------------------------------- phase A
+    {
+        const int sw = tid >> 6;                                    // staging: this thread's voxel `lane` of sample sw
+        const int ns = n0 + sw < a.n ? n0 + sw : a.n - 1;           // ragged last group: re-reads the last sample, its stores are masked
+        const float4* __restrict__ aff = a.affine + (size_t)ns * cin;
+        const float* __restrict__ s0 = a.src0 + (size_t)ns * c0 * 64 + lane;
+        unsigned char* const myslot = lds + (sw * 216 + ((lane >> 4) + 1) * 36 + (((lane >> 2) & 3) + 1) * 6 + (lane & 3) + 1) * 16;
+        auto stage_load = [&](float (&x)[8], int ca) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(ca * 8 + j) * 64];
+        };
+        auto stage_store = [&](const float (&x)[8], int ca) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 af = aff[ca * 8 + j];
+                y[j] = fmaf(x[j] - af.x, af.y, af.z);
+            }
+            h8 h, l;
+            us_split8(y, h, l);
+            *reinterpret_cast<h8*>(myslot) = h;
+            *reinterpret_cast<h8*>(myslot + U4_A_PLANE) = l;
+        };
+        // row ri of m-block m: sample 2m + (ri >> 3), parity-class voxel j = ri & 7 -> (z, y, x) = (2 (j >> 2) + pz, 2 ((j >> 1) & 1) + py, 2 (j & 1) + px)
+        const int j = ri & 7;
+        const unsigned char* const abase = lds + ((ri >> 3) * 216 + (2 * (j >> 2) + pz + 1) * 36 + (2 * ((j >> 1) & 1) + py + 1) * 6 + 2 * (j & 1) + px + 1) * 16;
+        auto tapoff = [](int tp) { return ((tp / 9 - 1) * 36 + ((tp / 3) % 3 - 1) * 6 + (tp % 3 - 1)) * 16; };       // tap 27: zero weights, reads tap 26
+        float xr[8];
+        if (nA) stage_load(xr, 0);
+        zero_lds(2 * U4_A_PLANE);                                   // the rings are the zero padding and are written once
+        __syncthreads();
+        if (nA) stage_store(xr, 0);
+        __syncthreads();
+        for (int ca = 0; ca < nA; ++ca) {
+            const bool more = ca + 1 < nA;
+            if (more) stage_load(xr, ca + 1);
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                if constexpr (PRE) load_b(++t, nh, nl);
+                else if (t++ > 0) load_b(t - 1, bh, bl);
+                // the lane group's tap offset of this k-step: four compile-time constants, selected by g (7 registers less than a table)
+                const int o01 = g & 1 ? tapoff(4 * s + 1) : tapoff(4 * s), o23 = g & 1 ? tapoff(4 * s + 3 < 27 ? 4 * s + 3 : 26) : tapoff(4 * s + 2);
+                const int at = g & 2 ? o23 : o01;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const h8 ah = *reinterpret_cast<const h8*>(abase + m * (2 * 216 * 16) + at);
+                    const h8 al = *reinterpret_cast<const h8*>(abase + m * (2 * 216 * 16) + at + U4_A_PLANE);
+                    us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
+                }
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                stage_store(xr, ca + 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- phase B: [chunk in group][sample][4^3 halo cube], h and l plane per chunk
+    {
+        // staging item (thread < 64 * U4_BG): chunk-in-group tid >> 6, sample (tid >> 3) & 7, low-res voxel tid & 7
+        const int scg = tid >> 6, ssm = (tid >> 3) & 7, sv = tid & 7;
+        const int ns = n0 + ssm < a.n ? n0 + ssm : a.n - 1;
+        const float4* __restrict__ aff = a.affine + (size_t)ns * cin + c0;
+        const float* __restrict__ s1 = a.src1 + (size_t)ns * c1 * 8 + sv;
+        unsigned char* const myslot = lds + scg * 2 * U4_B_PLANE + (ssm * 64 + ((sv >> 2) + 1) * 16 + (((sv >> 1) & 1) + 1) * 4 + (sv & 1) + 1) * 16;
+        // row (sample 2m + (ri >> 3), q = ri & 7), k-step tz, lane group (ty, tx): low-res halo voxel (qz + tz + pz, qy + ty + py, qx + tx + px)
+        const int q = ri & 7;
+        const unsigned char* const bbase = lds + ((ri >> 3) * 64 + ((q >> 2) + pz) * 16 + (((q >> 1) & 1) + py + (g >> 1)) * 4 + (q & 1) + px + (g & 1)) * 16;
+        zero_lds(U4_BG * 2 * U4_B_PLANE);                           // (phase A ended on a barrier)
+        __syncthreads();
+        for (int cb0 = 0; cb0 < nB; cb0 += U4_BG) {
+            const int ng = nB - cb0 < U4_BG ? nB - cb0 : U4_BG;
+            if (cb0) __syncthreads();                               // everyone left the previous group
+            if (scg < ng) {
+                float y[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float4 af = aff[(cb0 + scg) * 8 + jj];
+                    y[jj] = fmaf(s1[(size_t)((cb0 + scg) * 8 + jj) * 8] - af.x, af.y, af.z);
+                }
+                h8 h, l;
+                us_split8(y, h, l);
+                *reinterpret_cast<h8*>(myslot) = h;
+                *reinterpret_cast<h8*>(myslot + U4_B_PLANE) = l;
+            }
+            __syncthreads();
+            for (int cg = 0; cg < ng; ++cg) {
+#pragma unroll
+                for (int tz = 0; tz < 2; ++tz) {
+                    if constexpr (PRE) load_b(++t, nh, nl);
+                    else if (t++ > 0) load_b(t - 1, bh, bl);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const unsigned char* p = bbase + cg * 2 * U4_B_PLANE + m * (2 * 64 * 16) + tz * (16 * 16);
+                        const h8 ah = *reinterpret_cast<const h8*>(p);
+                        const h8 al = *reinterpret_cast<const h8*>(p + U4_B_PLANE);
+                        us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
+                    }
+                    if constexpr (PRE) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- epilogue: relu(hi + lo / 2^11) -> LDS tile [cout][sample][64] -> float4 rows
+    float* e = reinterpret_cast<float*>(lds);
+    {
+        const int col = lane & 15;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * g + r, sm = 2 * m + (row >> 3), jq = row & 7;
+                    const int lin = sm * 64 + (2 * (jq >> 2) + pz) * 16 + (2 * ((jq >> 1) & 1) + py) * 4 + 2 * (jq & 1) + px;
+                    e[(nb * 16 + col) * U4_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
+                }
+    }
+    __syncthreads();
+    const int cout = a.cout, cob = nb0 * 16;
+    for (int qd = tid; qd < NB * 16 * 128; qd += 512) {             // (cout, sample, float4): 16 float4 per (cout, sample)
+        const int co = qd >> 7, sm = (qd >> 4) & 7, l4 = qd & 15;
+        if (cob + co < cout && n0 + sm < a.n)
+            *reinterpret_cast<float4*>(a.out + ((size_t)(n0 + sm) * cout + cob + co) * 64 + l4 * 4) =
+                *reinterpret_cast<const float4*>(e + co * U4_E_STRIDE + sm * 64 + l4 * 4);
+    }
+    if (a.stats) {
+        // per (cout, sample): two threads sum 32 values each (float64), then the two partial sums
+        const int co = tid >> 4, sm = (tid >> 1) & 7, part = tid & 1;
+        double s = 0.0, sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (co >= NB * 16) break;
+            const float4 v = *reinterpret_cast<const float4*>(e + co * U4_E_STRIDE + sm * 64 + (part * 8 + i) * 4);
+            s += (double)v.x; sq += (double)v.x * v.x;
+            s += (double)v.y; sq += (double)v.y * v.y;
+            s += (double)v.z; sq += (double)v.z * v.z;
+            s += (double)v.w; sq += (double)v.w * v.w;
+        }
+        s += __shfl_xor(s, 1, 64); sq += __shfl_xor(sq, 1, 64);
+        if (part == 0 && co < NB * 16 && cob + co < cout && n0 + sm < a.n) a.stats[(size_t)(n0 + sm) * cout + cob + co] = make_double2(s, sq);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------------------------- host
 extern "C" int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int cout) {
+    // whole 4^3 samples (k_conv3_up_split_s4): 8 per workgroup, 32 couts per workgroup
+    if (edge == 4) return n >= 1024 && c0 >= 0 && c1 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && cout > 0;
     if (edge != 8 || n < 256 || c0 < 0 || c1 <= 0 || c0 % 8 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0) return 0;
     const int nb = rf_round_up(cout, 16) / 16;
     return nb == 3 || nb == 4;
@@ -362,11 +573,21 @@ static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
 extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                               const void* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256), c0 and c1 in multiples of 8, c1 <= 64, 33..64 couts (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts) or 4^3 samples (n >= 1024, couts in 32s), c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
                c0, c1, n, edge, cout);
     RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu: null pointer");
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = out; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    if (edge == 4) {
+        static RfLdsOptIn opt_in;
+        // 16 couts per workgroup: the 32-cout instance needs more than the 128 VGPRs that four waves per SIMD allow (35-45 spills) and was
+        // no faster (629-641 us against 610 on dec0)
+        if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_conv3_up_split_s4<1, true>), U4_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+        hipLaunchKernelGGL((k_conv3_up_split_s4<1, true>), dim3((unsigned)((n + 7) / 8), (unsigned)(rf_round_up(cout, 16) / 16)), dim3(512), U4_LDS_BYTES,
+                           (hipStream_t)stream, a);
+        RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
+        return RF_OK;
+    }
     return rf_round_up(cout, 16) == 48 ? launch_up_split<3>(a, (hipStream_t)stream) : launch_up_split<4>(a, (hipStream_t)stream);
 }

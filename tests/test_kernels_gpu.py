@@ -265,6 +265,10 @@ SPLIT_UP_CASES = [
     (257, 0, 16, 8, 64, 8),     # no skip source
     (260, 8, 8, 8, 33, 4),      # one chunk each
     (515, 40, 64, 8, 64, 8),    # five skip chunks, full couts
+    (1030, 64, 128, 4, 64, 8),  # whole 4^3 samples (k_conv3_up_split_s4): retrieval backbone dec0, ragged sample count, four groups of low-res chunks
+    (1024, 0, 16, 4, 32, 8),    # no skip source, one partial group
+    (2050, 8, 8, 4, 60, 4),     # one chunk each, padded couts
+    (1100, 32, 72, 4, 32, 8),   # nine low-res chunks: groups of 4 + 4 + 1
 ]
 
 
