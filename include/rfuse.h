@@ -181,8 +181,8 @@ int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1
  * products, fp32 accumulation in two separate accumulators, combined once.  Same inputs, outputs, statistics layout (one tile per
  * sample) and arithmetic contract as rf_conv3d_up_k3_gn_relu -- measured rounding error against float64 is half that of the
  * fp32 MFMA chain (tools/micro/split_probe.hip) at three 16-cycle MFMAs per 8192 multiply-adds instead of eight 32-cycle ones.
- * Takes whole 8^3 samples (edge == 8, n >= 256), c0 and c1 in multiples of 8, c1 <= 64, 33..64 couts
- * (rf_conv3d_up_split_supported).  Weight image: rf_conv3_up_split_pack_weight -> rf_conv3_up_split_packed_bytes bytes
+ * Takes whole 8^3 samples (edge == 8, n >= 256), c0 and c1 in multiples of 8, c1 <= 64, 33..64 couts, or whole 4^3 samples
+ * (edge == 4, n >= 1024, c0 and c1 in multiples of 8, any cout) (rf_conv3d_up_split_supported).  Weight image: rf_conv3_up_split_pack_weight -> rf_conv3_up_split_packed_bytes bytes
  * (f16 fragment order, pre-sums in float64 and split from the float64 value). */
 size_t rf_conv3_up_split_packed_bytes(int cout, int c0, int c1);
 int rf_conv3_up_split_pack_weight(const float* w_oidhw, int cout, int c0, int c1, void* w_packed, void* stream);
@@ -194,8 +194,8 @@ int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, 
  * rf_conv3d_up_split_k3_gn_relu above), 8^3 output boxes, one full-resolution source.  out / stats / pool_out / pool_stats as in
  * rf_conv3d_k3_gn_relu_pool (pool_out NULL: no pooling; out NULL: pooled tensor only); statistics tiles per sample: (edge/8)^3 =
  * rf_conv3d_stats_tiles of the same shape.  Takes cin >= 8 (channel counts between multiples of 8 are padded with zero slots and
- * taken when at least 3/4 of the slots are real: 12, 20, 28, 42 ...), up to 32 couts, edge >= 8, and enough boxes
- * (rf_conv3d_split_supported).  Weight image: rf_conv3_split_pack_weight -> rf_conv3_split_packed_bytes bytes. */
+ * taken when at least 3/4 of the slots are real: 12, 20, 28, 42 ...), up to 32 couts, edge >= 8, and enough boxes; also whole 4^3
+ * samples (n >= 1024, cin in eights, any cout, no fused max-pool: pool_out must be NULL) (rf_conv3d_split_supported).  Weight image: rf_conv3_split_pack_weight -> rf_conv3_split_packed_bytes bytes. */
 size_t rf_conv3_split_packed_bytes(int cout, int cin);
 int rf_conv3_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream);
 int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout);
