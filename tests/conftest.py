@@ -30,7 +30,8 @@ def golden_dir():
 def poison_gpu_memory(request):
     """Before every GPU test: fill the caching allocator's free memory with NaN bit patterns, so that `torch.empty` workspaces and
     outputs start as garbage, not as the zeros a fresh process usually sees -- a kernel that reads something it never wrote then
-    fails every time instead of once in a blue moon (when the VRAM still holds another process's data)."""
+    fails every time instead of once in a blue moon (when the VRAM still holds another process's data).  The LDS of every CU and the
+    vector register files get the same treatment (rf_debug_poison_lds / rf_debug_poison_vgprs): neither is cleared between kernels."""
     if 'gpu' not in request.keywords:
         yield
         return
@@ -47,5 +48,6 @@ def poison_gpu_memory(request):
         del blocks                                                      # back to the allocator's cache, contents intact
         from rfuse import _lib
         _lib.check(_lib.load().rf_debug_poison_lds(None), 'rf_debug_poison_lds')       # and NaNs in the LDS of every CU
+        _lib.check(_lib.load().rf_debug_poison_vgprs(None), 'rf_debug_poison_vgprs')   # and in the vector register files (not cleared at wave launch)
         torch.cuda.synchronize()
     yield
