@@ -147,6 +147,9 @@ __device__ __forceinline__ void us_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
 template <int NB>
 __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // allocation pinned at 256 VGPRs (the NB 3 instance needs 202): the workgroup's two waves per SIMD then fill the register file and no
+    // wave of another stream's fp32-MFMA kernel can run interleaved with this kernel's F16 MFMAs
+    if constexpr (NB == 3) asm volatile("" ::: "v255");             // (NB 4 uses 254 of them anyway)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
