@@ -417,8 +417,8 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
     a.floor = 0.f;
     // 32 couts run as two 16-cout workgroups per box (grid.y = 2).  A 2-n-block instance (158 VGPRs, one workgroup per CU) was 15 % faster
-    // on its own but left room for other kernels' waves on its SIMDs -- and an fp32 MFMA chain of another stream returns slightly different
-    // bits when F16 MFMAs are interleaved with it on the same SIMD (tools/hazard_probe.py); the 16-cout instance fills the
+    // on its own but left room for other kernels' waves on its SIMDs -- and the fp32 conv kernels of another stream return slightly different
+    // bits when a kernel issuing F16 MFMAs shares their SIMD (tools/hazard_probe.py); the 16-cout instance fills the
     // register file with its own four waves per SIMD.
     // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
     // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and

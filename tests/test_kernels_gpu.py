@@ -229,8 +229,8 @@ def test_conv3d_split_operand_box_kernel(ops, case):
 @pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (8, 16)])
 def test_split_box_kernel_leaves_concurrent_kernels_alone(ops, cin, cout):
     """Two-stream regression (the engine runs the U-Net backbone on a side stream): small fp32 convs on a second stream must return
-    their solo results bit for bit while split-operand box convs run on the main stream.  An fp32 MFMA chain changes its last bits when
-    another wave's F16 MFMAs are interleaved with it on the same SIMD; a 2-n-block instance of the box kernel (158 VGPRs)
+    their solo results bit for bit while split-operand box convs run on the main stream.  The fp32 conv kernels change their last bits when a
+    kernel issuing F16 MFMAs shares their SIMD; a 2-n-block instance of the box kernel (158 VGPRs)
     left room for foreign waves on its SIMDs and so let that happen; 32 couts now run as two 16-cout workgroups whose four waves per
     SIMD fill the register file.  (cin = 8 is the single-chunk instance: 80 VGPRs, six waves per SIMD.)"""
     gen = torch.Generator().manual_seed(3)

@@ -37,4 +37,77 @@ for kind, kname in ((0, 'f16 MFMA'), (1, 'fp32 MFMA'), (2, 'VALU only')):
             torch.cuda.synchronize()
             bad += sum(0 if torch.equal(v, vref) else 1 for v in outs)
         print(f'aggressor {kname:10s} {rname:26s}: victim launches with different bits {bad}/180', flush=True)
+
+bad = 0
+for it in range(6):
+    outs = []
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(30):
+            outs.append(ops.conv3d_gn_relu(xs, None, aff, wp, 32))
+    lib.launch_aggressor(0, 1, 256, 60000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    bad += sum(0 if torch.equal(v, vref) else 1 for v in outs)
+print(f'library victim beside ONE f16-MFMA aggressor workgroup per CU (one wave per SIMD): different bits in {bad}/180 launches', flush=True)
+
+# ---- what does a disturbed fp32 MFMA chain compute?  A synthetic victim (one chain of K MFMAs per wave, same operands in every wave)
+import numpy as np
+lib.launch_victim.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+K, VB = 64, 4096
+rng = np.random.default_rng(0)
+A = rng.standard_normal((K, 16, 4)).astype(np.float32)             # [k-step][row][kk]
+B = rng.standard_normal((K, 4, 16)).astype(np.float32)             # [k-step][kk][col]
+lanes = np.arange(64)
+a_l = torch.from_numpy(np.ascontiguousarray(A[:, lanes & 15, lanes >> 4])).to(dev)      # lane: row = l & 15, kk = l >> 4
+b_l = torch.from_numpy(np.ascontiguousarray(B[:, lanes >> 4, lanes & 15])).to(dev)      # lane: col = l & 15, kk = l >> 4
+vout = torch.empty(VB * 64 * 4, device=dev)
+
+
+def emulate(fused):
+    acc = np.zeros((16, 16), dtype=np.float32)
+    for k in range(K):
+        if fused:                                                   # one rounding per MFMA: acc + exact dot-4
+            acc = (acc.astype(np.longdouble) + (A[k].astype(np.longdouble) @ B[k].astype(np.longdouble))).astype(np.float32)
+        else:                                                       # four fp32 FMAs in kk order
+            for kk in range(4):
+                acc = (acc.astype(np.longdouble) + np.outer(A[k][:, kk].astype(np.longdouble), B[k][kk].astype(np.longdouble))).astype(np.float32)
+    return acc
+
+
+def tile_of(flat):                                                  # [64 lanes][4] -> [row][col]: lane: col = l & 15, rows 4 (l >> 4) + r
+    t = np.zeros((16, 16), dtype=np.float32)
+    v = flat.reshape(64, 4)
+    for l in range(64):
+        t[4 * (l >> 4):4 * (l >> 4) + 4, l & 15] = v[l]
+    return t
+
+
+lib.launch_victim(a_l.data_ptr(), b_l.data_ptr(), K, VB, vout.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+solo = vout.cpu().numpy().reshape(VB, 256)
+assert (solo == solo[0]).all(), 'solo victim waves disagree'
+chain, fused = emulate(False), emulate(True)
+st = tile_of(solo[0])
+print('solo victim == fp32 FMA chain emulation:', bool((st == chain).all()), '| == one-rounding-per-MFMA emulation:', bool((st == fused).all()),
+      '| elements where the two emulations differ:', int((chain != fused).sum()), 'of 256', flush=True)
+diff_waves = 0
+seen = []
+for it in range(10):
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            lib.launch_victim(a_l.data_ptr(), b_l.data_ptr(), K, VB, vout.data_ptr(), side.cuda_stream)
+    # one aggressor workgroup per CU (one wave per SIMD, 154 VGPRs): the victims certainly share its SIMDs
+    lib.launch_aggressor(0, 1, 256, 60000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = vout.cpu().numpy().reshape(VB, 256)
+    bad = np.nonzero((got != solo[0]).any(axis=1))[0]
+    diff_waves += len(bad)
+    for w in bad[:3]:
+        seen.append(tile_of(got[w]))
+print(f'beside the f16-MFMA aggressor: {diff_waves} victim waves (of 10 x {VB} checked after the last launch) returned different bits', flush=True)
+for t in seen[:4]:
+    d = t != st
+    print('   a disturbed wave: elements changed', int(d.sum()), '| of those equal to the one-rounding emulation', int((t[d] == fused[d]).sum()),
+          '| max |diff| in ulp-ish', float(np.max(np.abs(t[d] - st[d]) / np.maximum(np.abs(st[d]), 1e-30)) / 1.19e-7), flush=True)
 ops.CONV_ARITH = saved

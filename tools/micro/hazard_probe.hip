@@ -47,3 +47,21 @@ extern "C" int launch_aggressor(int kind, int regs, int blocks, int iters, float
     else return -1;
     return (int)hipGetLastError();
 }
+
+// Synthetic victim: every wave runs the same chain of K fp32 MFMAs (16x16x4) on the same operands; out[block][lane][4].  All blocks must
+// return the same bits -- tools/hazard_probe.py compares them with each other and with two host emulations of the chain.
+__global__ __launch_bounds__(64) void k_victim(const float* __restrict__ a, const float* __restrict__ b, int K, float* __restrict__ out) {
+    // operands first, then the K (= 64) MFMAs back to back on one accumulator, as a conv kernel's k-loop issues them
+    float av[64], bv[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { av[k] = a[k * 64 + threadIdx.x]; bv[k] = b[k * 64 + threadIdx.x]; }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k], acc, 0, 0, 0);
+    reinterpret_cast<f32x4*>(out)[blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
+extern "C" int launch_victim(const float* a, const float* b, int K, int blocks, float* out, void* stream) {
+    hipLaunchKernelGGL(k_victim, dim3(blocks), dim3(64), 0, (hipStream_t)stream, a, b, K, out);
+    return (int)hipGetLastError();
+}
