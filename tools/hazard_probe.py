@@ -110,4 +110,44 @@ for t in seen[:4]:
     d = t != st
     print('   a disturbed wave: elements changed', int(d.sum()), '| of those equal to the one-rounding emulation', int((t[d] == fused[d]).sum()),
           '| max |diff| in ulp-ish', float(np.max(np.abs(t[d] - st[d]) / np.maximum(np.abs(st[d]), 1e-30)) / 1.19e-7), flush=True)
+
+# ---- which of the library's fp32 kernels are sensitive?  (one F16-MFMA aggressor workgroup per CU beside 30 launches, 4 rounds)
+import torch.nn.functional as F
+
+
+def sensitive(name, fn, rounds=4):
+    ref = fn().clone()
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(rounds):
+        outs = []
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(30):
+                outs.append(fn())
+        lib.launch_aggressor(0, 1, 256, 60000, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(v, ref) else 1 for v in outs)
+    print(f'{name}: different bits in {bad}/{30 * rounds} launches', flush=True)
+
+
+g = torch.Generator(device='cpu').manual_seed(1)
+def rn(*shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+# box tiles of the fp32 conv (8^3 boxes, n large)
+xb = rn(2048, 16, 8, 8, 8).relu_(); wb = rn(16, 16, 3, 3, 3, scale=0.05)
+ab = ops.gn_affine(xb, None, torch.ones(16, device=dev), torch.zeros(16, device=dev), 8); wpb = ops.pack_conv3_weight(wb)
+sensitive('k_conv3_mfma, 8^3 box tiles (16->16 @8^3 x 2048)', lambda: ops.conv3d_gn_relu(xb, None, ab, wpb, 16))
+# position-major 4^3
+x4 = rn(64, 32, 4, 4, 4).relu_(); w4 = rn(32, 32, 3, 3, 3, scale=0.05)
+a4 = ops.gn_affine(x4, None, torch.ones(32, device=dev), torch.zeros(32, device=dev), 8); wp4 = ops.pack_conv3_weight(w4)
+sensitive('k_conv3_small, position-major 4^3 (32->32 x 64)', lambda: ops.conv3d_gn_relu(x4, None, a4, wp4, 32))
+# generic direct (VALU) conv
+sensitive('direct VALU conv (32->32 @16^3 x 8)', lambda: ops.conv3d_gn_relu(xs, None, aff, None, 32, direct_weight=w))
+# fp32 MFMA valid conv (LDS-staged, no LDS-DMA of weights?) and the VALU valid conv
+xv = rn(64, 24, 22, 22, 22); wv = rn(24, 24, 3, 3, 3, scale=0.07); bv = rn(24)
+wvl = ops.pack_convv_lds_weight(wv)
+sensitive('k_convv_lds (fp32 MFMA valid conv 24->24 s2 @22^3 x 64)', lambda: ops.conv3d_valid_leaky_lds(xv, wvl, bv, 24, 3, 2, 0.2))
+xv1 = rn(64, 12, 24, 24, 24); wv1 = rn(24, 12, 3, 3, 3, scale=0.07); wvt = ops.pack_convv_valu_weight(wv1)
+sensitive('k_convv_valu (VALU valid conv 12->24 @24^3 x 64)', lambda: ops.conv3d_valid_leaky_valu(xv1, wvt, bv, 1, 0.2))
 ops.CONV_ARITH = saved
