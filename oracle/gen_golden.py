@@ -398,6 +398,7 @@ def main():
         gen_dbrow_fixture(ref_model, c)
     gen_retrieval_fixture()
     gen_combine_fixture()
+    gen_loss_fixture()
 
 
 
@@ -461,5 +462,46 @@ def gen_dbrow_fixture(ref_model, cfg_name='C1', seed=8):
     print('dbrow', cfg_name, wins.shape, emb.shape, zero_row.shape)
 
 
+# ------------------------------------------------------------------------- model.loss (imported by the reference's trainers)
+def gen_loss_fixture(seed=11):
+    """NT-Xent (cosine / dot, with and without the IoU-dependent temperature), Gram-matrix style loss and the normal cosine similarity
+    from the reference's own model/loss.py.  Its forward pins the mask with ``.cuda(device)`` (model/loss.py:57,62), which refuses a CPU
+    device: for this call only, Tensor.cuda is mapped to Tensor.to."""
+    import importlib
+    ref_loss = importlib.import_module('model.loss')
+    assert str(REF) in ref_loss.__file__, ref_loss.__file__
+    g = torch.Generator().manual_seed(seed)
+    b, c = 6, 16
+    zis = torch.randn(b, c, generator=g)
+    zjs = zis + 0.3 * torch.randn(b, c, generator=g)
+    iou = torch.rand(2 * b, 2 * b, generator=g)
+    pn = torch.randn(2, 3, 4, 4, 4, generator=g)
+    tn = torch.randn(2, 3, 4, 4, 4, generator=g)
+    pn[:, :, 0] = 0
+    tn[:, :, :, 1] = 0
+    out = {'zis': zis.numpy(), 'zjs': zjs.numpy(), 'iou': iou.numpy(), 'pred_norms': pn.numpy(), 'target_norms': tn.numpy()}
+    with mock.patch.object(torch.Tensor, 'cuda', lambda self, device=None, **kw: self.to(device)):
+        for cos in (True, False):
+            for temp in (0.5, 0.07):
+                crit = ref_loss.NTXentLoss(temp, cos)
+                key = '%s_t%g' % ('cos' if cos else 'dot', temp)
+                zi = zis.clone().requires_grad_(True)
+                zj = zjs.clone().requires_grad_(True)
+                loss = crit(zi, zj)
+                loss.backward()
+                out['loss_' + key] = np.float64(loss.item())
+                out['grad_zis_' + key] = zi.grad.numpy()
+                out['grad_zjs_' + key] = zj.grad.numpy()
+                out['loss_iou_' + key] = np.float64(crit(zis, zjs, iou).item())
+    out['style'] = np.float64(ref_loss.patch_style_loss(zis, zjs).item())
+    out['normal_cos'] = np.float64(ref_loss.get_cosine_similarity(pn, tn).item())
+    save_fixture('loss', **out)
+    print('loss:', {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'loss':
+        import_reference_model()
+        gen_loss_fixture()
+    else:
+        main()
