@@ -35,11 +35,6 @@ extern "C" {
 
 int rf_abi_version(void);
 const char* rf_last_error(void);
-/* Test harness only: overwrite the LDS of every CU with NaN bit patterns (LDS is not cleared between workgroups), so that a kernel
- * reading LDS it never wrote fails deterministically under test.  Not on the product path. */
-int rf_debug_poison_lds(void* stream);
-/* Test harness only: the same for the vector register files (VGPRs are not cleared at wave launch). */
-int rf_debug_poison_vgprs(void* stream);
 
 /* ------------------------------------------------------------------------------------------ U-Net primitives */
 

@@ -77,8 +77,6 @@ SIGNATURES = {
     'rf_linear_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),
     'rf_linear_packed_floats': (c_sz, [c_i, c_i]),
     'rf_linear': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_f, c_fp, c_p]),
-    'rf_debug_poison_lds': (c_i, [c_p]),
-    'rf_debug_poison_vgprs': (c_i, [c_p]),
     'rf_linear_wgrad': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_p, c_sz, c_p]),
     'rf_linear_wgrad_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_l2_normalize_rows': (c_i, [c_fp, c_i, c_i, c_f, c_p]),

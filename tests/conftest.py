@@ -11,7 +11,7 @@ import pytest
 
 REPO = Path(__file__).resolve().parents[1]
 PKG = REPO / 'retrieval-fuse_amd'
-for p in (str(REPO), str(PKG)):
+for p in (str(REPO), str(PKG), str(REPO / 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -31,7 +31,7 @@ def poison_gpu_memory(request):
     """Before every GPU test: fill the caching allocator's free memory with NaN bit patterns, so that `torch.empty` workspaces and
     outputs start as garbage, not as the zeros a fresh process usually sees -- a kernel that reads something it never wrote then
     fails every time instead of once in a blue moon (when the VRAM still holds another process's data).  The LDS of every CU and the
-    vector register files get the same treatment (rf_debug_poison_lds / rf_debug_poison_vgprs): neither is cleared between kernels."""
+    vector register files get the same treatment (tests/testkit: rft_poison_lds / rft_poison_vgprs): neither is cleared between kernels."""
     if 'gpu' not in request.keywords:
         yield
         return
@@ -46,8 +46,9 @@ def poison_gpu_memory(request):
         except RuntimeError:
             pass
         del blocks                                                      # back to the allocator's cache, contents intact
-        from rfuse import _lib
-        _lib.check(_lib.load().rf_debug_poison_lds(None), 'rf_debug_poison_lds')       # and NaNs in the LDS of every CU
-        _lib.check(_lib.load().rf_debug_poison_vgprs(None), 'rf_debug_poison_vgprs')   # and in the vector register files (not cleared at wave launch)
+        import testkit
+        tk = testkit.load()
+        assert tk.rft_poison_lds(None) == 0                             # and NaNs in the LDS of every CU
+        assert tk.rft_poison_vgprs(None) == 0                           # and in the vector register files (not cleared at wave launch)
         torch.cuda.synchronize()
     yield

@@ -1,11 +1,12 @@
-"""Dev tool (GPU box): run kernels after filling every VGPR of every SIMD with NaN patterns (rf_debug_poison_vgprs); a kernel that reads a
+"""Dev tool (GPU box): run kernels after filling every VGPR of every SIMD with NaN patterns (tests/testkit: rft_poison_vgprs); a kernel that reads a
 register it never wrote changes its bits (or turns NaN)."""
 import sys
 from pathlib import Path
 import torch
 REPO = Path(__file__).resolve().parents[1]
-sys.path[:0] = [str(REPO / 'retrieval-fuse_amd')]
+sys.path[:0] = [str(REPO / 'retrieval-fuse_amd'), str(REPO / 'tests')]
 from rfuse import ops, _lib
+import testkit
 dev = torch.device('cuda:0')
 lib = _lib.load()
 torch.manual_seed(0)
@@ -16,7 +17,7 @@ def check(name, fn, reps=20):
     torch.cuda.synchronize()
     bad = nan = 0
     for _ in range(reps):
-        _lib.check(lib.rf_debug_poison_vgprs(None), 'poison')
+        assert testkit.load().rft_poison_vgprs(None) == 0
         v = fn()
         torch.cuda.synchronize()
         if not torch.equal(v, ref):
