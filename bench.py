@@ -211,7 +211,17 @@ def kernel_work(name, a, cfg):
         return 'mfma', rows * 2.0 * (n_in * 128 + 2 * 128 * 128 + 128 * 32), 'flop'
     if name in ('rf_l2_topk', 'rf_l2_topk_keys'):
         nq, dim, n = a[:3]
-        return 'mfma', 2.0 * nq * n * dim, 'flop (q.x per pair)'
+        algo = a[5] if len(a) > 5 else 0
+        if algo == 0:                                            # TOPK_AUTO: VALU scan below 100 k rows per shard, f16-MFMA-filtered scan above (retrieval.hip)
+            algo = 3 if n >= 100_000 else 1
+        bound = {1: 'valu', 2: 'mfma', 3: 'mfma-f16'}[algo]
+        return bound, 2.0 * nq * n * dim, 'flop (q.x per (query, row) pair; %s); the shard itself is %d B read once' % (
+            {1: 'exact distances on the packed-fp32 VALU', 2: 'fp32-MFMA filter + exact re-check', 3: 'f16-MFMA filter + exact re-check'}[algo], 4 * n * dim)
+    if name == 'rf_conv3d_valid_leaky_split':
+        n, cin, s, cout, k, stride = a[:6]
+        so = (s - k) // stride + 1
+        return 'mfma-f16', 3.0 * 2.0 * cin * k ** 3 * cout * so ** 3 * n, ('f16 flop, 3 MFMAs per product tile (operand splitting; channel / cout padding of the tiles not counted); '
+                                                                        'fp32-equivalent %.1f GFLOP' % (2.0 * cin * k ** 3 * cout * so ** 3 * n / 1e9))
     if name in ('rf_conv3d_valid_leaky_mfma', 'rf_conv3d_valid_leaky_lds', 'rf_conv3d_valid_leaky_valu'):
         n, cin, s, cout, k, stride = a[:6]
         so = (s - k) // stride + 1
@@ -267,13 +277,14 @@ def kernel_table(eng, raw_dev, cfg, steps=3, top=5):
         w = kernel_work(name, ints, cfg)
         if w:
             bound, work, unit = w
-            if bound in ('mfma', 'mfma-f16'):
-                peak = F16_MFMA_PEAK_TFLOPS if bound == 'mfma-f16' else FP32_MFMA_PEAK_TFLOPS
+            if bound in ('mfma', 'mfma-f16', 'valu'):
+                peak = F16_MFMA_PEAK_TFLOPS if bound == 'mfma-f16' else FP32_MFMA_PEAK_TFLOPS      # packed-fp32 VALU peak == fp32 MFMA peak
                 ach = work / (per_launch * 1e-3) / 1e12
-                row.update(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, work=unit)
+                row.update(bound='valu' if bound == 'valu' else 'mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, work=unit)
             else:
                 ach = work / (per_launch * 1e-3) / 1e9
                 row.update(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, work='algorithmic ' + unit)
+        assert 'frac' not in row or row['frac'] <= 1.0, 'a roofline fraction above 1 is a bookkeeping error, not a result: %s' % (row,)
         rows.append(row)
     return {'serial_ms_per_step': total, 'top': rows,
             'note': 'HIP events around each C-ABI launch, backbone kept on the main stream for this pass; a launch = all kernels of that entry point'}
@@ -349,9 +360,9 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if args.gpus != world and not (world == 1 and args.gpus == 1):
+        raise SystemExit('--gpus %d needs exactly that many ranks (WORLD_SIZE is %d): launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback for the hot path)'
     knobs = sorted(k for k in os.environ if k.startswith('RFUSE_') and k != 'RFUSE_LIB')
     assert not knobs, 'refusing to measure with developer switches set: %s' % knobs
@@ -360,6 +371,7 @@ def main():
     force_dist = world == 1 and args.force_collectives and 'RANK' in os.environ        # dev: run the whole RCCL protocol with one rank
     if world > 1 or force_dist:
         dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
+        assert dist.get_world_size() == args.gpus or force_dist, '--gpus %d but the process group has %d ranks' % (args.gpus, dist.get_world_size())
 
     from rfuse import configs, ops, synthetic
     from rfuse.database import PatchDatabase
@@ -429,7 +441,7 @@ def main():
         # gfx950 correction + WRITE_SIZE, summary committed under profiles/), scaled per sample to this launch; None when the
         # committed summary is of another kernel
         traffic = None
-        pmc_file = REPO / 'profiles' / 'r02_dominant_kernel.json'
+        pmc_file = REPO / 'profiles' / 'r03_dominant_kernel.json'
         pmc = json.loads(pmc_file.read_text()) if pmc_file.exists() else None
         roof = None
         if dom_label is not None:
@@ -439,11 +451,15 @@ def main():
             if pmc is not None and pmc.get('entry') == entry and pmc.get('shape') == [c0_, c1_, edge_, cout_]:
                 traffic = pmc['traffic_bytes_per_sample'] * n_
             src_bytes = 4.0 * n_ * (c0_ * edge_ ** 3 + (c1_ * (edge_ // 2) ** 3 if 'up' in entry else c1_ * edge_ ** 3) + cout_ * edge_ ** 3)
+            direct = 2.0 * 27 * (c0_ + c1_) * cout_ * edge_ ** 3 * n_                                      # the layer as the reference evaluates it
             roof = {'bound': 'mfma',
                     'kernel': '%s: %d+%d -> %d channels @%d^3 x %d samples, %s' % (entry, c0_, c1_, cout_, edge_, n_,
                               'fp32 operands as two f16 pieces on v_mfma_f32_16x16x32_f16 (3 MFMAs per product tile, exact products, hi/lo fp32 accumulators)'
                               if arith == 'f16 split' else 'v_mfma_f32_16x16x4_f32'),
                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                    # `frac` prices the flop ISSUED on the matrix pipe of `peak` (pipe occupancy); `useful_frac` prices the layer's direct-form
+                    # multiply-adds (2 * 27 * cin * cout per voxel) against the same peak: what the reference's arithmetic would cost there
+                    'useful_frac': direct / (kern_ms * 1e-3) / 1e12 / peak, 'direct_form_flops_per_launch': direct,
                     'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_file.name if traffic is not None else 'no summary of this kernel committed'),
                     'launch_ms': kern_ms,
                     'flops_per_launch': kern_flops,          # flop ISSUED on the matrix pipe of `peak` (f16 split: 3 f16 MFMAs per product tile, 28 tap slots per 27 taps, couts padded to 16)
@@ -451,6 +467,7 @@ def main():
                     'fp32_equivalent_tflops': useful / (kern_ms * 1e-3) / 1e12,
                     'algorithmic_bytes_per_launch': src_bytes,
                     'heavy_launches_ms': {'%s %s' % (lab[0], list(lab[2])): float(np.mean([t for t, _ in v])) for lab, v in sorted(by_launch.items(), key=lambda kv: -np.mean([t for t, _ in kv[1]]))}}
+            assert roof['frac'] <= 1.0 and roof['useful_frac'] <= 1.0, roof
         out = {
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -465,12 +482,27 @@ def main():
             'roofline': roof,
             'recall_at_k': recall,
         }
+        out['rccl_ranks'] = dist.get_world_size() if (world > 1 or force_dist) else 0
         if collective_events:
             q_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in collective_events]))
             k_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in collective_events]))
-            out['collectives'] = {'rccl_ranks': world, 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_to_all_keys_ms': k_ms,
-                                  'keys_bytes_received_per_rank': world * B * 64 * 2 * K * 8,
-                                  'note': 'HIP events on the issuing stream around each collective (includes waiting for the slowest rank)'}
+            out['collectives'] = {'rccl_ranks': dist.get_world_size(), 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_to_all_keys_ms': k_ms,
+                                  'keys_bytes_received_per_rank': world * B * 64 * 2 * K * 8, 'step_ms': 1e3 * elapsed / args.steps,
+                                  'note': 'HIP events on the issuing stream around each collective (includes waiting for the slowest rank); the U-Net backbone '
+                                          'forked onto the side stream before the search keeps running while they are in flight'}
+            if force_dist:
+                # one rank, protocol forced: the same timed loop WITHOUT the collectives -> what the exchange adds to a step once overlap is counted
+                database.force_collectives = False
+                for _ in range(2):
+                    eng.refine(raw_dev)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.refine(raw_dev)
+                torch.cuda.synchronize()
+                plain_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+                database.force_collectives = True
+                out['collectives'].update(step_ms_without_collectives=plain_ms, exposed_ms_per_step=1e3 * elapsed / args.steps - plain_ms)
         state = None
         if world == 1 and not args.no_extras:
             state = {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}

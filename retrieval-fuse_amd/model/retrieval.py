@@ -106,7 +106,7 @@ class _ConvPatchEncoder(nn.Module):
         x = x.contiguous()
         for layer in self.layers:
             if isinstance(layer, Conv3dParams):
-                if ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
+                if ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride) and ops.split_range_ok(layer.weight):
                     x = ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size,
                                                      layer.stride, 0.2)
                 elif ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride):

@@ -121,6 +121,11 @@ class SingleConv(nn.Module):
             return out if pool is None else (out, torch.nn.functional.max_pool3d(out, 2))
         aff = ops.gn_affine(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
+        # the split-operand (F16 matrix core) forms only where they cannot saturate: weights and GroupNorm outputs inside the f16 pair's range
+        # (ops.split_range_ok, decided from the parameters once per version); otherwise the fp32 kernels, like the reference's fp32 path
+        split_ok = ops.CONV_ARITH == 'split' and ops.split_range_ok(self.conv.weight, gn.weight, gn.bias, (gn.num_channels // gn.num_groups) * edge ** 3)
+        if not split_ok:
+            return self._forward_fp32(x, upsampled, aff, cout, edge, _direct, pool)
         if upsampled is None and not _direct and ops.conv_split_supported(x, None, cout):
             return ops.conv3d_split_gn_relu(x, aff, self.conv.packed_split(), cout, pool=pool)
         if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
@@ -133,6 +138,18 @@ class SingleConv(nn.Module):
         elif ops.conv_up_supported(x, upsampled, cout):
             c0 = x.shape[1] if x is not None else 0
             out = ops.conv3d_up_gn_relu(x, upsampled, aff, self.conv.packed_up(c0), cout)
+        else:
+            out = ops.conv3d_gn_relu(x, upsampled, aff, self.conv.packed(), cout)
+        return out if pool is None else (out, ops.maxpool2(out))
+
+    def _forward_fp32(self, x, upsampled, aff, cout, edge, _direct, pool):
+        """the same layer on the fp32-MFMA kernels only (a parameter outside the split forms' range)"""
+        if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
+            return ops.conv3d_gn_relu_pool(x, None, aff, self.conv.packed(), cout, keep_full=(pool == 'also'))
+        if _direct or edge == 1:
+            out = ops.conv3d_gn_relu(x, upsampled, aff, None, cout, direct_weight=self.conv.weight)
+        elif ops.conv_up_supported(x, upsampled, cout):
+            out = ops.conv3d_up_gn_relu(x, upsampled, aff, self.conv.packed_up(x.shape[1] if x is not None else 0), cout)
         else:
             out = ops.conv3d_gn_relu(x, upsampled, aff, self.conv.packed(), cout)
         return out if pool is None else (out, ops.maxpool2(out))

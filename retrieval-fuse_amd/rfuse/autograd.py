@@ -26,19 +26,21 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 
-_p, _stream = ops._p, ops._stream
+_p, _stream = ops._p, ops._stream         # (the helpers below launch on the device of their tensors: ops._device_scoped)
 
 
 def _ws(dev, nbytes):
     return ops._workspace(dev, nbytes)
 
 
+@ops._device_scoped
 def relu_backward(dy, y):
     out = torch.empty_like(y)
     _lib.check(_lib.load().rf_relu_backward(_p(dy), _p(y), y.numel(), _p(out), _stream()), 'rf_relu_backward')
     return out
 
 
+@ops._device_scoped
 def conv3d_gn(x, aff, w_packed, cout, relu):
     n, c, edge = x.shape[0], x.shape[1], x.shape[2]
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=x.device)
@@ -46,6 +48,7 @@ def conv3d_gn(x, aff, w_packed, cout, relu):
     return out
 
 
+@ops._device_scoped
 def gn_backward(x, dxn, gamma, groups, eps):
     n, c, edge = x.shape[0], x.shape[1], x.shape[2]
     lib = _lib.load()
@@ -57,6 +60,7 @@ def gn_backward(x, dxn, gamma, groups, eps):
     return dx, dg.sum(0).float(), db.sum(0).float()
 
 
+@ops._device_scoped
 def conv3d_wgrad(x, aff, dz, cout):
     n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
     lib = _lib.load()

@@ -25,21 +25,36 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-_checked_query_counts = set()
+_host_groups = {}
+
+
+def _host_group(group):
+    """A gloo twin of ``group`` for host-side agreement checks (no GPU work, no device synchronisation).  Created collectively the first
+    time every rank reaches the sharded search; a gloo group is its own twin."""
+    import torch.distributed as dist
+    key = id(group)
+    hg = _host_groups.get(key)
+    if hg is None:
+        if dist.get_backend(group) == 'gloo':
+            hg = group
+        else:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            hg = dist.new_group(ranks=ranks, backend='gloo')
+        _host_groups[key] = hg
+    return hg
 
 
 def _check_equal_query_counts(nq, group):
-    """all_gather_into_tensor needs the same number of queries on every rank (chunk batches are split evenly); unequal
-    counts would hang or mis-slice silently.  Checked once per (group, count) -- it costs a host round trip."""
+    """all_gather_into_tensor needs the same number of queries on every rank (chunk batches are split evenly); unequal counts would hang
+    or mis-slice silently.  Checked on EVERY call, symmetrically on every rank (a per-rank cache let one rank skip the check the
+    other entered), over the gloo twin of the group: a host-only exchange of one integer, no device synchronisation -- it overlaps the GPU
+    work already enqueued."""
     import torch.distributed as dist
-    key = (id(group), nq)
-    if key in _checked_query_counts:
-        return
-    counts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(counts, int(nq), group=group)
+    hg = _host_group(group)
+    counts = [None] * dist.get_world_size(hg)
+    dist.all_gather_object(counts, int(nq), group=hg)
     if len(set(counts)) != 1:
         raise ValueError('sharded search: every rank must pass the same number of queries, got %s' % (counts,))
-    _checked_query_counts.add(key)
 
 
 def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings=None):
@@ -216,7 +231,7 @@ class PatchDatabase:
 
     def search(self, q, k2):
         """Top-k2 over the whole database for this rank's queries.  One process: a single scan.  W processes:
-        all-gather(queries) -> shard scans -> ONE all-gather of the packed candidate keys -> merge (sharded_search).
+        all-gather(queries) -> shard scans -> ONE all-to-all of the packed candidate keys -> merge (sharded_search).
         The collectives are issued from the caller's stream (torch runs them on RCCL's own stream, ordered by events), so the
         U-Net backbone the engine forked onto its side stream keeps the GPU busy while they are in flight."""
         if self.world == 1 and not self.force_collectives:

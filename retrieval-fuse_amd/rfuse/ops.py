@@ -99,7 +99,7 @@ class PackedWeight:
             self._key = key
             self._ready.packed_on(w.device)
         else:
-            self._ready.wait(w.device)
+            self._ready.wait(w.device, self._packed)
         return self._packed
 
 
@@ -118,11 +118,16 @@ class _PackedReady:
             self._event.record(st)
             self._ok_streams = {st.cuda_stream}
 
-    def wait(self, device):
+    def wait(self, device, packed=None):
         st = torch.cuda.current_stream(device)
         if st.cuda_stream not in self._ok_streams and not torch.cuda.is_current_stream_capturing():
             st.wait_event(self._event)
             self._ok_streams.add(st.cuda_stream)
+            # a reader on another stream: when the image is dropped (re-pack after an optimizer step / load_state_dict) the caching allocator
+            # must not hand its block out again before this stream's kernels have read it
+            for t in (packed if isinstance(packed, (tuple, list)) else (packed,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(st)
 
 
 # ------------------------------------------------------------------------------------------------ U-Net primitives
@@ -315,6 +320,37 @@ def conv3d_up_gn_relu(src0, src1, aff, w_up_packed, cout):
 # two f16 pieces on the F16 matrix cores (exact products, fp32 accumulation; measured closer to float64 than the fp32 MFMA chain),
 # 'fp32' = v_mfma_f32_16x16x4_f32 everywhere.  An API switch, not an environment variable.
 CONV_ARITH = 'split'
+
+# ---- value range of the split-operand (f16 x f16) forms.  They carry activations scaled by 2^-4 and weights scaled by 2^4 as pairs of f16 values
+# (csrc/conv3d_split.hip:20-24): |GroupNorm output| above 65504 * 16 or a (pre-summed) weight above 65504 / 16 would CLAMP where the reference
+# computes in fp32 range.  Both are decidable from the parameters alone, once per parameter version:
+#   weights      max |w| <= SPLIT_MAX_ABS_WEIGHT (the decoder form adds up to 8 taps before it splits: 65504 / 16 / 8);
+#   activations  a GroupNorm output is (x - mean) * rstd * gamma + beta with |x - mean| * rstd <= sqrt(elements of the group), so
+#                max |gamma| * sqrt(group elements) + max |beta| <= SPLIT_MAX_ABS_ACT rules saturation out for every input.
+# A layer outside the range runs the fp32 kernels (model/unet.py:SingleConv) -- same results as the reference's fp32 path, no clamp.
+SPLIT_MAX_ABS_WEIGHT = 65504.0 / 16 / 8
+SPLIT_MAX_ABS_ACT = 65504.0 * 16
+_range_cache = {}
+
+
+def _abs_max(t):
+    key = (t.data_ptr(), t._version, tuple(t.shape), t.device)
+    v = _range_cache.get(key)
+    if v is None:
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('range check of a parameter inside a graph capture: run one step before capturing (RefinementEngine.capture_graph does)')
+        if len(_range_cache) > 4096:
+            _range_cache.clear()
+        v = _range_cache[key] = float(t.detach().abs().max().item())        # one host sync per parameter version
+    return v
+
+
+def split_range_ok(weight, gamma=None, beta=None, group_elements=0):
+    """True when the split-operand forms cannot saturate for this layer, whatever the input (see SPLIT_MAX_ABS_* above)."""
+    w_ok = _abs_max(weight) <= SPLIT_MAX_ABS_WEIGHT                      # NaN / inf weights compare False: fp32 path, like the reference
+    if gamma is None:
+        return w_ok
+    return w_ok and _abs_max(gamma) * (float(group_elements) ** 0.5) + _abs_max(beta) <= SPLIT_MAX_ABS_ACT
 
 
 def pack_conv3_split_weight(w):
@@ -681,10 +717,13 @@ class PackedAttnMLP:
         params = [t for l in layers for t in (l.weight, l.bias)]
         key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.device) for t in params)
         if key != self._key:
-            self._packed, self._key = pack_attn_mlp(params), key
+            img, split = pack_attn_mlp(params)
+            if not all(split_range_ok(w) for w in params[0::2]):
+                split = None                                           # a weight outside the f16 pair's range: the fp32-MFMA form runs (no clamp)
+            self._packed, self._key = (img, split), key
             self._ready.packed_on(params[0].device)
         else:
-            self._ready.wait(params[0].device)
+            self._ready.wait(params[0].device, self._packed)
         return self._packed
 
 
@@ -712,7 +751,7 @@ def attn_mlp_rows(x, packed):
     rows, n_in = x.shape
     out = torch.empty((rows, 32), dtype=torch.float32, device=x.device)
     img, split = packed
-    if CONV_ARITH == 'split':
+    if CONV_ARITH == 'split' and split is not None:
         _lib.check(_lib.load().rf_attn_mlp_split_rows(_p(x), rows, n_in, _p(img), _p(split), _p(out), _stream()), 'rf_attn_mlp_split_rows')
     else:
         _lib.check(_lib.load().rf_attn_mlp_rows(_p(x), rows, n_in, _p(img), _p(out), _stream()), 'rf_attn_mlp_rows')
@@ -728,7 +767,7 @@ def attn_mlp_volume(src, b, kv, c, s, t, packed):
     r = s // 2
     out = torch.empty((b * r * r * r * kv, 32), dtype=torch.float32, device=src.device)
     img, split = packed
-    if CONV_ARITH == 'split':
+    if CONV_ARITH == 'split' and split is not None:
         _lib.check(_lib.load().rf_attn_mlp_split_volume(_p(src), b, kv, c, s, t, _p(img), _p(split), _p(out), _stream()), 'rf_attn_mlp_split_volume')
     else:
         _lib.check(_lib.load().rf_attn_mlp_volume(_p(src), b, kv, c, s, t, _p(img), _p(out), _stream()), 'rf_attn_mlp_volume')

@@ -107,7 +107,11 @@ def _worker(rank, world, port, n_rows, nq_local, K, out_dir, unequal):
     q_local = torch.from_numpy(q_all[sl])
     if unequal:
         try:
-            db.search(q_local[: nq_local - rank], 2 * K)
+            if unequal == 2:                                   # a first call with equal counts, then rank 0 passes a NEW count and rank 1 one it has seen
+                db.search(q_local, 2 * K)
+                db.search(q_local[: nq_local - 1] if rank == 0 else q_local, 2 * K)
+            else:
+                db.search(q_local[: nq_local - rank], 2 * K)
             msg = 'no error'
         except ValueError as e:
             msg = str(e)
@@ -119,10 +123,10 @@ def _worker(rank, world, port, n_rows, nq_local, K, out_dir, unequal):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_rows,nq_local,K', [(1001, 64, 4), (13, 5, 4), (1, 3, 4)])
-def test_sharded_search_world2_equals_single_process(tmp_path, n_rows, nq_local, K):
-    """(1 row, 2 ranks): rank 1's shard is EMPTY -- it contributes all-NONE lists."""
-    world = 2
+@pytest.mark.parametrize('world,n_rows,nq_local,K', [(2, 1001, 64, 4), (2, 13, 5, 4), (2, 1, 3, 4), (4, 1003, 16, 8)])
+def test_sharded_search_equals_single_process(tmp_path, world, n_rows, nq_local, K):
+    """(1 row, 2 ranks): rank 1's shard is EMPTY -- it contributes all-NONE lists.  (4 ranks, 1003 rows, K = 8): shards of unequal size
+    (n % W != 0), the C4 list length."""
     mp.spawn(_worker, args=(world, _free_port(), n_rows, nq_local, K, str(tmp_path), False), nprocs=world, join=True)
     sys.path.insert(0, str(REPO / 'retrieval-fuse_amd'))
     emb, meta, q_all, qscene = _problem(n_rows, world, nq_local)
@@ -144,9 +148,12 @@ def test_sharded_search_world2_equals_single_process(tmp_path, n_rows, nq_local,
         assert (z0['i'][:, 0] == 0).all() and (z0['i'][:, 1:] == -1).all()
 
 
-def test_unequal_query_counts_are_refused(tmp_path):
+@pytest.mark.parametrize('mode', [1, 2])
+def test_unequal_query_counts_are_refused(tmp_path, mode):
+    """mode 2: the counts differ only on a LATER call, and only one rank's count is new (a per-rank cache of checked counts would let the
+    other rank skip the check and walk into mismatched collectives)"""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), 100, 6, 4, str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), 100, 6, 4, str(tmp_path), mode), nprocs=world, join=True)
     for rank in range(world):
         assert 'same number of queries' in (tmp_path / f'rank{rank}.txt').read_text()
 

@@ -926,3 +926,45 @@ def test_linear_wgrad_split_k_gemm(ops, case):
     scale = float(want.abs().max())
     assert float((got.double() - want).abs().max()) <= 2e-6 * scale * max(1.0, (k / 4096) ** 0.5)
     assert torch.equal(got, ops.linear_wgrad(a, b))
+
+
+def test_split_forms_fall_back_to_fp32_outside_their_range(ops):
+    """The split-operand kernels carry weights x 16 and activations / 16 as f16 pairs and clamp beyond 65504.
+    A layer whose parameters could reach that range (|w| > 511, or |gamma| sqrt(group elements) + |beta| > 1.05e6) must run the fp32 kernels and
+    give THEIR bits -- not a finite-but-clamped result."""
+    from model.unet import SingleConv
+    gen = torch.Generator().manual_seed(21)
+    x = rnd(gen, 2048, 16, 8, 8, 8).relu_().to(DEV)
+    layer = SingleConv(16, 16, num_groups=8).to(DEV)
+    with torch.no_grad():
+        layer.conv.weight.copy_(rnd(gen, 16, 16, 3, 3, 3, scale=0.05))
+        layer.groupnorm.weight.copy_(1.0 + 0.2 * rnd(gen, 16))
+        layer.groupnorm.bias.copy_(rnd(gen, 16, scale=0.3))
+
+    def run(arith):
+        saved, ops.CONV_ARITH = ops.CONV_ARITH, arith
+        try:
+            with torch.no_grad():
+                return layer(x).clone()
+        finally:
+            ops.CONV_ARITH = saved
+
+    assert ops.split_range_ok(layer.conv.weight, layer.groupnorm.weight, layer.groupnorm.bias, 2 * 512)
+    in_range_split, in_range_fp32 = run('split'), run('fp32')
+    assert not torch.equal(in_range_split, in_range_fp32)                  # inside the range the split kernel is the one that runs
+    assert (in_range_split - in_range_fp32).abs().max().item() <= 1e-4 * in_range_fp32.abs().max().item()
+    for what in ('weight', 'gamma', 'beta'):
+        with torch.no_grad():
+            saved = {k: v.clone() for k, v in layer.state_dict().items()}
+            if what == 'weight':
+                layer.conv.weight[3, 5, 1, 1, 1] = 3.0e4                  # x 16 = 4.8e5 > 65504
+            elif what == 'gamma':
+                layer.groupnorm.weight[2] = 4.0e4                          # |GN output| can reach 4e4 * sqrt(1024) = 1.3e6 > 65504 * 16
+            else:
+                layer.groupnorm.bias[7] = 2.0e6
+        assert not ops.split_range_ok(layer.conv.weight, layer.groupnorm.weight, layer.groupnorm.bias, 2 * 512), what
+        got, ref = run('split'), run('fp32')
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, ref), 'out-of-range %s: the layer did not take the fp32 kernels' % what
+        layer.load_state_dict(saved)
+    assert torch.equal(run('split'), in_range_split)                       # back in range: the split kernel again
