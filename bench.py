@@ -195,7 +195,10 @@ def kernel_work(name, a, cfg):
         from rfuse import ops
         return 'mfma-f16', ops.conv_up_split_issued_flops(c0, c1, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; decoder form; 28 tap slots per 27 taps, couts padded to 16); '
                                                                                   'fp32-equivalent %.1f GFLOP' % (2.0 * (27 * c0 + 8 * c1) * cout * edge ** 3 * n / 1e9))
-    if name == 'rf_conv3d_split_k3_gn_relu':
+    if name == 'rf_conv3d_cin1_presplit':
+        n, edge, cout = a[:3]
+        return 'hbm', 4.0 * n * edge ** 3 * (1 + cout), 'bytes'
+    if name in ('rf_conv3d_split_k3_gn_relu', 'rf_conv3d_split_pre_k3_relu'):
         cin, n, edge, cout = a[:4]
         from rfuse import ops
         return 'mfma-f16', ops.conv_split_issued_flops(cin, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; 28 tap slots per 27 taps, couts padded to 16); '

@@ -197,6 +197,23 @@ int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
 
+/* Activations in split form end to end ("pre-split" tensors).  Layout of C channels on edge^3 voxels: [n][cg = ceil(C/8)][plane h | plane l]
+ * [voxel][8 halves] -- per (sample, 8-channel group) the LDS image of the split box kernel in global memory (rf_split_act_bytes bytes, as
+ * many as the fp32 tensor), ALREADY normalised by the consumer's GroupNorm, scaled by 2^-4 and split into f16 pairs, so that the consumer
+ * stages it with copies instead of re-normalising and re-splitting every input voxel (1.95x with the halo).
+ *   rf_conv3d_cin1_presplit       first conv of a level-0 DoubleConv (model/unet.py:125-144: GroupNorm(1) -> Conv3d(1, 8, 3, pad 1) -> ReLU) on
+ *                                 whole 16^3 samples, emitting the SECOND conv's input: statistics of the 8 output channels over the sample,
+ *                                 that layer's GroupNorm(next_groups, 8, eps; next_gamma / next_beta [8]) applied, split, written.
+ *                                 The conv result is bit-identical to rf_conv3d_k3_gn_relu's; the GroupNorm arithmetic is gn_affine's.
+ *   rf_conv3d_split_pre_k3_relu   rf_conv3d_split_k3_gn_relu on such an input (no affine table); outputs / statistics / fused max-pool alike. */
+size_t rf_split_act_bytes(int n, int c, int edge);
+int rf_conv3d_cin1_presplit_supported(int n, int edge, int cout, int next_groups);
+int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* gn_affine_in, const float* w_packed, int cout,
+                            const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit, void* stream);
+int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout);
+int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout,
+                                float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
+
 /* ------------------------------------------------------------------------------- backward (training slice, N4) */
 
 /* rf_conv3d_k3_gn_relu with the ReLU optional (relu = 0: plain GroupNorm + conv): the DATA-GRADIENT convolution of the

@@ -64,3 +64,15 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// GroupNorm as the conv kernels apply it: y = (x - center) * scale + shift with, per (sample, channel),
+//   center = fl32(mean),  scale = fl32(gamma * rstd),  shift = fl32(beta - (mean - center) * gamma * rstd).
+// Subtracting the (fp32-representable) centre first keeps the product at the magnitude of the RESULT: the plain two-term form
+// x*scale' + shift' carries an absolute error of eps * |mean * rstd * gamma|, which for near-constant inputs (a truncation-
+// saturated TSDF patch: rstd up to 316) is 100x the fp32 resolution of y and was the largest single error source of the path
+// (tools/error_budget.py, first layer of the retrieval backbone).  What fl32(mean) loses is folded into `shift` in float64.
+__device__ __forceinline__ float4 gn_affine(double mean, double rstd, float gamma, float beta) {
+    const double sc = (double)gamma * rstd;
+    const float center = (float)mean;
+    return make_float4(center, (float)sc, (float)((double)beta - (mean - (double)center) * sc), 0.f);
+}

@@ -90,8 +90,11 @@ __device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
 // ONE: the layer has a single 8-channel chunk (no prefetch of a next chunk, one chunk buffer)
 // PADC: cin is not a multiple of 8 -- the last chunk's missing channels are staged as zeros (they re-read channel cin-1 with a zero affine
 // triple; their weights are zero too)
-template <int NB, int WPS, bool ONE, bool PADC>
+// PRE: the input is a PRE-SPLIT tensor (rf_split_act_bytes: per (sample, 8-channel group) an h plane and an l plane of 16-byte voxel slots) that
+// its producer already normalised for THIS layer's GroupNorm and split -- staging is a copy of slots, no affine table, no conversion
+template <int NB, int WPS, bool ONE, bool PADC, bool PRE = false>
 __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
+    static_assert(!(PRE && PADC), "pre-split tensors carry whole 8-channel groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,23 +125,40 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
         voff[r] = vin[r] ? (z * edge + y) * edge + x : 0;
     }
     const float* __restrict__ s0 = a.src0 + (size_t)n0 * cin * vol;
-    auto stage_load = [&](float (&x)[2][8], int ca) {
+    const unsigned char* __restrict__ sp0 = reinterpret_cast<const unsigned char*>(a.src0) + (size_t)n0 * nC * 2 * vol * 16;      // PRE
+    struct Staged { float x[PRE ? 1 : 2][PRE ? 1 : 8]; h8 ph[PRE ? 2 : 1], pl[PRE ? 2 : 1]; };
+    auto stage_load = [&](Staged& st, int ca) {
+        if constexpr (PRE) {
+            const unsigned char* p = sp0 + (size_t)ca * 2 * vol * 16;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r) {
+                st.ph[r] = *reinterpret_cast<const h8*>(p + (size_t)voff[r] * 16);
+                st.pl[r] = *reinterpret_cast<const h8*>(p + (vol + (size_t)voff[r]) * 16);
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[r][j] = s0[(size_t)chan(ca * 8 + j) * vol + voff[r]];
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) st.x[r][j] = s0[(size_t)chan(ca * 8 + j) * vol + voff[r]];
+        }
     };
-    auto stage_store = [&](const float (&x)[2][8], int ca, int buf) {      // zeros outside the volume (the padding of the NORMALISED tensor)
+    auto stage_store = [&](const Staged& st, int ca, int buf) {      // zeros outside the volume (the padding of the NORMALISED tensor)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            float y[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 af = triple(ca * 8 + j);
-                y[j] = vin[r] ? fmaf(x[r][j] - af.x, af.y, af.z) : 0.f;
-            }
             h8 h, l;
-            cs_split8(y, h, l);
+            if constexpr (PRE) {
+                const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                h = vin[r] ? st.ph[r] : zero;
+                l = vin[r] ? st.pl[r] : zero;
+            } else {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 af = triple(ca * 8 + j);
+                    y[j] = vin[r] ? fmaf(st.x[r][j] - af.x, af.y, af.z) : 0.f;
+                }
+                cs_split8(y, h, l);
+            }
             if (r == 0 || tid < CS_SLOTS - 512) {
                 unsigned char* p = lds + buf * CS_BUF + (tid + r * 512) * 16;
                 *reinterpret_cast<h8*>(p) = h;
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     };
     // the first chunk's voxels are requested now and staged after the addressing set-up and the first weight fragments are under way
     // (measured with s_memtime: set-up + first weight load cost a quarter of a workgroup's life when they came after the staging)
-    float xs0[2][8];
+    Staged xs0;
     stage_load(xs0, 0);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -217,11 +237,11 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
     // (vmcnt retires in order and k-step 2 waits for its weight fragments); k-steps 2..5 convert one value per m-block in the shadow of that
     // block's MFMAs; after k-step 6 only the four ds_write_b128 are left.
     auto chunk = [&](int ca, h8 (&ch)[NB], h8 (&cl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
-        float x[ONE ? 1 : 2][8];
+        Staged x;
         h8 hq[ONE ? 1 : 2], lq[ONE ? 1 : 2];
         const int cx = ca + 1 < nC ? ca + 1 : ca;
-        float4 afn[ONE ? 1 : 8];
-        if constexpr (!ONE) {
+        float4 afn[(ONE || PRE) ? 1 : 8];
+        if constexpr (!ONE && !PRE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) afn[j] = triple(cx * 8 + j);      // uniform: scalar loads, before the k-steps' LDS traffic
         }
@@ -234,9 +254,9 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
         for (int s = 0; s < 7; ++s) {
             const unsigned char* ap = buf + atap[s];
             auto conv_hook = [&](int m) {
-                if constexpr (!ONE) {
+                if constexpr (!ONE && !PRE) {
                     const int e = (s - 2) * 4 + m, r = e >> 3, j = e & 7;
-                    const float y = vin[r] ? fmaf(x[r][j] - afn[j].x, afn[j].y, afn[j].z) : 0.f;
+                    const float y = vin[r] ? fmaf(x.x[r][j] - afn[j].x, afn[j].y, afn[j].z) : 0.f;
                     const float v = __builtin_amdgcn_fmed3f(y * CS_ACT_SCALE, -65504.f, 65504.f);
                     const _Float16 hh = (_Float16)v;
                     hq[r][j] = hh;
@@ -250,6 +270,11 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
             else kstep(std::true_type{}, no_x, conv_hook, ap, buf + atap[s + 1], ch, cl, nh, nl);
         }
         if constexpr (!ONE) {
+            if constexpr (PRE) {
+                const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { hq[r] = vin[r] ? x.ph[r] : zero; lq[r] = vin[r] ? x.pl[r] : zero; }
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r)
                 if (r == 0 || tid < CS_SLOTS - 512) {
@@ -381,6 +406,160 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
     conv_box_epilogue<4, 4, 4, 8, 8, 4, 1, (size_t)S4_LDS_BYTES>(a, acc, reinterpret_cast<float*>(lds), tid, lane, wave, n0, 0, 0, 0, cob, lblock);
 }
 
+// ------------------------------------------------------------------------------------------- pre-split activations: a producer
+// Pre-split tensor of C channels on S^3 voxels: [n][cg = C / 8][plane h | plane l][voxel][8 halves] -- per (sample, 8-channel group) the LDS
+// image of the split box kernel in global memory: as many bytes as the fp32 tensor, but already normalised by the CONSUMER's GroupNorm,
+// scaled and split, so the consumer stages it with copies.  A producer can write it when one workgroup sees a whole sample (it needs the
+// sample's statistics before it can normalise).
+//
+// k_conv3_cin1_presplit: the first conv of a U-Net's level-0 DoubleConv (1 -> 8 channels, model/unet.py:125-144) on whole 16^3 samples, one
+// workgroup of 512 threads per sample; thread = one (y, x) column of 8 z voxels, all 8 couts in registers (cout pairs on v_pk_fma_f32, taps
+// accumulated in the (dy, dx, dz) order of k_conv3_cin1: the conv result is bit-identical to that kernel's).  Then: ReLU, per-channel
+// sums in float64 (recursive halving over the lanes, fixed order), the NEXT layer's GroupNorm triple (gn_affine), normalise, split, store --
+// a thread owns whole slots (8 channels of a voxel), and the 256 threads of a z plane write 4 KB contiguously.
+struct Cin1PreArgs {
+    const float* src;          // [n][16^3]
+    const float4* affine;      // [n] GroupNorm of the input (cin = 1)
+    const float* wp;           // conv3 weight image [27][cin4][cout16]
+    int n, cin4, cout16;
+    const float* gamma;        // the consumer's GroupNorm over the 8 output channels
+    const float* beta;
+    int cpg;                   // channels per group there (1, 2, 4 or 8)
+    double eps;
+    unsigned char* out;        // pre-split [n][1][2][4096][8 halves]
+};
+
+__global__ __launch_bounds__(512, 4) void k_conv3_cin1_presplit(Cin1PreArgs a) {
+    constexpr int E = 16, H = 18, VOL = E * E * E;
+    __shared__ float xs[H * H * H];
+    __shared__ __attribute__((aligned(16))) float wl[27 * 8];
+    __shared__ double red[8 * 16];
+    __shared__ float4 nxt[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nn = blockIdx.x;
+    for (int i = tid; i < H * H * H; i += 512) xs[i] = 0.f;
+    for (int i = tid; i < 27 * 8; i += 512) wl[i] = a.wp[(size_t)(i / 8) * a.cin4 * a.cout16 + (i % 8)];
+    const float4 af = a.affine[nn];
+    const float* src = a.src + (size_t)nn * VOL;
+    float raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = src[tid + i * 512];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int v = tid + i * 512;
+        xs[((v >> 8) + 1) * (H * H) + (((v >> 4) & 15) + 1) * H + (v & 15) + 1] = fmaf(raw[i] - af.x, af.y, af.z);
+    }
+    __syncthreads();
+    const int x = tid & 15, y = (tid >> 4) & 15, z0 = (tid >> 8) * 8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[8][4];
+#pragma unroll
+    for (int z = 0; z < 8; ++z)
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) acc2[z][cp] = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float col[10];
+#pragma unroll
+            for (int hz = 0; hz < 10; ++hz) col[hz] = xs[(z0 + hz) * (H * H) + (y + dy) * H + x + dx];
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wl + ((dz * 3 + dy) * 3 + dx) * 8 + 4);
+                const f32x2 wv[4] = {(f32x2){w0.x, w0.y}, (f32x2){w0.z, w0.w}, (f32x2){w1.x, w1.y}, (f32x2){w1.z, w1.w}};
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    const f32x2 c2 = (f32x2){col[z + dz], col[z + dz]};
+#pragma unroll
+                    for (int cp = 0; cp < 4; ++cp) acc2[z][cp] = __builtin_elementwise_fma(c2, wv[cp], acc2[z][cp]);
+                }
+            }
+        }
+    float act[8][8];                                                // ReLU'd outputs [z][cout]
+#pragma unroll
+    for (int z = 0; z < 8; ++z)
+#pragma unroll
+        for (int co = 0; co < 8; ++co) act[z][co] = fmaxf(acc2[z][co >> 1][co & 1], 0.f);
+    {   // statistics of the sample: per (wave, cout) float64 sums by recursive halving, then the 8 waves in order
+        double v[16];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            double sm = 0.0, sq = 0.0;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) { const double t = (double)act[z][co]; sm += t; sq += t * t; }
+            v[2 * co] = sm; v[2 * co + 1] = sq;
+        }
+        auto halve = [&](auto kc) {
+            constexpr int K = decltype(kc)::value, C = 8 >> K;
+            const bool up = (lane >> K) & 1;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const double send = up ? v[i] : v[i + C], keep = up ? v[i + C] : v[i];
+                v[i] = keep + __shfl_xor(send, 1 << K, 64);
+            }
+        };
+        halve(std::integral_constant<int, 0>{});
+        halve(std::integral_constant<int, 1>{});
+        halve(std::integral_constant<int, 2>{});
+        halve(std::integral_constant<int, 3>{});
+        v[0] += __shfl_xor(v[0], 16, 64);
+        v[0] += __shfl_xor(v[0], 32, 64);
+        if (lane < 16) red[wave * 16 + ((lane & 1) * 8 + ((lane >> 1) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1))] = v[0];
+    }
+    __syncthreads();
+    if (tid < 8) {                                                  // the consumer's GroupNorm triple of channel tid
+        const int g0 = tid / a.cpg * a.cpg;
+        double sm = 0.0, sq = 0.0;
+        for (int c = g0; c < g0 + a.cpg; ++c)
+            for (int w = 0; w < 8; ++w) { sm += red[w * 16 + 2 * c]; sq += red[w * 16 + 2 * c + 1]; }
+        const double count = (double)a.cpg * VOL, mean = sm / count;
+        double var = sq / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        nxt[tid] = gn_affine(mean, 1.0 / sqrt(var + a.eps), a.gamma[tid], a.beta[tid]);
+    }
+    __syncthreads();
+    float4 t[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) t[co] = nxt[co];
+    unsigned char* outp = a.out + (size_t)nn * 2 * VOL * 16;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        float yv[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) yv[co] = fmaf(act[z][co] - t[co].x, t[co].y, t[co].z);
+        h8 h, l;
+        cs_split8(yv, h, l);
+        const size_t vox = ((size_t)(z0 + z) * E + y) * E + x;
+        *reinterpret_cast<h8*>(outp + vox * 16) = h;
+        *reinterpret_cast<h8*>(outp + ((size_t)VOL + vox) * 16) = l;
+    }
+}
+
+extern "C" size_t rf_split_act_bytes(int n, int c, int edge) {
+    return (size_t)n * (size_t)((c + 7) / 8) * 2 * (size_t)edge * edge * edge * 16;
+}
+
+extern "C" int rf_conv3d_cin1_presplit_supported(int n, int edge, int cout, int next_groups) {
+    return n > 0 && edge == 16 && cout == 8 && next_groups > 0 && 8 % next_groups == 0;
+}
+
+extern "C" int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* gn_affine_in, const float* w_packed, int cout,
+                                       const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit, void* stream) {
+    RF_REQUIRE(rf_conv3d_cin1_presplit_supported(n, edge, cout, next_groups), RF_E_UNSUPPORTED,
+               "rf_conv3d_cin1_presplit: takes 1 -> 8 channels on 16^3 samples with 1, 2, 4 or 8 groups in the consumer's GroupNorm (got n=%d edge=%d cout=%d groups=%d)",
+               n, edge, cout, next_groups);
+    RF_REQUIRE(src && gn_affine_in && w_packed && next_gamma && next_beta && out_presplit, RF_E_INVALID, "rf_conv3d_cin1_presplit: null pointer");
+    Cin1PreArgs a;
+    a.src = src; a.affine = reinterpret_cast<const float4*>(gn_affine_in); a.wp = w_packed; a.n = n; a.cin4 = 4; a.cout16 = 16;
+    a.gamma = next_gamma; a.beta = next_beta; a.cpg = 8 / next_groups; a.eps = (double)eps; a.out = reinterpret_cast<unsigned char*>(out_presplit);
+    hipLaunchKernelGGL(k_conv3_cin1_presplit, dim3((unsigned)n), dim3(512), 0, (hipStream_t)stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_cin1_presplit");
+    return RF_OK;
+}
+
 // -------------------------------------------------------------------------------------------------------------------- host
 extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout) {
     // whole 4^3 samples (8 per workgroup, k_conv3_split_s4): cin in eights, any cout (16 per workgroup), enough samples to fill the chip
@@ -391,9 +570,9 @@ extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int co
     return cout16 <= 32 && rf_conv_use_big(n, edge, cout16);
 }
 
-template <int NB, int WPS, bool ONE, bool PADC = false>
+template <int NB, int WPS, bool ONE, bool PADC = false, bool PRE = false>
 static int launch_split(const ConvArgs& a, hipStream_t stream) {
-    auto kern = k_conv3_split<NB, WPS, ONE, PADC>;
+    auto kern = k_conv3_split<NB, WPS, ONE, PADC, PRE>;
     const unsigned gx = (unsigned)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), ONE ? CS_BUF : CS_LDS_BYTES, stream, a);
     RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
@@ -416,10 +595,10 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
     a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
     a.floor = 0.f;
-    // 32 couts run as two 16-cout workgroups per box (grid.y = 2).  A 2-n-block instance (158 VGPRs, one workgroup per CU) was 15 % faster
-    // on its own but left room for other kernels' waves on its SIMDs -- and the fp32 conv kernels of another stream return slightly different
-    // bits when a kernel issuing F16 MFMAs shares their SIMD (tools/hazard_probe.py); the 16-cout instance fills the
-    // register file with its own four waves per SIMD.
+    // 32 couts: one workgroup with two n-blocks per box (158 VGPRs: every A operand read from LDS feeds six MFMAs instead of three -- the
+    // 16-cout instance asks the LDS for 170 B/clk of A operands and gets 128).  Round 2 ran 32 couts as two 16-cout workgroups because this
+    // instance leaves room for other kernels' waves on its SIMDs and fp32 kernels of another stream then returned different bits beside its
+    // F16 MFMAs; that was an unsafe packed-fp32 instruction form in THOSE kernels, gone since round 3.
     // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
     // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and
     // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
@@ -430,5 +609,31 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
         return RF_OK;
     }
     if (cin % 8) return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
+    if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
+}
+
+// The same layer on a PRE-SPLIT input (already normalised for this layer's GroupNorm and split by its producer: rf_conv3d_cin1_presplit):
+// cin in whole 8-channel groups, 16 couts per workgroup (32: two n-blocks), edge >= 8.
+extern "C" int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout) {
+    return cin >= 8 && cin % 8 == 0 && edge >= 8 && rf_conv3d_split_supported(cin, 0, n, edge, cout);
+}
+
+extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout,
+                                           float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_pre_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_pre_k3_relu: takes cin in eights, up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
+    RF_REQUIRE(src_presplit && w_packed && (out || pool_out), RF_E_INVALID, "rf_conv3d_split_pre_k3_relu: null pointer");
+    RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_split_pre_k3_relu: statistics of an output that is not written");
+    RF_REQUIRE(pool_out || !pool_stats, RF_E_INVALID, "rf_conv3d_split_pre_k3_relu: pooled statistics without a pooled output");
+    ConvArgs a;
+    a.src0 = reinterpret_cast<const float*>(src_presplit); a.src1 = nullptr; a.affine = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.out = out;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = rf_round_up(cout, 16);
+    a.stats = reinterpret_cast<double2*>(stats);
+    a.stats_tiles = (stats || pool_stats) ? (edge / 8) * (edge / 8) * (edge / 8) : 0;
+    a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
+    a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
+    a.floor = 0.f;
+    if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false, false, true>(a, (hipStream_t)stream);
+    return cin == 8 ? launch_split<1, 6, true, false, true>(a, (hipStream_t)stream) : launch_split<1, 4, false, false, true>(a, (hipStream_t)stream);
 }

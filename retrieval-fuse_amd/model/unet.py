@@ -170,7 +170,25 @@ class DoubleConv(nn.Module):
         self.SingleConv2 = SingleConv(c2_in, c2_out, kernel_size, order, num_groups)
 
     def forward(self, x, upsampled=None, pool=None):
-        return self.SingleConv2(self.SingleConv1(x, upsampled), pool=pool)
+        c1, c2 = self.SingleConv1, self.SingleConv2
+        if upsampled is None and self._presplit_ok(x):
+            # level 0 of a U-Net on 16^3 samples: the first conv hands the second its input already normalised (second GroupNorm) and split
+            # into f16 pairs (ops.conv3d_cin1_presplit) -- the second conv stages it with copies
+            g1, g2 = c1.groupnorm, c2.groupnorm
+            aff = ops.gn_affine(x, None, g1.weight, g1.bias, g1.num_groups, g1.eps)
+            pre = ops.conv3d_cin1_presplit(x, aff, c1.conv.packed(), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
+            return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
+        return c2(c1(x, upsampled), pool=pool)
+
+    def _presplit_ok(self, x):
+        c1, c2 = self.SingleConv1, self.SingleConv2
+        g1, g2 = c1.groupnorm, c2.groupnorm
+        if x is None or ops.needs_grad(x, c1.conv.weight, c2.conv.weight, g1.weight, g2.weight):
+            return False
+        if not ops.cin1_presplit_supported(x, c1.conv.out_channels, g2.num_groups, c2.conv.out_channels):
+            return False
+        edge = x.shape[2]
+        return ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (g2.num_channels // g2.num_groups) * edge ** 3)
 
 
 class StepDownDoubleConv(nn.Module):

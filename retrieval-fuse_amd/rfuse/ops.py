@@ -405,6 +405,59 @@ def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
     return out if pool is None else (out, pooled)
 
 
+USE_PRESPLIT = True             # False: every layer normalises and splits its own input (the round-2 routes; kept for cross-checks)
+
+
+def cin1_presplit_supported(x, cout, next_groups, next_cout):
+    """True when a level-0 DoubleConv on this input can run as rf_conv3d_cin1_presplit -> rf_conv3d_split_pre_k3_relu."""
+    if not USE_PRESPLIT or CONV_ARITH != 'split' or x is None or x.shape[1] != 1:
+        return False
+    n, edge = x.shape[0], x.shape[2]
+    lib = _lib.load()
+    return bool(lib.rf_conv3d_cin1_presplit_supported(n, edge, cout, next_groups)) and bool(lib.rf_conv3d_split_pre_supported(cout, n, edge, next_cout))
+
+
+def conv3d_cin1_presplit(x, aff, w_packed, cout, next_gamma, next_beta, next_groups, eps):
+    """ReLU(conv3(GN(x))) of a 1-channel input, emitted as the pre-split input of the NEXT layer (its GroupNorm applied): uint8 buffer."""
+    _req(x, 'x')
+    n, edge = x.shape[0], x.shape[2]
+    _check_affine(aff, n, 1)
+    lib = _lib.load()
+    out = torch.empty(lib.rf_split_act_bytes(n, cout, edge), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.rf_conv3d_cin1_presplit(_p(x), n, edge, _p(aff), _p(w_packed), cout, _p(next_gamma.detach()), _p(next_beta.detach()), next_groups, eps,
+                                           _p(out), _stream()), 'rf_conv3d_cin1_presplit')
+    return out
+
+
+def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None):
+    """conv3d_split_gn_relu on a pre-split input (already normalised for this layer and split by its producer)."""
+    dev = pre.device
+    lib = _lib.load()
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if pool != 'only' else None
+    pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev) if pool is not None else None
+    tiles = max(1, (edge // 8) ** 3)
+    stats = pstats = None
+    if USE_FUSED_STATS:
+        stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if out is not None else None
+        pstats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if pooled is not None else None
+    timed = conv_event_filter is not None and conv_event_filter(cin, cout, edge, n)
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.rf_conv3d_split_pre_k3_relu(_p(pre), cin, n, edge, _p(w_split_packed), cout, _p(out), _p(stats), _p(pooled), _p(pstats), _stream()),
+               'rf_conv3d_split_pre_k3_relu')
+    if timed:
+        ev1.record()
+        conv_events.append((ev0, ev1, conv_split_issued_flops(cin, n, edge, cout), ('rf_conv3d_split_pre_k3_relu', 'f16 split', (cin, 0, n, edge, cout))))
+    if stats is not None:
+        out._rf_stats = (stats, tiles, out._version)
+    if pstats is not None:
+        pooled._rf_stats = (pstats, tiles, pooled._version)
+    if pool is None:
+        return out
+    return out, pooled
+
+
 def conv_split_issued_flops(cin, n, edge, cout):
     """f16 flop rf_conv3d_split_k3_gn_relu ISSUES: three MFMAs per k-step of 32, 7 k-steps (28 tap slots) per 8 input channels, on
     round_up(cout, 16) columns."""

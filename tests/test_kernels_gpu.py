@@ -968,3 +968,56 @@ def test_split_forms_fall_back_to_fp32_outside_their_range(ops):
         assert torch.equal(got, ref), 'out-of-range %s: the layer did not take the fp32 kernels' % what
         layer.load_state_dict(saved)
     assert torch.equal(run('split'), in_range_split)                       # back in range: the split kernel again
+
+
+@pytest.mark.parametrize('n,pool', [(2048, 'only'), (2049, 'also'), (2048, None)])
+def test_presplit_route_of_a_level0_double_conv(ops, n, pool):
+    """Activations in split form end to end: the first conv of a level-0 DoubleConv (1 -> 8 @16^3) writes the second conv's input
+    already normalised by ITS GroupNorm and split into f16 pairs (rf_conv3d_cin1_presplit), the second conv (8 -> 16, rf_conv3d_split_pre_k3_relu)
+    stages copies.  Same arithmetic as the plain route (conv, gn_affine, cs_split8) -- only the order of the float64 statistics sums differs --
+    so the two routes must agree to fp32 round-off, and both with float64 torch."""
+    from model.unet import DoubleConv
+    gen = torch.Generator().manual_seed(31)
+    x = rnd(gen, n, 1, 16, 16, 16).to(DEV)
+    blk = DoubleConv(1, 16, encoder=True, num_groups=8).to(DEV)
+    with torch.no_grad():
+        for name, p in blk.named_parameters():
+            if 'groupnorm.weight' in name:
+                p.copy_(1.0 + 0.3 * rnd(gen, *p.shape))
+            elif 'groupnorm.bias' in name:
+                p.copy_(rnd(gen, *p.shape, scale=0.4))
+            else:
+                p.copy_(rnd(gen, *p.shape, scale=0.2))
+
+    def run(flag):
+        saved, ops.USE_PRESPLIT = ops.USE_PRESPLIT, flag
+        try:
+            with torch.no_grad():
+                return blk(x, pool=pool) if pool is not None else blk(x)
+        finally:
+            ops.USE_PRESPLIT = saved
+
+    with torch.no_grad():
+        assert blk._presplit_ok(x)
+    fast, plain = run(True), run(False)
+    fast = fast if isinstance(fast, tuple) else (fast,)
+    plain = plain if isinstance(plain, tuple) else (plain,)
+    with torch.no_grad():
+        c1, c2 = blk.SingleConv1, blk.SingleConv2
+        xd = x.double()
+        y = torch.nn.functional.group_norm(xd, 1, c1.groupnorm.weight.double(), c1.groupnorm.bias.double(), 1e-5)
+        y = torch.nn.functional.conv3d(y, c1.conv.weight.double(), padding=1).relu()
+        y = torch.nn.functional.group_norm(y, 8, c2.groupnorm.weight.double(), c2.groupnorm.bias.double(), 1e-5)
+        ref = torch.nn.functional.conv3d(y, c2.conv.weight.double(), padding=1).relu()
+        refs = {None: (ref,), 'also': (ref, torch.nn.functional.max_pool3d(ref, 2)), 'only': (None, torch.nn.functional.max_pool3d(ref, 2))}[pool]
+    for f, p_, r in zip(fast, plain, refs):
+        assert (f is None) == (p_ is None) == (r is None)
+        if f is None:
+            continue
+        scale = r.abs().max().item()
+        ef, ep = (f.double() - r).abs().max().item() / scale, (p_.double() - r).abs().max().item() / scale
+        assert (f - p_).abs().max().item() <= 2e-6 * scale, 'routes differ by %.2e' % ((f - p_).abs().max().item() / scale)
+        assert ef <= max(2e-6, 1.5 * ep), 'pre-split route %.2e from float64, plain route %.2e' % (ef, ep)
+        if getattr(f, '_rf_stats', None) is not None:                          # the statistics that ride along feed the next GroupNorm
+            sf, sp = f._rf_stats[0].sum(dim=2), p_._rf_stats[0].sum(dim=2)
+            assert torch.allclose(sf, sp, rtol=1e-5, atol=1e-5)
