@@ -327,6 +327,29 @@ def batch_sweep(cfg, database, state, device, sizes=(1, 8, 64), steps=10):
     return out
 
 
+def scene_driver_rate(eng, cfg, scenes=4, grid=(4, 4, 2)):
+    """rfuse.scene.refine_scene (scene -> chunk grid -> batched refine -> float16 -> recomposition) on synthetic scenes of
+    grid[0] x grid[1] x grid[2] chunks: scenes/s including the device -> host copies and the host-side pasting.  A side line, never `value`."""
+    from rfuse import configs, scene, synthetic
+    trunc_i, _ = configs.truncations(cfg)
+    s_in = cfg['dataset_train']['input_chunk_size']
+    n = grid[0] * grid[1] * grid[2]
+    base = np.stack([synthetic.make_chunk(30_000 + i, cfg)['input_raw'] for i in range(n)])
+    if base.ndim != 4 or base.shape[1] != s_in:
+        return None                                                  # point-cloud inputs (C5) are not tiled scenes
+    low = base.reshape(grid + (s_in,) * 3).transpose(0, 3, 1, 4, 2, 5).reshape(grid[0] * s_in, grid[1] * s_in, grid[2] * s_in)
+    names, chunks = scene.split_scene(low, s_in, 'bench', pad_value=trunc_i)
+    scene.refine_scene(eng, names, chunks, batch=32)                 # warm-up
+    t0 = time.perf_counter()
+    for _ in range(scenes):
+        vols = scene.refine_scene(eng, names, chunks, batch=32)
+    el = time.perf_counter() - t0
+    shape = list(next(iter(vols.values())).shape)
+    return {'value': scenes / el, 'unit': 'scenes/s', 'chunks_per_scene': n, 'scene_voxels': shape, 'chunks_per_s': scenes * n / el,
+            'note': 'rfuse.scene.refine_scene: chunk grid -> RefinementEngine.refine in batches of 32 -> float16 -> pinned host -> combine_chunks (float64 canvas); '
+                    'host-side pasting included'}
+
+
 def host_io_rate(eng, raws_host, device, steps=10):
     """The same step when the boundary hands over HOST buffers (the reference's DataLoader does): pinned input -> device on the
     compute stream, refined chunks -> pinned host buffers on a copy stream, double buffered so that the copy of step i runs under
@@ -512,6 +535,7 @@ def main():
             out['kernels'] = kernel_table(eng, raw_dev, cfg)
             out['batch_sweep'] = batch_sweep(cfg, database, state, device)
             out['host_io'] = host_io_rate(eng, torch.from_numpy(raws), device)
+            out['scene_driver'] = scene_driver_rate(eng, cfg)
         if args.feature_cache and world == 1 and n_patches <= 200_000:
             # Reported separately, NEVER as `value`: optional serving mode that fetches per-database-row retrieval-backbone
             # features (query independent) from a 32 KB/row HBM cache instead of recomputing them (skips 87 % of the FLOPs).

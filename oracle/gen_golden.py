@@ -423,6 +423,13 @@ def gen_combine_fixture(seed=9):
         s_in = cfg['dataset_train']['input_chunk_size']
         res_t = ds.combine_chunks(1, 64, trunc_t, lambda obj, n: obj[n], tgt)                       # combine_targets, :179-180
         res_i = ds.combine_chunks(64 / s_in, s_in, trunc_i, lambda obj, n: obj[n], inp)             # combine_inputs, :176-177
+        # the inference loop's recomposition (trainer/train_refinement.py:166): combine_retrievals(predictions [n, 1, 64^3] as float16, 0)
+        preds = np.stack([synthetic.uniform_stress_volume(seed * 1000 + i, (64, 64, 64), trunc_t) for i in range(len(names))])[:, None].astype(np.float16)
+        ds.scene_handler = types.SimpleNamespace(target_chunk_size=64, target_trunc=trunc_t)      # what the two properties read (:44-45, :72-73)
+        res_p = ds.combine_retrievals(preds, 0)
+        for k in sorted(res_p):
+            out['%s_pred_%s_shape' % (tag, k)] = np.array(res_p[k].shape)
+            out['%s_pred_%s_sha' % (tag, k)] = sha(res_p[k])
         out[tag + '_names'] = np.array(names)
         out[tag + '_cfg'] = cfg_name
         out[tag + '_keys'] = np.array(sorted(res_t))
@@ -503,5 +510,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'loss':
         import_reference_model()
         gen_loss_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'combine':
+        import_reference_model()
+        gen_combine_fixture()
     else:
         main()

@@ -135,3 +135,26 @@ def test_combine_chunks_matches_reference_golden():
             assert helpers.sha(tgt[k]) == str(fix['%s_target_%s_sha' % (tag, k)])
             assert tuple(fix['%s_input_%s_shape' % (tag, k)]) == inp[k].shape
             assert helpers.sha(inp[k]) == str(fix['%s_input_%s_sha' % (tag, k)])
+
+
+def test_scene_driver_recomposition_matches_reference_golden():
+    """N3: the inference loop's recomposition (trainer/train_refinement.py:166 -> PatchedSceneDataset.combine_retrievals(pred_shapes, 0)) pinned by
+    the reference's own method on float16 predictions; ``split_scene`` names parse back to the positions it cut."""
+    from rfuse import scene
+    fix = helpers.load_fixture('combine_chunks')
+    seed = int(fix['seed'])
+    for tag in ('front', 'shapenet'):
+        cfg = rf_configs.get_config(str(fix[tag + '_cfg']))
+        _, trunc_t = rf_configs.truncations(cfg)
+        names = [str(n) for n in fix[tag + '_names']]
+        preds = np.stack([synthetic.uniform_stress_volume(seed * 1000 + i, (64, 64, 64), trunc_t) for i in range(len(names))])[:, None].astype(np.float16)
+        got = scene.combine_predictions(names, preds, cfg['dataset_train']['dataset_name'], trunc_t)
+        assert sorted(got) == [str(k) for k in fix[tag + '_keys']]
+        for k, vol in got.items():
+            assert tuple(vol.shape) == tuple(fix['%s_pred_%s_shape' % (tag, k)])
+            assert helpers.sha(vol) == str(fix['%s_pred_%s_sha' % (tag, k)])
+    low = np.arange(16 * 8 * 12, dtype=np.float32).reshape(16, 8, 12)
+    names, chunks = scene.split_scene(low, 8, 'sceneZ', pad_value=-1.0)
+    assert chunks.shape == (4, 8, 8, 8) and names[0] == 'sceneZ__room0__0_0_0' and names[-1] == 'sceneZ__room0__64_0_64'
+    back = scene.combine_chunks(names, list(chunks), '3DFront', scale_factor=8, chunk_size=8, trunc_val=-1.0)['sceneZ__room0']
+    assert np.array_equal(back[:16, :8, :12], low) and (back[:, :, 12:] == -1.0).all()

@@ -435,3 +435,28 @@ def test_engine_at_the_bench_batch_size_matches_oracle(gpu, cfg_name, B, chunks)
     print(f'\n{cfg_name} B={B}, chunks {chunks}: df max abs err vs float64 oracle {worst:.2e}, vs fp32 oracle {worst32:.2e} (fp32 oracle vs float64: {oracle32:.2e})')
     bar = max(DF_TOL, 1.25 * oracle32)
     assert worst <= bar and worst32 <= bar + oracle32
+
+
+def test_scene_driver_matches_chunkwise_refinement(gpu):
+    """N3: rfuse.scene.refine_scene (scene -> chunk grid -> batched RefinementEngine.refine -> float16 -> recomposition; the reference's vis_infer
+    loop, trainer/train_refinement.py:158-169) against refining every chunk on its own and pasting it by hand."""
+    from rfuse import scene
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C3')
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    db = synthetic.make_database(8, cfg, 64 * 20)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 500 + len(n)) for n, m in eng.modules().items()}
+    eng.load_state_dicts(sds)
+    low = np.concatenate([np.concatenate([synthetic.make_chunk(900 + 2 * i + j, cfg)['input_raw'] for j in range(2)], axis=1) for i in range(2)], axis=0)
+    low = np.concatenate([low, synthetic.make_chunk(950, cfg)['input_raw'][:, :, :4].repeat(2, axis=0).repeat(2, axis=1)], axis=2)     # [16, 16, 12]: ragged in z
+    names, chunks = scene.split_scene(low, 8, 'sceneQ', pad_value=trunc_i)
+    assert chunks.shape[0] == 8
+    out = scene.refine_scene(eng, names, chunks, batch=3)
+    assert list(out) == ['sceneQ__room0'] and out['sceneQ__room0'].shape == (128, 128, 128)
+    ref = np.full((128, 128, 128), trunc_t, dtype=np.float64)
+    for name, ch in zip(names, chunks):
+        x, y, z = [int(t) for t in name.split('__')[-1].split('_')]
+        ref[x:x + 64, y:y + 64, z:z + 64] = eng.refine(torch.from_numpy(ch[None]).to(gpu))[0, 0].half().cpu().numpy()
+    assert np.abs(out['sceneQ__room0'] - ref).max() <= 2e-4                    # batch size changes the tile dispatch, not the arithmetic contract; float16 steps are 1.2e-4 at trunc
