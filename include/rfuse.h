@@ -202,13 +202,14 @@ int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const
  * many as the fp32 tensor), ALREADY normalised by the consumer's GroupNorm, scaled by 2^-4 and split into f16 pairs, so that the consumer
  * stages it with copies instead of re-normalising and re-splitting every input voxel (1.95x with the halo).
  *   rf_conv3d_cin1_presplit       first conv of a level-0 DoubleConv (model/unet.py:125-144: GroupNorm(1) -> Conv3d(1, 8, 3, pad 1) -> ReLU) on
- *                                 whole 16^3 samples, emitting the SECOND conv's input: statistics of the 8 output channels over the sample,
+ *                                 whole 16^3 samples (in_gamma / in_beta [1]: the first GroupNorm, statistics taken in the kernel), emitting the SECOND
+ *                                 conv's input: statistics of the 8 output channels over the sample,
  *                                 that layer's GroupNorm(next_groups, 8, eps; next_gamma / next_beta [8]) applied, split, written.
- *                                 The conv result is bit-identical to rf_conv3d_k3_gn_relu's; the GroupNorm arithmetic is gn_affine's.
+ *                                 Conv in the tap order of rf_conv3d_k3_gn_relu's first-layer kernel; GroupNorm arithmetic = gn_affine.
  *   rf_conv3d_split_pre_k3_relu   rf_conv3d_split_k3_gn_relu on such an input (no affine table); outputs / statistics / fused max-pool alike. */
 size_t rf_split_act_bytes(int n, int c, int edge);
 int rf_conv3d_cin1_presplit_supported(int n, int edge, int cout, int next_groups);
-int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* gn_affine_in, const float* w_packed, int cout,
+int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* in_gamma, const float* in_beta, float in_eps, const float* w_packed, int cout,
                             const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit, void* stream);
 int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout);
 int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout,
@@ -314,6 +315,11 @@ int rf_attn_mlp_rows(const float* x, int rows, int n_in, const float* packed, fl
 int rf_attn_mlp_volume(const float* src, int b, int kv, int c, int s, int t, const float* packed, float* out, void* stream);
 int rf_attn_weights(const float* xf, const float* pf, const float* noise, int rows, int k, int f, int mode, float sharpness,
                     float* weights, float* switches, float* scores_out, void* stream);
+/* Gumbel-hard weights with the noise of gumbel_softmax (model/attention.py:100-103) drawn INSIDE the kernel: Philox4x32-10 keyed by
+ * rng_state[0] (seed), counter (row, draw, rng_state[1] = offset); rng_state = 3 x uint64 on the device {seed, offset, 0}, the offset advances by one
+ * per call (also under graph replay).  noise_out (optional, [rows][k]) receives the noise used: rf_attn_weights on it reproduces the weights. */
+int rf_attn_weights_sampled(const float* xf, const float* pf, int rows, int k, int f, float sharpness, void* rng_state,
+                            float* weights, float* switches, float* scores_out, float* noise_out, void* stream);
 int rf_attn_blend(const float* x, const float* retrieved, int b, int k, int c, int s, int t, const float* weights,
                   const float* switches, float* out, void* stream);
 

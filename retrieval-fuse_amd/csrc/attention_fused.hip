@@ -469,36 +469,96 @@ static int am_volume(const float* src, int b, int kv, int c, int s, int t, const
 }
 
 // ------------------------------------------------------------------------------------------------ weights per row
+// Gumbel(0, 1) noise for the hard attention (reference model/attention.py:100-103: -log(Exponential(1)) per (row, k), drawn by torch's
+// exponential_ from the global generator): Philox4x32-10 keyed by a 64-bit seed, counter = (row, draw index, offset), four draws per call;
+// u = (24 random bits + 0.5) / 2^24 in (0, 1), g = -log(-log(u)).  The stream is this library's own (torch's generator cannot be advanced from
+// inside a kernel); what the reference fixes is the DISTRIBUTION, which tests/test_kernels_gpu.py checks against torch's sampler.
+__device__ __forceinline__ void rf_philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ void rf_gumbel_row(unsigned long long seed, unsigned long long offset, int row, int K, float (&g)[RF_MAX_K]) {
+#pragma unroll
+    for (int q = 0; q < RF_MAX_K / 4; ++q) {
+        if (4 * q < K) {
+            unsigned c[4] = {(unsigned)row, (unsigned)q, (unsigned)offset, (unsigned)(offset >> 32)};
+            rf_philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = ((float)(c[j] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                g[4 * q + j] = -logf(-logf(u));
+            }
+        }
+    }
+}
+
 // one THREAD per attention row (a row is 32 + K*32 floats of features: nothing to share across lanes); the arithmetic is
-// rf_attn_row_weights, shared with k_attn_fuse
+// rf_attn_row_weights, shared with k_attn_fuse.  rng (Gumbel-hard mode without a noise tensor): {seed, offset, finished-blocks counter}; the
+// last block to finish advances the offset, so a captured graph draws fresh noise at every replay.
 __global__ __launch_bounds__(256) void k_attn_weights(const float* __restrict__ xf, const float* __restrict__ pf, const float* __restrict__ noise,
-                                                      int rows, int K, int f, int mode, float sharpness, float* __restrict__ w_out,
-                                                      float* __restrict__ sw_out, float* __restrict__ scores_out) {
+                                                      unsigned long long* __restrict__ rng, int rows, int K, int f, int mode, float sharpness,
+                                                      float* __restrict__ w_out, float* __restrict__ sw_out, float* __restrict__ scores_out,
+                                                      float* __restrict__ noise_out) {
+    const unsigned long long seed = rng ? rng[0] : 0ull, offset = rng ? rng[1] : 0ull;
     for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
-        float sc[RF_MAX_K], w[RF_MAX_K], sw;
-        rf_attn_row_weights(xf + (size_t)row * f, pf + (size_t)row * K * f, noise ? noise + (size_t)row * K : nullptr, K, f, mode, sharpness, sc, w, sw);
+        float sc[RF_MAX_K], w[RF_MAX_K], sw, g[RF_MAX_K];
+        const float* nrow = noise ? noise + (size_t)row * K : nullptr;
+        if (!noise && mode == RF_ATTN_GUMBEL_HARD) {
+            rf_gumbel_row(seed, offset, row, K, g);
+            nrow = g;
+        }
+        rf_attn_row_weights(xf + (size_t)row * f, pf + (size_t)row * K * f, nrow, K, f, mode, sharpness, sc, w, sw);
 #pragma unroll
         for (int k = 0; k < RF_MAX_K; ++k) {
             if (k < K) {
                 w_out[(size_t)row * K + k] = w[k];
                 if (scores_out) scores_out[(size_t)row * K + k] = sc[k];
+                if (noise_out && nrow) noise_out[(size_t)row * K + k] = nrow[k];
             }
         }
         sw_out[row] = sw;
     }
+    if (rng && !noise && mode == RF_ATTN_GUMBEL_HARD) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(rng + 2, 1ull) == (unsigned long long)gridDim.x - 1ull) { rng[1] = offset + 1ull; rng[2] = 0ull; }
+        }
+    }
+}
+
+static int attn_weights_launch(const float* xf, const float* pf, const float* noise, unsigned long long* rng, int rows, int k, int f, int mode,
+                               float sharpness, float* weights, float* switches, float* scores_out, float* noise_out, void* stream, const char* who) {
+    RF_REQUIRE(xf && pf && weights && switches && rows > 0, RF_E_INVALID, "%s: bad arguments", who);
+    RF_REQUIRE(k >= 1 && k <= RF_MAX_K, RF_E_UNSUPPORTED, "%s: K=%d outside 1..%d", who, k, RF_MAX_K);
+    RF_REQUIRE(f >= 1 && f <= 128, RF_E_UNSUPPORTED, "%s: feature width %d outside 1..128", who, f);
+    const int want = (rows + 255) / 256;
+    hipLaunchKernelGGL(k_attn_weights, dim3(want < 8192 ? want : 8192), dim3(256), 0, (hipStream_t)stream, xf, pf, noise, rng, rows, k, f, mode, sharpness,
+                       weights, switches, scores_out, noise_out);
+    RF_CHECK_LAUNCH(who);
+    return RF_OK;
 }
 
 extern "C" int rf_attn_weights(const float* xf, const float* pf, const float* noise, int rows, int k, int f, int mode, float sharpness,
                                float* weights, float* switches, float* scores_out, void* stream) {
-    RF_REQUIRE(xf && pf && weights && switches && rows > 0, RF_E_INVALID, "rf_attn_weights: bad arguments");
-    RF_REQUIRE(k >= 1 && k <= RF_MAX_K, RF_E_UNSUPPORTED, "rf_attn_weights: K=%d outside 1..%d", k, RF_MAX_K);
-    RF_REQUIRE(f >= 1 && f <= 128, RF_E_UNSUPPORTED, "rf_attn_weights: feature width %d outside 1..128", f);
-    RF_REQUIRE(mode == RF_ATTN_SOFTMAX || (mode == RF_ATTN_GUMBEL_HARD && noise), RF_E_INVALID, "rf_attn_weights: Gumbel-hard mode needs the noise tensor");
-    const int want = (rows + 255) / 256;
-    hipLaunchKernelGGL(k_attn_weights, dim3(want < 8192 ? want : 8192), dim3(256), 0, (hipStream_t)stream, xf, pf, noise, rows, k, f, mode, sharpness,
-                       weights, switches, scores_out);
-    RF_CHECK_LAUNCH("rf_attn_weights");
-    return RF_OK;
+    RF_REQUIRE(mode == RF_ATTN_SOFTMAX || (mode == RF_ATTN_GUMBEL_HARD && noise), RF_E_INVALID,
+               "rf_attn_weights: Gumbel-hard mode needs the noise tensor (or rf_attn_weights_sampled)");
+    return attn_weights_launch(xf, pf, noise, nullptr, rows, k, f, mode, sharpness, weights, switches, scores_out, nullptr, stream, "rf_attn_weights");
+}
+
+// Gumbel-hard weights with the noise drawn inside the kernel (see rf_gumbel_row).  rng_state: 3 x uint64 on the device = {seed, offset, 0};
+// every call advances the offset.  noise_out (optional) receives the noise that was used: feeding it to rf_attn_weights reproduces the weights.
+extern "C" int rf_attn_weights_sampled(const float* xf, const float* pf, int rows, int k, int f, float sharpness, void* rng_state,
+                                       float* weights, float* switches, float* scores_out, float* noise_out, void* stream) {
+    RF_REQUIRE(rng_state, RF_E_INVALID, "rf_attn_weights_sampled: null generator state");
+    return attn_weights_launch(xf, pf, nullptr, reinterpret_cast<unsigned long long*>(rng_state), rows, k, f, RF_ATTN_GUMBEL_HARD, sharpness, weights,
+                               switches, scores_out, noise_out, stream, "rf_attn_weights_sampled");
 }
 
 // ------------------------------------------------------------------------------------------------ blend in the folded layout

@@ -252,6 +252,39 @@ __global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, s
     }
 }
 
+// Small volumes (edge 2, 4, 8: 1, 8, 64 pooled voxels per plane -- the deep levels of the retrieval backbone, thousands of samples): a wave per
+// plane leaves 63 / 56 / 0 lanes idle and pays one wave's launch + a 64-lane float64 reduction per 8 outputs (173 us for 64 ch x 8192 samples
+// @4^3).  Here a wave takes 64 / OV planes, lane = (plane, pooled voxel); the statistics are a butterfly over the OV lanes of a plane.
+template <int OV>
+__global__ __launch_bounds__(256) void k_maxpool2_small(const float* __restrict__ x, size_t planes, float* __restrict__ out, double2* __restrict__ stats) {
+    constexpr int H = OV == 1 ? 1 : (OV == 8 ? 2 : 4), E = 2 * H, PPW = 64 / OV;
+    const size_t gl = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t plane = gl / OV;
+    const int o = (int)(gl % OV);
+    const bool live = plane < planes;
+    float m = 0.f;
+    if (live) {
+        const int ox = o % H, oy = (o / H) % H, oz = o / (H * H);
+        const float* b = x + plane * (size_t)(E * E * E) + ((size_t)(2 * oz) * E + 2 * oy) * E + 2 * ox;
+        m = -INFINITY;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const float2 v = *reinterpret_cast<const float2*>(b + ((size_t)dz * E + dy) * E);
+                m = fmaxf(m, fmaxf(v.x, v.y));
+            }
+        out[plane * OV + o] = m;
+    }
+    if (stats) {
+        double sm = (double)m, sq = (double)m * m;
+#pragma unroll
+        for (int d = OV >> 1; d > 0; d >>= 1) { sm += __shfl_xor(sm, d, 64); sq += __shfl_xor(sq, d, 64); }
+        if (live && o == 0) stats[plane] = make_double2(sm, sq);
+    }
+    (void)PPW;
+}
+
 extern "C" int rf_maxpool_stats_tiles(int edge) {
     const size_t ovol = (size_t)(edge / 2) * (edge / 2) * (edge / 2);
     return (int)((ovol + RF_POOL_CHUNK - 1) / RF_POOL_CHUNK);
@@ -260,6 +293,16 @@ extern "C" int rf_maxpool_stats_tiles(int edge) {
 static int maxpool_impl(const float* x, int n, int c, int edge, float* out, double* stats, void* stream) {
     RF_REQUIRE(x && out && n > 0 && c > 0, RF_E_INVALID, "rf_maxpool3d_2: bad arguments");
     RF_REQUIRE(rf_is_pow2(edge) && edge >= 2 && edge <= 128, RF_E_INVALID, "rf_maxpool3d_2: edge %d", edge);
+    if (edge <= 8) {
+        const size_t planes = (size_t)n * c, ov = (size_t)(edge / 2) * (edge / 2) * (edge / 2);
+        const unsigned blocks = (unsigned)((planes * ov + 255) / 256);
+        double2* st = reinterpret_cast<double2*>(stats);
+        if (edge == 2) hipLaunchKernelGGL(k_maxpool2_small<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, planes, out, st);
+        else if (edge == 4) hipLaunchKernelGGL(k_maxpool2_small<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, planes, out, st);
+        else hipLaunchKernelGGL(k_maxpool2_small<64>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, planes, out, st);
+        RF_CHECK_LAUNCH("rf_maxpool3d_2");
+        return RF_OK;
+    }
     const int chunks = rf_maxpool_stats_tiles(edge);
     const size_t units = (size_t)n * c * chunks;
     hipLaunchKernelGGL(k_maxpool2, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, units, edge, chunks, out,

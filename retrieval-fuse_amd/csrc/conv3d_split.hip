@@ -414,12 +414,15 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
 //
 // k_conv3_cin1_presplit: the first conv of a U-Net's level-0 DoubleConv (1 -> 8 channels, model/unet.py:125-144) on whole 16^3 samples, one
 // workgroup of 512 threads per sample; thread = one (y, x) column of 8 z voxels, all 8 couts in registers (cout pairs on v_pk_fma_f32, taps
-// accumulated in the (dy, dx, dz) order of k_conv3_cin1: the conv result is bit-identical to that kernel's).  Then: ReLU, per-channel
+// accumulated in the (dy, dx, dz) order of k_conv3_cin1).  The input's own GroupNorm (one channel) is computed here too: the workgroup holds the
+// whole sample.  Then: ReLU, per-channel
 // sums in float64 (recursive halving over the lanes, fixed order), the NEXT layer's GroupNorm triple (gn_affine), normalise, split, store --
 // a thread owns whole slots (8 channels of a voxel), and the 256 threads of a z plane write 4 KB contiguously.
 struct Cin1PreArgs {
     const float* src;          // [n][16^3]
-    const float4* affine;      // [n] GroupNorm of the input (cin = 1)
+    const float* gamma_in;     // GroupNorm of the input (cin = 1: one channel, one group): weight [1], bias [1]
+    const float* beta_in;
+    double eps_in;
     const float* wp;           // conv3 weight image [27][cin4][cout16]
     int n, cin4, cout16;
     const float* gamma;        // the consumer's GroupNorm over the 8 output channels
@@ -439,12 +442,28 @@ __global__ __launch_bounds__(512, 4) void k_conv3_cin1_presplit(Cin1PreArgs a) {
     const int nn = blockIdx.x;
     for (int i = tid; i < H * H * H; i += 512) xs[i] = 0.f;
     for (int i = tid; i < 27 * 8; i += 512) wl[i] = a.wp[(size_t)(i / 8) * a.cin4 * a.cout16 + (i % 8)];
-    const float4 af = a.affine[nn];
     const float* src = a.src + (size_t)nn * VOL;
     float raw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) raw[i] = src[tid + i * 512];
+    {   // GroupNorm of the input sample (1 channel): float64 sums, wave butterflies, the 8 waves in order
+        double sm = 0.0, sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sm += (double)raw[i]; sq += (double)raw[i] * raw[i]; }
+        sm = wave_sum(sm); sq = wave_sum(sq);
+        if (lane == 0) { red[2 * wave] = sm; red[2 * wave + 1] = sq; }
+    }
     __syncthreads();
+    float4 af;
+    {
+        double sm = 0.0, sq = 0.0;
+        for (int w = 0; w < 8; ++w) { sm += red[2 * w]; sq += red[2 * w + 1]; }
+        const double mean = sm / VOL;
+        double var = sq / VOL - mean * mean;
+        if (var < 0.0) var = 0.0;
+        af = gn_affine(mean, 1.0 / sqrt(var + a.eps_in), a.gamma_in[0], a.beta_in[0]);
+    }
+    __syncthreads();                                                // red is reused for the output statistics
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int v = tid + i * 512;
@@ -546,14 +565,15 @@ extern "C" int rf_conv3d_cin1_presplit_supported(int n, int edge, int cout, int 
     return n > 0 && edge == 16 && cout == 8 && next_groups > 0 && 8 % next_groups == 0;
 }
 
-extern "C" int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* gn_affine_in, const float* w_packed, int cout,
-                                       const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit, void* stream) {
+extern "C" int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* in_gamma, const float* in_beta, float in_eps, const float* w_packed,
+                                       int cout, const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit,
+                                       void* stream) {
     RF_REQUIRE(rf_conv3d_cin1_presplit_supported(n, edge, cout, next_groups), RF_E_UNSUPPORTED,
                "rf_conv3d_cin1_presplit: takes 1 -> 8 channels on 16^3 samples with 1, 2, 4 or 8 groups in the consumer's GroupNorm (got n=%d edge=%d cout=%d groups=%d)",
                n, edge, cout, next_groups);
-    RF_REQUIRE(src && gn_affine_in && w_packed && next_gamma && next_beta && out_presplit, RF_E_INVALID, "rf_conv3d_cin1_presplit: null pointer");
+    RF_REQUIRE(src && in_gamma && in_beta && w_packed && next_gamma && next_beta && out_presplit, RF_E_INVALID, "rf_conv3d_cin1_presplit: null pointer");
     Cin1PreArgs a;
-    a.src = src; a.affine = reinterpret_cast<const float4*>(gn_affine_in); a.wp = w_packed; a.n = n; a.cin4 = 4; a.cout16 = 16;
+    a.src = src; a.gamma_in = in_gamma; a.beta_in = in_beta; a.eps_in = (double)in_eps; a.wp = w_packed; a.n = n; a.cin4 = 4; a.cout16 = 16;
     a.gamma = next_gamma; a.beta = next_beta; a.cpg = 8 / next_groups; a.eps = (double)eps; a.out = reinterpret_cast<unsigned char*>(out_presplit);
     hipLaunchKernelGGL(k_conv3_cin1_presplit, dim3((unsigned)n), dim3(512), 0, (hipStream_t)stream, a);
     RF_CHECK_LAUNCH("rf_conv3d_cin1_presplit");

@@ -111,6 +111,14 @@ class AttentionBlock(nn.Module):
         self.use_switching = use_switching
         self.normalize = normalize
 
+    def _gumbel_state(self, device):
+        """per-device generator state of the in-kernel Gumbel sampler, seeded from torch's seed at first use (torch.manual_seed before that)"""
+        states = self.__dict__.setdefault('_gumbel_states', {})
+        key = str(device)
+        if key not in states:
+            states[key] = ops.gumbel_rng_state(device)
+        return states[key]
+
     @staticmethod
     def sample_gumbel(rows, k, device):
         """-log(Exponential(1)) samples, the draw torch's gumbel_softmax makes (reference :102)."""
@@ -178,7 +186,10 @@ class AttentionBlock(nn.Module):
         x_feat = ops.attn_mlp_volume(x_predicted, b, 1, c, s, s, self.theta.packed_fused())
         p_feat = ops.attn_mlp_volume(retrieved, b, self.K, c, s, patch_edge, self.phi.packed_fused())
         rows = x_feat.shape[0]
-        if self.retrieval_mode:
+        if self.retrieval_mode and gumbel_noise is None and debug is None:
+            # the noise of gumbel_softmax drawn inside the weights kernel (Philox; no sampling launches, fresh noise under graph replay)
+            res = ops.attn_weights_sampled(x_feat, p_feat, self.K, 25.0, self._gumbel_state(x_predicted.device))
+        elif self.retrieval_mode:
             if gumbel_noise is None:
                 gumbel_noise = self.sample_gumbel(rows, self.K, x_predicted.device)
             res = ops.attn_weights(x_feat, p_feat, gumbel_noise.contiguous(), self.K, ops.ATTN_GUMBEL_HARD, 25.0, debug=debug is not None)

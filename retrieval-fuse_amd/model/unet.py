@@ -175,8 +175,7 @@ class DoubleConv(nn.Module):
             # level 0 of a U-Net on 16^3 samples: the first conv hands the second its input already normalised (second GroupNorm) and split
             # into f16 pairs (ops.conv3d_cin1_presplit) -- the second conv stages it with copies
             g1, g2 = c1.groupnorm, c2.groupnorm
-            aff = ops.gn_affine(x, None, g1.weight, g1.bias, g1.num_groups, g1.eps)
-            pre = ops.conv3d_cin1_presplit(x, aff, c1.conv.packed(), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
+            pre = ops.conv3d_cin1_presplit(x, g1.weight, g1.bias, g1.eps, c1.conv.packed(), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
             return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
         return c2(c1(x, upsampled), pool=pool)
 

@@ -64,7 +64,7 @@ SIGNATURES = {
     'rf_conv3d_split_k3_gn_relu': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_split_act_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_cin1_presplit_supported': (c_i, [c_i, c_i, c_i, c_i]),
-    'rf_conv3d_cin1_presplit': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_p, c_p]),
+    'rf_conv3d_cin1_presplit': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_p, c_p]),
     'rf_conv3d_split_pre_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_pre_k3_relu': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_conv3_up_split_packed_bytes': (c_sz, [c_i, c_i, c_i]),
@@ -96,6 +96,7 @@ SIGNATURES = {
     'rf_attn_mlp_split_volume': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
     'rf_attn_mlp_volume': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_p]),
     'rf_attn_weights': (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_p]),
+    'rf_attn_weights_sampled': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_f, c_p, c_fp, c_fp, c_fp, c_fp, c_p]),
     'rf_attn_blend': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
     'rf_query_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_p]),
     'rf_db_pack_embeddings': (c_i, [c_fp, c_i64, c_i, c_fp, c_p]),

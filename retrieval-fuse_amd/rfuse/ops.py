@@ -417,15 +417,15 @@ def cin1_presplit_supported(x, cout, next_groups, next_cout):
     return bool(lib.rf_conv3d_cin1_presplit_supported(n, edge, cout, next_groups)) and bool(lib.rf_conv3d_split_pre_supported(cout, n, edge, next_cout))
 
 
-def conv3d_cin1_presplit(x, aff, w_packed, cout, next_gamma, next_beta, next_groups, eps):
-    """ReLU(conv3(GN(x))) of a 1-channel input, emitted as the pre-split input of the NEXT layer (its GroupNorm applied): uint8 buffer."""
+def conv3d_cin1_presplit(x, in_gamma, in_beta, in_eps, w_packed, cout, next_gamma, next_beta, next_groups, eps):
+    """ReLU(conv3(GN(x))) of a 1-channel input (its GroupNorm computed in the kernel), emitted as the pre-split input of the NEXT layer (that
+    layer's GroupNorm applied): uint8 buffer."""
     _req(x, 'x')
     n, edge = x.shape[0], x.shape[2]
-    _check_affine(aff, n, 1)
     lib = _lib.load()
     out = torch.empty(lib.rf_split_act_bytes(n, cout, edge), dtype=torch.uint8, device=x.device)
-    _lib.check(lib.rf_conv3d_cin1_presplit(_p(x), n, edge, _p(aff), _p(w_packed), cout, _p(next_gamma.detach()), _p(next_beta.detach()), next_groups, eps,
-                                           _p(out), _stream()), 'rf_conv3d_cin1_presplit')
+    _lib.check(lib.rf_conv3d_cin1_presplit(_p(x), n, edge, _p(in_gamma.detach()), _p(in_beta.detach()), in_eps, _p(w_packed), cout, _p(next_gamma.detach()),
+                                           _p(next_beta.detach()), next_groups, eps, _p(out), _stream()), 'rf_conv3d_cin1_presplit')
     return out
 
 
@@ -841,6 +841,27 @@ def attn_weights(xf, pf, noise, k, mode, sharpness, debug=False):
     _lib.check(_lib.load().rf_attn_weights(_p(xf), _p(pf), _p(noise), rows, k, f, mode, sharpness, _p(w), _p(sw), _p(sc), _stream()),
                'rf_attn_weights')
     return (w, sw, sc) if debug else (w, sw)
+
+
+def gumbel_rng_state(device, seed=None):
+    """{seed, offset, 0} as int64[3] on ``device`` for attn_weights_sampled; the seed defaults to torch's CUDA seed of that device."""
+    if seed is None:
+        seed = torch.cuda.initial_seed() if torch.device(device).type == 'cuda' else torch.initial_seed()
+    return torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+
+
+def attn_weights_sampled(xf, pf, k, sharpness, rng_state, want_noise=False):
+    """Gumbel-hard weights with the noise drawn inside the kernel (Philox; advances ``rng_state``) -> (weights, switches[, noise used])."""
+    _req(xf, 'xf'), _req(pf, 'pf'), _req(rng_state, 'rng_state', torch.int64)
+    rows, f = xf.shape
+    if pf.shape[0] != rows * k:
+        raise ValueError('attn_weights_sampled: %d phi rows for %d theta rows and K=%d' % (pf.shape[0], rows, k))
+    w = torch.empty((rows, k), dtype=torch.float32, device=xf.device)
+    sw = torch.empty((rows,), dtype=torch.float32, device=xf.device)
+    nz = torch.empty((rows, k), dtype=torch.float32, device=xf.device) if want_noise else None
+    _lib.check(_lib.load().rf_attn_weights_sampled(_p(xf), _p(pf), rows, k, f, sharpness, _p(rng_state), _p(w), _p(sw), _p(None), _p(nz), _stream()),
+               'rf_attn_weights_sampled')
+    return (w, sw, nz) if want_noise else (w, sw)
 
 
 def attn_blend(x, retrieved, k, t, weights, switches):

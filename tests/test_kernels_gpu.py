@@ -400,6 +400,14 @@ def test_maxpool_and_conv1x1_tanh(ops):
     gen = torch.Generator().manual_seed(3)
     x = rnd(gen, 3, 5, 8, 8, 8)
     assert torch.equal(ops.maxpool2(x.to(DEV)).cpu(), F.max_pool3d(x, 2))
+    for n, c, e in ((67, 5, 2), (130, 24, 4), (33, 7, 8), (3, 2, 16)):             # the small-volume kernel (edge <= 8: several planes per wave), ragged plane counts
+        x = rnd(gen, n, c, e, e, e)
+        got = ops.maxpool2(x.to(DEV))
+        ref = F.max_pool3d(x, 2)
+        assert torch.equal(got.cpu(), ref)
+        st = got._rf_stats[0].sum(dim=2).cpu()                                     # [n, c, 2] float64 (sum, sum of squares) of the pooled planes
+        want = torch.stack([ref.double().sum(dim=(2, 3, 4)), (ref.double() ** 2).sum(dim=(2, 3, 4))], dim=-1)
+        assert torch.allclose(st, want, rtol=1e-12, atol=1e-12)
     x = rnd(gen, 2, 16, 16, 16, 16)
     w, b = rnd(gen, 1, 16, 1, 1, 1, scale=0.3), rnd(gen, 1)
     ref = torch.tanh(F.conv3d(x, w, b))
@@ -1021,3 +1029,34 @@ def test_presplit_route_of_a_level0_double_conv(ops, n, pool):
         if getattr(f, '_rf_stats', None) is not None:                          # the statistics that ride along feed the next GroupNorm
             sf, sp = f._rf_stats[0].sum(dim=2), p_._rf_stats[0].sum(dim=2)
             assert torch.allclose(sf, sp, rtol=1e-5, atol=1e-5)
+
+
+def test_in_kernel_gumbel_sampler(ops):
+    """rf_attn_weights_sampled draws the Gumbel noise of gumbel_softmax(hard=True) (reference model/attention.py:100-103) inside the kernel:
+    (a) the noise it reports, fed to the explicit-noise entry point, reproduces its weights bit for bit; (b) the noise is Gumbel(0, 1) --
+    moments and quantiles against torch's own -log(Exponential(1)) sampler; (c) consecutive calls draw different noise, equal seeds equal noise."""
+    gen = torch.Generator().manual_seed(41)
+    rows, K = 1 << 18, 8
+    xf, pf = rnd(gen, rows, 32).to(DEV), rnd(gen, rows * K, 32).to(DEV)
+    st = ops.gumbel_rng_state(DEV, seed=1234)
+    w, sw, nz = ops.attn_weights_sampled(xf, pf, K, 25.0, st, want_noise=True)
+    w2, sw2 = ops.attn_weights(xf, pf, nz, K, ops.ATTN_GUMBEL_HARD, 25.0)
+    assert torch.equal(w, w2) and torch.equal(sw, sw2)
+    assert st.cpu().tolist() == [1234, 1, 0]
+    _, _, nz_b = ops.attn_weights_sampled(xf, pf, K, 25.0, st, want_noise=True)
+    assert not torch.equal(nz, nz_b) and st.cpu().tolist()[1] == 2
+    _, _, nz_c = ops.attn_weights_sampled(xf, pf, K, 25.0, ops.gumbel_rng_state(DEV, seed=1234), want_noise=True)
+    assert torch.equal(nz, nz_c)
+    ref = -torch.empty(rows * K, device=DEV).exponential_().log()
+    a, b = nz.flatten().double(), ref.double()
+    assert torch.isfinite(a).all()
+    assert abs(a.mean().item() - 0.5772156649) < 5e-3 and abs(a.var().item() - 1.6449340668) < 2e-2
+    qs = torch.tensor([0.001, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 0.999], device=DEV, dtype=torch.float64)
+    qa, qb = torch.quantile(a[:1 << 20], qs), torch.quantile(b[:1 << 20], qs)
+    exact = -torch.log(-torch.log(qs))
+    assert (qa - exact).abs().max().item() < 0.03 and (qb - exact).abs().max().item() < 0.03
+    # independence across the K draws of a row and across rows: correlations of a white sample
+    m = nz.double() - nz.double().mean()
+    c01 = (m[:, 0] * m[:, 1]).mean().item() / m.var().item()
+    crow = (m[:-1, 0] * m[1:, 0]).mean().item() / m.var().item()
+    assert abs(c01) < 0.01 and abs(crow) < 0.01
