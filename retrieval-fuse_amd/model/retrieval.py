@@ -85,20 +85,6 @@ class _ConvPatchEncoder(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.final_layer = LinearParams(self.SPEC[-1][1] * nf, z_dim)
 
-    def uses_split_valid_convs(self, window, device):
-        """True when a layer of this encoder, applied to window^3 inputs, runs on rf_conv3d_valid_leaky_split (the engine keeps such
-        an encoder from overlapping with other streams' kernels)"""
-        s = window
-        for layer in self.layers:
-            if isinstance(layer, Conv3dParams):
-                if s < layer.kernel_size:
-                    return False
-                if ops.conv_valid_split_supported(torch.empty((1, layer.in_channels, s, 0, 0), device=device), layer.out_channels,
-                                                  layer.kernel_size, layer.stride):
-                    return True
-                s = (s - layer.kernel_size) // layer.stride + 1
-        return False
-
     def forward(self, x):
         if self.BATCHNORM:
             raise NotImplementedError(f'{type(self).__name__}: BatchNorm patch encoders are not built (no shipped config selects them)')

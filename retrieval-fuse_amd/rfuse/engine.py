@@ -102,11 +102,6 @@ class RefinementEngine:
         s = input_raw.shape[-1]
         return ops.query_windows(input_raw, s, 0, 0.0, d['input_mean'], d['input_std']).reshape(input_raw.shape[0], 1, s, s, s)
 
-    def _encoder_runs_alone(self, input_raw):
-        g = self.config['query_geometry']
-        uses = getattr(self.fenc_input, 'uses_split_valid_convs', None)
-        return bool(uses and not self.serial and uses(g['patch_size_input'] + 2 * g['patch_context_input'], input_raw.device))
-
     def _fork_backbone(self, x_in):
         """Launch the U-Net backbone on a second HIP stream: it depends only on the input chunk, is made of small
         launches (1^3..32^3 volumes of a few chunks) that cannot fill 256 CUs, and so runs in the shadow of the
@@ -149,13 +144,11 @@ class RefinementEngine:
         ``use_feature_cache=True`` (needs ``database.build_feature_cache``) fetches the retrieval-backbone features of the
         retrieved database rows from HBM instead of recomputing them -- an optional serving mode that skips 87 % of the
         FLOPs; results agree with the full path to GroupNorm-statistics rounding."""
-        # The split-operand valid convs of the large-window patch encoders (PCPatch48 ...) must not share a SIMD with fp32-MFMA kernels
-        # of another stream (DESIGN 4.7, "two-stream hazard": the co-resident kernel's results move by a few ulp): such an encoder
-        # runs before the backbone is forked.  Its launches fill the GPU anyway, there was nothing to overlap.
-        q = self.embed_queries(input_raw) if self._encoder_runs_alone(input_raw) else None
+        # the backbone is forked first and runs beside everything else of the step (round 2 ran the large-window patch encoders before the
+        # fork to keep their F16 MFMAs away from fp32 kernels of the other stream; the cause of that hazard is fixed, DESIGN 4.7, and the order
+        # makes no measurable difference: C5 23.9 vs 23.8 ms per step)
         x_back, side = self._fork_backbone(self.normalise_input(input_raw))
-        if q is None:
-            q = self.embed_queries(input_raw)
+        q = self.embed_queries(input_raw)
         if use_feature_cache:
             if self.database.feature_cache is None:
                 raise RuntimeError('use_feature_cache=True needs database.build_feature_cache(retrieval_backbone, config) first')
