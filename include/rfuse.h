@@ -125,11 +125,7 @@ size_t rf_convv_lds_packed_floats(int cout, int cin, int k);
  * accumulation; closer to float64 than the fp32 MFMA chain): the large layers with cin a multiple of 4 (PCPatch48's 12 -> 24 k3
  * @44^3, 24 -> 48 k3 s2 @42^3, 48 -> 48 k3 s2 @20^3, model/retrieval.py:222-228; Patch32's, :9-15).  K is walked in pieces of
  * (tap, 4 channels); the tile / chunk plan depends on (cin, s, cout, k, stride) only and the weight image is packed for it:
- * rf_convv_split_packed_bytes is 0 when the form does not take the layer.
- * Scheduling: do not run this entry point concurrently with fp32-MFMA kernels of another stream on the same device -- the fp32
- * conv kernels return slightly different bits (1-8 ulp on a few outputs) when a kernel issuing F16 MFMAs shares their SIMD (a bare
- * fp32 MFMA chain does not: the sensitive path is open), and this kernel's 2-3 workgroups per CU leave room for foreign waves (tools/hazard_probe.py,
- * tools/two_stream_convv.py); its own results are unaffected.  The engine runs such encoders before it forks its second stream. */
+ * rf_convv_split_packed_bytes is 0 when the form does not take the layer. */
 int rf_conv3d_valid_split_supported(int n, int cin, int s, int cout, int k, int stride);
 int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
                                 int stride, float slope, float* out, void* stream);

@@ -317,9 +317,6 @@ constexpr int S4_LDS_BYTES = 2 * S4_PLANE;                       // 55,296: one 
 
 __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // the wave's allocation is pinned at 128 VGPRs: four waves per SIMD then fill the register file and no wave of another stream's fp32-MFMA
-    // kernel can share the SIMD with this kernel's F16 MFMAs
-    asm volatile("" ::: "v127");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cin = a.c0, nC = cin >> 3;

@@ -147,9 +147,6 @@ __device__ __forceinline__ void us_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
 template <int NB>
 __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // allocation pinned at 256 VGPRs (the NB 3 instance needs 202): the workgroup's two waves per SIMD then fill the register file and no
-    // wave of another stream's fp32-MFMA kernel can run interleaved with this kernel's F16 MFMAs
-    if constexpr (NB == 3) asm volatile("" ::: "v255");             // (NB 4 uses 254 of them anyway)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
@@ -364,7 +361,6 @@ static_assert(2 * U4_A_PLANE <= U4_LDS_BYTES && U4_BG * 2 * U4_B_PLANE <= U4_LDS
 template <int NB, bool PRE>
 __global__ __launch_bounds__(512, 4) void k_conv3_up_split_s4(UpSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    asm volatile("" ::: "v127");                                    // allocation pinned at 128 VGPRs: four waves per SIMD fill the register file
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3;

@@ -229,10 +229,9 @@ def test_conv3d_split_operand_box_kernel(ops, case):
 @pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (8, 16)])
 def test_split_box_kernel_leaves_concurrent_kernels_alone(ops, cin, cout):
     """Two-stream regression (the engine runs the U-Net backbone on a side stream): small fp32 convs on a second stream must return
-    their solo results bit for bit while split-operand box convs run on the main stream.  The fp32 conv kernels change their last bits when a
-    kernel issuing F16 MFMAs shares their SIMD; a 2-n-block instance of the box kernel (158 VGPRs)
-    left room for foreign waves on its SIMDs and so let that happen; 32 couts now run as two 16-cout workgroups whose four waves per
-    SIMD fill the register file.  (cin = 8 is the single-chunk instance: 80 VGPRs, six waves per SIMD.)"""
+    their solo results bit for bit while split-operand box convs run on the main stream -- including the two-n-block instance (32 couts,
+    158 VGPRs) that leaves room for foreign waves on its SIMDs.  Round 2 saw the fp32 kernels' bits move there; the cause was an unsafe
+    packed-fp32 instruction form in the fp32 kernels (tests/test_two_stream_gpu.py), not this kernel."""
     gen = torch.Generator().manual_seed(3)
     x = rnd(gen, 2048, cin, 8, 8, 8).relu_().to(DEV)
     aff = ops.gn_affine(x, None, torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV), 8)

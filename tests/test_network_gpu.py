@@ -257,9 +257,8 @@ def test_engine_fast_routes_match_plain_routes_at_bench_sizes(gpu, cfg_name, B):
 
 @pytest.mark.parametrize('cfg_name,B', [('C1', 8), ('C5', 4)])
 def test_engine_two_stream_schedule_is_bit_equal_to_serial(gpu, cfg_name, B):
-    """The backbone runs on a second stream beside the retrieval path.  Kernels of the two streams share SIMDs, and the fp32 conv kernels
-    return slightly different bits when a kernel issuing F16 MFMAs shares their SIMD (tools/hazard_probe.py): the engine's schedule keeps fp32-MFMA work away from F16-MFMA kernels that leave room for foreign waves
-    (the large-window patch encoder runs before the fork), so both schedules must give the same bits."""
+    """The backbone runs on a second stream beside the retrieval path; both schedules must give the same bits (see tests/test_two_stream_gpu.py for
+    the full matrix and DESIGN 4.7 for what once made them differ)."""
     from rfuse.database import PatchDatabase
     from rfuse.engine import RefinementEngine
     cfg = rf_configs.get_config(cfg_name)
