@@ -178,6 +178,9 @@ int rf_conv3d_up_k3_gn_relu(const float* src0, int c0, const float* src1, int c1
 size_t rf_conv3_up_split_packed_bytes(int cout, int c0, int c1);
 int rf_conv3_up_split_pack_weight(const float* w_oidhw, int cout, int c0, int c1, void* w_packed, void* stream);
 int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int cout);
+/* statistics tiles per (sample, cout) of rf_conv3d_up_split_k3_gn_relu's `stats` [n][cout][tiles]: 1 for whole-sample workgroups, (edge/8)^3 for the
+ * box-tiled form (c0 == 0, edge >= 16: DecoderNoJoining's first conv, model/unet.py:311-322) */
+int rf_conv3d_up_split_stats_tiles(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge,
                                   const float* gn_affine, const void* w_packed, int cout, float* out, double* stats, void* stream);
 

@@ -551,9 +551,139 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_s4(UpSplitArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------- host
+// ------------------------------------------------------------------------------------- box tiles of a large volume, no skip source
+// DecoderNoJoining's first conv (model/unet.py:311-322: x2 nearest upsample, GroupNorm -> conv3 -> ReLU; the final decoder's 16 -> 16 @64^3 from
+// 32^3, the U-Net backbone's 32 -> 32 @16^3 / 32 -> 16 @32^3): only upsampled channels, so only phase B of the kernel above -- the 8 pre-summed
+// low-resolution taps per output parity.  A workgroup owns one 8^3 output box of an edge^3 volume: its low-res halo box is 6^3 voxels of the
+// half-resolution source (zeros outside the volume), all channel groups staged at once (thread = (group, halo voxel)); wave = output parity,
+// m-block m = z pair m; per channel group two k-steps (tz = 0 / 1), lane group = (ty, tx).  With 16 input channels that is 48 MFMAs per wave:
+// the kernel is its staging (216 x c1 values in) and its epilogue (512 x cout values out + statistics), and small enough in registers and
+// LDS (33 KB) for four workgroups per CU to overlap them.
+namespace {
+constexpr int UB_E_STRIDE = 516;
+}
+template <int NB>
+__global__ __launch_bounds__(512, 4) void k_conv3_up_split_box(UpSplitArgs a, int edge) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    const int c1 = a.c1, nB = c1 >> 3, half = edge >> 1, tpe = edge >> 3;
+    // XCD-contiguous box order (conv_box.h): neighbouring boxes share halo voxels and output cache lines
+    const unsigned g_ = gridDim.x, per = g_ >> 3, rem = g_ & 7u, kx = blockIdx.x & 7u;
+    int t = (int)(kx * per + (kx < rem ? kx : rem) + (blockIdx.x >> 3));
+    const int tile = t % (tpe * tpe * tpe);
+    const int x0 = (t % tpe) * 8; t /= tpe;
+    const int y0 = (t % tpe) * 8; t /= tpe;
+    const int z0 = (t % tpe) * 8; t /= tpe;
+    const int n = t;
+    const float4* __restrict__ aff = a.affine + (size_t)n * c1;
+    const size_t hvol = (size_t)half * half * half;
+
+    // ---- stage: thread = (channel group, halo voxel); 216 voxels per group
+    for (int u = tid; u < nB * US_BSLOTS; u += 512) {
+        const int cg = u / US_BSLOTS, v = u % US_BSLOTS;
+        const int hz = v / US_BZ, hy = (v / US_BY) % 6, hx = v % 6;
+        const int z = (z0 >> 1) + hz - 1, y = (y0 >> 1) + hy - 1, x = (x0 >> 1) + hx - 1;
+        const bool in = (unsigned)z < (unsigned)half && (unsigned)y < (unsigned)half && (unsigned)x < (unsigned)half;
+        float yv[8];
+        const float* __restrict__ sp = a.src1 + ((size_t)n * c1 + cg * 8) * hvol + (in ? ((size_t)z * half + y) * half + x : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 af = aff[cg * 8 + j];
+            yv[j] = in ? fmaf(sp[(size_t)j * hvol] - af.x, af.y, af.z) : 0.f;       // zero padding of the NORMALISED tensor
+        }
+        h8 h, l;
+        us_split8(yv, h, l);
+        unsigned char* p = lds + cg * 2 * US_B_PLANE + v * 16;
+        *reinterpret_cast<h8*>(p) = h;
+        *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
+    }
+
+    const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
+    const int bbase = (pz * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;        // + (m + tz) BZ
+    f32x4 hi[4][NB], lo[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    constexpr int STEP_U4 = NB * 2 * 64;
+    const h8* __restrict__ wn = a.wp + (size_t)wave * nB * 2 * STEP_U4 + lane;       // this parity's stream: [group][tz][nb][h|l][64]
+    h8 bh[NB], bl[NB];
+    __syncthreads();
+    for (int cb = 0; cb < nB; ++cb) {
+#pragma unroll
+        for (int tz = 0; tz < 2; ++tz) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { bh[nb] = wn[(nb * 2) * 64]; bl[nb] = wn[(nb * 2 + 1) * 64]; }
+            wn += STEP_U4;
+            const unsigned char* ap = lds + cb * 2 * US_B_PLANE + bbase + tz * US_BZ * 16;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const h8 ah = *reinterpret_cast<const h8*>(ap + m * US_BZ * 16);
+                const h8 al = *reinterpret_cast<const h8*>(ap + m * US_BZ * 16 + US_B_PLANE);
+                us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: relu(hi + lo / 2^11) -> LDS tile [cout][z][y][x] of the box -> float4 half rows, statistics of the box per cout
+    float* e = reinterpret_cast<float*>(lds);
+    {
+        const int col = lane & 15, yj = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lin = (2 * m + pz) * 64 + (2 * yj + py) * 8 + 2 * r + px;
+                    e[(nb * 16 + col) * UB_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
+                }
+    }
+    __syncthreads();
+    const int cout = a.cout;
+    const size_t vol = (size_t)edge * edge * edge;
+    float* __restrict__ o = a.out + (size_t)n * cout * vol + ((size_t)z0 * edge + y0) * edge + x0;
+    for (int q = tid; q < cout * 128; q += 512) {
+        const int co = q >> 7, l4 = q & 127;                          // l4: float4 index inside the box: (z, y, half row)
+        const int z = l4 >> 4, y = (l4 >> 1) & 7, xh = l4 & 1;
+        *reinterpret_cast<float4*>(o + (size_t)co * vol + ((size_t)z * edge + y) * edge + xh * 4) = *reinterpret_cast<const float4*>(e + co * UB_E_STRIDE + l4 * 4);
+    }
+    if (a.stats) {
+        const int tiles = tpe * tpe * tpe;
+        const int co = tid >> 3, part = tid & 7;
+        double sm = 0.0, sq = 0.0;
+        if (co < cout) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(e + co * UB_E_STRIDE + (part * 16 + i) * 4);
+                sm += (double)v.x; sq += (double)v.x * v.x;
+                sm += (double)v.y; sq += (double)v.y * v.y;
+                sm += (double)v.z; sq += (double)v.z * v.z;
+                sm += (double)v.w; sq += (double)v.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
+        if (part == 0 && co < cout) a.stats[((size_t)n * cout + co) * tiles + tile] = make_double2(sm, sq);
+    }
+}
+
+static bool up_split_box_takes(int c0, int c1, int n, int edge, int cout) {
+    if (c0 != 0 || c1 <= 0 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0 || cout > 32 || !rf_is_pow2(edge) || edge < 16 || edge > 128) return false;
+    return (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 1024;        // enough boxes to fill the chip
+}
+
+extern "C" int rf_conv3d_up_split_stats_tiles(int c0, int c1, int n, int edge, int cout) {
+    return up_split_box_takes(c0, c1, n, edge, cout) ? (edge / 8) * (edge / 8) * (edge / 8) : 1;
+}
+
 extern "C" int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int cout) {
     // whole 4^3 samples (k_conv3_up_split_s4): 8 per workgroup, 32 couts per workgroup
     if (edge == 4) return n >= 1024 && c0 >= 0 && c1 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && cout > 0;
+    if (up_split_box_takes(c0, c1, n, edge, cout)) return 1;      // box tiles of a large volume, upsampled channels only (k_conv3_up_split_box)
     if (edge != 8 || n < 256 || c0 < 0 || c1 <= 0 || c0 % 8 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0) return 0;
     const int nb = rf_round_up(cout, 16) / 16;
     return nb == 3 || nb == 4;
@@ -572,12 +702,26 @@ static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
 extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                               const void* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts) or 4^3 samples (n >= 1024, couts in 32s), c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts), 4^3 samples (n >= 1024) or 8^3 boxes of edge >= 16 volumes without a skip source (c1 <= 64, <= 32 couts); c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
                c0, c1, n, edge, cout);
     RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu: null pointer");
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = out; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    if (up_split_box_takes(c0, c1, n, edge, cout)) {
+        const unsigned boxes = (unsigned)n * (edge / 8) * (edge / 8) * (edge / 8);
+        const int nbq = rf_round_up(cout, 16) / 16;
+        const size_t lds_bytes = (size_t)(nbq * 16) * UB_E_STRIDE * 4 > (size_t)(c1 / 8) * 2 * US_B_PLANE ? (size_t)(nbq * 16) * UB_E_STRIDE * 4 : (size_t)(c1 / 8) * 2 * US_B_PLANE;
+        if (nbq == 1) {
+            hipLaunchKernelGGL(k_conv3_up_split_box<1>, dim3(boxes), dim3(512), lds_bytes, (hipStream_t)stream, a, edge);
+        } else {
+            static RfLdsOptIn opt_in;
+            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_conv3_up_split_box<2>), (int)lds_bytes, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+            hipLaunchKernelGGL(k_conv3_up_split_box<2>, dim3(boxes), dim3(512), lds_bytes, (hipStream_t)stream, a, edge);
+        }
+        RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
+        return RF_OK;
+    }
     if (edge == 4) {
         static RfLdsOptIn opt_in;
         // 16 couts per workgroup: the 32-cout instance needs more than the 128 VGPRs that four waves per SIMD allow (35-45 spills) and was

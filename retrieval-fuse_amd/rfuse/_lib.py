@@ -70,6 +70,7 @@ SIGNATURES = {
     'rf_conv3_up_split_packed_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3_up_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_p, c_p]),
     'rf_conv3d_up_split_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_up_split_stats_tiles': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_up_split_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_p, c_p]),
     'rf_conv3d_k3_gn': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_p]),
     'rf_relu_backward': (c_i, [c_fp, c_fp, c_sz, c_fp, c_p]),

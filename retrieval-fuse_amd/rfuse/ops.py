@@ -489,7 +489,8 @@ def conv3d_up_split_gn_relu(src0, src1, aff, w_split_packed, cout):
     n, c0, c1, edge = _src_dims(src0, src1)
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=_check_affine(aff, n, c0 + c1))
     lib = _lib.load()
-    stats = torch.empty((n, cout, 1, 2), dtype=torch.float64, device=out.device) if USE_FUSED_STATS else None
+    tiles = lib.rf_conv3d_up_split_stats_tiles(c0, c1, n, edge, cout)
+    stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=out.device) if USE_FUSED_STATS else None
     timed = conv_event_filter is not None and conv_event_filter(c0 + c1, cout, edge, n)
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -500,7 +501,7 @@ def conv3d_up_split_gn_relu(src0, src1, aff, w_split_packed, cout):
         ev1.record()
         conv_events.append((ev0, ev1, conv_up_split_issued_flops(c0, c1, n, edge, cout), ('rf_conv3d_up_split_k3_gn_relu', 'f16 split', (c0, c1, n, edge, cout))))
     if stats is not None:
-        out._rf_stats = (stats, 1, out._version)
+        out._rf_stats = (stats, tiles, out._version)
     return out
 
 
