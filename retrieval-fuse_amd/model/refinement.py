@@ -9,48 +9,51 @@ from model.unet import UNet3D, DecoderNoJoining
 from rfuse import ops
 
 
-class Superresolution08UNetBackbone(nn.Module):
-    """1x8^3 -> nf x 32^3 (reference model/refinement.py:6-19): UNet3D + two DecoderNoJoining."""
+def _unet(width, out_channels, order, levels, f_maps=None, trim=0):
+    """The one U-Net flavour every refinement network uses: 1 input channel, GroupNorm groups = width / 2, no final conv / activation head;
+    ``trim`` = remove_n_final_layers (decoder stages dropped at the fine end)."""
+    return UNet3D(1, out_channels, f_maps=width if f_maps is None else f_maps, num_groups=width // 2, num_levels=levels, layer_order=order,
+                  remove_n_final_layers=trim, final_sigmoid=False, final_conv=False, is_segmentation=False)
 
-    def __init__(self, nf, num_levels, layer_order):
+
+def _up_stage(width, cin, cout, order):
+    """x2 nearest upsample + DoubleConv without a skip connection"""
+    return DecoderNoJoining(cin, cout, conv_layer_order=order, num_groups=width // 2)
+
+
+class _Chain(nn.Module):
+    """``self.network`` = ModuleList applied in order (the list indices are part of the state_dict key contract: network.0, network.1, ...)"""
+
+    def __init__(self, stages):
         super().__init__()
-        self.network = nn.ModuleList([
-            UNet3D(in_channels=1, out_channels=2 * nf, final_sigmoid=False, final_conv=False, f_maps=nf, num_groups=nf // 2,
-                   layer_order=layer_order, num_levels=num_levels, is_segmentation=False),
-            DecoderNoJoining(2 * nf, 2 * nf, conv_layer_order=layer_order, num_groups=nf // 2),
-            DecoderNoJoining(2 * nf, nf, conv_layer_order=layer_order, num_groups=nf // 2),
-        ])
+        self.network = nn.ModuleList(stages)
 
     def forward(self, x):
-        for net in self.network:
-            x = net(x)
+        for stage in self.network:
+            x = stage(x)
         return x
 
 
-class Superresolution16UNetBackbone(nn.Module):
-    """1x16^3 -> nf x 32^3 (reference model/refinement.py:22-34)."""
+class Superresolution08UNetBackbone(_Chain):
+    """1 x 8^3 -> nf x 32^3 (reference model/refinement.py:6-19): U-Net to 2 nf channels at 8^3, then two up stages (2 nf @16^3, nf @32^3)."""
 
     def __init__(self, nf, num_levels, layer_order):
-        super().__init__()
-        self.network = nn.ModuleList([
-            UNet3D(in_channels=1, out_channels=2 * nf, final_sigmoid=False, final_conv=False, f_maps=nf, num_groups=nf // 2,
-                   layer_order=layer_order, num_levels=num_levels, is_segmentation=False),
-            DecoderNoJoining(2 * nf, nf, conv_layer_order=layer_order, num_groups=nf // 2),
-        ])
+        super().__init__([_unet(nf, 2 * nf, layer_order, num_levels), _up_stage(nf, 2 * nf, 2 * nf, layer_order), _up_stage(nf, 2 * nf, nf, layer_order)])
 
-    def forward(self, x):
-        for net in self.network:
-            x = net(x)
-        return x
+
+class Superresolution16UNetBackbone(_Chain):
+    """1 x 16^3 -> nf x 32^3 (reference model/refinement.py:22-34): the same with a single up stage."""
+
+    def __init__(self, nf, num_levels, layer_order):
+        super().__init__([_unet(nf, 2 * nf, layer_order, num_levels), _up_stage(nf, 2 * nf, nf, layer_order)])
 
 
 class SurfaceReconstructionUNetBackbone(nn.Module):
-    """1x128^3 occupancy grid -> nf x 32^3 (reference model/refinement.py:37-45)."""
+    """1 x 128^3 occupancy grid -> nf x 32^3 (reference model/refinement.py:37-45): U-Net whose two finest decoder stages are dropped."""
 
     def __init__(self, nf, num_levels, layer_order):
         super().__init__()
-        self.network = UNet3D(in_channels=1, out_channels=nf, final_sigmoid=False, final_conv=False, remove_n_final_layers=2, f_maps=nf,
-                              layer_order=layer_order, num_groups=nf // 2, num_levels=num_levels, is_segmentation=False)
+        self.network = _unet(nf, nf, layer_order, num_levels, trim=2)
 
     def forward(self, x):
         return self.network(x)
@@ -80,11 +83,7 @@ class Superresolution08FinalDecoder(nn.Module):
 
     def __init__(self, nf, layer_order):
         super().__init__()
-        self.network = nn.ModuleList([
-            DecoderNoJoining(nf, nf, conv_layer_order=layer_order, num_groups=nf // 2),
-            PointwiseConvParams(nf, 1),
-            TanhMarker(),
-        ])
+        self.network = nn.ModuleList([_up_stage(nf, nf, nf, layer_order), PointwiseConvParams(nf, 1), TanhMarker()])
 
     def forward(self, x):
         x = self.network[0](x)
@@ -106,8 +105,7 @@ class RetrievalUNetBackbone(nn.Module):
     def __init__(self, f_maps, nf, num_levels, layer_order):
         super().__init__()
         self.nf = nf
-        self.network = UNet3D(in_channels=1, out_channels=nf, num_groups=nf // 2, final_sigmoid=False, final_conv=False,
-                              remove_n_final_layers=1, f_maps=f_maps, layer_order=layer_order, num_levels=num_levels, is_segmentation=False)
+        self.network = _unet(nf, nf, layer_order, num_levels, f_maps=f_maps, trim=1)
 
     def forward(self, x):
         return self.network(x)
