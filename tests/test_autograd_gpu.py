@@ -69,12 +69,26 @@ def test_single_conv_gradients_match_float64_oracle(gpu, case):
 
 
 def test_attention_feature_encoder_gradients(gpu):
+    """4 Linear layers + LeakyReLU through rfuse.autograd.Linear against float64 autograd of the oracle.
+    LeakyReLU has a kink at 0: a row with a pre-activation within fp32 round-off of zero takes the other slope in fp32 than in float64 and its
+    whole gradient differs by percents -- with unseeded weights that happened in 1 process of ~40 (round 2's "known flake", hunted down in
+    round 3 with tools/flake_hunt.py: one row of dx and every weight gradient off, identically on every repetition inside the process).  The
+    weights are seeded now and the rows whose float64 pre-activations come within 1e-4 of zero are left out of the problem."""
     from model.attention import AttentionFeatureEncoder
+    torch.manual_seed(1234)
     gen = torch.Generator().manual_seed(3)
     with contextlib.redirect_stdout(io.StringIO()):
         enc = AttentionFeatureEncoder(16, 32, 2).to(gpu)
     x = torch.randn(700, 128, generator=gen)
     r = torch.randn(700, 32, generator=gen)
+    with torch.no_grad():
+        h, far = x.double(), torch.ones(700, dtype=torch.bool)
+        for i in (0, 2, 4):
+            pre = h @ enc.encoder[i].weight.detach().cpu().double().t() + enc.encoder[i].bias.detach().cpu().double()
+            far &= pre.abs().min(dim=1).values > 1e-4
+            h = torch.nn.functional.leaky_relu(pre, 0.01)
+    assert 500 <= int(far.sum()) < 700                               # ~100 of the 700 rows have one of their 384 units within 1e-4 of a kink; the rest is the test problem
+    x, r = x[far].contiguous(), r[far].contiguous()
     xg = x.to(gpu).requires_grad_(True)
     y = enc(xg)
     (y * r.to(gpu)).sum().backward()
