@@ -37,6 +37,7 @@ def test_single_conv_gradients_match_float64_oracle(gpu, case):
     n, c0, c1, edge, cout, groups = case
     gen = torch.Generator().manual_seed(sum(case))
     cin = c0 + c1
+    torch.manual_seed(100 + sum(case))                               # the conv weight's default init: seeded (a ReLU input within round-off of 0 would route differently in fp32 and float64)
     layer = SingleConv(cin, cout, num_groups=groups)
     with torch.no_grad():
         layer.groupnorm.weight.copy_(1 + 0.3 * torch.randn(cin, generator=gen))
