@@ -19,7 +19,12 @@ LOADS = """                st.ph[r] = *reinterpret_cast<const h8*>(p + (size_t)v
                 st.pl[r] = *reinterpret_cast<const h8*>(p + (vol + (size_t)voff[r]) * 16);"""
 NO_LOADS = """                st.ph[r] = h8{(_Float16)(float)tid, 0, 0, 0, 0, 0, 0, 0};
                 st.pl[r] = h8{(_Float16)(float)r, 0, 0, 0, 0, 0, 0, 0};"""
-VARIANTS = {'base': [], 'no_mfma': [(MFMA, NO_MFMA)], 'no_epilogue': [(EPI, NO_EPI)], 'no_loads': [(LOADS, NO_LOADS)],
+LOADS_F32 = "                for (int j = 0; j < 8; ++j) st.x[r][j] = s0[(size_t)chan(ca * 8 + j) * vol + voff[r]];"
+NO_LOADS_F32 = "                for (int j = 0; j < 8; ++j) st.x[r][j] = (float)(tid + j);"
+HOOK = "                if constexpr (!ONE && !PRE) {\n                    const int e = (s - 2) * 4 + m, r = e >> 3, j = e & 7;"
+NO_HOOK = "                if constexpr (false) {\n                    const int e = (s - 2) * 4 + m, r = e >> 3, j = e & 7;"
+VARIANTS = {'base': [], 'no_loads_f32': [(LOADS_F32, NO_LOADS_F32)], 'no_loads_no_conv': [(LOADS_F32, NO_LOADS_F32), (HOOK, NO_HOOK)],
+            'no_loads_no_conv_no_epilogue': [(LOADS_F32, NO_LOADS_F32), (HOOK, NO_HOOK), (EPI, NO_EPI)], 'no_mfma': [(MFMA, NO_MFMA)], 'no_epilogue': [(EPI, NO_EPI)], 'no_loads': [(LOADS, NO_LOADS)],
             'no_mfma_no_epilogue': [(MFMA, NO_MFMA), (EPI, NO_EPI)], 'nothing': [(MFMA, NO_MFMA), (EPI, NO_EPI), (LOADS, NO_LOADS)]}
 
 def build():
@@ -35,6 +40,32 @@ def build():
         subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', str(CSRC), '-c', str(p), '-o', str(obj)], check=True)
         subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(OUT / ('libsplit_%s.so' % name)), str(obj), str(CSRC / 'build' / 'capi.o')], check=True)
         print(name)
+
+def run_multi():
+    import torch
+    sys.path[:0] = [str(REPO / 'retrieval-fuse_amd')]
+    from rfuse import ops
+    dev = torch.device('cuda:0')
+    VP = ctypes.c_void_p
+    for (n, cin, edge, cout) in ((8192, 56, 8, 16), (32, 16, 64, 16), (8192, 16, 8, 32)):
+        x = torch.randn(n, cin, edge, edge, edge, device=dev).relu_()
+        aff = torch.zeros(n, cin, 4, device=dev); aff[..., 1] = 1.0
+        w = ops.pack_conv3_split_weight(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+        out = torch.empty(n, cout, edge, edge, edge, device=dev); stats = torch.empty(n, cout, (edge // 8) ** 3, 2, dtype=torch.float64, device=dev)
+        for name in ('base', 'no_loads_f32', 'no_loads_no_conv', 'no_loads_no_conv_no_epilogue', 'no_mfma', 'no_epilogue'):
+            lib = ctypes.CDLL(str(OUT / ('libsplit_%s.so' % name)))
+            f = lib.rf_conv3d_split_k3_gn_relu
+            f.argtypes = [VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, VP, ctypes.c_int, VP, VP, VP, VP, VP]
+            st = torch.cuda.current_stream().cuda_stream
+            call = lambda: f(x.data_ptr(), cin, n, edge, aff.data_ptr(), w.data_ptr(), cout, out.data_ptr(), stats.data_ptr(), None, None, st)
+            for _ in range(3): assert call() == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): call()
+            e1.record(); torch.cuda.synchronize()
+            print('%d->%d @%d^3 x %d  %-30s %8.1f us' % (cin, cout, edge, n, name, e0.elapsed_time(e1) * 100), flush=True)
+
 
 def run():
     import torch
@@ -62,4 +93,4 @@ def run():
         print('%-22s %8.1f us' % (name, e0.elapsed_time(e1) * 100), flush=True)
 
 if __name__ == '__main__':
-    build() if len(sys.argv) > 1 and sys.argv[1] == 'build' else run()
+    build() if len(sys.argv) > 1 and sys.argv[1] == 'build' else (run_multi() if len(sys.argv) > 1 and sys.argv[1] == 'multi' else run())
