@@ -163,6 +163,44 @@ class RefinementEngine:
         torch.cuda.current_stream(self.device).wait_stream(side)
         return self._attend_and_decode(x_back, feats, gumbel_noise)
 
+    def refine_stream(self, batches, query_scenes=None, patch_masks=None):
+        """Software-pipelined ``refine`` over a sequence of batches (a generator of refined TSDFs, one per batch, in order).
+
+        The front end of batch i + 1 -- query windows, query encoder, exact top-k, demotion, patch gather, and the U-Net backbone on the low-resolution
+        input -- depends on nothing of batch i, is VALU / HBM work of ~2 ms and is issued on a helper stream BEFORE the back end of batch i
+        (retrieval backbone, attention, decoder: LDS / MFMA work of ~7 ms on the caller's stream), so the two overlap on the GPU instead of following
+        each other.  Same kernels on the same data as ``refine``: results are bit-identical; only the latency of a batch grows by one front end."""
+        with torch.cuda.device(self.device), torch.no_grad():
+            main = torch.cuda.current_stream(self.device)
+            front = self._side_streams.get(('front', main.cuda_stream))
+            if front is None:
+                front = self._side_streams[('front', main.cuda_stream)] = torch.cuda.Stream(self.device)
+            pending = None
+            for i, raw in enumerate(batches):
+                qs = query_scenes[i] if query_scenes is not None else None
+                pm = patch_masks[i] if patch_masks is not None else None
+                ready = torch.cuda.Event()
+                ready.record(main)                                   # whatever produced `raw` on the caller's stream
+                front.wait_event(ready)
+                with torch.cuda.stream(front):
+                    raw.record_stream(front)
+                    patches, _ = self.retrieve(raw, qs, pm)
+                    x_back = self.unet_backbone(self.normalise_input(raw))
+                    done = torch.cuda.Event()
+                    done.record(front)
+                if pending is not None:
+                    yield self._finish_pipelined(main, *pending)
+                pending = (patches, x_back, done)
+            if pending is not None:
+                yield self._finish_pipelined(main, *pending)
+
+    def _finish_pipelined(self, main, patches, x_back, done):
+        main.wait_event(done)
+        patches.record_stream(main)
+        x_back.record_stream(main)
+        feats = self.retrieval_backbone(patches)
+        return self._attend_and_decode(x_back, feats, None)
+
     @_on_engine_device
     def capture_graph(self, input_raw, query_scene=None, patch_mask=None):
         """Capture one whole refine() step for a FIXED batch shape into a HIP graph: -> (graph, static_input, static_output).

@@ -459,3 +459,29 @@ def test_scene_driver_matches_chunkwise_refinement(gpu):
         x, y, z = [int(t) for t in name.split('__')[-1].split('_')]
         ref[x:x + 64, y:y + 64, z:z + 64] = eng.refine(torch.from_numpy(ch[None]).to(gpu))[0, 0].half().cpu().numpy()
     assert np.abs(out['sceneQ__room0'] - ref).max() <= 2e-4                    # batch size changes the tile dispatch, not the arithmetic contract; float16 steps are 1.2e-4 at trunc
+
+
+@pytest.mark.parametrize('cfg_name,B', [('C3', 8), ('C4', 4)])
+def test_refine_stream_is_bit_equal_to_refine(gpu, cfg_name, B):
+    """RefinementEngine.refine_stream (front end of batch i + 1 on a helper stream beside the back end of batch i) runs the same kernels on the same
+    data as refine(): every batch of a stream of different batches (with same-scene demotion and a query-side patch mask on some) must come out
+    bit for bit as from refine() alone."""
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config(cfg_name)
+    db = synthetic.make_database(12, cfg, 64 * 30)
+    eng = RefinementEngine(cfg, gpu, PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu))
+    sds = {n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 300 + len(n)) for n, m in eng.modules().items()}
+    eng.load_state_dicts(sds)
+    batches, scenes, masks = [], [], []
+    for i in range(5):
+        batches.append(torch.from_numpy(np.stack([synthetic.make_chunk(6000 + 10 * i + b, cfg)['input_raw'] for b in range(B)])).to(gpu))
+        scenes.append(torch.full((B * 64,), i % 3 - 1, dtype=torch.int32, device=gpu) if i % 2 else None)
+        m = torch.ones(B, 64, dtype=torch.bool, device=gpu)
+        m[:, ::5] = False
+        masks.append(m if i in (1, 4) else None)
+    want = [eng.refine(x, query_scene=s, patch_mask=m).clone() for x, s, m in zip(batches, scenes, masks)]
+    got = list(eng.refine_stream(batches, scenes, masks))
+    assert len(got) == 5
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), 'batch %d differs' % i
