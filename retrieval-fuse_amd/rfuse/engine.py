@@ -184,8 +184,9 @@ class RefinementEngine:
                 front.wait_event(ready)
                 with torch.cuda.stream(front):
                     raw.record_stream(front)
+                    x_back, side = self._fork_backbone(self.normalise_input(raw))      # ... the backbone beside the retrieval on its own stream, as in refine()
                     patches, _ = self.retrieve(raw, qs, pm)
-                    x_back = self.unet_backbone(self.normalise_input(raw))
+                    front.wait_stream(side)
                     done = torch.cuda.Event()
                     done.record(front)
                 if pending is not None:
