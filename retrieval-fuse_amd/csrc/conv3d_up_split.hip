@@ -46,6 +46,7 @@ constexpr int US_MAX_CGB = 8;                                    // low-res chan
 constexpr int US_LDS_BYTES = US_B_OFF + US_MAX_CGB * 2 * US_B_PLANE;      // 132,608
 constexpr int US_E_STRIDE = 516;                                 // epilogue tile row (floats)
 constexpr float US_ACT_SCALE = 1.0f / 16, US_W_SCALE = 16.0f, US_LO = 2048.0f;
+constexpr bool US_ZSKIP = true;
 static_assert(64 * US_E_STRIDE * 4 <= US_LDS_BYTES, "epilogue tile must fit");
 }   // namespace
 
@@ -207,6 +208,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     }
     const int bbase = (pz * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;        // + (m + tz) BZ
 
+    // Z-BORDER TAPS: the wave's m-block 0 (pz = 0: output plane z = 0) reads nothing but zero padding through the dz = -1 taps (k-steps 0, 1 of a
+    // phase-A chunk, step tz = 0 of a phase-B chunk), its m-block 3 (pz = 1: plane z = 7) through the dz = +1 taps (k-steps 5, 6; tz = 1): those
+    // MFMAs would add exact zeros and are not issued (2 of 28 per phase-A chunk, 1 of 8 per phase-B chunk: 9.1 % of the kernel's MFMAs).  The
+    // whole K loop + epilogue is instantiated per pz (a run-time test inside the loop makes hipcc copy the accumulators at every join).
+    auto run = [&](auto PZ_) {
+    constexpr int PZ = decltype(PZ_)::value;
     f32x4 hi[4][NB], lo[4][NB];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     // requests the next chunk's raw voxels BEHIND them -- vmcnt retires in order, so the wait for the next step's weights must not have
     // the HBM loads in front of it; A operands of m-block m+1 are fetched under the MFMAs of m-block m, `pre`: the NEXT step's m-block 0.
     // The sched_barriers pin this order (hipcc otherwise sinks every load to just before its first use).
-    auto kstep = [&](auto has_pre, auto&& xload, const unsigned char* ap, const unsigned char* pre, int mstride, int lplane, const h8 (&bh)[NB], const h8 (&bl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
+    auto kstep = [&](auto skip_m, auto has_pre, auto&& xload, const unsigned char* ap, const unsigned char* pre, int mstride, int lplane, const h8 (&bh)[NB], const h8 (&bl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
         load_b(nh, nl);
         xload();
         __builtin_amdgcn_sched_barrier(0);
@@ -248,35 +255,70 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
                 al[0] = *reinterpret_cast<const h8*>(pre + lplane);
             }
             __builtin_amdgcn_sched_barrier(0);
-            us_mfma_block<NB>(hi[m], lo[m], ah[m & 1], al[m & 1], bh, bl);
+            if (m != decltype(skip_m)::value) us_mfma_block<NB>(hi[m], lo[m], ah[m & 1], al[m & 1], bh, bl);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto no_x = [] {};
+    using no_skip = std::integral_constant<int, -1>;
+    using skip_lo = std::integral_constant<int, US_ZSKIP && PZ == 0 ? 0 : -1>;      // steps whose taps all have dz = -1 / tz = 0
+    using skip_hi = std::integral_constant<int, US_ZSKIP && PZ == 1 ? 3 : -1>;      // ... dz = +1 / tz = 1
 
     // ---- phase A: skip channels.  No branch inside a chunk (hipcc's s_waitcnt insertion assumes the worst at every join): the last chunk
     // re-loads its own channels and stages them into the idle buffer.
+    // Staging of the next chunk is the job of waves 0..3 (PZ = 0) alone, two voxels per thread (z and z + 4): the SIMD arbiter favours the older
+    // wave of each pair (w, w + 4), which therefore finishes its seven k-steps ~4 k cycles before its partner and used to idle at the chunk
+    // barrier, while the partner -- last to finish -- still had its own conversion in front of that barrier.  Now the early wave converts (once
+    // after k-step 2, once after k-step 6, each time while its partner has the matrix pipe to itself) and the late wave goes straight to the
+    // barrier.  Requests sit BEHIND the step's weight loads (vmcnt retires in order); the voxels land within two k-steps (measured 1.8-2.1 k
+    // cycles), three / four pass before they are used.
     auto chunk_a = [&](int ca, h8 (&ch)[NB], h8 (&cl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
         float x[8];
         const bool more = ca + 1 < nA;
-        const int cx = more ? ca + 1 : ca;
-        auto xload = [&] {
+        const int cx = more ? ca + 1 : ca;                              // past the last chunk: harmless re-staging of the last one into the idle buffer
+        auto xload_a = [&] {
+            if constexpr (PZ == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(cx * 8 + j) * 512];
+                for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(cx * 8 + j) * 512];
+            }
+        };
+        auto xload_b = [&] {
+            if constexpr (PZ == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(cx * 8 + j) * 512 + 256];
+            }
+        };
+        auto convert_store = [&](int half) {
+            if constexpr (PZ == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 af = aff[cx * 8 + j];
+                    y[j] = fmaf(x[j] - af.x, af.y, af.z);
+                }
+                h8 h, l;
+                us_split8(y, h, l);
+                unsigned char* p = lds + ((ca + 1) & 1) * US_A_BUF + (vslot + half * 4 * US_SZ) * 16;
+                *reinterpret_cast<h8*>(p) = h;
+                *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         const unsigned char* buf = lds + (ca & 1) * US_A_BUF + abase;
         ah[0] = *reinterpret_cast<const h8*>(buf + atap[0]);
         al[0] = *reinterpret_cast<const h8*>(buf + atap[0] + US_A_PLANE);
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            if (s == 6) wn = more ? wn : wB;                            // the last phase-A step fetches the first phase-B step
-            const unsigned char* ap = buf + atap[s];
-            if (s == 0) kstep(std::true_type{}, xload, ap, buf + atap[s + 1], 2 * US_SZ * 16, US_A_PLANE, ch, cl, nh, nl);
-            else if (s == 6) kstep(std::false_type{}, no_x, ap, ap, 2 * US_SZ * 16, US_A_PLANE, ch, cl, nh, nl);
-            else if (s & 1) kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], 2 * US_SZ * 16, US_A_PLANE, nh, nl, ch, cl);
-            else kstep(std::true_type{}, no_x, ap, buf + atap[s + 1], 2 * US_SZ * 16, US_A_PLANE, ch, cl, nh, nl);
-        }
-        stage_store(x, ca + 1);
+        constexpr int MS = 2 * US_SZ * 16;
+        kstep(skip_lo{}, std::true_type{}, xload_a, buf + atap[0], buf + atap[1], MS, US_A_PLANE, ch, cl, nh, nl);     // taps 0..3:   dz = -1
+        kstep(skip_lo{}, std::true_type{}, no_x, buf + atap[1], buf + atap[2], MS, US_A_PLANE, nh, nl, ch, cl);        // taps 4..7:   dz = -1
+        kstep(no_skip{}, std::true_type{}, no_x, buf + atap[2], buf + atap[3], MS, US_A_PLANE, ch, cl, nh, nl);        // taps 8..11
+        convert_store(0);
+        kstep(no_skip{}, std::true_type{}, xload_b, buf + atap[3], buf + atap[4], MS, US_A_PLANE, nh, nl, ch, cl);
+        kstep(no_skip{}, std::true_type{}, no_x, buf + atap[4], buf + atap[5], MS, US_A_PLANE, ch, cl, nh, nl);        // taps 16..19
+        kstep(skip_hi{}, std::true_type{}, no_x, buf + atap[5], buf + atap[6], MS, US_A_PLANE, nh, nl, ch, cl);        // taps 20..23: dz = +1
+        wn = more ? wn : wB;                                            // the last phase-A step fetches the first phase-B step
+        kstep(skip_hi{}, std::false_type{}, no_x, buf + atap[6], buf + atap[6], MS, US_A_PLANE, ch, cl, nh, nl);       // taps 24..26 + the dummy
+        convert_store(1);
         __syncthreads();
     };
     for (int ca = 0; ca < nA; ca += 2) {
@@ -295,8 +337,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         al[0] = *reinterpret_cast<const h8*>(bb + US_B_PLANE);
         for (int cb = 0; cb < nB; ++cb) {
             const unsigned char* ap = bb + cb * 2 * US_B_PLANE;
-            kstep(std::true_type{}, no_x, ap, ap + US_BZ * 16, US_BZ * 16, US_B_PLANE, b0h, b0l, b1h, b1l);                                   // tz = 0
-            kstep(std::true_type{}, no_x, ap + US_BZ * 16, cb + 1 < nB ? ap + 2 * US_B_PLANE : ap, US_BZ * 16, US_B_PLANE, b1h, b1l, b0h, b0l);   // tz = 1
+            kstep(skip_lo{}, std::true_type{}, no_x, ap, ap + US_BZ * 16, US_BZ * 16, US_B_PLANE, b0h, b0l, b1h, b1l);                                   // tz = 0
+            kstep(skip_hi{}, std::true_type{}, no_x, ap + US_BZ * 16, cb + 1 < nB ? ap + 2 * US_B_PLANE : ap, US_BZ * 16, US_B_PLANE, b1h, b1l, b0h, b0l);   // tz = 1
         }
     }
     __syncthreads();
@@ -340,6 +382,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
         if (part == 0 && co < cout) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);
     }
+    };   // run
+    if (pz == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------- 4^3 volumes
