@@ -92,8 +92,8 @@ ST = [
     ("        if (part == 0 && co < cout) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);\n    }\n    };   // run",
      "        if (part == 0 && co < cout) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);\n    }\n    STAMP(10);\n    };   // run"),
 ]
-SW = 'constexpr bool US_ZSKIP = true;'
-VARIANTS = {'base': [], 'no_zskip': [(SW, SW.replace('US_ZSKIP = true', 'US_ZSKIP = false'))], 'no_shadow': [(SW, SW.replace('US_SHADOW = true', 'US_SHADOW = false'))],
+SW = 'constexpr bool US_ZSKIP = true, US_PERSISTENT = true;'
+VARIANTS = {'base': [], 'no_zskip': [(SW, SW.replace('US_ZSKIP = true', 'US_ZSKIP = false'))], 'one_sample': [(SW, SW.replace('US_PERSISTENT = true', 'US_PERSISTENT = false'))], 'no_shadow': [(SW, SW.replace('US_SHADOW = true', 'US_SHADOW = false'))],
             'no_epilogue': [(EPI_HEAD, NO_EPI_HEAD)], 'no_conv': [(CONV, NO_CONV)], 'no_xload_no_bload': [(XLOAD, NO_XLOAD), (BLOAD, NO_BLOAD)],
             'mfma_only': [(XLOAD, NO_XLOAD), (BLOAD, NO_BLOAD), (EPI_HEAD, NO_EPI_HEAD), (ZERO, NO_ZERO), (CONV, NO_CONV)],
             'stamps0': [(a, b.replace('STW', '0')) for a, b in ST], 'stamps7': [(a, b.replace('STW', '7')) for a, b in ST]}
