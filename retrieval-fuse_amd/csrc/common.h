@@ -44,13 +44,6 @@ struct RfLdsOptIn {
     }
 };
 
-// compute units of the current device (persistent kernels launch one workgroup per CU); 256 on MI355X
-static inline int rf_compute_units() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
-    return cus;
-}
-
 static inline bool rf_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int rf_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int rf_round_up(int v, int m) { return (v + m - 1) / m * m; }

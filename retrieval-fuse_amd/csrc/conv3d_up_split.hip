@@ -44,10 +44,11 @@ constexpr int US_B_OFF = 2 * US_A_BUF;
 constexpr int US_B_PLANE = US_BSLOTS * 16;
 constexpr int US_MAX_CGB = 8;                                    // low-res channel groups that fit (c1 <= 64)
 constexpr int US_LDS_BYTES = US_B_OFF + US_MAX_CGB * 2 * US_B_PLANE;      // 132,608
-constexpr int US_E_STRIDE = 516;                                 // epilogue tile row (floats)
+constexpr int US_E_STRIDE = 516;                                 // epilogue tile row (floats) of the 4^3 / box kernels
+constexpr int US_T_STRIDE = 517;                                 // ... of the whole-sample kernel: odd (bank-conflict-free scalar writes)
 constexpr float US_ACT_SCALE = 1.0f / 16, US_W_SCALE = 16.0f, US_LO = 2048.0f;
-constexpr bool US_ZSKIP = true, US_PERSISTENT = true;
-static_assert(64 * US_E_STRIDE * 4 <= US_LDS_BYTES, "epilogue tile must fit");
+constexpr bool US_ZSKIP = true;
+static_assert(64 * US_T_STRIDE * 4 <= US_LDS_BYTES, "epilogue tile must fit");
 }   // namespace
 
 // ------------------------------------------------------------------------------------------------------------ weight image
@@ -155,6 +156,21 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3;
     const float4* __restrict__ aff = a.affine + (size_t)n * cin;
 
+    // ---- the first voxels (this wave's low-res channel group, the first skip chunk) are requested before the LDS is zeroed: their HBM
+    // latency passes under the zero-fill
+    const float* __restrict__ s0 = a.src0 + (size_t)n * c0 * 512 + tid;
+    float xl[8], x0[8];
+    {
+        const int cg = wave < nB ? wave : nB - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xl[j] = a.src1[((size_t)n * c1 + cg * 8 + j) * 64 + lane];
+        if (nA > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x0[j] = s0[(size_t)j * 512];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- zero the halo boxes (the padding slots are never written again)
     for (int i = tid; i < US_LDS_BYTES / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float4 af = aff[c0 + cg * 8 + j];
-            y[j] = fmaf(a.src1[((size_t)n * c1 + cg * 8 + j) * 64 + lane] - af.x, af.y, af.z);
+            y[j] = fmaf((cg == wave ? xl[j] : a.src1[((size_t)n * c1 + cg * 8 + j) * 64 + lane]) - af.x, af.y, af.z);
         }
         h8 h, l;
         us_split8(y, h, l);
@@ -175,7 +191,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
     }
     const int vslot = ((tid >> 6) + 1) * US_SZ + (((tid >> 3) & 7) + 1) * US_SY + (tid & 7) + 1;     // this thread's voxel in the full-res halo box
-    const float* __restrict__ s0 = a.src0 + (size_t)n * c0 * 512 + tid;
     auto stage_store = [&](const float (&x)[8], int ca) {           // ca: chunk slot; past the last chunk: harmless re-staging of the last one
         float y[8];
         const int cc = ca < nA ? ca : nA - 1;
@@ -190,12 +205,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         *reinterpret_cast<h8*>(p) = h;
         *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
     };
-    if (nA > 0) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)j * 512];
-        stage_store(x, 0);
-    }
+    if (nA > 0) stage_store(x0, 0);
 
     // ---- per-lane operand addressing
     const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
@@ -354,337 +364,30 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int lin = (2 * m + pz) * 64 + (2 * yj + py) * 8 + 2 * r + px;
-                    e[(nb * 16 + col) * US_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
+                    e[(nb * 16 + col) * US_T_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
                 }
     }
     __syncthreads();
     const int cout = a.cout;
     float* __restrict__ o = a.out + (size_t)n * cout * 512;
-    for (int q = tid; q < cout * 128; q += 512) {
-        const int co = q >> 7, l4 = q & 127;
-        *reinterpret_cast<float4*>(o + (size_t)co * 512 + l4 * 4) = *reinterpret_cast<const float4*>(e + co * US_E_STRIDE + l4 * 4);
-    }
+    // rows of 517 floats: the scalar tile writes above (16 couts x 2 y per half wave) and these row reads hit 32 different banks; a row
+    // stride that is a multiple of 4 (needed for 16-byte reads) leaves every write 4-way conflicted.  A wave stores 256 contiguous bytes.
+#pragma unroll 4
+    for (int co = 0; co < cout; ++co) o[(size_t)co * 512 + tid] = e[co * US_T_STRIDE + tid];
     if (a.stats) {
-        // per cout: eight threads sum 64 values each (float64), then the eight partial sums in a fixed order
+        // per cout: eight threads sum 64 values each (voxels part, part + 8, ...; float64), then the eight partial sums in a fixed order
         const int co = tid >> 3, part = tid & 7;
         double sm = 0.0, sq = 0.0;
         if (co < cout) {
-#pragma unroll 4
-            for (int i = 0; i < 16; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(e + co * US_E_STRIDE + (part * 16 + i) * 4);
-                sm += (double)v.x; sq += (double)v.x * v.x;
-                sm += (double)v.y; sq += (double)v.y * v.y;
-                sm += (double)v.z; sq += (double)v.z * v.z;
-                sm += (double)v.w; sq += (double)v.w * v.w;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) {
+                const float v = e[co * US_T_STRIDE + part + 8 * i];
+                sm += (double)v; sq += (double)v * v;
             }
         }
 #pragma unroll
         for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
         if (part == 0 && co < cout) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);
-    }
-    };   // run
-    if (pz == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
-}
-
-// ---------------------------------------------------------------------------------- persistent form (an even number of skip chunks)
-// The same arithmetic per output as k_conv3_up_split (same order of accumulation: bit-identical results), but ONE workgroup per CU walks samples
-// box, box + grid, ... and most of what a sample needs before its first MFMA is prepared during the previous sample (the one-sample kernel
-// spends 10 k of its 96 k cycles per sample on LDS zero-fill, first loads at HBM latency, conversion and a barrier before the matrix pipe sees
-// work):
-//   * the next sample's first skip chunk takes the place of "the chunk after the last" in the double buffer (it is staged into buffer 0 during
-//     the last chunk, which reads buffer 1);
-//   * the epilogue tile [cout][8^3] starts BEHIND buffer 0 (it covers buffer 1, the low-res image and 21 KB more: 154 KB of LDS in all);
-//   * the next sample's low-res voxels are requested before the epilogue and normalised + split after it (wave = channel group zeroes and
-//     refills its own two planes; buffer 1 is zeroed by everybody) -- the one part of a sample's preparation that stays exposed;
-//   * the weight stream wraps around (last phase-B step of a sample prefetches the first phase-A step);
-//   * the GroupNorm triples of a sample sit in LDS (three rotating tables: this sample, the next, the one after -- fetched two samples ahead by
-//     waves 4..7 in the even chunks), read as broadcasts by the conversions: no scalar loads and no SGPR blocks inside the loop.
-// Everything that is invariant across samples but only needed outside the k-steps (thread -> voxel / slot maps of staging and epilogue) is
-// recomputed per sample from an opaque copy of the thread index: hoisted out of the sample loop it would sit in -- spilled -- registers.
-namespace {
-constexpr int UP_TILE_OFF = US_A_BUF;
-constexpr int UP_AFF_OFF = UP_TILE_OFF + 56 * US_E_STRIDE * 4 > US_LDS_BYTES ? UP_TILE_OFF + 56 * US_E_STRIDE * 4 : US_LDS_BYTES;      // 154,240
-constexpr int UP_AFF_TABLE = 128 * 16;                                 // three tables of up to 128 float4 (cin <= 128)
-constexpr int UP_LDS_BYTES = UP_AFF_OFF + 3 * UP_AFF_TABLE;            // 160,384
-static_assert(UP_LDS_BYTES <= 160 * 1024, "persistent form: LDS");
-}   // namespace
-
-template <int NB>
-__global__ __launch_bounds__(512, 2) void k_conv3_up_split_p(UpSplitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
-    const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3, cout = a.cout;
-    const int step = (int)gridDim.x;
-    int box = blockIdx.x;
-
-    for (int i = tid; i < US_LDS_BYTES / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < cin) {                                                     // tables of the first two samples (table index = sample ordinal % 3)
-        const int b1 = box + step < a.n ? box + step : box;
-        reinterpret_cast<float4*>(lds + UP_AFF_OFF)[tid] = a.affine[(size_t)box * cin + tid];
-        reinterpret_cast<float4*>(lds + UP_AFF_OFF + UP_AFF_TABLE)[tid] = a.affine[(size_t)b1 * cin + tid];
-    }
-    __syncthreads();
-    // normalise + split + store one low-res channel group (wave = group, lane = low-res voxel)
-    auto put_lowres = [&](const float (&x)[8], int cg, int table, int ln) {
-        const float4* tab = reinterpret_cast<const float4*>(lds + UP_AFF_OFF + table * UP_AFF_TABLE) + c0 + cg * 8;
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 af = tab[j];
-            y[j] = fmaf(x[j] - af.x, af.y, af.z);
-        }
-        h8 h, l;
-        us_split8(y, h, l);
-        const int bslot = ((ln >> 4) + 1) * US_BZ + (((ln >> 2) & 3) + 1) * US_BY + (ln & 3) + 1;
-        unsigned char* p = lds + US_B_OFF + cg * 2 * US_B_PLANE + bslot * 16;
-        *reinterpret_cast<h8*>(p) = h;
-        *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
-    };
-    {   // first sample: low-res channels, first skip chunk (thread = voxel) -> buffer 0
-        if (wave < nB) {
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = a.src1[((size_t)box * c1 + wave * 8 + j) * 64 + lane];
-            put_lowres(x, wave, 0, lane);
-        }
-        const float4* tab = reinterpret_cast<const float4*>(lds + UP_AFF_OFF);
-        const int vslot = ((tid >> 6) + 1) * US_SZ + (((tid >> 3) & 7) + 1) * US_SY + (tid & 7) + 1;
-        const float* __restrict__ sp = a.src0 + (size_t)box * c0 * 512 + tid;
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 af = tab[j];
-            y[j] = fmaf(sp[(size_t)j * 512] - af.x, af.y, af.z);
-        }
-        h8 h, l;
-        us_split8(y, h, l);
-        unsigned char* p = lds + vslot * 16;
-        *reinterpret_cast<h8*>(p) = h;
-        *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
-    }
-
-    // ---- per-lane operand addressing of the k-steps (the only thread-dependent values that stay in registers across samples)
-    const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
-    const int abase = ((pz + 1) * US_SZ + (2 * rj + py + 1) * US_SY + (2 * ri + px + 1)) * 16;
-    int atap[7];
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const int t = 4 * s + g < 27 ? 4 * s + g : 26;
-        atap[s] = ((t / 9 - 1) * US_SZ + ((t / 3) % 3 - 1) * US_SY + (t % 3 - 1)) * 16;
-    }
-    const int bbase = (pz * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;
-
-    auto run = [&](auto PZ_) {
-    constexpr int PZ = decltype(PZ_)::value;
-    constexpr int STEP_U4 = NB * 2 * 64;
-    const unsigned offB = (unsigned)(nA * 7 + wave * nB * 2) * STEP_U4;  // this parity's phase-B stream (uniform)
-    const h8* __restrict__ wn = a.wp + lane;                              // next k-step to fetch (a 32-bit offset from a uniform base costs more registers in address temporaries)
-    h8 b0h[NB], b0l[NB], b1h[NB], b1l[NB];
-    auto load_b = [&](h8 (&bh)[NB], h8 (&bl)[NB]) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            bh[nb] = wn[(nb * 2) * 64];
-            bl[nb] = wn[(nb * 2 + 1) * 64];
-        }
-        wn += STEP_U4;
-    };
-    load_b(b0h, b0l);
-    __syncthreads();
-
-    auto kstep = [&](f32x4 (&hi)[4][NB], f32x4 (&lo)[4][NB], h8 (&ah)[2], h8 (&al)[2], auto skip_m, auto has_pre, auto&& xload, const unsigned char* ap, const unsigned char* pre, int mstride, int lplane, const h8 (&bh)[NB], const h8 (&bl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
-        load_b(nh, nl);
-        xload();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (m < 3) {
-                ah[(m + 1) & 1] = *reinterpret_cast<const h8*>(ap + (m + 1) * mstride);
-                al[(m + 1) & 1] = *reinterpret_cast<const h8*>(ap + (m + 1) * mstride + lplane);
-            } else if constexpr (decltype(has_pre)::value) {
-                ah[0] = *reinterpret_cast<const h8*>(pre);
-                al[0] = *reinterpret_cast<const h8*>(pre + lplane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (m != decltype(skip_m)::value) us_mfma_block<NB>(hi[m], lo[m], ah[m & 1], al[m & 1], bh, bl);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto no_x = [] {};
-    using no_skip = std::integral_constant<int, -1>;
-    using skip_lo = std::integral_constant<int, US_ZSKIP && PZ == 0 ? 0 : -1>;
-    using skip_hi = std::integral_constant<int, US_ZSKIP && PZ == 1 ? 3 : -1>;
-
-    int tb = 0;                                                          // table of this sample's GroupNorm triples
-    for (; box < a.n; box += step) {
-        const int nxt = box + step < a.n ? box + step : box;            // the last sample stages itself once more (harmless)
-        const int nx2 = nxt + step < a.n ? nxt + step : nxt;
-        const int tn = tb == 2 ? 0 : tb + 1, tn2 = tn == 2 ? 0 : tn + 1;
-        int t = tid;                                                     // opaque: whatever is derived from it is recomputed per sample
-        asm volatile("" : "+v"(t));
-        f32x4 hi[4][NB], lo[4][NB];
-        h8 ah[2], al[2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-        // ---- phase A: skip channels (an even number of chunks); chunk ca reads buffer ca & 1 and stages its successor -- the next chunk of this
-        // sample, or the first chunk of the next sample -- into the other one (waves 0..3: two voxels per thread, one after k-step 2, one after
-        // k-step 6: the SIMD arbiter favours the older wave of each pair (w, w + 4), which finishes its k-steps ~4 k cycles before its partner).
-        // In the even chunks waves 4..7 fetch the table of the sample after the next.  Two instances (even / odd chunk), called in pairs: the
-        // roles of the two weight register sets are the same at every join.
-        auto chunk_a = [&](auto EVEN_, int ca, h8 (&ch)[NB], h8 (&cl)[NB], h8 (&nh)[NB], h8 (&nl)[NB]) {
-            constexpr bool EVEN = decltype(EVEN_)::value;
-            float x[8];
-            float4 tv;
-            const bool more = ca + 1 < nA;
-            const int sbox = more ? box : nxt, sc = more ? ca + 1 : 0;
-            const float* __restrict__ sbase = a.src0 + ((size_t)sbox * c0 + sc * 8) * 512;      // uniform
-            auto xload_a = [&] {
-                if constexpr (PZ == 0) {
-                    const unsigned v = (unsigned)(t & 255);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = sbase[j * 512 + v];
-                } else if constexpr (EVEN) {
-                    const int ti = (t & 255) < cin ? (t & 255) : cin - 1;
-                    tv = a.affine[(size_t)nx2 * cin + ti];
-                }
-            };
-            auto xload_b = [&] {
-                if constexpr (PZ == 0) {
-                    const unsigned v = (unsigned)(t & 255) + 256u;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = sbase[j * 512 + v];
-                }
-            };
-            auto convert_store = [&](auto HALF_) {
-                constexpr int half = decltype(HALF_)::value;
-                if constexpr (PZ == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float4* tab = reinterpret_cast<const float4*>(lds + UP_AFF_OFF + (more ? tb : tn) * UP_AFF_TABLE) + sc * 8;
-                    float y[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {                              // two triples in flight: eight at once would cost 32 registers
-                        const float4 af0 = tab[j], af1 = tab[j + 1];
-                        y[j] = fmaf(x[j] - af0.x, af0.y, af0.z);
-                        y[j + 1] = fmaf(x[j + 1] - af1.x, af1.y, af1.z);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    h8 h, l;
-                    us_split8(y, h, l);
-                    const int vs = (((t >> 6) & 3) + 1 + half * 4) * US_SZ + (((t >> 3) & 7) + 1) * US_SY + (t & 7) + 1;
-                    unsigned char* p = lds + ((ca + 1) & 1) * US_A_BUF + vs * 16;
-                    *reinterpret_cast<h8*>(p) = h;
-                    *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
-                    __builtin_amdgcn_sched_barrier(0);
-                } else if constexpr (EVEN && half == 0) {
-                    reinterpret_cast<float4*>(lds + UP_AFF_OFF + tn2 * UP_AFF_TABLE)[(t & 255) < cin ? (t & 255) : cin - 1] = tv;
-                }
-            };
-            int bo = (ca & 1) * US_A_BUF + abase;
-            asm volatile("" : "+v"(bo));                                // per chunk: hoisted out of the sample loop the seven tap addresses of each buffer would sit in registers
-            const unsigned char* buf = lds + bo;
-            ah[0] = *reinterpret_cast<const h8*>(buf + atap[0]);
-            al[0] = *reinterpret_cast<const h8*>(buf + atap[0] + US_A_PLANE);
-            constexpr int MS = 2 * US_SZ * 16;
-            kstep(hi, lo, ah, al, skip_lo{}, std::true_type{}, xload_a, buf + atap[0], buf + atap[1], MS, US_A_PLANE, ch, cl, nh, nl);     // taps 0..3:   dz = -1
-            kstep(hi, lo, ah, al, skip_lo{}, std::true_type{}, no_x, buf + atap[1], buf + atap[2], MS, US_A_PLANE, nh, nl, ch, cl);        // taps 4..7:   dz = -1
-            kstep(hi, lo, ah, al, no_skip{}, std::true_type{}, no_x, buf + atap[2], buf + atap[3], MS, US_A_PLANE, ch, cl, nh, nl);        // taps 8..11
-            convert_store(std::integral_constant<int, 0>{});
-            kstep(hi, lo, ah, al, no_skip{}, std::true_type{}, xload_b, buf + atap[3], buf + atap[4], MS, US_A_PLANE, nh, nl, ch, cl);
-            kstep(hi, lo, ah, al, no_skip{}, std::true_type{}, no_x, buf + atap[4], buf + atap[5], MS, US_A_PLANE, ch, cl, nh, nl);        // taps 16..19
-            kstep(hi, lo, ah, al, skip_hi{}, std::true_type{}, no_x, buf + atap[5], buf + atap[6], MS, US_A_PLANE, nh, nl, ch, cl);        // taps 20..23: dz = +1
-            wn = more ? wn : a.wp + offB + (t & 63);                 // the last phase-A step fetches the first phase-B step
-            kstep(hi, lo, ah, al, skip_hi{}, std::false_type{}, no_x, buf + atap[6], buf + atap[6], MS, US_A_PLANE, ch, cl, nh, nl);       // taps 24..26 + the dummy
-            convert_store(std::integral_constant<int, 1>{});
-            __syncthreads();
-        };
-        for (int ca = 0; ca < nA; ca += 2) {
-            chunk_a(std::true_type{}, ca, b0h, b0l, b1h, b1l);            // 7 steps: the fetched step ends up in the other register set
-            chunk_a(std::false_type{}, ca + 1, b1h, b1l, b0h, b0l);
-        }
-
-        // ---- phase B: upsampled channels in low resolution
-        {
-            int bq = US_B_OFF + bbase;
-            asm volatile("" : "+v"(bq));
-            const unsigned char* bb = lds + bq;
-            ah[0] = *reinterpret_cast<const h8*>(bb);
-            al[0] = *reinterpret_cast<const h8*>(bb + US_B_PLANE);
-            for (int cb = 0; cb < nB; ++cb) {
-                const unsigned char* ap = bb + cb * 2 * US_B_PLANE;
-                const bool last = cb + 1 == nB;
-                kstep(hi, lo, ah, al, skip_lo{}, std::true_type{}, no_x, ap, ap + US_BZ * 16, US_BZ * 16, US_B_PLANE, b0h, b0l, b1h, b1l);                     // tz = 0
-                wn = last ? a.wp + (t & 63) : wn;                                 // the last phase-B step fetches the next sample's first step
-                kstep(hi, lo, ah, al, skip_hi{}, std::true_type{}, no_x, ap + US_BZ * 16, last ? ap : ap + 2 * US_B_PLANE, US_BZ * 16, US_B_PLANE, b1h, b1l, b0h, b0l);   // tz = 1
-            }
-        }
-
-        // ---- the next sample's low-res voxels are requested now and used after the epilogue
-        const int ln = t & 63;
-        float xl[8];
-        {
-            const int cg = wave < nB ? wave : nB - 1;
-            const float* __restrict__ lbase = a.src1 + ((size_t)nxt * c1 + cg * 8) * 64;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xl[j] = lbase[j * 64 + ln];
-        }
-        __syncthreads();
-
-        // ---- epilogue: out = relu(hi + lo / 2^11) -> LDS tile [cout][z][y][x] behind buffer 0 -> float4 rows
-        float* e = reinterpret_cast<float*>(lds + UP_TILE_OFF);
-        {
-            const int col = ln & 15, yj = ln >> 4;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                if (nb * 16 + col < cout) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int lin = (2 * m + pz) * 64 + (2 * yj + py) * 8 + 2 * r + px;
-                            e[(nb * 16 + col) * US_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
-                        }
-                }
-        }
-        __syncthreads();
-        float* __restrict__ o = a.out + (size_t)box * cout * 512;
-        for (int q = t; q < cout * 128; q += 512) {
-            const int co = q >> 7, l4 = q & 127;
-            *reinterpret_cast<float4*>(o + (size_t)co * 512 + l4 * 4) = *reinterpret_cast<const float4*>(e + co * US_E_STRIDE + l4 * 4);
-        }
-        if (a.stats) {
-            // per cout: eight threads sum 64 values each (float64), then the eight partial sums in a fixed order
-            const int co = t >> 3, part = t & 7;
-            double sm = 0.0, sq = 0.0;
-            if (co < cout) {
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const float4 v = *reinterpret_cast<const float4*>(e + co * US_E_STRIDE + (part * 16 + i) * 4);
-                    sm += (double)v.x; sq += (double)v.x * v.x;
-                    sm += (double)v.y; sq += (double)v.y * v.y;
-                    sm += (double)v.z; sq += (double)v.z * v.z;
-                    sm += (double)v.w; sq += (double)v.w * v.w;
-                }
-            }
-#pragma unroll
-            for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
-            if (part == 0 && co < cout) a.stats[(size_t)box * cout + co] = make_double2(sm, sq);
-        }
-        __syncthreads();
-
-        // ---- the tile is dead: buffer 1 back to zeros (everybody), each wave its own low-res planes (zeros, then the next sample's voxels)
-        for (int i = t; i < US_A_BUF / 16; i += 512) reinterpret_cast<uint4*>(lds + US_A_BUF)[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (wave < nB) {
-            uint4* pl = reinterpret_cast<uint4*>(lds + US_B_OFF + wave * 2 * US_B_PLANE);
-            for (int i = ln; i < 2 * US_BSLOTS; i += 64) pl[i] = make_uint4(0u, 0u, 0u, 0u);
-            put_lowres(xl, wave, tn, ln);
-        }
-        __syncthreads();
-        tb = tn;
     }
     };   // run
     if (pz == 0) run(std::integral_constant<int, 0>{});
@@ -1040,15 +743,6 @@ extern "C" int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int
 
 template <int NB>
 static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
-    if (US_PERSISTENT && a.c0 >= 16 && a.c0 % 16 == 0 && a.c1 <= 64 && a.c0 + a.c1 <= 128 && a.cout <= 56) {     // persistent form: one workgroup per CU walks the samples
-        auto kern = k_conv3_up_split_p<NB>;
-        static RfLdsOptIn opt_in;
-        if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), UP_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu")) return rc;
-        const int cus = rf_compute_units();
-        hipLaunchKernelGGL(kern, dim3((unsigned)(a.n < cus ? a.n : cus)), dim3(512), UP_LDS_BYTES, stream, a);
-        RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
-        return RF_OK;
-    }
     auto kern = k_conv3_up_split<NB>;
     static RfLdsOptIn opt_in;
     if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), US_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu")) return rc;

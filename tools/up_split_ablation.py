@@ -130,6 +130,23 @@ XL = [
 WARM = (SW, SW.replace('US_WARM = false', 'US_WARM = true'))
 VARIANTS.update({'xlat': [(a, b.replace('STW', '0')) for a, b in XL] , 'xlat_warm': [(a, b.replace('STW', '0')) for a, b in XL] + [(SW, SW.replace('US_WARM = false', 'US_WARM = true'))]})
 
+# ---- persistent form: stamps per sample (SGPRs, stored by lane 0 of each wave at the end of the sample)
+def PS(k):
+    return "        __builtin_amdgcn_sched_barrier(0); pts[%d] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);\n" % k
+PST = [
+    ("template <int NB>\n__global__ __launch_bounds__(512, 2) void k_conv3_up_split_p(UpSplitArgs a) {",
+     "__device__ unsigned g_pts[8192 * 8 * 8];\nextern \"C\" int rft_read_pts(unsigned* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pts), sizeof(unsigned) * 8192 * 8 * 8); }\ntemplate <int NB>\n__global__ __launch_bounds__(512, 2) void k_conv3_up_split_p(UpSplitArgs a) {"),
+    ("        f32x4 hi[4][NB], lo[4][NB];\n        h8 ah[2], al[2];\n", "        unsigned pts[8];\n" + PS(0) + "        f32x4 hi[4][NB], lo[4][NB];\n        h8 ah[2], al[2];\n"),
+    ("        // ---- phase B: upsampled channels in low resolution\n        {\n            int bq", PS(1) + "        // ---- phase B: upsampled channels in low resolution\n        {\n            int bq"),
+    ("        // ---- the next sample's low-res voxels are requested now", PS(2) + "        // ---- the next sample's low-res voxels are requested now"),
+    ("        // ---- epilogue: out = relu(hi + lo / 2^11) -> LDS tile [cout][z][y][x] behind buffer 0", PS(3) + "        // ---- epilogue: out = relu(hi + lo / 2^11) -> LDS tile [cout][z][y][x] behind buffer 0"),
+    ("        float* __restrict__ o = a.out + (size_t)box * cout * 512;\n        for (int q = t;", PS(4) + "        float* __restrict__ o = a.out + (size_t)box * cout * 512;\n        for (int q = t;"),
+    ("        // ---- the tile is dead: buffer 1 back to zeros", PS(5) + "        // ---- the tile is dead: buffer 1 back to zeros"),
+    ("        __syncthreads();\n        tb = tn;\n", "        __syncthreads();\n" + PS(6) + "        if ((t & 63) == 0) for (int q = 0; q < 7; ++q) g_pts[(box * 8 + wave) * 8 + q] = pts[q];\n        tb = tn;\n"),
+]
+VARIANTS.update({'pstamps': list(PST)})
+PST_LABELS = ['phase A (4 chunks x 7 k-steps)', 'phase B (8 chunks x 2 k-steps)', 'request next low-res + barrier', 'accumulators -> LDS tile + barrier', 'tile -> stores, statistics, barrier', 're-zero, next low-res, barrier']
+
 
 def build(only=None):
     OUT.mkdir(exist_ok=True)
@@ -204,6 +221,19 @@ def run():
             for ca in range(4):
                 d = t[:, 2 * ca + 1] - t[:, 2 * ca]
                 print('  %s: chunk %d requests its successor: issue -> all 8 loads landed: mean %.0f median %.0f p10 %.0f p90 %.0f ticks' % (name, ca, d.mean(), np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+        if name.startswith('pstamps'):
+            lib.rft_read_pts.argtypes = [VP]
+            buf = np.zeros((8192, 8, 8), dtype=np.uint32)
+            f(s0.data_ptr(), c0, s1.data_ptr(), c1, n, edge, aff.data_ptr(), ws.data_ptr(), cout, out.data_ptr(), stats.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert lib.rft_read_pts(buf.ctypes.data) == 0
+            d = np.diff(buf[:, :, :7].astype(np.int64), axis=-1) % (1 << 32)
+            for wv in (0, 4):
+                print('  %s, wave %d: ticks per sample (samples of the steady state)' % (name, wv))
+                sel = d[512:7680, wv]
+                for i, lab in enumerate(PST_LABELS):
+                    print('    %-42s %8.0f (p90 %6.0f)  %5.1f %%' % (lab, sel[:, i].mean(), np.percentile(sel[:, i], 90), 100 * sel[:, i].mean() / sel.sum(axis=-1).mean()))
+                print('    %-42s %8.0f' % ('sample', sel.sum(axis=-1).mean()))
         if name.startswith('ks'):
             lib.rft_read_ts.argtypes = [VP]
             buf = np.zeros((8192, 8, 2, 10), dtype=np.uint32)
