@@ -330,6 +330,12 @@ int rf_attn_blend(const float* x, const float* retrieved, int b, int k, int c, i
 int rf_query_windows(const float* raw, int b, int s, int ps, int ctx, float pad_value, float mean, float stddev,
                      float* out, void* stream);
 
+/* Windows of a feature grid: grid [n][c][g^3] -> out [(n np^3)][c][w^3], window (p0, p1, p2) starts at step * (p0, p1, p2); windows in
+ * (sample, p0, p1, p2) order = the order of rf_query_windows.  Used by the fully-convolutional evaluation of the conv patch encoders (the
+ * reference evaluates model/retrieval.py:4-28,217-243 on every window of dataset/scene.py:152-160 separately; valid convolutions commute
+ * with the window cut as long as the window origins stay on the layers' sampling lattice). */
+int rf_gather_windows(const float* grid, int n, int c, int g, int w, int step, int np, float* out, void* stream);
+
 /* Database embedding image for the scans: emb [n][dim] row-major (dim = 64) -> rf_db_packed_floats(n, dim) floats holding
  * the blocked view [ceil(n/64)][dim][64] of the VALU scan, the chunk-permuted row view [n32][64] of the MFMA-filtered scans and
  * its per-row half norms [n32], the rows rounded to f16 [n32][64] and their half norms [n32] for the f16 filter (n32 = n rounded up

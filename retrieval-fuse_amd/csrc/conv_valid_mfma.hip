@@ -649,7 +649,112 @@ __global__ __launch_bounds__(256) void k_convv_valu(ConvVVArgs a) {
     }
 }
 
+// The same arithmetic (same FMA order per output: bit-identical results) for single-channel volumes wider than a workgroup's 256 columns --
+// the first layer of a patch encoder evaluated ONCE on a whole padded chunk instead of on its 64 overlapping windows (model/retrieval.py
+// forward_grid): workgroup = 4 output rows x 64 columns x 4 planes, input tile [4 + K - 1][4 + K - 1][64 + K - 1 rounded up to 4] staged with
+// 16-byte loads (s and the tile origin are multiples of 4).
+template <int COUT, int K>
+__global__ __launch_bounds__(256, 2) void k_convv_valu_xt(ConvVVArgs a) {
+    constexpr int TZ = 4, TY = 4, TX = 64, ZI = TZ + K - 1, YI = TY + K - 1, XW = (TX + K - 1 + 3) / 4 * 4, XW4 = XW / 4, K3 = K * K * K;
+    static_assert(COUT % 4 == 0, "weight vectors are read as float4");
+    __shared__ __attribute__((aligned(16))) float xs[ZI * YI * XW];
+    const int tid = threadIdx.x;
+    const int s = a.s, so = a.so;
+    const int ntx = (so + TX - 1) / TX, nty = (so + TY - 1) / TY, ntz = (so + TZ - 1) / TZ;
+    const int tiles = ntz * nty * ntx;
+    const int tb = blockIdx.x % tiles, nn = blockIdx.x / tiles;
+    const int cob = blockIdx.y * COUT;
+    const int x0 = (tb % ntx) * TX, y0 = ((tb / ntx) % nty) * TY, z0 = (tb / (ntx * nty)) * TZ;
+    const int ly = tid >> 6, lx = tid & 63;
+    const bool col_ok = y0 + ly < so && x0 + lx < so;
+    const size_t ivol = (size_t)s * s * s;
+    const float* xin = a.x + (size_t)nn * ivol;
+
+    constexpr int TOTAL4 = ZI * YI * XW4, PASSES = (TOTAL4 + 255) / 256;
+    {
+        float4 st[PASSES];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int i = tid + p * 256;
+            st[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < TOTAL4) {
+                const int r = i / XW4, x4 = i - r * XW4;
+                const int yy = r % YI, zz = r / YI;
+                const int iz = z0 + zz, iy = y0 + yy, ix = x0 + x4 * 4;
+                if (iz < s && iy < s && ix < s) st[p] = *reinterpret_cast<const float4*>(xin + ((size_t)iz * s + iy) * s + ix);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int i = tid + p * 256;
+            if (i < TOTAL4) reinterpret_cast<float4*>(xs)[i] = st[p];
+        }
+    }
+    __syncthreads();
+    if (!col_ok) return;
+
+    rf_v2 acc[TZ][COUT / 2];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z)
+#pragma unroll
+        for (int c = 0; c < COUT / 2; ++c) acc[z][c] = (rf_v2){0.f, 0.f};
+    // (a loop over the -- one -- input channel, as in k_convv_valu: without it hipcc requests all K^3 weight vectors up front and spills
+    // 1,700 SGPRs into lanes of vector registers.  The columns of the next (dy, dx) are read under the FMAs of this one and no further ahead:
+    // every LDS address is the thread's base plus a constant, and left alone the scheduler hoists all 25 x 8 reads to the top -- 450 registers)
+    for (int cc = 0; cc < a.cin; ++cc) {
+        const float* xb = xs + ly * XW + lx;
+        float col[2][ZI];
+#pragma unroll
+        for (int i = 0; i < ZI; ++i) col[0][i] = xb[i * YI * XW];
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) {
+            const int dy = t / K, dx = t % K;
+            if (t + 1 < K * K) {
+                const float* xc = xb + ((t + 1) / K) * XW + (t + 1) % K;
+#pragma unroll
+                for (int i = 0; i < ZI; ++i) col[(t + 1) & 1][i] = xc[i * YI * XW];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dz = 0; dz < K; ++dz) {
+                const float* wv = a.w + ((size_t)cc * K3 + (dz * K + dy) * K + dx) * a.cout + cob;      // wave-uniform: scalar loads
+#pragma unroll
+                for (int q = 0; q < COUT / 4; ++q) {
+                    const rf_v2 wa = {wv[4 * q], wv[4 * q + 1]}, wb = {wv[4 * q + 2], wv[4 * q + 3]};
+#pragma unroll
+                    for (int z = 0; z < TZ; ++z) {
+                        const rf_v2 xv = {col[t & 1][z + dz], col[t & 1][z + dz]};
+                        acc[z][2 * q] = __builtin_elementwise_fma(xv, wa, acc[z][2 * q]);
+                        acc[z][2 * q + 1] = __builtin_elementwise_fma(xv, wb, acc[z][2 * q + 1]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const size_t ovol = (size_t)so * so * so;
+#pragma unroll
+    for (int c = 0; c < COUT / 2; ++c) {
+        const float b0 = a.bias ? a.bias[cob + 2 * c] : 0.f, b1 = a.bias ? a.bias[cob + 2 * c + 1] : 0.f;
+        float* o0 = a.out + ((size_t)nn * a.cout + cob + 2 * c) * ovol + ((size_t)z0 * so + y0 + ly) * so + x0 + lx;
+#pragma unroll
+        for (int z = 0; z < TZ; ++z) {
+            if (z0 + z < so) {
+                const float v0 = acc[z][c][0] + b0, v1 = acc[z][c][1] + b1;
+                o0[(size_t)z * so * so] = v0 > 0.f ? v0 : v0 * a.slope;
+                o0[(size_t)z * so * so + ovol] = v1 > 0.f ? v1 : v1 * a.slope;
+            }
+        }
+    }
+}
+
+// big single-channel volumes (fully-convolutional evaluation of a patch encoder's first layer): the x-tiled kernel
+static bool convv_valu_xt_takes(int cin, int s, int cout, int k, int stride) {
+    return stride == 1 && cin == 1 && (k == 3 || k == 5) && (cout == 8 || cout == 12 || cout == 16) && s > 64 && s <= 1024 && (s & 3) == 0;
+}
+
 static bool convv_valu_takes(int cin, int s, int cout, int k, int stride) {
+    if (convv_valu_xt_takes(cin, s, cout, k, stride)) return true;
     if (stride != 1 || (k != 3 && k != 5) || s > 64 || s - k + 1 < 8) return false;
     if (k == 5) return cin == 1 && (cout == 8 || cout == 12);
     return (cin == 1 && (cout == 8 || cout == 12 || cout == 16)) || (cin == 8 && cout == 16) || (cin == 12 && cout == 24);
@@ -668,6 +773,22 @@ extern "C" int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s,
                "rf_conv3d_valid_leaky_valu: shape not taken by the VALU form (ask rf_conv3d_valid_valu_supported)");
     ConvVVArgs a;
     a.x = x; a.w = w_oidhw; a.bias = bias; a.out = out; a.n = n; a.cin = cin; a.cout = cout; a.s = s; a.so = s - k + 1; a.slope = slope;
+    if (convv_valu_xt_takes(cin, s, cout, k, stride)) {
+        const size_t tiles = (size_t)((a.so + 3) / 4) * ((a.so + 3) / 4) * ((a.so + 63) / 64) * n;
+        RF_REQUIRE(tiles < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_valu: too many tiles (%zu)", tiles);
+        a.ty = 4; a.nty = (a.so + 3) / 4; a.ntz = (a.so + 3) / 4;
+        hipStream_t sx = (hipStream_t)stream;
+#define RF_VX(COUT_, K_) hipLaunchKernelGGL((k_convv_valu_xt<COUT_, K_>), dim3((unsigned)tiles), dim3(256), 0, sx, a)
+        if (k == 5 && cout == 8) RF_VX(8, 5);
+        else if (k == 5 && cout == 12) RF_VX(12, 5);
+        else if (k == 5) RF_VX(16, 5);
+        else if (cout == 8) RF_VX(8, 3);
+        else if (cout == 12) RF_VX(12, 3);
+        else RF_VX(16, 3);
+#undef RF_VX
+        RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_valu");
+        return RF_OK;
+    }
     a.ty = 256 / a.so;
     if (a.ty > a.so) a.ty = a.so;
     a.nty = (a.so + a.ty - 1) / a.ty;

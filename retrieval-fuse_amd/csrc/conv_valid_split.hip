@@ -4,12 +4,13 @@
 //     x = h + l / 2^11,  h = f16(x),  l = f16((x - h) * 2^11);   a*b ~ ah*bh + (ah*bl + al*bh) / 2^11,   exact f16 x f16 products,
 //     fp32 accumulation in two accumulators (hi, lo), combined once in the epilogue.
 //
-// GEMM view: M = output voxels of a tile (tz x ty whole output rows of one window, linear index, 4 waves x 4 m-blocks = 256), N = cout
+// GEMM view: M = output voxels of a tile (tz x ty x tx voxels of one volume -- whole output rows for the encoders' windows, x segments for
+// the big grids of the fully-convolutional evaluation -- linear index, 4 waves x 4 m-blocks = 256), N = cout
 // (NB <= 3 n-blocks per workgroup), K = k^3 * cin walked in PIECES: a piece is (tap, group of 4 input channels); an MFMA k-step (k = 32)
 // is 8 pieces, lane group g = lane >> 4 supplies pieces 8q + 2g and 8q + 2g + 1.  The encoders' channel counts are multiples of 4, not
 // of 8 (PCPatch48: 12, 24, 48, 96), and with 4-channel pieces in flat order a 12-channel layer needs 11 k-steps where 8-channel slots
 // would need 14.  LDS image of a chunk of `cgc` channel groups: [group][input position] in 8-byte slots (4 channels of one input voxel),
-// one plane for h, one for l; positions are the tile's (tz-1)*stride + k input planes of (ty-1)*stride + k whole input rows.  An A
+// one plane for h, one for l; positions are the tile's (tz-1)*stride + k input planes of (ty-1)*stride + k input rows of (tx-1)*stride + k voxels.  An A
 // operand is four ds_read_b64 at (output corner + piece offset), the piece offsets of a k-step come from a table in LDS.
 // Staging: 4 channel planes -> one item (position, group) per thread step, scaled, clamped and split on the way in; no LDS double
 // buffer -- two or three workgroups per CU overlap one's staging with the other's MFMAs.
@@ -36,8 +37,8 @@ struct ConvVSArgs {
     float* out;
     int n, cin, s, cout, k, stride, so;
     float slope;
-    int tz, ty, ntz, nty, gz;      // output rows per tile, tiles per dim, groups of NB cout blocks
-    int zi, yi, npos;              // staged input planes / rows per plane, positions per channel group (zi * yi * s)
+    int tz, ty, tx, ntz, nty, ntx, gz;   // output voxels per tile and dim, tiles per dim, groups of NB cout blocks
+    int zi, yi, xi, npos;          // staged input planes / rows per plane / voxels per row, positions per channel group (zi * yi * xi)
     int cgc, nchunk, ksteps;       // 4-channel groups per chunk, chunks, k-steps per chunk
     int nbt;                       // n-blocks of the weight image (cout16 / 16)
     int hdr;                       // ints of the image's table header, a multiple of 4
@@ -45,39 +46,43 @@ struct ConvVSArgs {
 
 // tile and chunk choice; depends on the layer only (not on n): the weight image is packed for it
 static bool convv_split_plan(int cin, int s, int cout, int k, int stride, ConvVSArgs& a, int& nb_out, size_t& lds_out) {
-    if (cin <= 0 || cout <= 0 || k < 2 || k > 5 || stride < 1 || stride > 2 || s < k || s > 64 || (cin & 3)) return false;
+    if (cin <= 0 || cout <= 0 || k < 2 || k > 5 || stride < 1 || stride > 2 || s < k || s > 255 || (cin & 3)) return false;
     const int so = (s - k) / stride + 1;
     if (so < 6) return false;
     const int cout16 = rf_round_up(cout, 16);
     const int nbw = cout16 <= 48 ? cout16 / 16 : (cout16 % 48 == 0 ? 3 : 2);
     const int k3 = k * k * k, cgt = cin / 4;
     double best = 0.0;
-    for (int tz = 1; tz <= so; ++tz)
-        for (int ty = 1; ty <= so; ++ty) {
-            const int V = tz * ty * so;
-            if (V > VS_M) continue;
-            const int zi = (tz - 1) * stride + k, yi = (ty - 1) * stride + k;
-            const int npos = zi * yi * s;
-            const int ntz = (so + tz - 1) / tz, nty = (so + ty - 1) / ty;
-            const double tile_eff = (double)so * so * so / ((double)ntz * nty * VS_M);
-            for (int cgc = 1; cgc <= cgt; ++cgc) {
-                if (cgt % cgc) continue;
-                const int ksteps = (k3 * cgc + 7) / 8;
-                if (ksteps > 64) continue;                          // piece table: two entries per thread
-                const int items_pad = rf_round_up(cgc * npos, VS_SB * VS_NT);       // the staging loop writes whole batches
-                size_t lds = (size_t)2 * items_pad * 8 + (size_t)ksteps * 8 * 4 + (size_t)(items_pad / s + 2) * 4;
-                if (lds > VS_LDS_MAX) continue;
-                if (lds < (size_t)16 * VS_EV * 4) lds = (size_t)16 * VS_EV * 4;     // the epilogue tile aliases the image
-                const double eff = tile_eff * (double)(k3 * cgc) / (8.0 * ksteps);
-                if (eff > best + 1e-9 || (eff > best - 1e-9 && npos < a.npos)) {    // ties: the smaller staged tile
-                    best = eff;
-                    a.tz = tz; a.ty = ty; a.ntz = ntz; a.nty = nty; a.zi = zi; a.yi = yi; a.npos = npos;
-                    a.cgc = cgc; a.nchunk = cgt / cgc; a.ksteps = ksteps;
-                    lds_out = lds;
+    a.npos = 0; a.tx = 0;
+    for (int tz = 1; tz <= so && tz <= VS_M; ++tz)
+        for (int ty = 1; ty <= so && tz * ty <= VS_M; ++ty)
+            for (int tx = so; tx >= 4; --tx) {
+                // whole rows when they fit (the windows of the patch encoders); segments of at least 16 voxels (64-byte runs) otherwise
+                if (tx != so && (so <= VS_M / 4 || tx < 16 || (tx & 3))) continue;
+                const int V = tz * ty * tx;
+                if (V > VS_M) continue;
+                const int zi = (tz - 1) * stride + k, yi = (ty - 1) * stride + k, xi = (tx - 1) * stride + k;
+                const int npos = zi * yi * xi;
+                const int ntz = (so + tz - 1) / tz, nty = (so + ty - 1) / ty, ntx = (so + tx - 1) / tx;
+                const double tile_eff = (double)so * so * so / ((double)ntz * nty * ntx * VS_M);
+                for (int cgc = 1; cgc <= cgt; ++cgc) {
+                    if (cgt % cgc) continue;
+                    const int ksteps = (k3 * cgc + 7) / 8;
+                    if (ksteps > 64) continue;                          // piece table: two entries per thread
+                    const int items_pad = rf_round_up(cgc * npos, VS_SB * VS_NT);       // the staging loop writes whole batches
+                    size_t lds = (size_t)2 * items_pad * 8 + (size_t)ksteps * 8 * 4 + (size_t)(items_pad / xi + 2) * 4;
+                    if (lds > VS_LDS_MAX) continue;
+                    if (lds < (size_t)16 * VS_EV * 4) lds = (size_t)16 * VS_EV * 4;     // the epilogue tile aliases the image
+                    const double eff = tile_eff * (double)(k3 * cgc) / (8.0 * ksteps);
+                    if (eff > best + 1e-9 || (eff > best - 1e-9 && npos < a.npos)) {    // ties: the smaller staged tile
+                        best = eff;
+                        a.tz = tz; a.ty = ty; a.tx = tx; a.ntz = ntz; a.nty = nty; a.ntx = ntx; a.zi = zi; a.yi = yi; a.xi = xi; a.npos = npos;
+                        a.cgc = cgc; a.nchunk = cgt / cgc; a.ksteps = ksteps;
+                        lds_out = lds;
+                    }
                 }
             }
-        }
-    if (best < 0.55) return false;
+    if (best < 0.5) return false;
     a.cin = cin; a.s = s; a.cout = cout; a.k = k; a.stride = stride; a.so = so;
     a.nbt = cout16 / 16;
     a.gz = (a.nbt + nbw - 1) / nbw;
@@ -100,7 +105,7 @@ extern "C" size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, i
 //   [ksteps * 8] byte offset of piece p in the h plane (zero-weight pad pieces: 0, a position that is always staged);
 //   [VS_M]       byte offset of the input corner of tile voxel m in a plane (m >= tile size: 0 -- computed, never stored);
 //   [VS_M]       offset of tile voxel m in the output window relative to the tile's first voxel (m >= tile size: -1);
-//   [VS_M]       (lz << 8) | ly of tile voxel m (ragged last tiles)
+//   [VS_M]       (lz << 16) | (ly << 8) | lx of tile voxel m (ragged last tiles)
 __global__ void k_convv_split_header(ConvVSArgs a, int* __restrict__ hdr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int np = a.ksteps * 8;
@@ -109,17 +114,17 @@ __global__ void k_convv_split_header(ConvVSArgs a, int* __restrict__ hdr) {
         int off = 0;
         if (i < k * k * k * a.cgc) {
             const int tap = i / a.cgc, cg = i - tap * a.cgc;
-            off = (cg * a.npos + ((tap / (k * k)) * a.yi + (tap / k) % k) * a.s + tap % k) * 8;
+            off = (cg * a.npos + ((tap / (k * k)) * a.yi + (tap / k) % k) * a.xi + tap % k) * 8;
         }
         hdr[i] = off;
     } else if (i < np + 3 * VS_M) {
         const int which = (i - np) / VS_M, m0 = (i - np) % VS_M;
-        const bool in = m0 < a.tz * a.ty * a.so;
+        const bool in = m0 < a.tz * a.ty * a.tx;
         const int m = in ? m0 : 0;
-        const int x = m % a.so, r = m / a.so, ly = r % a.ty, lz = r / a.ty;
-        if (which == 0) hdr[i] = (((lz * a.stride) * a.yi + ly * a.stride) * a.s + x * a.stride) * 8;
+        const int x = m % a.tx, r = m / a.tx, ly = r % a.ty, lz = r / a.ty;
+        if (which == 0) hdr[i] = (((lz * a.stride) * a.yi + ly * a.stride) * a.xi + x * a.stride) * 8;
         else if (which == 1) hdr[i] = in ? (lz * a.so + ly) * a.so + x : -1;
-        else hdr[i] = (lz << 8) | ly;
+        else hdr[i] = (lz << 16) | (ly << 8) | x;
     } else if (i < a.hdr) {
         hdr[i] = 0;
     }
@@ -180,22 +185,24 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int so = a.so, s = a.s, st = a.stride;
+    const int so = a.so, s = a.s, st = a.stride, xi = a.xi;
     const int items = a.cgc * a.npos;
     const int items_pad = (items + SB * NT - 1) / (SB * NT) * (SB * NT);    // the staging loop writes whole batches (pad slots: never read)
     const int plane = items_pad * 8;                                // bytes of the h plane (l plane follows)
     int* poff = reinterpret_cast<int*>(lds + 2 * plane);            // [ksteps * 8] byte offset of a piece in the h plane
     int* rowsrc = poff + a.ksteps * 8;                              // [rows_pad] float offset of a staged row (< 0: outside the volume / the chunk)
-    const int nrows = a.cgc * a.zi * a.yi, rows_pad = items_pad / s + 2;
+    const int nrows = a.cgc * a.zi * a.yi, rows_pad = items_pad / xi + 2;
     const size_t ivol = (size_t)s * s * s;
 
     // XCD-aware 1-D grid as in k_convv_lds: an XCD walks whole windows (tiles fastest, then cout block groups)
     const unsigned total = gridDim.x, per = total >> 3, rem = total & 7u, xk = blockIdx.x & 7u;
     const unsigned lb = xk * per + (xk < rem ? xk : rem) + (blockIdx.x >> 3);
-    const unsigned tiles = (unsigned)(a.ntz * a.nty);
+    const unsigned tiles = (unsigned)(a.ntz * a.nty * a.ntx);
     const unsigned tb = lb % tiles, zb = (lb / tiles) % (unsigned)a.gz;
     const int nn = (int)(lb / (tiles * (unsigned)a.gz));
-    const int z0 = (int)(tb / (unsigned)a.nty) * a.tz, y0 = (int)(tb % (unsigned)a.nty) * a.ty;
+    const unsigned tzy = tb / (unsigned)a.ntx;
+    const int z0 = (int)(tzy / (unsigned)a.nty) * a.tz, y0 = (int)(tzy % (unsigned)a.nty) * a.ty, x0t = (int)(tb % (unsigned)a.ntx) * a.tx;
+    const int xin0 = x0t * st, xlast = s - 1 - xin0;              // first staged input column; the last column of the row relative to it
     const int nb0 = (int)zb * NB;                                   // first n-block of this workgroup
 
     // tables from the image header; the staged rows of this tile
@@ -211,13 +218,13 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             const int cg = (int)(((float)r + 0.5f) * inv_g), rr = r - cg * rows_g;
             const int rz = (int)(((float)rr + 0.5f) * inv_y), ry = rr - rz * a.yi;
             const int iz = z0 * st + rz, iy = y0 * st + ry;
-            rowsrc[r] = r >= nrows ? 0 : (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s : -1;   // ragged last tile: rows past the volume
+            rowsrc[r] = r >= nrows ? 0 : (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s + xin0 : -1;   // ragged last tile: rows past the volume
         }
     }
     int base[MB];                                                   // byte offset of the input corner of voxel (m-block, j) in a plane
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) base[mb] = hdr[a.ksteps * 8 + (wave * MB + mb) * 16 + j];
-    int eoff[4], ezy[4];                                            // epilogue: voxel m = lane + 64 i -> offset in the output window, (lz << 8) | ly
+    int eoff[4], ezy[4];                                            // epilogue: voxel m = lane + 64 i -> offset in the output volume, (lz << 16) | (ly << 8) | lx
 #pragma unroll
     for (int i = 0; i < 4; ++i) { eoff[i] = hdr[a.ksteps * 8 + VS_M + lane + 64 * i]; ezy[i] = hdr[a.ksteps * 8 + 2 * VS_M + lane + 64 * i]; }
     float bz[NB];                                                   // before any store (see above)
@@ -227,8 +234,8 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
         bz[nb] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
 
-    const int step_r = NT / s, step_x = NT - step_r * s;            // item index advances by NT: (row, x) += (step_r, step_x) with carry
-    const int row0 = tid / s, x0 = tid - row0 * s;
+    const int step_r = NT / xi, step_x = NT - step_r * xi;          // item index advances by NT: (row, x) += (step_r, step_x) with carry
+    const int row0 = tid / xi, x0 = tid - row0 * xi;
 
     f32x4 hi[MB][NB], lo[MB][NB];
 #pragma unroll
@@ -259,14 +266,15 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
 #pragma unroll
                     for (int b = 0; b < SB; ++b) {
                         const int ro = rowsrc[row];
+                        const int ixc = ix < xlast ? ix : xlast;       // columns past the row (last x tile): some value of the row, only unstored voxels see it
                         if constexpr (RAGGED) {
-                            off[b] = ro >= 0 ? (unsigned)(ro + ix) * 4u : 0u;
+                            off[b] = ro >= 0 ? (unsigned)(ro + ixc) * 4u : 0u;
                             real |= (ro >= 0 ? 1u : 0u) << b;
                         } else {
-                            off[b] = (unsigned)(ro + ix) * 4u;
+                            off[b] = (unsigned)(ro + ixc) * 4u;
                         }
                         row += step_r; ix += step_x;
-                        if (ix >= s) { ix -= s; ++row; }
+                        if (ix >= xi) { ix -= xi; ++row; }
                     }
 #pragma unroll
                     for (int b = 0; b < SB; ++b)
@@ -334,14 +342,16 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     // contiguous runs -- per cout block the 4 waves each stream four cout rows out, lane = consecutive voxel of the tile
     static_assert(VS_ACT_SCALE * VS_W_SCALE == 1.0f, "epilogue assumes the operand scales cancel");
     float* eb = reinterpret_cast<float*>(lds);                      // [16][VS_EV]
-    const int ovol = so * so * so;
+    const size_t ovol = (size_t)so * so * so;
     int zlim = so - z0;
     if (zlim > a.tz) zlim = a.tz;
     int ylim = so - y0;
     if (ylim > a.ty) ylim = a.ty;
+    int xlim = so - x0t;
+    if (xlim > a.tx) xlim = a.tx;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (!((ezy[i] >> 8) < zlim && (ezy[i] & 255) < ylim)) eoff[i] = -1;
+        if (!((ezy[i] >> 16) < zlim && ((ezy[i] >> 8) & 255) < ylim && (ezy[i] & 255) < xlim)) eoff[i] = -1;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
         for (int h = 0; h < 4; ++h) {
             const int col = wave * 4 + h, co = (nb0 + nb) * 16 + col;
             if (co < a.cout) {                                      // wave-uniform
-                float* o = a.out + ((size_t)nn * a.cout + co) * ovol + ((size_t)z0 * so + y0) * so;
+                float* o = a.out + ((size_t)nn * a.cout + co) * ovol + ((size_t)z0 * so + y0) * so + x0t;
                 const float* src = eb + col * VS_EV + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -387,7 +397,7 @@ extern "C" int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s
     RF_REQUIRE(convv_split_plan(cin, s, cout, k, stride, a, nbw, lds), RF_E_UNSUPPORTED,
                "rf_conv3d_valid_leaky_split: layer not taken by the split form (ask rf_conv3d_valid_split_supported)");
     a.n = n; a.x = x; a.wp = reinterpret_cast<const h8*>(w_packed); a.bias = bias; a.out = out; a.slope = slope;
-    const size_t grid64 = (size_t)a.ntz * a.nty * a.gz * n;
+    const size_t grid64 = (size_t)a.ntz * a.nty * a.ntx * a.gz * n;
     RF_REQUIRE(grid64 < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_split: too many tiles (%zu)", grid64);
     const unsigned grid = (unsigned)grid64;
     hipStream_t st = (hipStream_t)stream;

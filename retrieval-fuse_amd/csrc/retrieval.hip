@@ -52,6 +52,33 @@ extern "C" int rf_query_windows(const float* raw, int b, int s, int ps, int ctx,
     return RF_OK;
 }
 
+// ---------------------------------------------------------------------------------------- windows of a feature grid
+// The patch encoders evaluated fully convolutionally (model/retrieval.py forward_grid): the first layers run once on the padded chunk, then
+// the (np)^3 windows of edge w at stride `step` are cut out of the feature grid [n][c][g^3] -> [(n np^3)][c][w^3] for the remaining layers.
+__global__ __launch_bounds__(256) void k_gather_windows(const float* __restrict__ grid, int n, int c, int g, int w, int step, int np,
+                                                        float* __restrict__ out) {
+    const size_t w3 = (size_t)w * w * w, g3 = (size_t)g * g * g, total = (size_t)n * np * np * np * c * w3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w2 = (int)(i % w), w1 = (int)((i / w) % w), w0 = (int)((i / ((size_t)w * w)) % w);
+        const size_t cw = i / w3;
+        const int ch = (int)(cw % c);
+        const size_t win = cw / c;
+        const int p2 = (int)(win % np), p1 = (int)((win / np) % np), p0 = (int)((win / ((size_t)np * np)) % np);
+        const size_t bb = win / ((size_t)np * np * np);
+        out[i] = grid[(bb * c + ch) * g3 + ((size_t)(p0 * step + w0) * g + (p1 * step + w1)) * g + (p2 * step + w2)];
+    }
+}
+
+extern "C" int rf_gather_windows(const float* grid, int n, int c, int g, int w, int step, int np, float* out, void* stream) {
+    RF_REQUIRE(grid && out && n > 0 && c > 0 && g > 0 && w > 0 && step > 0 && np > 0 && (np - 1) * step + w <= g, RF_E_INVALID,
+               "rf_gather_windows: bad arguments (the last window must end inside the grid)");
+    const size_t total = (size_t)n * np * np * np * c * w * w * w;
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_gather_windows, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, grid, n, c, g, w, step, np, out);
+    RF_CHECK_LAUNCH("rf_gather_windows");
+    return RF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- DB packing
 // The packed image holds three views of the shard's embedding matrix (dim = 64):
 //   blocked  [ceil(n/64)][64 dims][64 rows]      the VALU scan: one coalesced 256-byte load per dim per wave

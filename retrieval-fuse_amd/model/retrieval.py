@@ -85,6 +85,26 @@ class _ConvPatchEncoder(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.final_layer = LinearParams(self.SPEC[-1][1] * nf, z_dim)
 
+    def _conv(self, layer, x):
+        if ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride) and ops.split_range_ok(layer.weight):
+            return ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
+        if ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
+            return ops.conv3d_valid_leaky_valu(x, layer.packed_valu(), layer.bias, layer.stride, 0.2)
+        if ops.conv_valid_lds_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
+            return ops.conv3d_valid_leaky_lds(x, layer.packed_lds(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
+        return ops.conv3d_valid_leaky_mfma(x, layer.packed(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
+
+    def _grid_conv_ok(self, layer, x):
+        """the two forms that tile a big volume efficiently (the others assume a window-sized input)"""
+        return ((ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride) and ops.split_range_ok(layer.weight))
+                or ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride))
+
+    def _head(self, x):
+        if tuple(x.shape[2:]) != (1, 1, 1):
+            raise ValueError(f'{type(self).__name__}: input window does not reduce to 1^3 (got {tuple(x.shape[2:])})')
+        x = self.final_layer.apply_to(x.reshape(x.shape[0], x.shape[1]))
+        return x.reshape([x.shape[0], x.shape[1], 1, 1, 1])
+
     def forward(self, x):
         if self.BATCHNORM:
             raise NotImplementedError(f'{type(self).__name__}: BatchNorm patch encoders are not built (no shipped config selects them)')
@@ -92,19 +112,51 @@ class _ConvPatchEncoder(nn.Module):
         x = x.contiguous()
         for layer in self.layers:
             if isinstance(layer, Conv3dParams):
-                if ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride) and ops.split_range_ok(layer.weight):
-                    x = ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size,
-                                                     layer.stride, 0.2)
-                elif ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
-                    x = ops.conv3d_valid_leaky_valu(x, layer.packed_valu(), layer.bias, layer.stride, 0.2)
-                elif ops.conv_valid_lds_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
-                    x = ops.conv3d_valid_leaky_lds(x, layer.packed_lds(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
-                else:
-                    x = ops.conv3d_valid_leaky_mfma(x, layer.packed(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
-        if tuple(x.shape[2:]) != (1, 1, 1):
-            raise ValueError(f'{type(self).__name__}: input window does not reduce to 1^3 (got {tuple(x.shape[2:])})')
-        x = self.final_layer.apply_to(x.reshape(x.shape[0], x.shape[1]))
-        return x.reshape([x.shape[0], x.shape[1], 1, 1, 1])
+                x = self._conv(layer, x)
+        return self._head(x)
+
+    def grid_plan(self, window, step, npatch):
+        """How many leading conv layers to evaluate on the whole grid of npatch^3 windows (edge `window`, stride `step`) instead of per window:
+        a layer stays on the grid while the window origins stay on its sampling lattice (step divisible by the accumulated stride) and the
+        grid has fewer output voxels than the windows together.  -> (layers on the grid, window edge / lattice step after them)"""
+        sw, sg, lat, on_grid = window, (npatch - 1) * step + window, step, 0
+        for layer in self.layers:
+            if not isinstance(layer, Conv3dParams):
+                continue
+            k, st = layer.kernel_size, layer.stride
+            if lat % st or sw < k:
+                break
+            sw2, sg2 = (sw - k) // st + 1, (sg - k) // st + 1
+            if sg2 ** 3 >= npatch ** 3 * sw2 ** 3 or (npatch - 1) * (lat // st) + sw2 > sg2:
+                break
+            sw, sg, lat, on_grid = sw2, sg2, lat // st, on_grid + 1
+        return on_grid, sw, lat
+
+    def forward_grid(self, grid, window, step):
+        """grid [B,1,G,G,G] (a padded, normalised chunk) -> the embeddings of its ((G - window) / step + 1)^3 windows, [B * np^3, z, 1,1,1] in
+        rf_query_windows order.  Valid convolutions are translation equivariant: the leading layers run ONCE on the grid (the windows overlap:
+        PCPatch48 on 48^3 windows at stride 32 computes every first-layer output 2x, Patch32 at stride 16 3.2x), the windows are cut out of
+        the feature grid where that stops paying, the remaining layers run per window.  Same kernels, same per-output arithmetic."""
+        if self.BATCHNORM:
+            raise NotImplementedError(f'{type(self).__name__}: BatchNorm patch encoders are not built (no shipped config selects them)')
+        ops._no_grad_only(grid, self.final_layer.weight)
+        g = grid.shape[2]
+        if (g - window) % step:
+            raise ValueError(f'{type(self).__name__}.forward_grid: grid edge {g} is not window {window} + a multiple of stride {step}')
+        npatch = (g - window) // step + 1
+        on_grid, _, _ = self.grid_plan(window, step, npatch)
+        x = grid.contiguous()
+        convs = [layer for layer in self.layers if isinstance(layer, Conv3dParams)]
+        sw, lat, done = window, step, 0
+        for layer in convs[:on_grid]:
+            if not self._grid_conv_ok(layer, x):
+                break
+            x = self._conv(layer, x)
+            sw, lat, done = (sw - layer.kernel_size) // layer.stride + 1, lat // layer.stride, done + 1
+        x = ops.gather_windows(x, sw, lat, npatch)
+        for layer in convs[done:]:
+            x = self._conv(layer, x)
+        return self._head(x)
 
 
 class Patch32(_ConvPatchEncoder):

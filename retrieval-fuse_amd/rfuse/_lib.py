@@ -100,6 +100,7 @@ SIGNATURES = {
     'rf_attn_weights_sampled': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_f, c_p, c_fp, c_fp, c_fp, c_fp, c_p]),
     'rf_attn_blend': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
     'rf_query_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_p]),
+    'rf_gather_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_db_pack_embeddings': (c_i, [c_fp, c_i64, c_i, c_fp, c_p]),
     'rf_db_packed_floats': (c_sz, [c_i64, c_i]),
     'rf_l2_topk': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_i, c_fp, c_p, c_p, c_sz, c_p]),

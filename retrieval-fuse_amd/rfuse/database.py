@@ -148,8 +148,7 @@ def build_database_rows(config, fenc_target, volumes, device, patch_mask=None, c
     embs = []
     for s0 in range(0, n_scenes, chunks_per_batch):
         raw = vols[s0:s0 + chunks_per_batch].to(device, torch.float32).contiguous()
-        win = ops.query_windows(raw, ps, ctx, trunc_t, d['target_mean'], d['target_std'])
-        z = fenc_target(win)
+        z = ops.embed_windows(fenc_target, raw, ps, ctx, trunc_t, d['target_mean'], d['target_std'])
         embs.append(ops.l2_normalize_rows_(z.reshape(z.shape[0], z.shape[1])))
     w = ps + 2 * ctx
     ones = torch.ones((1, 1, w, w, w), dtype=torch.float32, device=device)

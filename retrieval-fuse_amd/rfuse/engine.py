@@ -4,7 +4,8 @@ This is the build's own runner for the data flow of ``RefinementTrainingModule.f
 (reference trainer/train_refinement.py:108-116) + ``network_pred_to_df`` (:242-243), with the reference's OFFLINE
 retrieval (util/retrieval.py ``--mode map`` / ``--mode compose``, :222-248) done online on the device:
 
-   raw input chunk  --rf_query_windows-->  query windows --fenc_input + normalise-->  unit embeddings        (A11, A16)
+   raw input chunk  --rf_query_windows-->  query windows (or the padded chunk: conv encoders run fully convolutionally, ops.embed_windows)
+                    --fenc_input + normalise-->  unit embeddings                                              (A11, A16)
                     --rf_l2_topk (+ all-gather of the queries, all-to-all of the keys, rf_topk_merge when the DB is sharded)-->  top-2K             (A12)
                     --rf_demote_same_scene-->  top-K (scene, box)                                             (A13)
                     --rf_gather_patches-->  K*64 retrieved 16^3 patches per chunk, normalised, already in the
@@ -74,8 +75,7 @@ class RefinementEngine:
         """input_raw [B,S,S,S] un-normalised -> unit query embeddings [B*P, latent] (P = 64 windows per chunk)."""
         g, d = self.config['query_geometry'], self.config['dataset_train']
         pad = 0.0 if self.config['task'] == 'surface_reconstruction' else self.input_trunc
-        win = ops.query_windows(input_raw, g['patch_size_input'], g['patch_context_input'], pad, d['input_mean'], d['input_std'])
-        z = self.fenc_input(win)
+        z = ops.embed_windows(self.fenc_input, input_raw, g['patch_size_input'], g['patch_context_input'], pad, d['input_mean'], d['input_std'])
         return ops.l2_normalize_rows_(z.reshape(z.shape[0], z.shape[1]))
 
     @_on_engine_device

@@ -887,6 +887,30 @@ def query_windows(raw, ps, ctx, pad_value, mean, std):
     return out
 
 
+def gather_windows(grid, w, step, npatch):
+    """grid [n,c,g,g,g] -> the npatch^3 windows of edge w at stride step of every sample: [n*npatch^3, c, w, w, w] (rf_query_windows order)"""
+    _req(grid, 'grid')
+    n, c, g = grid.shape[0], grid.shape[1], grid.shape[2]
+    out = torch.empty((n * npatch ** 3, c, w, w, w), dtype=torch.float32, device=grid.device)
+    _lib.check(_lib.load().rf_gather_windows(_p(grid), n, c, g, w, step, npatch, _p(out), _stream()), 'rf_gather_windows')
+    return out
+
+
+USE_FCN_ENCODER = True          # False: the conv patch encoders run on every window separately (the reference's form)
+
+
+def embed_windows(encoder, raw, ps, ctx, pad_value, mean, std):
+    """The embeddings of the (s/ps)^3 windows (edge ps + 2 ctx, stride ps, padded with pad_value, normalised) of raw chunks [b,s,s,s], in
+    rf_query_windows order: [b * (s/ps)^3, latent, 1,1,1].  A conv patch encoder whose leading layers pay on the whole padded chunk
+    (model/retrieval.py grid_plan) gets the chunk as ONE window with context -- the same padded, normalised voxels -- and cuts the windows
+    out of its feature grid; everything else gets the windows."""
+    s = raw.shape[-1]
+    if USE_FCN_ENCODER and hasattr(encoder, 'grid_plan') and not getattr(encoder, 'BATCHNORM', False) and encoder.grid_plan(ps + 2 * ctx, ps, s // ps)[0] > 0:
+        grid = query_windows(raw, s, ctx, pad_value, mean, std)
+        return encoder.forward_grid(grid, ps + 2 * ctx, ps)
+    return encoder(query_windows(raw, ps, ctx, pad_value, mean, std))
+
+
 def db_pack_embeddings(emb):
     _req(emb, 'emb')
     n, dim = emb.shape

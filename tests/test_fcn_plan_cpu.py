@@ -1,0 +1,44 @@
+"""CPU: the planner of the fully-convolutional patch-encoder evaluation (model/retrieval.py grid_plan) -- which leading layers run on the
+whole padded chunk.  The rule: the window origins must stay on the layers' sampling lattice, and the grid must have fewer output voxels
+than the windows together.  (The arithmetic itself is GPU-tested: tests/test_kernels_gpu.py.)"""
+import sys
+from pathlib import Path
+
+import pytest
+
+sys.path[:0] = [str(Path(__file__).resolve().parents[1] / 'retrieval-fuse_amd')]
+import model as rf_model  # noqa: E402
+
+
+def brute_force_plan(spec, window, step, npatch):
+    """window / grid sizes layer by layer, straight from the definition of a valid strided convolution"""
+    sw, sg, lat, n = window, (npatch - 1) * step + window, step, 0
+    for _, _, k, st in spec:
+        if lat % st:
+            break
+        sw2, sg2 = (sw - k) // st + 1, (sg - k) // st + 1
+        origins = [a * (lat // st) for a in range(npatch)]
+        if origins[-1] + sw2 > sg2 or sg2 ** 3 >= npatch ** 3 * sw2 ** 3:
+            break
+        sw, sg, lat, n = sw2, sg2, lat // st, n + 1
+    return n, sw, lat
+
+
+@pytest.mark.parametrize('name,nf,window,step', [('PCPatch48', 12, 48, 32), ('Patch32', 8, 32, 16), ('Patch24V2', 8, 24, 16), ('PCPatch32', 12, 32, 32),
+                                                 ('Patch16', 8, 16, 16), ('PCPatch64', 12, 64, 32), ('Patch24', 8, 24, 16), ('Patch12', 8, 12, 8)])
+def test_grid_plan(name, nf, window, step):
+    enc = getattr(rf_model, name)(nf, 64)
+    got = enc.grid_plan(window, step, 4)
+    assert got == brute_force_plan(enc.SPEC, window, step, 4)
+    on_grid, sw, lat = got
+    if window == step:
+        assert on_grid == 0                                      # windows that do not overlap: nothing to share
+    # the windows of the feature grid reduce to 1^3 through the remaining layers
+    for _, _, k, st in enc.SPEC[on_grid:]:
+        sw = (sw - k) // st + 1
+    assert sw == 1
+
+
+def test_known_plans():
+    assert rf_model.PCPatch48(12, 64).grid_plan(48, 32, 4) == (4, 9, 8)       # 144 -> 140 -> 138 -> 68 -> 33, windows of 9^3 every 8
+    assert rf_model.Patch32(8, 64).grid_plan(32, 16, 4) == (4, 10, 8)         # 80 -> 76 -> 74 -> 36 -> 34, windows of 10^3 every 8

@@ -885,6 +885,85 @@ def test_conv3d_valid_leaky_split(ops, spec):
     assert e_split.max() <= 1.25 * e_fp32.max()
 
 
+@pytest.mark.parametrize('spec', [(1, 12, 140, 24, 3, 1), (1, 24, 138, 48, 3, 2), (2, 48, 68, 48, 3, 2), (1, 8, 76, 16, 3, 1), (2, 16, 74, 32, 3, 2), (1, 32, 36, 64, 3, 1),
+                                  (1, 8, 70, 16, 3, 1)])
+def test_conv3d_valid_leaky_split_on_big_volumes(ops, spec):
+    """the x-tiled form of the split valid conv -- the layers of PCPatch48 / Patch32 on a whole padded chunk (140^3 ... 36^3, model/retrieval.py
+    forward_grid) and an edge that leaves ragged tiles in x, y and z -- vs float64 torch, and vs the same kernel run on windows of the volume
+    (the per-output arithmetic does not depend on the tile)"""
+    n, cin, s, cout, k, stride = spec
+    gen = torch.Generator().manual_seed(sum(spec) + 5)
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    xd = x.to(DEV)
+    assert ops.conv_valid_split_supported(xd, cout, k, stride)
+    got = ops.conv3d_valid_leaky_split(xd, ops.pack_convv_split_weight(w.to(DEV), s, stride), b.to(DEV), cout, k, stride, 0.2)
+    ref = F.leaky_relu(F.conv3d(x.double(), w.double(), b.double(), stride=stride), 0.2)
+    err = (got.cpu().double() - ref).abs()
+    print(f'valid split on {s}^3 {spec}: rms {err.pow(2).mean().sqrt():.3e} max {err.max():.3e}')
+    close(got, ref.float(), 1e-5, 'valid conv (split, big volume)')
+    # a 44-voxel window of the same volume through the whole-row plan of that size: same products, same order within a chunk of channels
+    sw = 44 if s > 60 else 20
+    o0 = 8 * stride
+    xw = xd[:, :, o0:o0 + sw, o0:o0 + sw, o0:o0 + sw].contiguous()
+    if ops.conv_valid_split_supported(xw, cout, k, stride):
+        gw = ops.conv3d_valid_leaky_split(xw, ops.pack_convv_split_weight(w.to(DEV), sw, stride), b.to(DEV), cout, k, stride, 0.2)
+        so_w = gw.shape[-1]
+        sub = got[:, :, 8:8 + so_w, 8:8 + so_w, 8:8 + so_w]
+        close(sub, gw.cpu(), 2e-6, 'grid vs window evaluation')
+
+
+@pytest.mark.parametrize('spec', [(2, 144, 12, 5), (1, 80, 8, 5), (1, 72, 16, 3), (1, 68, 12, 3)])
+def test_conv3d_valid_leaky_valu_on_big_volumes(ops, spec):
+    """the x-tiled VALU form (a patch encoder's first layer on a whole padded chunk) vs float64 torch; BIT-equal to the window kernel on a window"""
+    n, s, cout, k = spec
+    gen = torch.Generator().manual_seed(sum(spec) + 6)
+    x, w, b = rnd(gen, n, 1, s, s, s), rnd(gen, cout, 1, k, k, k, scale=1 / np.sqrt(k ** 3)), rnd(gen, cout)
+    xd = x.to(DEV)
+    assert ops.conv_valid_valu_supported(xd, cout, k, 1)
+    wt = ops.pack_convv_valu_weight(w.to(DEV))
+    got = ops.conv3d_valid_leaky_valu(xd, wt, b.to(DEV), 1, 0.2)
+    ref = F.leaky_relu(F.conv3d(x.double(), w.double(), b.double()), 0.2).float()
+    close(got, ref, 1e-5, 'valid conv (valu, big volume)')
+    for o0 in (0, s - 48, 16):
+        xw = xd[:, :, o0:o0 + 48, o0:o0 + 48, o0:o0 + 48].contiguous()
+        gw = ops.conv3d_valid_leaky_valu(xw, wt, b.to(DEV), 1, 0.2)
+        so_w = gw.shape[-1]
+        assert torch.equal(got[:, :, o0:o0 + so_w, o0:o0 + so_w, o0:o0 + so_w], gw)
+
+
+def test_gather_windows(ops):
+    gen = torch.Generator().manual_seed(11)
+    grid = rnd(gen, 2, 5, 33, 33, 33)
+    got = ops.gather_windows(grid.to(DEV), 9, 8, 4).cpu()
+    ref = grid.unfold(2, 9, 8).unfold(3, 9, 8).unfold(4, 9, 8).permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(2 * 64, 5, 9, 9, 9)
+    assert torch.equal(got, ref)
+    with pytest.raises(RuntimeError, match='last window'):
+        ops.gather_windows(grid.to(DEV), 9, 9, 4)
+
+
+@pytest.mark.parametrize('enc', [('PCPatch48', 12, 48, 32), ('Patch32', 8, 32, 16), ('Patch24V2', 8, 24, 16), ('Patch16', 8, 16, 16)])
+def test_patch_encoder_on_the_grid_equals_the_encoder_on_the_windows(ops, enc):
+    """forward_grid (leading layers once on the padded chunk, windows cut out of the feature grid) against forward on the 64 windows: the same
+    embeddings (the VALU layers bit for bit; the split layers may pick another channel chunking for the big volume: <= 2e-6 of the scale)"""
+    import model as rf_model
+    name, nf, window, step = enc
+    torch.manual_seed(5)
+    m = getattr(rf_model, name)(nf, 64).to(DEV).eval()
+    g = 3 * step + window
+    gen = torch.Generator().manual_seed(9)
+    grid = rnd(gen, 2, 1, g, g, g).to(DEV)
+    with torch.no_grad():
+        win = grid[:, 0].unfold(1, window, step).unfold(2, window, step).unfold(3, window, step).reshape(2 * 64, 1, window, window, window).contiguous()
+        ref = m(win)
+        got = m.forward_grid(grid, window, step)
+    on_grid = m.grid_plan(window, step, 4)[0]
+    print(f'{name}: {on_grid} layers on the grid, max |grid - windows| = {(got - ref).abs().max():.3e} of {ref.abs().max():.3e}')
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max()))
+    if on_grid == 0:
+        assert torch.equal(got, ref)
+
+
 def test_conv3d_valid_split_saturates_instead_of_overflowing(ops):
     """activations beyond the f16 range (|x|/16 > 65504) are clamped, not turned into inf / NaN"""
     gen = torch.Generator().manual_seed(77)
