@@ -581,8 +581,8 @@ extern "C" int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const 
 extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout) {
     // whole 4^3 samples (8 per workgroup, k_conv3_split_s4): cin in eights, any cout (16 per workgroup), enough samples to fill the chip
     if (edge == 4) return c1 == 0 && c0 >= 8 && c0 % 8 == 0 && n >= 1024 && cout > 0;
-    // channel counts that are not multiples of 8 are padded up with zero channels: taken when at least 3/4 of the slots are real (12, 20, 28, 42 ...)
-    if (c1 != 0 || c0 < 8 || 4 * c0 < 3 * rf_round_up(c0, 8) || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
+    // channel counts that are not multiples of 8 are padded up with zero channels: taken when at least 3/4 of the slots are real (6, 12, 20, 28, 42 ...)
+    if (c1 != 0 || c0 < 6 || 4 * c0 < 3 * rf_round_up(c0, 8) || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
     const int cout16 = rf_round_up(cout, 16);
     return cout16 <= 32 && rf_conv_use_big(n, edge, cout16);
 }
@@ -599,7 +599,7 @@ static int launch_split(const ConvArgs& a, hipStream_t stream) {
 extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                            float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
     RF_REQUIRE(rf_conv3d_split_supported(cin, 0, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_split_k3_gn_relu: takes cin >= 8 (at least 3/4 of the next multiple of 8), up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_split_k3_gn_relu: takes cin >= 6 (at least 3/4 of the next multiple of 8), up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
                cin, n, edge, cout);
     RF_REQUIRE(src && gn_affine && w_packed && (out || pool_out), RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: null pointer");
     RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: statistics of an output that is not written");
@@ -625,7 +625,11 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
         RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
         return RF_OK;
     }
-    if (cin % 8) return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
+    if (cin % 8) {
+        if (cin < 8) return launch_split<1, 6, true, true>(a, (hipStream_t)stream);                   // 6 -> 12 of the nf = 12 U-Nets: one chunk, two zero slots
+        if (a.cout16 == 32) return launch_split<2, 2, false, true>(a, (hipStream_t)stream);
+        return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
+    }
     if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
 }

@@ -179,6 +179,9 @@ SPLIT_BOX_CASES = [
     (1030, 42, 8, 12, 6),      # 42 -> 48 slots, six chunks
     (3, 12, 64, 12, 6),        # C5's final decoder
     (140, 20, 16, 24, 4),
+    (3, 6, 128, 12, 3),        # C5's U-Net, second conv of level 0: six of eight slots real, one chunk
+    (1030, 6, 16, 12, 6),      # ... of its retrieval backbone
+    (20, 12, 64, 24, 6),       # 12 -> 24: zero slots and two n-blocks in one workgroup
     (1030, 32, 4, 64, 8),      # whole 4^3 samples, 8 per workgroup (k_conv3_split_s4): ragged sample count, four cout blocks
     (1024, 64, 4, 64, 8),
     (2050, 8, 4, 12, 4),       # one chunk, cout < 16
