@@ -124,7 +124,7 @@ class HipSearchBackend:
 
 
 @torch.no_grad()
-def build_database_rows(config, fenc_target, volumes, device, patch_mask=None, chunks_per_batch=8):
+def build_database_rows(config, fenc_target, volumes, device, patch_mask=None, chunks_per_batch=32):
     """``create_dictionary`` on the device (reference util/retrieval.py:29-45).
 
     volumes [S,64,64,64] raw (un-normalised) target chunks.  For every chunk the 64 target windows
