@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
 
     // ---- the first voxels (this wave's low-res channel group, the first skip chunk) are requested before the LDS is zeroed: their HBM
     // latency passes under the zero-fill
-    const float* __restrict__ s0 = a.src0 + (size_t)n * c0 * 512 + tid;
+    const float* __restrict__ sb0 = a.src0 + (size_t)n * c0 * 512;     // uniform: the voxel loads are SGPR base + a 32-bit lane offset
     float xl[8], x0[8];
     {
         const int cg = wave < nB ? wave : nB - 1;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         for (int j = 0; j < 8; ++j) xl[j] = a.src1[((size_t)n * c1 + cg * 8 + j) * 64 + lane];
         if (nA > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x0[j] = s0[(size_t)j * 512];
+            for (int j = 0; j < 8; ++j) x0[j] = sb0[j * 512 + tid];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -286,16 +286,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         float x[8];
         const bool more = ca + 1 < nA;
         const int cx = more ? ca + 1 : ca;                              // past the last chunk: harmless re-staging of the last one into the idle buffer
+        const float* __restrict__ sbx = sb0 + (size_t)cx * 8 * 512;      // uniform
         auto xload_a = [&] {
             if constexpr (PZ == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(cx * 8 + j) * 512];
+                for (int j = 0; j < 8; ++j) x[j] = sbx[j * 512 + (tid & 255)];
             }
         };
         auto xload_b = [&] {
             if constexpr (PZ == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = s0[(size_t)(cx * 8 + j) * 512 + 256];
+                for (int j = 0; j < 8; ++j) x[j] = sbx[j * 512 + 256 + (tid & 255)];
             }
         };
         auto convert_store = [&](int half) {
@@ -354,9 +355,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     __syncthreads();
 
     // ---- epilogue: out = relu(hi + lo / 2^11) -> LDS tile [cout][z][y][x] -> float4 rows
+    // (what the epilogue derives from the thread index is computed here, from an opaque copy: hoisted above the K loops those values sit in
+    // spilled registers through 44 k-steps -- 430 MB of scratch traffic per launch in the PMC counters)
+    int te = tid;
+    asm volatile("" : "+v"(te));
     float* e = reinterpret_cast<float*>(lds);
     {
-        const int col = lane & 15, yj = lane >> 4;
+        const int col = te & 15, yj = (te >> 4) & 3;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -373,10 +378,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     // rows of 517 floats: the scalar tile writes above (16 couts x 2 y per half wave) and these row reads hit 32 different banks; a row
     // stride that is a multiple of 4 (needed for 16-byte reads) leaves every write 4-way conflicted.  A wave stores 256 contiguous bytes.
 #pragma unroll 4
-    for (int co = 0; co < cout; ++co) o[(size_t)co * 512 + tid] = e[co * US_T_STRIDE + tid];
+    for (int co = 0; co < cout; ++co) o[(size_t)co * 512 + te] = e[co * US_T_STRIDE + te];
     if (a.stats) {
         // per cout: eight threads sum 64 values each (voxels part, part + 8, ...; float64), then the eight partial sums in a fixed order
-        const int co = tid >> 3, part = tid & 7;
+        const int co = te >> 3, part = te & 7;
         double sm = 0.0, sq = 0.0;
         if (co < cout) {
 #pragma unroll 8

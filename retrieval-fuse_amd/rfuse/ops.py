@@ -507,8 +507,13 @@ def conv3d_up_split_gn_relu(src0, src1, aff, w_split_packed, cout):
 
 def conv_up_split_issued_flops(c0, c1, n, edge, cout):
     """f16 multiply-adds (x2 = flop) rf_conv3d_up_split_k3_gn_relu ISSUES: three MFMAs per k-step of 32, k-steps = 7 per 8 skip
-    channels (28 tap slots for 27 taps) + 2 per 8 upsampled channels, on round_up(cout, 16) columns."""
+    channels (28 tap slots for 27 taps) + 2 per 8 upsampled channels, on round_up(cout, 16) columns, minus the z-border MFMAs the
+    whole-sample kernel leaves out."""
     ksteps = (c0 // 8) * 7 + (c1 // 8) * 2
+    if edge == 8 and _lib.load().rf_conv3d_up_split_stats_tiles(c0, c1, n, edge, cout) == 1:
+        # whole 8^3 samples (k_conv3_up_split): the z-border taps of the first / last output plane are not issued -- 2 of the 28 (m-block, k-step)
+        # pairs of a skip chunk, 1 of the 8 of an upsampled chunk
+        ksteps = (c0 // 8) * 7 * 26.0 / 28 + (c1 // 8) * 2 * 7.0 / 8
     return 2.0 * 3 * ksteps * 32 * (-(-cout // 16) * 16) * edge ** 3 * n
 
 

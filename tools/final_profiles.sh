@@ -10,3 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final
 cd $R
 bash tools/pmc_conv.sh C2
 ls gpurun_out/pmc_C2
+python bench.py --config C5 --batch 16 > gpurun_out/bench_r3_C5.json 2> gpurun_out/bench_r3_C5.err
+python bench.py --config C4 --batch 16 --no-cpu-baseline > gpurun_out/bench_r3_C4.json 2> gpurun_out/bench_r3_C4.err
+python bench.py --config C1 --batch 16 --no-cpu-baseline > gpurun_out/bench_r3_C1.json 2> gpurun_out/bench_r3_C1.err
+python bench.py --config C3 --db 1000000 --no-cpu-baseline > gpurun_out/bench_r3_C3_1M.json 2> gpurun_out/bench_r3_C3_1M.err
+python tools/dbbuild_bench.py > gpurun_out/dbbuild_r3.log 2>&1
