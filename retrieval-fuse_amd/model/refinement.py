@@ -88,8 +88,11 @@ class Superresolution08FinalDecoder(nn.Module):
     def forward(self, x):
         x = self.network[0](x)
         if ops.needs_grad(x, self.network[1].weight):
-            # grad mode (training slice, rfuse/autograd.py): the 16 -> 1 pointwise conv + tanh is 0.1 % of the work, torch differentiates it
-            return torch.tanh(torch.nn.functional.conv3d(x, self.network[1].weight, self.network[1].bias))
+            # grad mode (training slice, rfuse/autograd.py): the 16 -> 1 pointwise conv + tanh is 0.1 % of the work and torch differentiates it --
+            # written as a weighted channel sum, not as F.conv3d: that was the one MIOpen call of the path, and its first use runs MIOpen's solver
+            # search (naive_conv_ab_nonpacked_wrw, a batched-GEMM bwd_weight, ...: 2.4 s of kernels before the first step finishes)
+            w, b = self.network[1].weight, self.network[1].bias
+            return torch.tanh((x.unsqueeze(1) * w.view(1, w.shape[0], w.shape[1], 1, 1, 1)).sum(dim=2) + b.view(1, -1, 1, 1, 1))
         return ops.conv1x1_tanh(x, self.network[1].weight, self.network[1].bias)
 
     def forward_df(self, x, target_trunc):
