@@ -129,6 +129,12 @@ size_t rf_convv_lds_packed_floats(int cout, int cin, int k);
 int rf_conv3d_valid_split_supported(int n, int cin, int s, int cout, int k, int stride);
 int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
                                 int stride, float slope, float* out, void* stream);
+/* ... with the activations BETWEEN two such layers in split form (no GroupNorm sits between the encoders' convs, so the producer can always
+ * write what the consumer would otherwise make of every value it stages -- with its halo, three times): a tensor [n][c][s^3] in split form is
+ * [n][c/4][h | l][s^3] 8-byte slots (4 channels of a voxel as f16: h = f16(x/16), l = f16((x/16 - h) * 2^11)), the same number of bytes as fp32.
+ * in_split / out_split select the form of x / out (out_split needs cout in multiples of 4).  Same results bit for bit. */
+int rf_conv3d_valid_leaky_split_ex(const void* x, int in_split, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
+                                   int stride, float slope, void* out, int out_split, void* stream);
 int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int cin, int k, int s, int stride, void* w_packed, void* stream);
 size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, int stride);
 
@@ -139,6 +145,8 @@ size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, int stride);
 int rf_conv3d_valid_valu_supported(int n, int cin, int s, int cout, int k, int stride);
 int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
                                int stride, float slope, float* out, void* stream);
+int rf_conv3d_valid_leaky_valu_ex(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
+                                  int stride, float slope, void* out, int out_split, void* stream);
 
 /* rf_conv3d_k3_gn_relu with the encoder's MaxPool3d(2) (model/unet.py:230-253) fused into the epilogue: additionally
  * writes pool_out [n][cout][(edge/2)^3] = maxpool2(out) and, when pool_stats is non-NULL, its (sum, sum of squares)
@@ -335,6 +343,7 @@ int rf_query_windows(const float* raw, int b, int s, int ps, int ctx, float pad_
  * reference evaluates model/retrieval.py:4-28,217-243 on every window of dataset/scene.py:152-160 separately; valid convolutions commute
  * with the window cut as long as the window origins stay on the layers' sampling lattice). */
 int rf_gather_windows(const float* grid, int n, int c, int g, int w, int step, int np, float* out, void* stream);
+int rf_gather_windows_split(const void* grid, int n, int c, int g, int w, int step, int np, void* out, void* stream);      /* grid / out in the valid convs' split form */
 
 /* Database embedding image for the scans: emb [n][dim] row-major (dim = 64) -> rf_db_packed_floats(n, dim) floats holding
  * the blocked view [ceil(n/64)][dim][64] of the VALU scan, the chunk-permuted row view [n32][64] of the MFMA-filtered scans and

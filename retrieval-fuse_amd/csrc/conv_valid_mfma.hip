@@ -532,7 +532,23 @@ struct ConvVVArgs {
     float* out;
     int n, cin, cout, s, so, ty, nty, ntz;     // cout: all output channels; a workgroup computes COUT of them (blockIdx.y picks the block)
     float slope;
+    int out_pre;          // 1: the output is written in split form for rf_conv3d_valid_leaky_split_ex (conv_valid_split.hip: [4-channel group][h | l][voxel][4 halves])
 };
+
+// the column's outputs of one 4-channel group -> bias, LeakyReLU, then the consumer's own scale / clamp / split; lane = consecutive x: 512-byte runs
+typedef _Float16 rf_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void convv_store_split(unsigned char* o, size_t plane_bytes, const float (&v)[4]) {
+    rf_h4 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = __builtin_amdgcn_fmed3f(v[e] * (1.0f / 16), -65504.f, 65504.f);
+        const _Float16 h = (_Float16)t;
+        hh[e] = h;
+        ll[e] = (_Float16)fmaf(-2048.0f, (float)h, t * 2048.0f);
+    }
+    *reinterpret_cast<rf_h4*>(o) = hh;
+    *reinterpret_cast<rf_h4*>(o + plane_bytes) = ll;
+}
 
 typedef float rf_v2 __attribute__((ext_vector_type(2)));
 
@@ -634,6 +650,24 @@ __global__ __launch_bounds__(256) void k_convv_valu(ConvVVArgs a) {
     }
     if (!col_ok) return;
     const size_t ovol = (size_t)so * so * so;
+    if (a.out_pre) {
+#pragma unroll
+        for (int g = 0; g < COUT / 4; ++g) {
+            float bz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bz[e] = a.bias ? a.bias[cob + 4 * g + e] : 0.f;
+            unsigned char* o = reinterpret_cast<unsigned char*>(a.out) + (((size_t)nn * (a.cout >> 2) + (cob >> 2) + g) * 2 * ovol + ((size_t)z0 * so + y0 + ly) * so + lx) * 8;
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+                if (z0 + z < so) {
+                    float v[4] = {acc[z][2 * g][0] + bz[0], acc[z][2 * g][1] + bz[1], acc[z][2 * g + 1][0] + bz[2], acc[z][2 * g + 1][1] + bz[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+                    convv_store_split(o + (size_t)z * so * so * 8, ovol * 8, v);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < COUT / 2; ++c) {
         const float b0 = a.bias ? a.bias[cob + 2 * c] : 0.f, b1 = a.bias ? a.bias[cob + 2 * c + 1] : 0.f;
@@ -733,6 +767,24 @@ __global__ __launch_bounds__(256, 2) void k_convv_valu_xt(ConvVVArgs a) {
         }
     }
     const size_t ovol = (size_t)so * so * so;
+    if (a.out_pre) {
+#pragma unroll
+        for (int g = 0; g < COUT / 4; ++g) {
+            float bz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bz[e] = a.bias ? a.bias[cob + 4 * g + e] : 0.f;
+            unsigned char* o = reinterpret_cast<unsigned char*>(a.out) + (((size_t)nn * (a.cout >> 2) + (cob >> 2) + g) * 2 * ovol + ((size_t)z0 * so + y0 + ly) * so + x0 + lx) * 8;
+#pragma unroll
+            for (int z = 0; z < TZ; ++z)
+                if (z0 + z < so) {
+                    float v[4] = {acc[z][2 * g][0] + bz[0], acc[z][2 * g][1] + bz[1], acc[z][2 * g + 1][0] + bz[2], acc[z][2 * g + 1][1] + bz[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+                    convv_store_split(o + (size_t)z * so * so * 8, ovol * 8, v);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < COUT / 2; ++c) {
         const float b0 = a.bias ? a.bias[cob + 2 * c] : 0.f, b1 = a.bias ? a.bias[cob + 2 * c + 1] : 0.f;
@@ -765,14 +817,24 @@ extern "C" int rf_conv3d_valid_valu_supported(int n, int cin, int s, int cout, i
 }
 
 // x [n][cin][s^3], w_t [cin][k^3][cout] (the OIDHW weight permuted to (1,2,3,4,0)), out [n][cout][so^3]
+extern "C" int rf_conv3d_valid_leaky_valu_ex(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
+                                             int stride, float slope, void* out, int out_split, void* stream);
 extern "C" int rf_conv3d_valid_leaky_valu(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
                                           int stride, float slope, float* out, void* stream) {
+    return rf_conv3d_valid_leaky_valu_ex(x, n, cin, s, w_t, bias, cout, k, stride, slope, out, 0, stream);
+}
+
+// out_split: the output in split form (cout a multiple of 4: every shape this form takes) for rf_conv3d_valid_leaky_split_ex
+extern "C" int rf_conv3d_valid_leaky_valu_ex(const float* x, int n, int cin, int s, const float* w_t, const float* bias, int cout, int k,
+                                             int stride, float slope, void* out_v, int out_split, void* stream) {
+    float* out = reinterpret_cast<float*>(out_v);
     const float* w_oidhw = w_t;
     RF_REQUIRE(x && w_oidhw && out && n > 0, RF_E_INVALID, "rf_conv3d_valid_leaky_valu: bad arguments");
     RF_REQUIRE(convv_valu_takes(cin, s, cout, k, stride), RF_E_UNSUPPORTED,
                "rf_conv3d_valid_leaky_valu: shape not taken by the VALU form (ask rf_conv3d_valid_valu_supported)");
     ConvVVArgs a;
     a.x = x; a.w = w_oidhw; a.bias = bias; a.out = out; a.n = n; a.cin = cin; a.cout = cout; a.s = s; a.so = s - k + 1; a.slope = slope;
+    a.out_pre = out_split ? 1 : 0;
     if (convv_valu_xt_takes(cin, s, cout, k, stride)) {
         const size_t tiles = (size_t)((a.so + 3) / 4) * ((a.so + 3) / 4) * ((a.so + 63) / 64) * n;
         RF_REQUIRE(tiles < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_valu: too many tiles (%zu)", tiles);

@@ -41,6 +41,7 @@ struct ConvVSArgs {
     int zi, yi, xi, npos;          // staged input planes / rows per plane / voxels per row, positions per channel group (zi * yi * xi)
     int cgc, nchunk, ksteps;       // 4-channel groups per chunk, chunks, k-steps per chunk
     int nbt;                       // n-blocks of the weight image (cout16 / 16)
+    int out_pre;                   // 1: the output is written in split form (rf_valid_split_act: [4-channel group][h | l][voxel][4 halves])
     int hdr;                       // ints of the image's table header, a multiple of 4
 };
 
@@ -178,7 +179,9 @@ extern "C" int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int ci
 // On gfx9 loads and stores retire through ONE in-order counter (vmcnt): a wait for any load that was requested after a store also waits
 // for that store's acknowledgement from L2.  The epilogue therefore requests nothing -- bias values and the store tables are loaded before
 // the MFMAs, nothing may spill (a reload is a scratch load) -- and its stores stay in flight while the workgroup retires.
-template <int NB, int WPE>
+// PRE: the input is in split form already (written by the previous layer: rf_conv3d_valid_leaky_valu_to_split / ..._split_to_split) -- its 8-byte
+// slots are the LDS image's slots, staging is a copy: no scaling, no conversion (47 % of this kernel's instruction issue was that VALU work)
+template <int NB, int WPE, bool PRE>
 __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
     constexpr int NT = VS_NT, MB = VS_MB, SB = VS_SB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             const int cg = (int)(((float)r + 0.5f) * inv_g), rr = r - cg * rows_g;
             const int rz = (int)(((float)rr + 0.5f) * inv_y), ry = rr - rz * a.yi;
             const int iz = z0 * st + rz, iy = y0 * st + ry;
-            rowsrc[r] = r >= nrows ? 0 : (iz < s && iy < s) ? (int)((size_t)cg * 4 * ivol) + (iz * s + iy) * s + xin0 : -1;   // ragged last tile: rows past the volume
+            rowsrc[r] = r >= nrows ? 0 : (iz < s && iy < s) ? (int)((size_t)cg * (PRE ? 2 : 4) * ivol) + (iz * s + iy) * s + xin0 : -1;   // ragged last tile: rows past the volume
         }
     }
     int base[MB];                                                   // byte offset of the input corner of voxel (m-block, j) in a plane
@@ -255,12 +258,13 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             // SB items (4 channels each) in flight per thread, no branches around the loads.  Rows of a ragged last tile that lie outside
             // the volume (table entry < 0) read the channel's first value and are zeroed by their scale; tiles without such rows (nearly
             // all) take the path without that bookkeeping.  Pad slots behind the last item hold whatever the first row holds: never read.
-            const char* xc = reinterpret_cast<const char*>(a.x + ((size_t)nn * a.cin + (size_t)c * a.cgc * 4) * ivol);
+            const char* xc = reinterpret_cast<const char*>(a.x + ((size_t)nn * a.cin + (size_t)c * a.cgc * 4) * ivol);       // (same byte offset in either form)
             auto stage = [&](auto ragged_tag) {
                 constexpr bool RAGGED = decltype(ragged_tag)::value;
                 int row = row0, ix = x0;
                 for (int i = tid; i < items; i += SB * NT) {
-                    float v[SB][4];
+                    float v[PRE ? 1 : SB][4];
+                    uint2 ph[PRE ? SB : 1], pl[PRE ? SB : 1];
                     unsigned off[SB];
                     unsigned real = 0;
 #pragma unroll
@@ -268,33 +272,49 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
                         const int ro = rowsrc[row];
                         const int ixc = ix < xlast ? ix : xlast;       // columns past the row (last x tile): some value of the row, only unstored voxels see it
                         if constexpr (RAGGED) {
-                            off[b] = ro >= 0 ? (unsigned)(ro + ixc) * 4u : 0u;
+                            off[b] = ro >= 0 ? (unsigned)(ro + ixc) * (PRE ? 8u : 4u) : 0u;
                             real |= (ro >= 0 ? 1u : 0u) << b;
                         } else {
-                            off[b] = (unsigned)(ro + ixc) * 4u;
+                            off[b] = (unsigned)(ro + ixc) * (PRE ? 8u : 4u);
                         }
                         row += step_r; ix += step_x;
                         if (ix >= xi) { ix -= xi; ++row; }
                     }
+                    if constexpr (PRE) {
 #pragma unroll
-                    for (int b = 0; b < SB; ++b)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[b][e] = *reinterpret_cast<const float*>(xc + (size_t)e * 4 * ivol + off[b]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < SB; ++b) {
-                        const float sc = (!RAGGED || ((real >> b) & 1u)) ? VS_ACT_SCALE : 0.f;
-                        h4 hh, ll;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float t = __builtin_amdgcn_fmed3f(v[b][e] * sc, -65504.f, 65504.f);
-                            const _Float16 h = (_Float16)t;
-                            hh[e] = h;
-                            ll[e] = (_Float16)fmaf(-VS_LO, (float)h, t * VS_LO);     // (t - h) * 2^11, exact either way; one v_fma_mix_f32
+                        for (int b = 0; b < SB; ++b) {
+                            ph[b] = *reinterpret_cast<const uint2*>(xc + off[b]);
+                            pl[b] = *reinterpret_cast<const uint2*>(xc + (size_t)8 * ivol + off[b]);
                         }
-                        const int idx = i + b * NT;
-                        *reinterpret_cast<h4*>(lds + idx * 8) = hh;
-                        *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = 0; b < SB; ++b) {
+                            const bool keep = !RAGGED || ((real >> b) & 1u);
+                            const int idx = i + b * NT;
+                            *reinterpret_cast<uint2*>(lds + idx * 8) = keep ? ph[b] : make_uint2(0u, 0u);
+                            *reinterpret_cast<uint2*>(lds + plane + idx * 8) = keep ? pl[b] : make_uint2(0u, 0u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < SB; ++b)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[b][e] = *reinterpret_cast<const float*>(xc + (size_t)e * 4 * ivol + off[b]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = 0; b < SB; ++b) {
+                            const float sc = (!RAGGED || ((real >> b) & 1u)) ? VS_ACT_SCALE : 0.f;
+                            h4 hh, ll;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = __builtin_amdgcn_fmed3f(v[b][e] * sc, -65504.f, 65504.f);
+                                const _Float16 h = (_Float16)t;
+                                hh[e] = h;
+                                ll[e] = (_Float16)fmaf(-VS_LO, (float)h, t * VS_LO);     // (t - h) * 2^11, exact either way; one v_fma_mix_f32
+                            }
+                            const int idx = i + b * NT;
+                            *reinterpret_cast<h4*>(lds + idx * 8) = hh;
+                            *reinterpret_cast<h4*>(lds + plane + idx * 8) = ll;
+                        }
                     }
                 }
             };
@@ -365,6 +385,28 @@ __global__ __launch_bounds__(VS_NT, WPE) void k_convv_split(ConvVSArgs a) {
             *reinterpret_cast<f32x4*>(eb + j * VS_EV + (wave * MB + mb) * 16 + g * 4) = v;
         }
         __syncthreads();
+        if (a.out_pre) {
+            // split-form output for the next layer: this wave's four cout rows are ONE 4-channel group; lane = voxel, the group's h and l slots (8 bytes
+            // each) leave as 512-byte runs.  Same scale / clamp / split as the consumer's staging would apply.
+            const int grp = (nb0 + nb) * 4 + wave;
+            if (grp * 4 < a.cout) {                                 // wave-uniform (cout is a multiple of 4)
+                unsigned char* o = reinterpret_cast<unsigned char*>(a.out) + (((size_t)nn * (a.cout >> 2) + grp) * 2 * ovol + ((size_t)z0 * so + y0) * so + x0t) * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (eoff[i] >= 0) {
+                        h4 hh, ll;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __builtin_amdgcn_fmed3f(eb[(wave * 4 + e) * VS_EV + lane + 64 * i] * VS_ACT_SCALE, -65504.f, 65504.f);
+                            const _Float16 h = (_Float16)t;
+                            hh[e] = h;
+                            ll[e] = (_Float16)fmaf(-VS_LO, (float)h, t * VS_LO);
+                        }
+                        *reinterpret_cast<h4*>(o + (size_t)eoff[i] * 8) = hh;
+                        *reinterpret_cast<h4*>(o + (ovol + (size_t)eoff[i]) * 8) = ll;
+                    }
+            }
+        } else
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int col = wave * 4 + h, co = (nb0 + nb) * 16 + col;
@@ -387,34 +429,50 @@ extern "C" int rf_conv3d_valid_split_supported(int n, int cin, int s, int cout, 
     return n > 0 && convv_split_plan(cin, s, cout, k, stride, a, nb, lds) ? 1 : 0;
 }
 
-// x [n][cin][s^3], w_packed from rf_convv_split_pack_weight for the same (cout, cin, k, s, stride), out [n][cout][so^3]
-extern "C" int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
-                                           int stride, float slope, float* out, void* stream) {
+// x [n][cin][s^3] (in_split: in split form, rf_valid_split_act_bytes), w_packed from rf_convv_split_pack_weight for the same (cout, cin, k, s, stride),
+// out [n][cout][so^3] (out_split: in split form; cout a multiple of 4)
+extern "C" int rf_conv3d_valid_leaky_split_ex(const void* x, int in_split, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
+                                              int stride, float slope, void* out, int out_split, void* stream) {
     RF_REQUIRE(x && w_packed && out && n > 0, RF_E_INVALID, "rf_conv3d_valid_leaky_split: bad arguments");
+    RF_REQUIRE(!out_split || (cout & 3) == 0, RF_E_INVALID, "rf_conv3d_valid_leaky_split: a split-form output needs cout in multiples of 4 (got %d)", cout);
     ConvVSArgs a;
     int nbw;
     size_t lds;
     RF_REQUIRE(convv_split_plan(cin, s, cout, k, stride, a, nbw, lds), RF_E_UNSUPPORTED,
                "rf_conv3d_valid_leaky_split: layer not taken by the split form (ask rf_conv3d_valid_split_supported)");
-    a.n = n; a.x = x; a.wp = reinterpret_cast<const h8*>(w_packed); a.bias = bias; a.out = out; a.slope = slope;
+    a.n = n; a.x = reinterpret_cast<const float*>(x); a.wp = reinterpret_cast<const h8*>(w_packed); a.bias = bias; a.out = reinterpret_cast<float*>(out); a.slope = slope;
+    a.out_pre = out_split ? 1 : 0;
     const size_t grid64 = (size_t)a.ntz * a.nty * a.ntx * a.gz * n;
     RF_REQUIRE(grid64 < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_split: too many tiles (%zu)", grid64);
     const unsigned grid = (unsigned)grid64;
     hipStream_t st = (hipStream_t)stream;
-#define RF_VS_LAUNCH(NB_, WPE_)                                                                                                  \
+#define RF_VS_LAUNCH(NB_, WPE_, PRE_)                                                                                            \
     do {                                                                                                                         \
         if (lds > 65536) {                                                                                                       \
             static RfLdsOptIn opt_in;                                                                                            \
-            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split<NB_, WPE_>), (int)VS_LDS_MAX, "rf_conv3d_valid_leaky_split")) return rc; \
+            if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split<NB_, WPE_, PRE_>), (int)VS_LDS_MAX, "rf_conv3d_valid_leaky_split")) return rc; \
         }                                                                                                                        \
-        hipLaunchKernelGGL((k_convv_split<NB_, WPE_>), dim3(grid), dim3(VS_NT), lds, st, a);                                     \
+        hipLaunchKernelGGL((k_convv_split<NB_, WPE_, PRE_>), dim3(grid), dim3(VS_NT), lds, st, a);                               \
     } while (0)
-    switch (nbw) {
-        case 1: RF_VS_LAUNCH(1, 3); break;
-        case 2: RF_VS_LAUNCH(2, 3); break;
-        default: RF_VS_LAUNCH(3, 2); break;
+    if (in_split) {
+        switch (nbw) {
+            case 1: RF_VS_LAUNCH(1, 3, true); break;
+            case 2: RF_VS_LAUNCH(2, 3, true); break;
+            default: RF_VS_LAUNCH(3, 2, true); break;
+        }
+    } else {
+        switch (nbw) {
+            case 1: RF_VS_LAUNCH(1, 3, false); break;
+            case 2: RF_VS_LAUNCH(2, 3, false); break;
+            default: RF_VS_LAUNCH(3, 2, false); break;
+        }
     }
 #undef RF_VS_LAUNCH
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_split");
     return RF_OK;
+}
+
+extern "C" int rf_conv3d_valid_leaky_split(const float* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k,
+                                           int stride, float slope, float* out, void* stream) {
+    return rf_conv3d_valid_leaky_split_ex(x, 0, n, cin, s, w_packed, bias, cout, k, stride, slope, out, 0, stream);
 }

@@ -55,8 +55,9 @@ extern "C" int rf_query_windows(const float* raw, int b, int s, int ps, int ctx,
 // ---------------------------------------------------------------------------------------- windows of a feature grid
 // The patch encoders evaluated fully convolutionally (model/retrieval.py forward_grid): the first layers run once on the padded chunk, then
 // the (np)^3 windows of edge w at stride `step` are cut out of the feature grid [n][c][g^3] -> [(n np^3)][c][w^3] for the remaining layers.
-__global__ __launch_bounds__(256) void k_gather_windows(const float* __restrict__ grid, int n, int c, int g, int w, int step, int np,
-                                                        float* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_windows(const T* __restrict__ grid, int n, int c, int g, int w, int step, int np,
+                                                        T* __restrict__ out) {
     const size_t w3 = (size_t)w * w * w, g3 = (size_t)g * g * g, total = (size_t)n * np * np * np * c * w3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int w2 = (int)(i % w), w1 = (int)((i / w) % w), w0 = (int)((i / ((size_t)w * w)) % w);
@@ -74,8 +75,20 @@ extern "C" int rf_gather_windows(const float* grid, int n, int c, int g, int w, 
                "rf_gather_windows: bad arguments (the last window must end inside the grid)");
     const size_t total = (size_t)n * np * np * np * c * w * w * w;
     const size_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_gather_windows, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, grid, n, c, g, w, step, np, out);
+    hipLaunchKernelGGL(k_gather_windows<float>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, grid, n, c, g, w, step, np, out);
     RF_CHECK_LAUNCH("rf_gather_windows");
+    return RF_OK;
+}
+
+// the same cut on a tensor in the valid convs' split form ([n][c/4][h | l][g^3] 8-byte slots): 2 c/4 planes of 8-byte voxels per sample
+extern "C" int rf_gather_windows_split(const void* grid, int n, int c, int g, int w, int step, int np, void* out, void* stream) {
+    RF_REQUIRE(grid && out && n > 0 && c > 0 && (c & 3) == 0 && g > 0 && w > 0 && step > 0 && np > 0 && (np - 1) * step + w <= g, RF_E_INVALID,
+               "rf_gather_windows_split: bad arguments (channels in fours; the last window must end inside the grid)");
+    const size_t total = (size_t)n * np * np * np * (c / 2) * w * w * w;
+    const size_t want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_gather_windows<double>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const double*>(grid), n, c / 2, g, w, step, np, reinterpret_cast<double*>(out));
+    RF_CHECK_LAUNCH("rf_gather_windows_split");
     return RF_OK;
 }
 

@@ -85,19 +85,47 @@ class _ConvPatchEncoder(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.final_layer = LinearParams(self.SPEC[-1][1] * nf, z_dim)
 
-    def _conv(self, layer, x):
-        if ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride) and ops.split_range_ok(layer.weight):
-            return ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
-        if ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
-            return ops.conv3d_valid_leaky_valu(x, layer.packed_valu(), layer.bias, layer.stride, 0.2)
+    @staticmethod
+    def _split_takes(layer, shape):
+        """does `layer` run as the split-operand F16-MFMA form on an input of shape (n, cin, edge)?"""
+        return (ops.CONV_ARITH == 'split' and layer.in_channels % 4 == 0 and ops.split_range_ok(layer.weight)
+                and bool(ops._lib.load().rf_conv3d_valid_split_supported(max(shape[0], 1), shape[1], shape[2], layer.out_channels, layer.kernel_size, layer.stride)))
+
+    @staticmethod
+    def _valu_takes(layer, shape):
+        return ops.USE_CONVV_VALU and bool(ops._lib.load().rf_conv3d_valid_valu_supported(max(shape[0], 1), shape[1], shape[2], layer.out_channels, layer.kernel_size,
+                                                                                             layer.stride))
+
+    def _conv(self, layer, x, out_split=False):
+        """one conv + bias + LeakyReLU; `x` fp32 or ops.SplitActs; out_split: leave the output in split form (the caller knows the next layer reads it)"""
+        shape = (x.shape[0], x.shape[1], x.shape[2])
+        if isinstance(x, ops.SplitActs) or self._split_takes(layer, shape):
+            return ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2,
+                                                out_split=out_split)
+        if self._valu_takes(layer, shape):
+            return ops.conv3d_valid_leaky_valu(x, layer.packed_valu(), layer.bias, layer.stride, 0.2, out_split=out_split)
+        assert not out_split
         if ops.conv_valid_lds_supported(x, layer.out_channels, layer.kernel_size, layer.stride):
             return ops.conv3d_valid_leaky_lds(x, layer.packed_lds(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
         return ops.conv3d_valid_leaky_mfma(x, layer.packed(), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
 
-    def _grid_conv_ok(self, layer, x):
-        """the two forms that tile a big volume efficiently (the others assume a window-sized input)"""
-        return ((ops.conv_valid_split_supported(x, layer.out_channels, layer.kernel_size, layer.stride) and ops.split_range_ok(layer.weight))
-                or ops.conv_valid_valu_supported(x, layer.out_channels, layer.kernel_size, layer.stride))
+    def _run(self, convs, x, cut=None):
+        """The conv layers in order on x.  cut = (index, window edge, lattice step, windows per axis): behind layer `index` the windows are cut out of the
+        feature grid (forward_grid).  Activations stay in SPLIT FORM between two layers when the producer can write it (the VALU and split forms;
+        couts in fours) and the consumer is a split-operand layer: no GroupNorm sits between the encoders' convs, so what the consumer would make
+        of every value it stages (scale, clamp, split -- with its halo, three times per value) the producer makes once."""
+        for i, layer in enumerate(convs):
+            shape = (x.shape[0], x.shape[1], x.shape[2])
+            so = (shape[2] - layer.kernel_size) // layer.stride + 1
+            cut_here = cut is not None and cut[0] == i
+            next_shape = (shape[0] * cut[3] ** 3, layer.out_channels, cut[1]) if cut_here else (shape[0], layer.out_channels, so)
+            writes_split = (ops.USE_SPLIT_CHAIN and i + 1 < len(convs) and layer.out_channels % 4 == 0
+                            and (isinstance(x, ops.SplitActs) or self._split_takes(layer, shape) or self._valu_takes(layer, shape))
+                            and self._split_takes(convs[i + 1], next_shape))
+            x = self._conv(layer, x, out_split=writes_split)
+            if cut_here:
+                x = ops.gather_windows(x, cut[1], cut[2], cut[3])
+        return x
 
     def _head(self, x):
         if tuple(x.shape[2:]) != (1, 1, 1):
@@ -109,11 +137,7 @@ class _ConvPatchEncoder(nn.Module):
         if self.BATCHNORM:
             raise NotImplementedError(f'{type(self).__name__}: BatchNorm patch encoders are not built (no shipped config selects them)')
         ops._no_grad_only(x, self.final_layer.weight)
-        x = x.contiguous()
-        for layer in self.layers:
-            if isinstance(layer, Conv3dParams):
-                x = self._conv(layer, x)
-        return self._head(x)
+        return self._head(self._run([layer for layer in self.layers if isinstance(layer, Conv3dParams)], x.contiguous()))
 
     def grid_plan(self, window, step, npatch):
         """How many leading conv layers to evaluate on the whole grid of npatch^3 windows (edge `window`, stride `step`) instead of per window:
@@ -145,18 +169,19 @@ class _ConvPatchEncoder(nn.Module):
             raise ValueError(f'{type(self).__name__}.forward_grid: grid edge {g} is not window {window} + a multiple of stride {step}')
         npatch = (g - window) // step + 1
         on_grid, _, _ = self.grid_plan(window, step, npatch)
-        x = grid.contiguous()
         convs = [layer for layer in self.layers if isinstance(layer, Conv3dParams)]
+        # how many of the planned layers the kernels that tile a big volume efficiently really take (the others assume a window-sized input)
         sw, lat, done = window, step, 0
+        shape = (grid.shape[0], 1, g)
         for layer in convs[:on_grid]:
-            if not self._grid_conv_ok(layer, x):
+            if not (self._split_takes(layer, shape) or self._valu_takes(layer, shape)):
                 break
-            x = self._conv(layer, x)
             sw, lat, done = (sw - layer.kernel_size) // layer.stride + 1, lat // layer.stride, done + 1
-        x = ops.gather_windows(x, sw, lat, npatch)
-        for layer in convs[done:]:
-            x = self._conv(layer, x)
-        return self._head(x)
+            shape = (shape[0], layer.out_channels, (shape[2] - layer.kernel_size) // layer.stride + 1)
+        x = grid.contiguous()
+        if done == 0:
+            return self._head(self._run(convs, ops.gather_windows(x, window, step, npatch)))
+        return self._head(self._run(convs, x, cut=(done - 1, sw, lat, npatch)))
 
 
 class Patch32(_ConvPatchEncoder):

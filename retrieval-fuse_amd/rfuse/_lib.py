@@ -44,10 +44,12 @@ SIGNATURES = {
     'rf_conv3d_valid_leaky_lds': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
     'rf_conv3d_valid_valu_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_valid_leaky_valu': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_conv3d_valid_leaky_valu_ex': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     'rf_convv_lds_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_convv_lds_packed_floats': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_valid_split_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_valid_leaky_split': (c_i, [c_fp, c_i, c_i, c_i, c_p, c_fp, c_i, c_i, c_i, c_f, c_fp, c_p]),
+    'rf_conv3d_valid_leaky_split_ex': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_fp, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     'rf_convv_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'rf_convv_split_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_pool_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
@@ -101,6 +103,7 @@ SIGNATURES = {
     'rf_attn_blend': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_p]),
     'rf_query_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_p]),
     'rf_gather_windows': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_p]),
+    'rf_gather_windows_split': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'rf_db_pack_embeddings': (c_i, [c_fp, c_i64, c_i, c_fp, c_p]),
     'rf_db_packed_floats': (c_sz, [c_i64, c_i]),
     'rf_l2_topk': (c_i, [c_fp, c_i, c_i, c_fp, c_i64, c_i64, c_i, c_i, c_fp, c_p, c_p, c_sz, c_p]),

@@ -623,15 +623,31 @@ def conv_valid_split_supported(x, cout, k, stride):
     return CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_valid_split_supported(x.shape[0], x.shape[1], x.shape[2], cout, k, stride))
 
 
-def conv3d_valid_leaky_split(x, w_packed, bias, cout, k, stride, slope):
-    """valid strided conv + bias + LeakyReLU on the F16 matrix cores by operand splitting (w_packed from pack_convv_split_weight)."""
-    _req(x, 'x')
-    n, cin, s = x.shape[0], x.shape[1], x.shape[2]
+class SplitActs:
+    """Activations between two valid-conv layers in split form (include/rfuse.h, rf_conv3d_valid_leaky_split_ex): ``data`` has the shape and byte size
+    of the fp32 tensor [n, c, s, s, s] it stands for, but holds [n][c/4][h | l][s^3] 8-byte slots.  Only the valid-conv kernels read it."""
+
+    def __init__(self, data):
+        self.data = data
+        self.shape = data.shape
+        self.device = data.device
+
+
+USE_SPLIT_CHAIN = True          # False: every valid-conv layer writes fp32 and the next one converts what it stages
+
+
+def conv3d_valid_leaky_split(x, w_packed, bias, cout, k, stride, slope, out_split=False):
+    """valid strided conv + bias + LeakyReLU on the F16 matrix cores by operand splitting (w_packed from pack_convv_split_weight).  ``x`` may be a
+    SplitActs (the previous layer wrote split form); ``out_split``: return a SplitActs for the next layer."""
+    in_split = isinstance(x, SplitActs)
+    xt = x.data if in_split else x
+    _req(xt, 'x')
+    n, cin, s = xt.shape[0], xt.shape[1], xt.shape[2]
     so = (s - k) // stride + 1
-    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rf_conv3d_valid_leaky_split(_p(x), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
-                                                       stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_split')
-    return out
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=xt.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_split_ex(_p(xt), int(in_split), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
+                                                          stride, slope, _p(out), int(out_split), _stream()), 'rf_conv3d_valid_leaky_split')
+    return SplitActs(out) if out_split else out
 
 
 USE_CONVV_VALU = True           # False: the first layers of the patch encoders stay on the matrix cores
@@ -648,16 +664,17 @@ def pack_convv_valu_weight(w):
     return w.detach().permute(1, 2, 3, 4, 0).contiguous()
 
 
-def conv3d_valid_leaky_valu(x, w_t, bias, stride, slope):
-    """valid stride-1 conv + bias + LeakyReLU on the vector unit (w_t from pack_convv_valu_weight: [cin, k, k, k, cout])."""
+def conv3d_valid_leaky_valu(x, w_t, bias, stride, slope, out_split=False):
+    """valid stride-1 conv + bias + LeakyReLU on the vector unit (w_t from pack_convv_valu_weight: [cin, k, k, k, cout]); ``out_split``: the output
+    in split form (a SplitActs) for a split-operand layer behind it."""
     _req(x, 'x'), _req(w_t, 'w_t')
     n, cin, s = x.shape[0], x.shape[1], x.shape[2]
     cout, k = w_t.shape[4], w_t.shape[1]
     so = (s - k) // stride + 1
     out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rf_conv3d_valid_leaky_valu(_p(x), n, cin, s, _p(w_t), _p(bias.detach() if bias is not None else None), cout, k,
-                                                      stride, slope, _p(out), _stream()), 'rf_conv3d_valid_leaky_valu')
-    return out
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_valu_ex(_p(x), n, cin, s, _p(w_t), _p(bias.detach() if bias is not None else None), cout, k,
+                                                         stride, slope, _p(out), int(out_split), _stream()), 'rf_conv3d_valid_leaky_valu')
+    return SplitActs(out) if out_split else out
 
 
 def conv3d_valid_leaky(x, w, bias, stride, slope):
@@ -893,11 +910,17 @@ def query_windows(raw, ps, ctx, pad_value, mean, std):
 
 
 def gather_windows(grid, w, step, npatch):
-    """grid [n,c,g,g,g] -> the npatch^3 windows of edge w at stride step of every sample: [n*npatch^3, c, w, w, w] (rf_query_windows order)"""
-    _req(grid, 'grid')
-    n, c, g = grid.shape[0], grid.shape[1], grid.shape[2]
-    out = torch.empty((n * npatch ** 3, c, w, w, w), dtype=torch.float32, device=grid.device)
-    _lib.check(_lib.load().rf_gather_windows(_p(grid), n, c, g, w, step, npatch, _p(out), _stream()), 'rf_gather_windows')
+    """grid [n,c,g,g,g] (or a SplitActs of that shape) -> the npatch^3 windows of edge w at stride step of every sample: [n*npatch^3, c, w, w, w]
+    (rf_query_windows order), in the form of the input"""
+    split = isinstance(grid, SplitActs)
+    gt = grid.data if split else grid
+    _req(gt, 'grid')
+    n, c, g = gt.shape[0], gt.shape[1], gt.shape[2]
+    out = torch.empty((n * npatch ** 3, c, w, w, w), dtype=torch.float32, device=gt.device)
+    if split:
+        _lib.check(_lib.load().rf_gather_windows_split(_p(gt), n, c, g, w, step, npatch, _p(out), _stream()), 'rf_gather_windows_split')
+        return SplitActs(out)
+    _lib.check(_lib.load().rf_gather_windows(_p(gt), n, c, g, w, step, npatch, _p(out), _stream()), 'rf_gather_windows')
     return out
 
 

@@ -967,6 +967,49 @@ def test_patch_encoder_on_the_grid_equals_the_encoder_on_the_windows(ops, enc):
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize('enc', [('PCPatch48', 12, 48, 32), ('Patch32', 8, 32, 16), ('Patch24V2', 8, 24, 16), ('Patch16', 8, 16, 16), ('PCPatch32', 12, 32, 32)])
+def test_split_form_between_the_encoder_layers_changes_no_bit(ops, enc):
+    """activations kept in split form between valid-conv layers (the producer scales / clamps / splits once, the consumer's staging is a copy):
+    the same embeddings bit for bit as with fp32 tensors between the layers -- on the windows and on the grid"""
+    import model as rf_model
+    name, nf, window, step = enc
+    torch.manual_seed(6)
+    m = getattr(rf_model, name)(nf, 64).to(DEV).eval()
+    gen = torch.Generator().manual_seed(10)
+    g = 3 * step + window
+    grid = rnd(gen, 2, 1, g, g, g).to(DEV)
+    win = rnd(gen, 70, 1, window, window, window).to(DEV)
+    res = {}
+    with torch.no_grad():
+        for flag in (False, True):
+            ops.USE_SPLIT_CHAIN = flag
+            res[flag] = (m(win), m.forward_grid(grid, window, step))
+    ops.USE_SPLIT_CHAIN = True
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
+def test_split_form_tensor_layout(ops):
+    """the split form is what include/rfuse.h says: [n][c/4][h | l][voxel][4 halves] with h = f16(x/16), l = f16((x/16 - h) * 2^11) -- read back from the
+    VALU first layer and the split layer, against the fp32 outputs of the same calls"""
+    gen = torch.Generator().manual_seed(12)
+    x, w, b = rnd(gen, 2, 1, 20, 20, 20), rnd(gen, 8, 1, 3, 3, 3, scale=0.3), rnd(gen, 8)
+    xd, wt = x.to(DEV), ops.pack_convv_valu_weight(w.to(DEV))
+    y = ops.conv3d_valid_leaky_valu(xd, wt, b.to(DEV), 1, 0.2)
+    ys = ops.conv3d_valid_leaky_valu(xd, wt, b.to(DEV), 1, 0.2, out_split=True)
+    w2, b2 = rnd(gen, 16, 8, 3, 3, 3, scale=0.1), rnd(gen, 16)
+    wp = ops.pack_convv_split_weight(w2.to(DEV), 18, 1)
+    z = ops.conv3d_valid_leaky_split(y, wp, b2.to(DEV), 16, 3, 1, 0.2)
+    zs = ops.conv3d_valid_leaky_split(ys, wp, b2.to(DEV), 16, 3, 1, 0.2, out_split=True)
+    for fp32, sp in ((y, ys), (z, zs)):
+        n, c, e = fp32.shape[0], fp32.shape[1], fp32.shape[2]
+        halves = sp.data.view(torch.float16).reshape(n, c // 4, 2, e, e, e, 4).float().cpu()
+        v = (fp32.cpu() / 16).reshape(n, c // 4, 4, e, e, e).permute(0, 1, 3, 4, 5, 2)
+        h = v.half().float()
+        assert torch.equal(halves[:, :, 0], h)
+        assert torch.equal(halves[:, :, 1], ((v - h) * 2048).half().float())
+    assert torch.equal(ops.conv3d_valid_leaky_split(ys, wp, b2.to(DEV), 16, 3, 1, 0.2), z)
+
+
 def test_conv3d_valid_split_saturates_instead_of_overflowing(ops):
     """activations beyond the f16 range (|x|/16 > 65504) are clamped, not turned into inf / NaN"""
     gen = torch.Generator().manual_seed(77)

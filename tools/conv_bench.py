@@ -14,7 +14,8 @@ LAYERS = [('rb enc0 1->8 @16', 256 * B, 1, 0, 16, 8), ('rb enc0 8->16 @16', 256 
           ('rb dec0 192->64 @4', 256 * B, 64, 128, 4, 64), ('rb dec1 96->56 @8', 256 * B, 32, 64, 8, 56), ('rb dec1 56->16 @8', 256 * B, 56, 0, 8, 16),
           ('dec 16->16 @64', B, 0, 16, 64, 16), ('dec 16->16 @64 (2)', B, 16, 0, 64, 16), ('unet 32->16 @32', B, 0, 32, 32, 16)]
 if len(sys.argv) > 2 and sys.argv[2] == 'c5':        # the nf = 12 family (C5's U-Net: channel counts that are not multiples of 8)
-    LAYERS = [('c5 12->12 @8', 256 * B, 12, 0, 8, 12), ('c5 42->12 @8', 256 * B, 42, 0, 8, 12), ('c5 12->12 @64', B, 12, 0, 64, 12),
+    LAYERS = [('c5 unet 6->12 @128', B, 6, 0, 128, 12), ('c5 unet 12->12 @64', B, 12, 0, 64, 12), ('c5 unet 12->24 @64', B, 12, 0, 64, 24), ('c5 unet 24->24 @32', B, 24, 0, 32, 24),
+              ('c5 unet 24->48 @32', B, 24, 0, 32, 48), ('c2-like 16->32 @64', B, 16, 0, 64, 32), ('c5 12->12 @8', 256 * B, 12, 0, 8, 12), ('c5 42->12 @8', 256 * B, 42, 0, 8, 12), ('c5 12->12 @64', B, 12, 0, 64, 12),
               ('c5 12->24 @8', 256 * B, 12, 0, 8, 24), ('c5 24->24 @8', 256 * B, 24, 0, 8, 24), ('c5 6->12 @16', 256 * B, 6, 0, 16, 12)]
 print('%-22s %9s %9s %9s | %9s %9s %8s' % ('layer', 'us', 'TFLOP/s', 'GB/s', 'split us', 'TF/s eq', 'f16 pipe'))
 for name, n, c0, c1, edge, cout in LAYERS:
