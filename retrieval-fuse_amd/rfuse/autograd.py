@@ -138,9 +138,22 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _Upsample2(torch.autograd.Function):
+    """nearest x2 upsample whose backward is a 2x2x2 sum pool (avg_pool3d * 8): torch's upsample_nearest3d_backward takes 0.48 ms per call on a
+    [4,16,64^3] gradient (3.8 ms of a 33-38 ms training step)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return F.interpolate(x, scale_factor=2, mode='nearest')
+
+    @staticmethod
+    def backward(ctx, g):
+        return F.avg_pool3d(g, 2) * 8.0
+
+
 def conv_gn_relu(x, upsampled, gamma, beta, weight, groups, eps):
     """grad-mode SingleConv: two-source (decoder) layers are differentiated through a materialised nearest-x2 upsample + concat"""
     if upsampled is not None:
-        up = F.interpolate(upsampled, scale_factor=2, mode='nearest')
+        up = _Upsample2.apply(upsampled)
         x = up if x is None else torch.cat((x, up), dim=1)
     return ConvGnRelu.apply(x, gamma, beta, weight, groups, eps)
