@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 static int wgrad_groups(int n, int edge) {
     const long long boxes = (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
-    return (int)(boxes < 64 ? boxes : 64);
+    return (int)(boxes < 256 ? boxes : 256);         // workgroups per (channel chunk, cout block): 64 left most CUs with one 8-wave workgroup
 }
 
 extern "C" size_t rf_conv3d_k3_wgrad_ws_bytes(int cin, int cout, int n, int edge) {
