@@ -44,6 +44,8 @@ constexpr int US_B_OFF = 2 * US_A_BUF;
 constexpr int US_B_PLANE = US_BSLOTS * 16;
 constexpr int US_MAX_CGB = 8;                                    // low-res channel groups that fit (c1 <= 64)
 constexpr int US_LDS_BYTES = US_B_OFF + US_MAX_CGB * 2 * US_B_PLANE;      // 132,608
+constexpr int US_PRE_STATS = US_LDS_BYTES, US_PRE_TRIPLES = US_PRE_STATS + 64 * 16;     // pre-split epilogue: per-channel (sum, sum of squares), then triples
+constexpr int US_LDS_ALLOC = US_PRE_TRIPLES + 64 * 16;                                     // 134,656
 constexpr int US_E_STRIDE = 516;                                 // epilogue tile row (floats) of the 4^3 / box kernels
 constexpr int US_T_STRIDE = 517;                                 // ... of the whole-sample kernel: odd (bank-conflict-free scalar writes)
 constexpr float US_ACT_SCALE = 1.0f / 16, US_W_SCALE = 16.0f, US_LO = 2048.0f;
@@ -122,6 +124,14 @@ struct UpSplitArgs {
     float* out;
     double2* stats;         // optional [n][cout][1]
     int c0, c1, n, cout;
+    // pre-split output (whole-sample kernel only): the NEXT layer's GroupNorm (its gamma / beta / groups / eps over THIS layer's cout
+    // channels) is applied to the ReLU'd output in the epilogue -- the workgroup holds the whole sample, so it has the statistics -- and the result is
+    // written as that layer's pre-split input [n][cout/8][h | l][voxel][8 halves]; `out` is then not written
+    h8* pre_out;
+    const float* ngamma;
+    const float* nbeta;
+    int ngroups;
+    float neps;
 };
 
 // 8 normalised channel values of one voxel -> the two f16 pieces (scaled by 2^-4; saturating, never inf)
@@ -374,6 +384,53 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
     }
     __syncthreads();
     const int cout = a.cout;
+    if (a.pre_out) {
+        // ---- pre-split output: statistics of the whole sample -> the next layer's triples -> normalise, split, 16-byte slots
+        double2* chst = reinterpret_cast<double2*>(lds + US_PRE_STATS);
+        float4* trip = reinterpret_cast<float4*>(lds + US_PRE_TRIPLES);
+        {
+            const int co = te >> 3, part = te & 7;
+            double sm = 0.0, sq = 0.0;
+            if (co < cout) {
+#pragma unroll 8
+                for (int i = 0; i < 64; ++i) {
+                    const float v = e[co * US_T_STRIDE + part + 8 * i];
+                    sm += (double)v; sq += (double)v * v;
+                }
+            }
+#pragma unroll
+            for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
+            if (part == 0 && co < cout) {
+                chst[co] = make_double2(sm, sq);
+                if (a.stats) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);
+            }
+        }
+        __syncthreads();
+        if (te < cout) {                                             // as rf_gn_from_stats: group sums in channel order, float64
+            const int cpg = cout / a.ngroups, ca = (te / cpg) * cpg;
+            double sm = 0.0, sq = 0.0;
+            for (int c = ca; c < ca + cpg; ++c) { sm += chst[c].x; sq += chst[c].y; }
+            const double count = (double)cpg * 512.0, mean = sm / count;
+            double var = sq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            trip[te] = gn_affine(mean, 1.0 / sqrt(var + (double)a.neps), a.ngamma[te], a.nbeta[te]);
+        }
+        __syncthreads();
+        h8* __restrict__ po = a.pre_out + (size_t)n * (cout >> 3) * 2 * 512 + te;
+        for (int sg = 0; sg < (cout >> 3); ++sg) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 t4 = trip[sg * 8 + j];
+                y[j] = fmaf(e[(sg * 8 + j) * US_T_STRIDE + te] - t4.x, t4.y, t4.z);
+            }
+            h8 h, l;
+            us_split8(y, h, l);
+            po[(size_t)sg * 2 * 512] = h;
+            po[(size_t)sg * 2 * 512 + 512] = l;
+        }
+        return;
+    }
     float* __restrict__ o = a.out + (size_t)n * cout * 512;
     // rows of 517 floats: the scalar tile writes above (16 couts x 2 y per half wave) and these row reads hit 32 different banks; a row
     // stride that is a multiple of 4 (needed for 16-byte reads) leaves every write 4-way conflicted.  A wave stores 256 contiguous bytes.
@@ -750,8 +807,8 @@ template <int NB>
 static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
     auto kern = k_conv3_up_split<NB>;
     static RfLdsOptIn opt_in;
-    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), US_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu")) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.n), dim3(512), US_LDS_BYTES, stream, a);
+    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(kern), US_LDS_ALLOC, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.n), dim3(512), US_LDS_ALLOC, stream, a);
     RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
     return RF_OK;
 }
@@ -765,6 +822,7 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = out; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f;
     if (up_split_box_takes(c0, c1, n, edge, cout)) {
         const unsigned boxes = (unsigned)n * (edge / 8) * (edge / 8) * (edge / 8);
         const int nbq = rf_round_up(cout, 16) / 16;
@@ -789,5 +847,27 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
         RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
         return RF_OK;
     }
+    return rf_round_up(cout, 16) == 48 ? launch_up_split<3>(a, (hipStream_t)stream) : launch_up_split<4>(a, (hipStream_t)stream);
+}
+
+// The whole-sample decoder form with its output handed to the NEXT SingleConv pre-split: relu(conv(GN(x))) of 8^3 samples, then the
+// next layer's GroupNorm (next_gamma / next_beta [cout], next_groups, eps) applied from the sample's own statistics, scaled and split into f16 pairs:
+// out_presplit = rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_k3_relu.  stats (optional) as rf_conv3d_up_split_k3_gn_relu.
+extern "C" int rf_conv3d_up_split_presplit_supported(int c0, int c1, int n, int edge, int cout, int next_groups) {
+    return edge == 8 && rf_conv3d_up_split_supported(c0, c1, n, edge, cout) && !up_split_box_takes(c0, c1, n, edge, cout) && cout % 8 == 0 && next_groups > 0 &&
+           cout % next_groups == 0 && cout <= 64;
+}
+
+extern "C" int rf_conv3d_up_split_presplit(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine, const void* w_packed,
+                                           int cout, const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit,
+                                           double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_up_split_presplit_supported(c0, c1, n, edge, cout, next_groups), RF_E_UNSUPPORTED,
+               "rf_conv3d_up_split_presplit: takes whole 8^3 samples (the shapes rf_conv3d_up_split_supported takes at edge 8) with cout in eights and in whole groups (got c0=%d c1=%d n=%d edge=%d cout=%d groups=%d)",
+               c0, c1, n, edge, cout, next_groups);
+    RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out_presplit && next_gamma && next_beta, RF_E_INVALID, "rf_conv3d_up_split_presplit: null pointer");
+    UpSplitArgs a;
+    a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
+    a.out = nullptr; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    a.pre_out = reinterpret_cast<h8*>(out_presplit); a.ngamma = next_gamma; a.nbeta = next_beta; a.ngroups = next_groups; a.neps = eps;
     return rf_round_up(cout, 16) == 48 ? launch_up_split<3>(a, (hipStream_t)stream) : launch_up_split<4>(a, (hipStream_t)stream);
 }

@@ -155,6 +155,30 @@ class SingleConv(nn.Module):
         return out if pool is None else (out, ops.maxpool2(out))
 
 
+def _decoder_pair_presplit_ok(c1, c2, x, upsampled):
+    """A decoder's conv pair on whole 8^3 samples: the first conv (decoder form, split operands) sees the whole sample, so it can apply the SECOND
+    conv's GroupNorm to its own output and hand it over pre-split: no fp32 intermediate, no rf_gn_from_stats, the second conv stages copies."""
+    g1, g2 = c1.groupnorm, c2.groupnorm
+    if ops.needs_grad(x, upsampled, c1.conv.weight, c2.conv.weight, g1.weight, g2.weight):
+        return False
+    cmid, n, edge = c1.conv.out_channels, upsampled.shape[0], 2 * upsampled.shape[2]
+    if not ops.conv_up_split_presplit_supported(x, upsampled, cmid, g2.num_groups):
+        return False
+    if not bool(ops._lib.load().rf_conv3d_split_pre_supported(cmid, n, edge, c2.conv.out_channels)):
+        return False
+    cin = (x.shape[1] if x is not None else 0) + upsampled.shape[1]
+    return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, (cin // g1.num_groups) * edge ** 3)
+            and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (cmid // g2.num_groups) * edge ** 3))
+
+
+def _decoder_pair_presplit(c1, c2, x, upsampled):
+    g1, g2 = c1.groupnorm, c2.groupnorm
+    aff = ops.gn_affine(x, upsampled, g1.weight, g1.bias, g1.num_groups, g1.eps)
+    c0 = x.shape[1] if x is not None else 0
+    pre = ops.conv3d_up_split_presplit(x, upsampled, aff, c1.conv.packed_up_split(c0), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
+    return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, upsampled.shape[0], 2 * upsampled.shape[2], c2.conv.packed_split(), c2.conv.out_channels)
+
+
 class DoubleConv(nn.Module):
     """Two SingleConvs; channel plan of reference model/unet.py:125-144."""
 
@@ -177,6 +201,8 @@ class DoubleConv(nn.Module):
             g1, g2 = c1.groupnorm, c2.groupnorm
             pre = ops.conv3d_cin1_presplit(x, g1.weight, g1.bias, g1.eps, c1.conv.packed(), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
             return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
+        if upsampled is not None and pool is None and _decoder_pair_presplit_ok(c1, c2, x, upsampled):
+            return _decoder_pair_presplit(c1, c2, x, upsampled)
         return c2(c1(x, upsampled), pool=pool)
 
     def _presplit_ok(self, x):
@@ -201,6 +227,8 @@ class StepDownDoubleConv(nn.Module):
         self.SingleConv2 = SingleConv(mid, out_channels, kernel_size, order, num_groups)
 
     def forward(self, x, upsampled=None):
+        if upsampled is not None and _decoder_pair_presplit_ok(self.SingleConv1, self.SingleConv2, x, upsampled):
+            return _decoder_pair_presplit(self.SingleConv1, self.SingleConv2, x, upsampled)
         return self.SingleConv2(self.SingleConv1(x, upsampled))
 
 

@@ -429,6 +429,27 @@ def conv3d_cin1_presplit(x, in_gamma, in_beta, in_eps, w_packed, cout, next_gamm
     return out
 
 
+def conv_up_split_presplit_supported(x, upsampled, cout, next_groups):
+    """the decoder-form split conv on whole 8^3 samples can hand its output to the next SingleConv pre-split (rf_conv3d_up_split_presplit)"""
+    if not USE_PRESPLIT or CONV_ARITH != 'split' or upsampled is None:
+        return False
+    c0 = x.shape[1] if x is not None else 0
+    return bool(_lib.load().rf_conv3d_up_split_presplit_supported(c0, upsampled.shape[1], upsampled.shape[0], 2 * upsampled.shape[2], cout, next_groups))
+
+
+def conv3d_up_split_presplit(x, upsampled, gn_affine_t, w_packed, cout, next_gamma, next_beta, next_groups, eps):
+    """relu(conv(GN([x, up(upsampled)]))) of whole 8^3 samples, emitted as the pre-split input of the NEXT layer (its GroupNorm applied from the
+    sample's own statistics): uint8 buffer for conv3d_split_pre_relu"""
+    _req(upsampled, 'upsampled')
+    n, edge = upsampled.shape[0], 2 * upsampled.shape[2]
+    c0 = x.shape[1] if x is not None else 0
+    lib = _lib.load()
+    out = torch.empty(lib.rf_split_act_bytes(n, cout, edge), dtype=torch.uint8, device=upsampled.device)
+    _lib.check(lib.rf_conv3d_up_split_presplit(_p(x), c0, _p(upsampled), upsampled.shape[1], n, edge, _p(gn_affine_t), _p(w_packed), cout, _p(next_gamma.detach()),
+                                               _p(next_beta.detach()), next_groups, eps, _p(out), _p(None), _stream()), 'rf_conv3d_up_split_presplit')
+    return out
+
+
 def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None):
     """conv3d_split_gn_relu on a pre-split input (already normalised for this layer and split by its producer)."""
     dev = pre.device

@@ -1166,6 +1166,39 @@ def test_presplit_route_of_a_level0_double_conv(ops, n, pool):
             assert torch.allclose(sf, sp, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('shape', [(32, 64, 56, 16, 1030), (32, 48, 48, 16, 1025)])
+def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
+    """StepDownDoubleConv of the retrieval backbone's last decoder (96 -> 56 -> 16 @8^3, reference model/unet.py:149-159): the first conv hands the second
+    its input pre-split (rf_conv3d_up_split_presplit -> rf_conv3d_split_pre_k3_relu, the multi-chunk consumer) -- against float64 torch and against the
+    plain route (fp32 intermediate + rf_gn_from_stats)"""
+    from model.unet import StepDownDoubleConv
+    c0, c1, cmid, cout, n = shape
+    torch.manual_seed(sum(shape))
+    blk = StepDownDoubleConv(c0 + c1, cout, encoder=False, num_groups=8).to(DEV).eval()
+    assert blk.SingleConv1.conv.out_channels == cmid
+    with torch.no_grad():
+        for g in (blk.SingleConv1.groupnorm, blk.SingleConv2.groupnorm):
+            g.weight.add_(0.2 * torch.randn_like(g.weight)); g.bias.add_(0.2 * torch.randn_like(g.bias))
+    gen = torch.Generator().manual_seed(3)
+    skip, low = rnd(gen, n, c0, 8, 8, 8).relu_(), rnd(gen, n, c1, 4, 4, 4).relu_()
+    with torch.no_grad():
+        from model import unet as unet_mod
+        assert unet_mod._decoder_pair_presplit_ok(blk.SingleConv1, blk.SingleConv2, skip.to(DEV), low.to(DEV))
+        got = blk(skip.to(DEV), low.to(DEV))
+        ops.USE_PRESPLIT = False
+        plain = blk(skip.to(DEV), low.to(DEV))
+        ops.USE_PRESPLIT = True
+        x64 = torch.cat((skip, F.interpolate(low, scale_factor=2, mode='nearest')), 1).double()
+        for sc in (blk.SingleConv1, blk.SingleConv2):
+            gn = sc.groupnorm
+            x64 = F.relu(F.conv3d(F.group_norm(x64, gn.num_groups, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), sc.conv.weight.double().cpu(), padding=1))
+    scale = float(x64.abs().max())
+    e_pre, e_plain = (got.cpu().double() - x64).abs().max().item(), (plain.cpu().double() - x64).abs().max().item()
+    print(f'decoder pair {shape}: |presplit - f64| {e_pre:.3e}, |plain - f64| {e_plain:.3e}, |presplit - plain| {(got - plain).abs().max().item():.3e} of {scale:.2f}')
+    assert e_pre <= 1e-5 * max(1.0, scale) and e_pre <= 1.5 * e_plain + 1e-7
+    assert (got - plain).abs().max().item() <= 2e-6 * max(1.0, scale)
+
+
 def test_in_kernel_gumbel_sampler(ops):
     """rf_attn_weights_sampled draws the Gumbel noise of gumbel_softmax(hard=True) (reference model/attention.py:100-103) inside the kernel:
     (a) the noise it reports, fed to the explicit-noise entry point, reproduces its weights bit for bit; (b) the noise is Gumbel(0, 1) --
