@@ -191,7 +191,7 @@ def kernel_work(name, a, cfg):
         c0, c1, n, edge, cout = a[:5]
         from rfuse import ops
         return 'mfma', ops.conv_up_issued_flops(c0, c1, n, edge, cout), 'flop ISSUED (decoder form, 8 pre-summed taps for the upsampled channels, minus the skipped padding taps)'
-    if name == 'rf_conv3d_up_split_k3_gn_relu':
+    if name in ('rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit'):
         c0, c1, n, edge, cout = a[:5]
         from rfuse import ops
         return 'mfma-f16', ops.conv_up_split_issued_flops(c0, c1, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; decoder form; 28 tap slots per 27 taps, couts padded to 16); '
@@ -493,7 +493,8 @@ def main():
             entry, arith, (c0_, c1_, n_, edge_, cout_) = dom_label
             peak = F16_MFMA_PEAK_TFLOPS if arith == 'f16 split' else FP32_MFMA_PEAK_TFLOPS
             useful = 2.0 * (27 * c0_ + (8 if 'up' in entry else 27) * c1_) * cout_ * edge_ ** 3 * n_       # multiply-adds of the layer in the form the kernel evaluates
-            if pmc is not None and pmc.get('entry') == entry and pmc.get('shape') == [c0_, c1_, edge_, cout_]:
+            same_kernel = pmc is not None and (pmc.get('entry') == entry or {pmc.get('entry'), entry} <= {'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit'})
+            if same_kernel and pmc.get('shape') == [c0_, c1_, edge_, cout_]:      # (both entry points launch k_conv3_up_split<NB>)
                 traffic = pmc['traffic_bytes_per_sample'] * n_
             src_bytes = 4.0 * n_ * (c0_ * edge_ ** 3 + (c1_ * (edge_ // 2) ** 3 if 'up' in entry else c1_ * edge_ ** 3) + cout_ * edge_ ** 3)
             direct = 2.0 * 27 * (c0_ + c1_) * cout_ * edge_ ** 3 * n_                                      # the layer as the reference evaluates it

@@ -445,8 +445,16 @@ def conv3d_up_split_presplit(x, upsampled, gn_affine_t, w_packed, cout, next_gam
     c0 = x.shape[1] if x is not None else 0
     lib = _lib.load()
     out = torch.empty(lib.rf_split_act_bytes(n, cout, edge), dtype=torch.uint8, device=upsampled.device)
-    _lib.check(lib.rf_conv3d_up_split_presplit(_p(x), c0, _p(upsampled), upsampled.shape[1], n, edge, _p(gn_affine_t), _p(w_packed), cout, _p(next_gamma.detach()),
+    c1 = upsampled.shape[1]
+    timed = conv_event_filter is not None and conv_event_filter(c0 + c1, cout, edge, n)
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(lib.rf_conv3d_up_split_presplit(_p(x), c0, _p(upsampled), c1, n, edge, _p(gn_affine_t), _p(w_packed), cout, _p(next_gamma.detach()),
                                                _p(next_beta.detach()), next_groups, eps, _p(out), _p(None), _stream()), 'rf_conv3d_up_split_presplit')
+    if timed:
+        ev1.record()
+        conv_events.append((ev0, ev1, conv_up_split_issued_flops(c0, c1, n, edge, cout), ('rf_conv3d_up_split_presplit', 'f16 split', (c0, c1, n, edge, cout))))
     return out
 
 
