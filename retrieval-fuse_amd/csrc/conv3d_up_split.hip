@@ -785,19 +785,230 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_box(UpSplitArgs a, in
     }
 }
 
+// ------------------------------------------------------------------------------ 8^3 boxes of a large volume WITH a skip source
+// The decoder form for the U-Nets' decoder stages on 16^3 ... 128^3 volumes (C5's 48 + 96 -> 78 @32^3, reference model/refinement.py:37-45 +
+// model/unet.py:297-308): phase A as k_conv3_up_split (27 taps on the full-res halo box, 7 k-steps per 8-channel chunk) with the halo read from the
+// neighbouring boxes (zero outside the volume: the padding of the NORMALISED tensor), phase B as k_conv3_up_split_box.  One workgroup per (box, group
+// of NB n-blocks): wave = output parity, 4 m-blocks x NB n-blocks.  LDS: one phase-A chunk image (38.6 KB) + all low-res groups (6.9 KB each), the
+// epilogue tile aliases both.  A chunk is staged by all threads (two halo voxels each), then its seven k-steps run: no double buffer -- the
+// layers this kernel serves have a few thousand boxes, not the retrieval backbone's 8192 x 32.
+namespace {
+constexpr int UK_A_OFF = 0, UK_B_OFF = US_A_BUF;                   // chunk image, then the low-res groups
+}
+template <int NB>
+__global__ __launch_bounds__(512, 2) void k_conv3_up_split_boxskip(UpSplitArgs a, int edge) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3, half = edge >> 1, tpe = edge >> 3;
+    const int nbt = (a.cout + 15) >> 4;                            // n-blocks of the weight image
+    const int nb0 = blockIdx.y * NB;                                // this workgroup's first n-block
+    const unsigned g_ = gridDim.x, per = g_ >> 3, rem = g_ & 7u, kx = blockIdx.x & 7u;
+    int t = (int)(kx * per + (kx < rem ? kx : rem) + (blockIdx.x >> 3));
+    const int tile = t % (tpe * tpe * tpe);
+    const int x0 = (t % tpe) * 8; t /= tpe;
+    const int y0 = (t % tpe) * 8; t /= tpe;
+    const int z0 = (t % tpe) * 8; t /= tpe;
+    const int n = t;
+    const float4* __restrict__ aff = a.affine + (size_t)n * cin;
+    const size_t vol = (size_t)edge * edge * edge, hvol = (size_t)half * half * half;
+
+    // ---- zero the chunk image's stride padding once (slots the staging never writes are never read either, but keep them defined)
+    for (int i = tid; i < US_A_BUF / 16; i += 512) reinterpret_cast<uint4*>(lds + UK_A_OFF)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- low-res groups: thread = (channel group, halo voxel); 216 voxels per group
+    for (int u = tid; u < nB * US_BSLOTS; u += 512) {
+        const int cg = u / US_BSLOTS, v = u % US_BSLOTS;
+        const int hz = v / US_BZ, hy = (v / US_BY) % 6, hx = v % 6;
+        const int z = (z0 >> 1) + hz - 1, y = (y0 >> 1) + hy - 1, x = (x0 >> 1) + hx - 1;
+        const bool in = (unsigned)z < (unsigned)half && (unsigned)y < (unsigned)half && (unsigned)x < (unsigned)half;
+        float yv[8];
+        const float* __restrict__ sp = a.src1 + ((size_t)n * c1 + cg * 8) * hvol + (in ? ((size_t)z * half + y) * half + x : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 af = aff[c0 + cg * 8 + j];
+            yv[j] = in ? fmaf(sp[(size_t)j * hvol] - af.x, af.y, af.z) : 0.f;
+        }
+        h8 h, l;
+        us_split8(yv, h, l);
+        unsigned char* p = lds + UK_B_OFF + cg * 2 * US_B_PLANE + v * 16;
+        *reinterpret_cast<h8*>(p) = h;
+        *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
+    }
+
+    // ---- phase-A staging: thread owns halo voxels tid and tid + 512 (the second only below 1000) of the 10^3 box
+    int voff[2], vsl[2];
+    bool vin[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int v = tid + r * 512;
+        const int hx = v % 10, hy = (v / 10) % 10, hz = v / 100;
+        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+        vin[r] = v < 1000 && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge;
+        voff[r] = vin[r] ? (z * edge + y) * edge + x : 0;
+        vsl[r] = v < 1000 ? hz * US_SZ + hy * US_SY + hx : -1;
+    }
+    const float* __restrict__ sb0 = a.src0 + (size_t)n * c0 * vol;
+
+    const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
+    const int abase = ((pz + 1) * US_SZ + (2 * rj + py + 1) * US_SY + (2 * ri + px + 1)) * 16;
+    int atap[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int tp = 4 * s + g < 27 ? 4 * s + g : 26;
+        atap[s] = ((tp / 9 - 1) * US_SZ + ((tp / 3) % 3 - 1) * US_SY + (tp % 3 - 1)) * 16;
+    }
+    const int bbase = (pz * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;
+
+    f32x4 hi[4][NB], lo[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // weight image: [k-step][n-block of nbt][h | l][64 lanes]; n-blocks past the image's last one re-read it (their couts are masked at the store)
+    const int wstep = nbt * 128;
+    int nbo[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) nbo[nb] = (nb0 + nb < nbt ? nb0 + nb : nbt - 1) * 128;
+    const h8* __restrict__ wA = a.wp + lane;
+    const h8* __restrict__ wB = a.wp + (size_t)nA * 7 * wstep + (size_t)wave * nB * 2 * wstep + lane;
+    h8 bh[NB], bl[NB], nh[NB], nl[NB];
+    auto load_w = [&](const h8* w, h8 (&h)[NB], h8 (&l)[NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { h[nb] = w[nbo[nb]]; l[nb] = w[nbo[nb] + 64]; }
+    };
+    load_w(nA > 0 ? wA : wB, bh, bl);
+
+    // ---- phase A
+    for (int ca = 0; ca < nA; ++ca) {
+        float x[2][8];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[r][j] = sb0[(size_t)(ca * 8 + j) * vol + voff[r]];
+        __syncthreads();                                           // the previous chunk's k-steps are done with the image
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 af = aff[ca * 8 + j];
+                y[j] = vin[r] ? fmaf(x[r][j] - af.x, af.y, af.z) : 0.f;
+            }
+            h8 h, l;
+            us_split8(y, h, l);
+            if (vsl[r] >= 0) {
+                unsigned char* p = lds + UK_A_OFF + vsl[r] * 16;
+                *reinterpret_cast<h8*>(p) = h;
+                *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
+            }
+        }
+        __syncthreads();
+        const unsigned char* buf = lds + UK_A_OFF + abase;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const bool last = ca + 1 == nA && s == 6;
+            const h8* wn = last ? wB : wA + (size_t)(ca * 7 + s + 1) * wstep;      // next k-step (the last phase-A step fetches the first phase-B step)
+            load_w(wn, nh, nl);
+            const unsigned char* ap = buf + atap[s];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const h8 ah = *reinterpret_cast<const h8*>(ap + m * 2 * US_SZ * 16);
+                const h8 al = *reinterpret_cast<const h8*>(ap + m * 2 * US_SZ * 16 + US_A_PLANE);
+                us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
+        }
+    }
+    if (nA == 0) __syncthreads();
+
+    // ---- phase B
+    for (int cb = 0; cb < nB; ++cb) {
+#pragma unroll
+        for (int tz = 0; tz < 2; ++tz) {
+            const int sidx = cb * 2 + tz + 1;
+            const h8* wn = wB + (size_t)(sidx < nB * 2 ? sidx : nB * 2 - 1) * wstep;   // (the last step re-reads itself)
+            load_w(wn, nh, nl);
+            const unsigned char* ap = lds + UK_B_OFF + cb * 2 * US_B_PLANE + bbase + tz * US_BZ * 16;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const h8 ah = *reinterpret_cast<const h8*>(ap + m * US_BZ * 16);
+                const h8 al = *reinterpret_cast<const h8*>(ap + m * US_BZ * 16 + US_B_PLANE);
+                us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: relu(hi + lo / 2^11) -> LDS tile [couts of this group][z][y][x] of the box -> float4 half rows, statistics of the box per cout
+    float* e = reinterpret_cast<float*>(lds);
+    {
+        const int col = lane & 15, yj = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lin = (2 * m + pz) * 64 + (2 * yj + py) * 8 + 2 * r + px;
+                    e[(nb * 16 + col) * UB_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
+                }
+    }
+    __syncthreads();
+    const int cob = nb0 * 16;
+    int rows = a.cout - cob;
+    if (rows > NB * 16) rows = NB * 16;
+    float* __restrict__ o = a.out + ((size_t)n * a.cout + cob) * vol + ((size_t)z0 * edge + y0) * edge + x0;
+    for (int q = tid; q < rows * 128; q += 512) {
+        const int co = q >> 7, l4 = q & 127;
+        const int z = l4 >> 4, y = (l4 >> 1) & 7, xh = l4 & 1;
+        *reinterpret_cast<float4*>(o + (size_t)co * vol + ((size_t)z * edge + y) * edge + xh * 4) = *reinterpret_cast<const float4*>(e + co * UB_E_STRIDE + l4 * 4);
+    }
+    if (a.stats) {
+        const int tiles = tpe * tpe * tpe;
+        const int co = tid >> 3, part = tid & 7;
+        double sm = 0.0, sq = 0.0;
+        if (co < rows) {
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(e + co * UB_E_STRIDE + (part * 16 + i) * 4);
+                sm += (double)v.x; sq += (double)v.x * v.x;
+                sm += (double)v.y; sq += (double)v.y * v.y;
+                sm += (double)v.z; sq += (double)v.z * v.z;
+                sm += (double)v.w; sq += (double)v.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
+        if (part == 0 && co < rows) a.stats[((size_t)n * a.cout + cob + co) * tiles + tile] = make_double2(sm, sq);
+    }
+}
+
+// 8^3 boxes with a skip source: channel counts in eights, up to 12 low-res groups (LDS), enough boxes
+static bool up_split_boxskip_takes(int c0, int c1, int n, int edge, int cout) {
+    if (c0 < 8 || c0 % 8 || c1 <= 0 || c1 % 8 || c1 > 96 || cout <= 0 || cout > 96 || !rf_is_pow2(edge) || edge < 16 || edge > 128) return false;
+    return (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 512;
+}
+
 static bool up_split_box_takes(int c0, int c1, int n, int edge, int cout) {
     if (c0 != 0 || c1 <= 0 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0 || cout > 32 || !rf_is_pow2(edge) || edge < 16 || edge > 128) return false;
     return (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 1024;        // enough boxes to fill the chip
 }
 
 extern "C" int rf_conv3d_up_split_stats_tiles(int c0, int c1, int n, int edge, int cout) {
-    return up_split_box_takes(c0, c1, n, edge, cout) ? (edge / 8) * (edge / 8) * (edge / 8) : 1;
+    return (up_split_box_takes(c0, c1, n, edge, cout) || up_split_boxskip_takes(c0, c1, n, edge, cout)) ? (edge / 8) * (edge / 8) * (edge / 8) : 1;
 }
 
 extern "C" int rf_conv3d_up_split_supported(int c0, int c1, int n, int edge, int cout) {
     // whole 4^3 samples (k_conv3_up_split_s4): 8 per workgroup, 32 couts per workgroup
     if (edge == 4) return n >= 1024 && c0 >= 0 && c1 > 0 && c0 % 8 == 0 && c1 % 8 == 0 && cout > 0;
     if (up_split_box_takes(c0, c1, n, edge, cout)) return 1;      // box tiles of a large volume, upsampled channels only (k_conv3_up_split_box)
+    if (up_split_boxskip_takes(c0, c1, n, edge, cout)) return 1;  // ... with a skip source (k_conv3_up_split_boxskip)
     if (edge != 8 || n < 256 || c0 < 0 || c1 <= 0 || c0 % 8 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0) return 0;
     const int nb = rf_round_up(cout, 16) / 16;
     return nb == 3 || nb == 4;
@@ -816,7 +1027,7 @@ static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
 extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                               const void* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts), 4^3 samples (n >= 1024) or 8^3 boxes of edge >= 16 volumes without a skip source (c1 <= 64, <= 32 couts); c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts), 4^3 samples (n >= 1024) or 8^3 boxes of edge >= 16 volumes (without a skip source: c1 <= 64, <= 32 couts, >= 1024 boxes; with one: c1 <= 96, <= 96 couts, >= 512 boxes); c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
                c0, c1, n, edge, cout);
     RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu: null pointer");
     UpSplitArgs a;
@@ -834,6 +1045,25 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
             if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_conv3_up_split_box<2>), (int)lds_bytes, "rf_conv3d_up_split_k3_gn_relu")) return rc;
             hipLaunchKernelGGL(k_conv3_up_split_box<2>, dim3(boxes), dim3(512), lds_bytes, (hipStream_t)stream, a, edge);
         }
+        RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
+        return RF_OK;
+    }
+    if (up_split_boxskip_takes(c0, c1, n, edge, cout)) {
+        const unsigned boxes = (unsigned)n * (edge / 8) * (edge / 8) * (edge / 8);
+        const int nbt = rf_round_up(cout, 16) / 16;
+        const size_t img = (size_t)US_A_BUF + (size_t)(c1 / 8) * 2 * US_B_PLANE;
+        static RfLdsOptIn opt3, opt2, opt1;
+#define RF_BOXSKIP(NB_, OPT_)                                                                                                        \
+        do {                                                                                                                         \
+            const size_t tile = (size_t)(NB_ * 16) * UB_E_STRIDE * 4;                                                                \
+            const size_t lds_bytes = tile > img ? tile : img;                                                                        \
+            if (int rc = OPT_.ensure(reinterpret_cast<const void*>(k_conv3_up_split_boxskip<NB_>), 160 * 1024, "rf_conv3d_up_split_k3_gn_relu")) return rc; \
+            hipLaunchKernelGGL(k_conv3_up_split_boxskip<NB_>, dim3(boxes, (unsigned)((nbt + NB_ - 1) / NB_)), dim3(512), lds_bytes, (hipStream_t)stream, a, edge); \
+        } while (0)
+        if (nbt == 1) RF_BOXSKIP(1, opt1);
+        else if (nbt == 2 || nbt == 4) RF_BOXSKIP(2, opt2);
+        else RF_BOXSKIP(3, opt3);
+#undef RF_BOXSKIP
         RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
         return RF_OK;
     }

@@ -275,6 +275,10 @@ SPLIT_UP_CASES = [
     (33, 0, 32, 32, 16, 8),     # the U-Net backbone's 32 -> 16 @32^3: four channel groups, ragged sample count
     (130, 0, 8, 16, 32, 4),     # one channel group, two n-blocks
     (3, 0, 24, 64, 20, 4),      # three channel groups, padded couts
+    (16, 48, 96, 32, 78, 6),    # boxes WITH a skip source (k_conv3_up_split_boxskip): C5's U-Net decoder 48 + 96 -> 78 @32^3: six + twelve chunks, 5 n-blocks as 3 + 2 (one re-read)
+    (70, 8, 8, 16, 20, 4),      # one chunk each, two n-blocks in one group, ragged sample count
+    (2, 24, 48, 64, 24, 6),     # 512 boxes per sample, halos from 26 neighbours
+    (9, 16, 40, 32, 16, 8),     # one n-block
 ]
 
 

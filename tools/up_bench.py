@@ -10,7 +10,7 @@ from rfuse import ops
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 CASES = [('dec1 32+64->56 @8', 256 * B, 32, 64, 8, 56), ('B only 0+64->56 @8', 256 * B, 0, 64, 8, 56), ('A only+1 32+8->56 @8', 256 * B, 32, 8, 8, 56),
-         ('C5 dec1 24+48->42 @8', 256 * B, 24, 48, 8, 42), ('dec0 64+128->64 @4', 256 * B, 64, 128, 4, 64), ('final 0+16->16 @64', B, 0, 16, 64, 16), ('C5 unet dec 24+48->24 @32', B // 2, 24, 48, 32, 24), ('C5 unet dec 48+96->48 @16', B // 2, 48, 96, 16, 48)]
+         ('C5 dec1 24+48->42 @8', 256 * B, 24, 48, 8, 42), ('dec0 64+128->64 @4', 256 * B, 64, 128, 4, 64), ('final 0+16->16 @64', B, 0, 16, 64, 16), ('C5 unet dec 48+96->78 @32', B // 2, 48, 96, 32, 78), ('C5 unet dec 24+48->24 @32', B // 2, 24, 48, 32, 24)]
 
 
 def timed(fn, reps=10):
