@@ -90,6 +90,17 @@ def victims(ops):
     if ops.conv_up_supported(None, xl, 16):
         wlp = ops.pack_conv3_up_weight(wl, 0)
         v['fp32 decoder-form conv on an upsampled source (0+16->16 @64^3 x 4)'] = lambda: ops.conv3d_up_gn_relu(None, xl, affl, wlp, 16)
+    if ops.conv_up_split_supported(None, xl, 16):
+        wls = ops.pack_conv3_up_split_weight(wl, 0)
+        v['split decoder-form conv on boxes of an upsampled source (0+16->16 @64^3 x 4)'] = lambda: ops.conv3d_up_split_gn_relu(None, xl, affl, wls, 16)
+    # boxes with a skip source (C5's U-Net decoder shape class)
+    xs0 = rnd(g, 16, 24, 32, 32, 32).relu_().to(DEV)
+    xs1 = rnd(g, 16, 48, 16, 16, 16).relu_().to(DEV)
+    affs = affine(ops, g, xs0, xs1, 6)
+    wsk = rnd(g, 42, 72, 3, 3, 3, scale=0.05).to(DEV)
+    if ops.conv_up_split_supported(xs0, xs1, 42):
+        wsks = ops.pack_conv3_up_split_weight(wsk, 24)
+        v['split decoder-form conv on boxes with a skip source (24+48->42 @32^3 x 16)'] = lambda: ops.conv3d_up_split_gn_relu(xs0, xs1, affs, wsks, 42)
     wlg = ops.pack_conv3_weight(wl)
 
     def generic_up():
