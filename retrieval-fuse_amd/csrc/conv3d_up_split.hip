@@ -21,15 +21,19 @@
 // consecutive channels of one voxel -- so the LDS image of the input is [8-channel group][voxel of the halo box] in 16-byte slots and every
 // A operand is ONE ds_read_b128 at (voxel + tap offset):
 //   A) skip channels: per 8-channel chunk 7 k-steps (27 taps + one zero-weight dummy) on the full-res halo box [10][10][10], double
-//      buffered: the next chunk's 8 values per voxel are loaded into registers before the chunk's MFMAs and normalised + split + written
-//      to the other buffer after them (thread = voxel; one barrier per chunk);
+//      buffered: the next chunk is staged by waves 0..3 (two voxels per thread: requested at k-steps 0 / 3, normalised + split + written to the
+//      other buffer after k-steps 2 / 6) -- the SIMD arbiter favours the older wave of each pair (w, w + 4), which would otherwise idle at the chunk
+//      barrier while its partner still had a conversion in front of it; one barrier per chunk;
 //   B) upsampled channels: per 8-channel chunk 2 k-steps (tz = 0 / 1, lane group = (ty,tx)) on the low-res halo box [6][6][6] of the
 //      chunk, all chunks staged once at kernel start (wave = channel group).
 // B operands (weights) are stored in HBM in fragment order (rf_conv3_up_split_pack_weight: [k-step][n-block][h|l][lane][8 halves], the
 // phase-B part once per parity), stay L2-resident (1.25 MB for 32+64->56) and go global -> VGPR with one 16-byte load per fragment, one
 // k-step ahead of their MFMAs (register double buffer).  A operands are read just in time per m-block (two m-blocks of registers).
-// Epilogue: accumulators -> ReLU -> LDS tile [cout][8^3] -> contiguous float4 rows; GroupNorm statistics of the output (float64, fixed
-// order) for the next layer.
+// The z-border MFMAs (output plane 0 through the dz = -1 taps, plane 7 through dz = +1: zero padding only) are not issued; the K loops are
+// instantiated per pz for that.
+// Epilogue: accumulators -> ReLU -> LDS tile [cout][8^3] (rows of 517 floats: conflict-free scalar writes) -> 256-byte row stores; GroupNorm
+// statistics of the output (float64, fixed order) for the next layer -- or (rf_conv3d_up_split_presplit) the next layer's GroupNorm applied on
+// the spot and the output written pre-split.
 #include "common.h"
 #include <type_traits>
 
