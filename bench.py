@@ -508,7 +508,7 @@ def main():
                     'useful_frac': direct / (kern_ms * 1e-3) / 1e12 / peak, 'direct_form_flops_per_launch': direct,
                     'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_file.name if traffic is not None else 'no summary of this kernel committed'),
                     'launch_ms': kern_ms,
-                    'issued_note': ('the whole-sample decoder form does not issue the z-border MFMAs (zero-padding taps of the first / last output plane: 9.1 % of the '
+                    'issued_note': ('the whole-sample decoder form does not issue the z-border MFMAs (zero-padding taps of the first / last output plane: 9.1 %% of the '
                                     'product tiles of 32+64 -> 56 @8^3): flops_per_launch counts what is issued; counted as in round 2 this launch would read frac %.3f'
                                     % (achieved / peak / (40.0 / 44.0))) if entry.startswith('rf_conv3d_up_split') and edge_ == 8 and (c0_, c1_) == (32, 64) else None,
                     'flops_per_launch': kern_flops,          # flop ISSUED on the matrix pipe of `peak` (f16 split: 3 f16 MFMAs per product tile, 28 tap slots per 27 taps, couts padded to 16)

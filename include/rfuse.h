@@ -223,6 +223,10 @@ int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* in_g
  * pre-split: the workgroup holds the sample, so it takes the output's statistics, applies the NEXT layer's GroupNorm (next_gamma / next_beta
  * [cout], next_groups, eps), splits and writes rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_k3_relu; the fp32 output is not
  * written.  StepDownDoubleConv / DoubleConv of a decoder: reference model/unet.py:125-159. */
+/* ... and the box form on whole 8^3 samples with up to 16 couts (an encoder level's first conv, model/unet.py:125-144): the same hand-over. */
+int rf_conv3d_split_presplit_supported(int cin, int n, int edge, int cout, int next_groups);
+int rf_conv3d_split_presplit(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout, const float* next_gamma,
+                             const float* next_beta, int next_groups, float eps, void* out_presplit, double* stats, void* stream);
 int rf_conv3d_up_split_presplit_supported(int c0, int c1, int n, int edge, int cout, int next_groups);
 int rf_conv3d_up_split_presplit(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine, const void* w_packed,
                                 int cout, const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit,

@@ -92,8 +92,21 @@ __device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
 // triple; their weights are zero too)
 // PRE: the input is a PRE-SPLIT tensor (rf_split_act_bytes: per (sample, 8-channel group) an h plane and an l plane of 16-byte voxel slots) that
 // its producer already normalised for THIS layer's GroupNorm and split -- staging is a copy of slots, no affine table, no conversion
+// pre-split OUTPUT (whole 8^3 samples, 16 couts in one workgroup): the NEXT layer's GroupNorm -- its gamma / beta / groups / eps over this layer's couts --
+// is applied in the epilogue from the sample's own statistics and the result written as that layer's pre-split input; null: off
+struct SplitPreOut {
+    h8* out;
+    const float* gamma;
+    const float* beta;
+    int groups;
+    float eps;
+};
+constexpr int CS_PO_STRIDE = 517;                                   // tile row (floats), odd: conflict-free scalar writes
+constexpr int CS_PO_STATS = 16 * CS_PO_STRIDE * 4, CS_PO_TRIPLES = CS_PO_STATS + 16 * 16;      // behind the tile: 16 x double2, 16 x float4
+static_assert(CS_PO_TRIPLES + 16 * 16 <= CS_LDS_BYTES, "pre-split epilogue must fit the multi-chunk instance's LDS");
+
 template <int NB, int WPS, bool ONE, bool PADC, bool PRE = false>
-__global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
+__global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a, SplitPreOut po) {
     static_assert(!(PRE && PADC), "pre-split tensors carry whole 8-channel groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -290,6 +303,67 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a) {
         if (ca + 1 < nC) chunk(ca + 1, b1h, b1l, b0h, b0l);
     }
 
+    if constexpr (NB == 1 && !ONE) {
+        if (po.out) {
+            // ---- pre-split output: ReLU'd tile [16 couts][8^3] -> statistics of the sample -> the next layer's triples -> normalise, split, slots
+            __syncthreads();                                           // the chunk images are dead
+            float* e = reinterpret_cast<float*>(lds);
+            {
+                const int col = lane & 15;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int sdummy, z, y, x;
+                        BoxOrder<8, 8, 8, 8, 4>::voxel(wave, m, 4 * (lane >> 4) + r, sdummy, z, y, x);
+                        e[col * CS_PO_STRIDE + (z * 8 + y) * 8 + x] = fmaxf(fmaf(lo[m][0][r], 1.0f / CS_LO, hi[m][0][r]), a.floor);
+                    }
+            }
+            __syncthreads();
+            double2* chst = reinterpret_cast<double2*>(lds + CS_PO_STATS);
+            float4* trip = reinterpret_cast<float4*>(lds + CS_PO_TRIPLES);
+            {
+                const int co = tid >> 5, part = tid & 31;               // 32 threads per cout, 16 values each, then a butterfly (fixed order)
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = e[co * CS_PO_STRIDE + part + 32 * i];
+                    sm += (double)v; sq += (double)v * v;
+                }
+#pragma unroll
+                for (int msk = 1; msk < 32; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
+                if (part == 0) {
+                    chst[co] = make_double2(sm, sq);
+                    if (a.stats && cob + co < a.cout) a.stats[(size_t)n0 * a.cout + cob + co] = make_double2(sm, sq);
+                }
+            }
+            __syncthreads();
+            if (tid < a.cout) {                                        // as rf_gn_from_stats: group sums in channel order, float64
+                const int cpg = a.cout / po.groups, ca = (tid / cpg) * cpg;
+                double sm = 0.0, sq = 0.0;
+                for (int c = ca; c < ca + cpg; ++c) { sm += chst[c].x; sq += chst[c].y; }
+                const double count = (double)cpg * 512.0, mean = sm / count;
+                double var = sq / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                trip[tid] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tid], po.beta[tid]);
+            }
+            __syncthreads();
+            h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * 512 + tid;
+            for (int sg = 0; sg < (a.cout >> 3); ++sg) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 t4 = trip[sg * 8 + j];
+                    y[j] = fmaf(e[(sg * 8 + j) * CS_PO_STRIDE + tid] - t4.x, t4.y, t4.z);
+                }
+                h8 h, l;
+                cs_split8(y, h, l);
+                o[(size_t)sg * 2 * 512] = h;
+                o[(size_t)sg * 2 * 512 + 512] = l;
+            }
+            return;
+        }
+    }
     // ---- epilogue (shared with the fp32 kernel): acc = hi + lo / 2^11
     f32x4 acc[4][NB];
 #pragma unroll
@@ -588,10 +662,10 @@ extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int co
 }
 
 template <int NB, int WPS, bool ONE, bool PADC = false, bool PRE = false>
-static int launch_split(const ConvArgs& a, hipStream_t stream) {
+static int launch_split(const ConvArgs& a, hipStream_t stream, const SplitPreOut& po = SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f}) {
     auto kern = k_conv3_split<NB, WPS, ONE, PADC, PRE>;
     const unsigned gx = (unsigned)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
-    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), ONE ? CS_BUF : CS_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), ONE ? CS_BUF : CS_LDS_BYTES, stream, a, po);
     RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
     return RF_OK;
 }
@@ -657,4 +731,25 @@ extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, in
     a.floor = 0.f;
     if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false, false, true>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true, false, true>(a, (hipStream_t)stream) : launch_split<1, 4, false, false, true>(a, (hipStream_t)stream);
+}
+
+// rf_conv3d_split_k3_gn_relu on whole 8^3 samples with up to 16 couts, its output handed to the NEXT SingleConv pre-split: the workgroup holds
+// the sample, so it applies the next layer's GroupNorm (next_gamma / next_beta [cout], next_groups, eps) from the sample's own statistics, splits and
+// writes rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_k3_relu; the fp32 output is not written.  stats (optional): [n][cout] (sum, sum of squares).
+extern "C" int rf_conv3d_split_presplit_supported(int cin, int n, int edge, int cout, int next_groups) {
+    return edge == 8 && cin >= 16 && cin % 8 == 0 && (cout == 8 || cout == 16) && next_groups > 0 && cout % next_groups == 0 && rf_conv3d_split_supported(cin, 0, n, edge, cout);
+}
+
+extern "C" int rf_conv3d_split_presplit(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout, const float* next_gamma,
+                                        const float* next_beta, int next_groups, float eps, void* out_presplit, double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_presplit_supported(cin, n, edge, cout, next_groups), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_presplit: takes whole 8^3 samples, cin >= 16 in eights, 8 or 16 couts in whole groups (got cin=%d n=%d edge=%d cout=%d groups=%d)", cin, n, edge, cout, next_groups);
+    RF_REQUIRE(src && gn_affine && w_packed && next_gamma && next_beta && out_presplit, RF_E_INVALID, "rf_conv3d_split_presplit: null pointer");
+    ConvArgs a;
+    a.src0 = src; a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const float*>(w_packed); a.out = nullptr;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
+    a.stats = reinterpret_cast<double2*>(stats); a.stats_tiles = stats ? 1 : 0;
+    a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
+    const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps};
+    return launch_split<1, 4, false>(a, (hipStream_t)stream, po);
 }

@@ -155,6 +155,11 @@ class SingleConv(nn.Module):
         return out if pool is None else (out, ops.maxpool2(out))
 
 
+def _groups_of(gn):
+    """the group count GroupNormParams really normalises with (reference model/unet.py:62-63: one group when there are fewer channels than groups)"""
+    return 1 if gn.num_channels < gn.num_groups else gn.num_groups
+
+
 def _decoder_pair_presplit_ok(c1, c2, x, upsampled):
     """A decoder's conv pair on whole 8^3 samples: the first conv (decoder form, split operands) sees the whole sample, so it can apply the SECOND
     conv's GroupNorm to its own output and hand it over pre-split: no fp32 intermediate, no rf_gn_from_stats, the second conv stages copies."""
@@ -162,7 +167,7 @@ def _decoder_pair_presplit_ok(c1, c2, x, upsampled):
     if ops.needs_grad(x, upsampled, c1.conv.weight, c2.conv.weight, g1.weight, g2.weight):
         return False
     cmid, n, edge = c1.conv.out_channels, upsampled.shape[0], 2 * upsampled.shape[2]
-    if not ops.conv_up_split_presplit_supported(x, upsampled, cmid, g2.num_groups):
+    if not ops.conv_up_split_presplit_supported(x, upsampled, cmid, _groups_of(g2)):
         return False
     if not bool(ops._lib.load().rf_conv3d_split_pre_supported(cmid, n, edge, c2.conv.out_channels)):
         return False
@@ -175,7 +180,7 @@ def _decoder_pair_presplit(c1, c2, x, upsampled):
     g1, g2 = c1.groupnorm, c2.groupnorm
     aff = ops.gn_affine(x, upsampled, g1.weight, g1.bias, g1.num_groups, g1.eps)
     c0 = x.shape[1] if x is not None else 0
-    pre = ops.conv3d_up_split_presplit(x, upsampled, aff, c1.conv.packed_up_split(c0), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
+    pre = ops.conv3d_up_split_presplit(x, upsampled, aff, c1.conv.packed_up_split(c0), c1.conv.out_channels, g2.weight, g2.bias, _groups_of(g2), g2.eps)
     return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, upsampled.shape[0], 2 * upsampled.shape[2], c2.conv.packed_split(), c2.conv.out_channels)
 
 
@@ -203,7 +208,25 @@ class DoubleConv(nn.Module):
             return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
         if upsampled is not None and pool is None and _decoder_pair_presplit_ok(c1, c2, x, upsampled):
             return _decoder_pair_presplit(c1, c2, x, upsampled)
+        if upsampled is None and x is not None and self._box_pair_presplit_ok(x):
+            # an encoder level on whole 8^3 samples (16 -> 16 -> 32 of the retrieval backbone): as above, the producer is the split box kernel
+            g1, g2 = c1.groupnorm, c2.groupnorm
+            aff = ops.gn_affine(x, None, g1.weight, g1.bias, g1.num_groups, g1.eps)
+            pre = ops.conv3d_split_presplit(x, aff, c1.conv.packed_split(), c1.conv.out_channels, g2.weight, g2.bias, _groups_of(g2), g2.eps)
+            return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
         return c2(c1(x, upsampled), pool=pool)
+
+    def _box_pair_presplit_ok(self, x):
+        c1, c2 = self.SingleConv1, self.SingleConv2
+        g1, g2 = c1.groupnorm, c2.groupnorm
+        if ops.needs_grad(x, c1.conv.weight, c2.conv.weight, g1.weight, g2.weight):
+            return False
+        cmid, n, edge = c1.conv.out_channels, x.shape[0], x.shape[2]
+        if not ops.conv_split_presplit_supported(x, cmid, _groups_of(g2)) or not bool(ops._lib.load().rf_conv3d_split_pre_supported(cmid, n, edge, c2.conv.out_channels)):
+            return False
+        g1n = 1 if x.shape[1] < g1.num_groups else g1.num_groups
+        return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, (x.shape[1] // g1n) * edge ** 3)
+                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (cmid // _groups_of(g2)) * edge ** 3))
 
     def _presplit_ok(self, x):
         c1, c2 = self.SingleConv1, self.SingleConv2

@@ -429,6 +429,23 @@ def conv3d_cin1_presplit(x, in_gamma, in_beta, in_eps, w_packed, cout, next_gamm
     return out
 
 
+def conv_split_presplit_supported(x, cout, next_groups):
+    """the split box conv on whole 8^3 samples can hand its output to the next SingleConv pre-split (rf_conv3d_split_presplit)"""
+    return (USE_PRESPLIT and CONV_ARITH == 'split' and x is not None
+            and bool(_lib.load().rf_conv3d_split_presplit_supported(x.shape[1], x.shape[0], x.shape[2], cout, next_groups)))
+
+
+def conv3d_split_presplit(x, gn_affine_t, w_split_packed, cout, next_gamma, next_beta, next_groups, eps):
+    """relu(conv(GN(x))) of whole 8^3 samples (<= 16 couts), emitted as the pre-split input of the NEXT layer: uint8 buffer for conv3d_split_pre_relu"""
+    _req(x, 'x')
+    n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
+    lib = _lib.load()
+    out = torch.empty(lib.rf_split_act_bytes(n, cout, edge), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.rf_conv3d_split_presplit(_p(x), cin, n, edge, _p(gn_affine_t), _p(w_split_packed), cout, _p(next_gamma.detach()), _p(next_beta.detach()),
+                                            next_groups, eps, _p(out), _p(None), _stream()), 'rf_conv3d_split_presplit')
+    return out
+
+
 def conv_up_split_presplit_supported(x, upsampled, cout, next_groups):
     """the decoder-form split conv on whole 8^3 samples can hand its output to the next SingleConv pre-split (rf_conv3d_up_split_presplit)"""
     if not USE_PRESPLIT or CONV_ARITH != 'split' or upsampled is None:

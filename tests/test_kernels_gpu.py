@@ -1203,6 +1203,35 @@ def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
     assert (got - plain).abs().max().item() <= 2e-6 * max(1.0, scale)
 
 
+def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops):
+    """DoubleConv of an encoder level on whole 8^3 samples (the retrieval backbone's 16 -> 16 -> 32 @8^3, fused pool): the split box kernel hands the second
+    conv its input pre-split (rf_conv3d_split_presplit) -- bit-equal to the plain route, close to float64"""
+    from model.unet import DoubleConv
+    torch.manual_seed(21)
+    blk = DoubleConv(16, 32, encoder=True, num_groups=8).to(DEV).eval()
+    with torch.no_grad():
+        for g in (blk.SingleConv1.groupnorm, blk.SingleConv2.groupnorm):
+            g.weight.add_(0.2 * torch.randn_like(g.weight)); g.bias.add_(0.2 * torch.randn_like(g.bias))
+    gen = torch.Generator().manual_seed(4)
+    x = rnd(gen, 1030, 16, 8, 8, 8).relu_()
+    with torch.no_grad():
+        assert blk._box_pair_presplit_ok(x.to(DEV))
+        outs = {}
+        for flag in (True, False):
+            ops.USE_PRESPLIT = flag
+            outs[flag] = [blk(x.to(DEV)), blk(x.to(DEV), pool='also'), blk(x.to(DEV), pool='only')]
+        ops.USE_PRESPLIT = True
+        x64 = x.double()
+        for sc in (blk.SingleConv1, blk.SingleConv2):
+            gn = sc.groupnorm
+            x64 = F.relu(F.conv3d(F.group_norm(x64, gn.num_groups, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), sc.conv.weight.double().cpu(), padding=1))
+    close(outs[True][0], x64.float(), 1e-5, 'encoder pair, pre-split route')
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1][0], outs[False][1][0]) and torch.equal(outs[True][1][1], outs[False][1][1])
+    assert outs[True][2][0] is None and torch.equal(outs[True][2][1], outs[False][2][1])
+    assert torch.equal(outs[True][1][1], F.max_pool3d(outs[True][0], 2))
+
+
 def test_in_kernel_gumbel_sampler(ops):
     """rf_attn_weights_sampled draws the Gumbel noise of gumbel_softmax(hard=True) (reference model/attention.py:100-103) inside the kernel:
     (a) the noise it reports, fed to the explicit-noise entry point, reproduces its weights bit for bit; (b) the noise is Gumbel(0, 1) --
