@@ -50,8 +50,7 @@ constexpr int US_MAX_CGB = 8;                                    // low-res chan
 constexpr int US_LDS_BYTES = US_B_OFF + US_MAX_CGB * 2 * US_B_PLANE;      // 132,608
 constexpr int US_PRE_STATS = US_LDS_BYTES, US_PRE_TRIPLES = US_PRE_STATS + 64 * 16;     // pre-split epilogue: per-channel (sum, sum of squares), then triples
 constexpr int US_LDS_ALLOC = US_PRE_TRIPLES + 64 * 16;                                     // 134,656
-constexpr int US_E_STRIDE = 516;                                 // epilogue tile row (floats) of the 4^3 / box kernels
-constexpr int US_T_STRIDE = 517;                                 // ... of the whole-sample kernel: odd (bank-conflict-free scalar writes)
+constexpr int US_T_STRIDE = 517;                                 // epilogue tile row (floats) of the whole-sample kernel: odd (bank-conflict-free scalar writes)
 constexpr float US_ACT_SCALE = 1.0f / 16, US_W_SCALE = 16.0f, US_LO = 2048.0f;
 constexpr bool US_ZSKIP = true;
 static_assert(64 * US_T_STRIDE * 4 <= US_LDS_BYTES, "epilogue tile must fit");
