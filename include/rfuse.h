@@ -223,6 +223,13 @@ int rf_conv3d_cin1_presplit(const float* src, int n, int edge, const float* in_g
  * pre-split: the workgroup holds the sample, so it takes the output's statistics, applies the NEXT layer's GroupNorm (next_gamma / next_beta
  * [cout], next_groups, eps), splits and writes rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_k3_relu; the fp32 output is not
  * written.  StepDownDoubleConv / DoubleConv of a decoder: reference model/unet.py:125-159. */
+/* rf_conv3d_split_k3_gn_relu with the final decoder's head (Conv3d(nf, 1, 1) + bias -> tanh -> (pred + post_add) * post_mul: reference
+ * model/refinement.py:48-61, trainer/train_refinement.py:242-243) fused into its epilogue: out1 [n][1][edge^3]; the arithmetic of rf_conv1x1_tanh on the
+ * conv's output, bit for bit, without the cout-channel tensor ever reaching memory. */
+int rf_conv3d_split_pointwise_supported(int cin, int n, int edge, int cout);
+int rf_conv3d_split_k3_gn_relu_pointwise_tanh(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
+                                              const float* pw_w, const float* pw_b, float post_add, float post_mul, float* out1, void* stream);
+
 /* ... and the box form on whole 8^3 samples with up to 16 couts (an encoder level's first conv, model/unet.py:125-144): the same hand-over. */
 int rf_conv3d_split_presplit_supported(int cin, int n, int edge, int cout, int next_groups);
 int rf_conv3d_split_presplit(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout, const float* next_gamma,

@@ -100,6 +100,12 @@ struct SplitPreOut {
     const float* beta;
     int groups;
     float eps;
+    // ... or the final decoder's pointwise head (reference model/refinement.py:48-61: Conv3d(nf, 1, 1) + bias -> tanh -> network_pred_to_df) applied to the
+    // ReLU'd output in the epilogue: pw_out [n][1][edge^3] = (tanh(sum_c w[c] y[c] + b) + post_add) * post_mul, the nf-channel tensor is never written
+    float* pw_out;
+    const float* pw_w;
+    const float* pw_b;
+    float post_add, post_mul;
 };
 constexpr int CS_PO_STRIDE = 517;                                   // tile row (floats), odd: conflict-free scalar writes
 constexpr int CS_PO_STATS = 16 * CS_PO_STRIDE * 4, CS_PO_TRIPLES = CS_PO_STATS + 16 * 16;      // behind the tile: 16 x double2, 16 x float4
@@ -361,6 +367,28 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a, SplitPreOu
                 o[(size_t)sg * 2 * 512] = h;
                 o[(size_t)sg * 2 * 512 + 512] = l;
             }
+            return;
+        }
+        if (po.pw_out) {
+            // ---- pointwise head: ReLU'd tile [couts][8^3] -> per voxel the channel sum in the order of rf_conv1x1_tanh (bias first, channels ascending: same bits)
+            __syncthreads();
+            float* e = reinterpret_cast<float*>(lds);
+            {
+                const int col = lane & 15;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int sdummy, z, y, x;
+                        BoxOrder<8, 8, 8, 8, 4>::voxel(wave, m, 4 * (lane >> 4) + r, sdummy, z, y, x);
+                        e[col * CS_PO_STRIDE + (z * 8 + y) * 8 + x] = fmaxf(fmaf(lo[m][0][r], 1.0f / CS_LO, hi[m][0][r]), a.floor);
+                    }
+            }
+            __syncthreads();
+            float accp = po.pw_b[0];
+            for (int c = 0; c < a.cout; ++c) accp = fmaf(e[c * CS_PO_STRIDE + tid], po.pw_w[c], accp);
+            const int z = tid >> 6, y = (tid >> 3) & 7, x = tid & 7;
+            po.pw_out[(size_t)n0 * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + x0 + x] = (tanhf(accp) + po.post_add) * po.post_mul;
             return;
         }
     }
@@ -662,7 +690,7 @@ extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int co
 }
 
 template <int NB, int WPS, bool ONE, bool PADC = false, bool PRE = false>
-static int launch_split(const ConvArgs& a, hipStream_t stream, const SplitPreOut& po = SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f}) {
+static int launch_split(const ConvArgs& a, hipStream_t stream, const SplitPreOut& po = SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}) {
     auto kern = k_conv3_split<NB, WPS, ONE, PADC, PRE>;
     const unsigned gx = (unsigned)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)(a.cout16 / (NB * 16))), dim3(512), ONE ? CS_BUF : CS_LDS_BYTES, stream, a, po);
@@ -750,6 +778,26 @@ extern "C" int rf_conv3d_split_presplit(const float* src, int cin, int n, int ed
     a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
     a.stats = reinterpret_cast<double2*>(stats); a.stats_tiles = stats ? 1 : 0;
     a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
-    const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps};
+    const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps, nullptr, nullptr, nullptr, 0.f, 0.f};
     return launch_split<1, 4, false>(a, (hipStream_t)stream, po);
+}
+
+// rf_conv3d_split_k3_gn_relu with the final decoder's head fused into the epilogue (reference model/refinement.py:48-61 + trainer/train_refinement.py:242-243):
+// out1 [n][1][edge^3] = (tanh(sum_c pw_w[c] * relu(conv(GN(x)))[c] + pw_b[0]) + post_add) * post_mul -- the arithmetic of rf_conv1x1_tanh on the conv's
+// output, bit for bit -- without writing or re-reading the cout-channel tensor.  cin >= 12 (two or more chunks), up to 16 couts.
+extern "C" int rf_conv3d_split_pointwise_supported(int cin, int n, int edge, int cout) {
+    return cin >= 12 && cout <= 16 && edge >= 8 && rf_conv3d_split_supported(cin, 0, n, edge, cout);
+}
+
+extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
+                                                         const float* pw_w, const float* pw_b, float post_add, float post_mul, float* out1, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_pointwise_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_k3_gn_relu_pointwise_tanh: takes the shapes of rf_conv3d_split_k3_gn_relu with cin >= 12 and up to 16 couts (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
+    RF_REQUIRE(src && gn_affine && w_packed && pw_w && pw_b && out1, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu_pointwise_tanh: null pointer");
+    ConvArgs a;
+    a.src0 = src; a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const float*>(w_packed); a.out = nullptr;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
+    a.stats = nullptr; a.stats_tiles = 0; a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
+    const SplitPreOut po{nullptr, nullptr, nullptr, 0, 0.f, out1, pw_w, pw_b, post_add, post_mul};
+    return cin % 8 ? launch_split<1, 4, false, true>(a, (hipStream_t)stream, po) : launch_split<1, 4, false>(a, (hipStream_t)stream, po);
 }

@@ -86,20 +86,33 @@ class Superresolution08FinalDecoder(nn.Module):
         self.network = nn.ModuleList([_up_stage(nf, nf, nf, layer_order), PointwiseConvParams(nf, 1), TanhMarker()])
 
     def forward(self, x):
+        if not ops.needs_grad(x, *self.parameters()):
+            return self._head(x, 0.0, 1.0)
+        # grad mode (training slice, rfuse/autograd.py): the 16 -> 1 pointwise conv + tanh is 0.1 % of the work and torch differentiates it --
+        # written as a weighted channel sum, not as F.conv3d: that was the one MIOpen call of the path, and its first use runs MIOpen's solver
+        # search (naive_conv_ab_nonpacked_wrw, a batched-GEMM bwd_weight, ...: 2.4 s of kernels before the first step finishes)
         x = self.network[0](x)
-        if ops.needs_grad(x, self.network[1].weight):
-            # grad mode (training slice, rfuse/autograd.py): the 16 -> 1 pointwise conv + tanh is 0.1 % of the work and torch differentiates it --
-            # written as a weighted channel sum, not as F.conv3d: that was the one MIOpen call of the path, and its first use runs MIOpen's solver
-            # search (naive_conv_ab_nonpacked_wrw, a batched-GEMM bwd_weight, ...: 2.4 s of kernels before the first step finishes)
-            w, b = self.network[1].weight, self.network[1].bias
-            return torch.tanh((x.unsqueeze(1) * w.view(1, w.shape[0], w.shape[1], 1, 1, 1)).sum(dim=2) + b.view(1, -1, 1, 1, 1))
-        return ops.conv1x1_tanh(x, self.network[1].weight, self.network[1].bias)
+        w, b = self.network[1].weight, self.network[1].bias
+        return torch.tanh((x.unsqueeze(1) * w.view(1, w.shape[0], w.shape[1], 1, 1, 1)).sum(dim=2) + b.view(1, -1, 1, 1, 1))
+
+    def _head(self, x, post_add, post_mul):
+        """the up stage's second conv + the pointwise head (+ network_pred_to_df).  Where the split box kernel takes the conv, the head runs in its epilogue:
+        the nf-channel 64^3 tensor (0.5 GB per 32 chunks) is neither written nor read back."""
+        dc = self.network[0].basic_module
+        c1, c2, pw = dc.SingleConv1, dc.SingleConv2, self.network[1]
+        y1 = c1(None, x)
+        g2 = c2.groupnorm
+        cout, edge = c2.conv.out_channels, y1.shape[2]
+        if (ops.conv_split_pointwise_supported(y1, cout)
+                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (g2.num_channels // max(1, min(g2.num_groups, g2.num_channels))) * edge ** 3)):
+            aff = ops.gn_affine(y1, None, g2.weight, g2.bias, g2.num_groups, g2.eps)
+            return ops.conv3d_split_pointwise_tanh(y1, aff, c2.conv.packed_split(), cout, pw.weight, pw.bias, post_add, post_mul)
+        return ops.conv1x1_tanh(c2(y1), pw.weight, pw.bias, post_add=post_add, post_mul=post_mul)
 
     def forward_df(self, x, target_trunc):
-        if ops.needs_grad(x, self.network[1].weight):
+        if ops.needs_grad(x, *self.parameters()):
             return (self.forward(x) + 1.0) * (float(target_trunc) / 2)
-        x = self.network[0](x)
-        return ops.conv1x1_tanh(x, self.network[1].weight, self.network[1].bias, post_add=1.0, post_mul=float(target_trunc) / 2)
+        return self._head(x, 1.0, float(target_trunc) / 2)
 
 
 class RetrievalUNetBackbone(nn.Module):

@@ -67,6 +67,8 @@ SIGNATURES = {
     'rf_split_act_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_cin1_presplit_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'rf_conv3d_cin1_presplit': (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_f, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_p, c_p]),
+    'rf_conv3d_split_pointwise_supported': (c_i, [c_i, c_i, c_i, c_i]),
+    'rf_conv3d_split_k3_gn_relu_pointwise_tanh': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_fp, c_f, c_f, c_fp, c_p]),
     'rf_conv3d_split_presplit_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_presplit': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_fp, c_i, c_f, c_p, c_p, c_p]),
     'rf_conv3d_up_split_presplit_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),

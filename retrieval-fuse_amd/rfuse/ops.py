@@ -429,6 +429,29 @@ def conv3d_cin1_presplit(x, in_gamma, in_beta, in_eps, w_packed, cout, next_gamm
     return out
 
 
+def conv_split_pointwise_supported(x, cout):
+    return CONV_ARITH == 'split' and x is not None and bool(_lib.load().rf_conv3d_split_pointwise_supported(x.shape[1], x.shape[0], x.shape[2], cout))
+
+
+def conv3d_split_pointwise_tanh(x, gn_affine_t, w_split_packed, cout, pw_w, pw_b, post_add=0.0, post_mul=1.0):
+    """(tanh(Conv3d(cout, 1, 1)(relu(conv(GN(x))))) + post_add) * post_mul with the pointwise head in the conv's epilogue: [n, 1, e, e, e]"""
+    _req(x, 'x')
+    n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
+    if pw_w.shape[0] != 1:
+        raise NotImplementedError('conv3d_split_pointwise_tanh: one output channel (Conv3d(nf,1,1), model/refinement.py:54)')
+    out = torch.empty((n, 1, edge, edge, edge), dtype=torch.float32, device=x.device)
+    timed = conv_event_filter is not None and conv_event_filter(cin, cout, edge, n)
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(_lib.load().rf_conv3d_split_k3_gn_relu_pointwise_tanh(_p(x), cin, n, edge, _p(gn_affine_t), _p(w_split_packed), cout, _p(pw_w.detach()), _p(pw_b.detach()),
+                                                                     post_add, post_mul, _p(out), _stream()), 'rf_conv3d_split_k3_gn_relu_pointwise_tanh')
+    if timed:
+        ev1.record()
+        conv_events.append((ev0, ev1, conv_split_issued_flops(cin, n, edge, cout), ('rf_conv3d_split_k3_gn_relu', 'f16 split', (cin, 0, n, edge, cout))))
+    return out
+
+
 def conv_split_presplit_supported(x, cout, next_groups):
     """the split box conv on whole 8^3 samples can hand its output to the next SingleConv pre-split (rf_conv3d_split_presplit)"""
     return (USE_PRESPLIT and CONV_ARITH == 'split' and x is not None

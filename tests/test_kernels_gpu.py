@@ -1232,6 +1232,32 @@ def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops):
     assert torch.equal(outs[True][1][1], F.max_pool3d(outs[True][0], 2))
 
 
+@pytest.mark.parametrize('nf', [16, 12])
+def test_final_decoder_head_in_the_conv_epilogue(ops, nf):
+    """Superresolution08FinalDecoder (reference model/refinement.py:48-61): the 1x1x1 conv + tanh (+ network_pred_to_df) run in the epilogue of the up
+    stage's second conv (rf_conv3d_split_k3_gn_relu_pointwise_tanh) -- the same bits as the conv followed by rf_conv1x1_tanh, and the float64 value"""
+    import model as rf_model
+    torch.manual_seed(nf)
+    dec = rf_model.Superresolution08FinalDecoder(nf, 'gcr').to(DEV).eval()
+    gen = torch.Generator().manual_seed(8)
+    x = rnd(gen, 3, nf, 32, 32, 32).relu_()
+    with torch.no_grad():
+        dc = dec.network[0].basic_module
+        y1 = dc.SingleConv1(None, x.to(DEV))
+        assert ops.conv_split_pointwise_supported(y1, nf)
+        fused, fused_df = dec(x.to(DEV)), dec.forward_df(x.to(DEV), 0.375)
+        y2 = dc.SingleConv2(y1)
+        plain = ops.conv1x1_tanh(y2, dec.network[1].weight, dec.network[1].bias)
+        plain_df = ops.conv1x1_tanh(y2, dec.network[1].weight, dec.network[1].bias, post_add=1.0, post_mul=0.375 / 2)
+        x64 = F.interpolate(x.double(), scale_factor=2, mode='nearest')
+        for sc in (dc.SingleConv1, dc.SingleConv2):
+            gn = sc.groupnorm
+            x64 = F.relu(F.conv3d(F.group_norm(x64, gn.num_groups, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), sc.conv.weight.double().cpu(), padding=1))
+        ref = torch.tanh(F.conv3d(x64, dec.network[1].weight.double().cpu(), dec.network[1].bias.double().cpu()))
+    assert torch.equal(fused, plain) and torch.equal(fused_df, plain_df)
+    close(fused, ref.float(), 1e-5, 'final decoder with the fused head')
+
+
 def test_in_kernel_gumbel_sampler(ops):
     """rf_attn_weights_sampled draws the Gumbel noise of gumbel_softmax(hard=True) (reference model/attention.py:100-103) inside the kernel:
     (a) the noise it reports, fed to the explicit-noise entry point, reproduces its weights bit for bit; (b) the noise is Gumbel(0, 1) --
