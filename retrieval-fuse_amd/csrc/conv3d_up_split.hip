@@ -52,7 +52,7 @@ constexpr int US_PRE_STATS = US_LDS_BYTES, US_PRE_TRIPLES = US_PRE_STATS + 64 * 
 constexpr int US_LDS_ALLOC = US_PRE_TRIPLES + 64 * 16;                                     // 134,656
 constexpr int US_T_STRIDE = 517;                                 // epilogue tile row (floats) of the whole-sample kernel: odd (bank-conflict-free scalar writes)
 constexpr float US_ACT_SCALE = 1.0f / 16, US_W_SCALE = 16.0f, US_LO = 2048.0f;
-constexpr bool US_ZSKIP = true;
+constexpr bool US_ZSKIP = true, US_S4_WIDE = true;
 static_assert(64 * US_T_STRIDE * 4 <= US_LDS_BYTES, "epilogue tile must fit");
 }   // namespace
 
@@ -476,7 +476,7 @@ static_assert(2 * U4_A_PLANE <= U4_LDS_BYTES && U4_BG * 2 * U4_B_PLANE <= U4_LDS
 
 // PRE: weight fragments one k-step ahead in a second register set
 template <int NB, bool PRE>
-__global__ __launch_bounds__(512, 4) void k_conv3_up_split_s4(UpSplitArgs a) {
+__global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -650,20 +650,23 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_s4(UpSplitArgs a) {
                 *reinterpret_cast<const float4*>(e + co * U4_E_STRIDE + sm * 64 + l4 * 4);
     }
     if (a.stats) {
-        // per (cout, sample): two threads sum 32 values each (float64), then the two partial sums
-        const int co = tid >> 4, sm = (tid >> 1) & 7, part = tid & 1;
-        double s = 0.0, sq = 0.0;
+        // per (cout, sample): two threads sum 32 values each (float64), then the two partial sums; 32 couts per pass of the 512 threads
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (co >= NB * 16) break;
-            const float4 v = *reinterpret_cast<const float4*>(e + co * U4_E_STRIDE + sm * 64 + (part * 8 + i) * 4);
-            s += (double)v.x; sq += (double)v.x * v.x;
-            s += (double)v.y; sq += (double)v.y * v.y;
-            s += (double)v.z; sq += (double)v.z * v.z;
-            s += (double)v.w; sq += (double)v.w * v.w;
+        for (int cpass = 0; cpass < NB * 16; cpass += 32) {
+            const int co = cpass + (tid >> 4), sm = (tid >> 1) & 7, part = tid & 1;
+            double s = 0.0, sq = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (co >= NB * 16) break;
+                const float4 v = *reinterpret_cast<const float4*>(e + co * U4_E_STRIDE + sm * 64 + (part * 8 + i) * 4);
+                s += (double)v.x; sq += (double)v.x * v.x;
+                s += (double)v.y; sq += (double)v.y * v.y;
+                s += (double)v.z; sq += (double)v.z * v.z;
+                s += (double)v.w; sq += (double)v.w * v.w;
+            }
+            s += __shfl_xor(s, 1, 64); sq += __shfl_xor(sq, 1, 64);
+            if (part == 0 && co < NB * 16 && cob + co < cout && n0 + sm < a.n) a.stats[(size_t)(n0 + sm) * cout + cob + co] = make_double2(s, sq);
         }
-        s += __shfl_xor(s, 1, 64); sq += __shfl_xor(sq, 1, 64);
-        if (part == 0 && co < NB * 16 && cob + co < cout && n0 + sm < a.n) a.stats[(size_t)(n0 + sm) * cout + cob + co] = make_double2(s, sq);
     }
 }
 
@@ -1071,11 +1074,22 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
         return RF_OK;
     }
     if (edge == 4) {
+        const int nbt = rf_round_up(cout, 16) / 16;
+        if (US_S4_WIDE && nbt == 4) {
+            // all 64 couts in one workgroup (256 VGPRs, 132 KB LDS, one workgroup per CU -- the shape of the 8^3 kernel): the samples are staged and
+            // converted ONCE instead of once per 16-cout block
+            static RfLdsOptIn opt_wide;
+            const int lds_wide = 64 * U4_E_STRIDE * 4;
+            if (int rc = opt_wide.ensure(reinterpret_cast<const void*>(k_conv3_up_split_s4<4, true>), lds_wide, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+            hipLaunchKernelGGL((k_conv3_up_split_s4<4, true>), dim3((unsigned)((n + 7) / 8), 1u), dim3(512), lds_wide, (hipStream_t)stream, a);
+            RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
+            return RF_OK;
+        }
         static RfLdsOptIn opt_in;
         // 16 couts per workgroup: the 32-cout instance needs more than the 128 VGPRs that four waves per SIMD allow (35-45 spills) and was
         // no faster (629-641 us against 610 on dec0)
         if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_conv3_up_split_s4<1, true>), U4_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu")) return rc;
-        hipLaunchKernelGGL((k_conv3_up_split_s4<1, true>), dim3((unsigned)((n + 7) / 8), (unsigned)(rf_round_up(cout, 16) / 16)), dim3(512), U4_LDS_BYTES,
+        hipLaunchKernelGGL((k_conv3_up_split_s4<1, true>), dim3((unsigned)((n + 7) / 8), (unsigned)nbt), dim3(512), U4_LDS_BYTES,
                            (hipStream_t)stream, a);
         RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
         return RF_OK;
