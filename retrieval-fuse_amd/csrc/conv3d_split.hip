@@ -26,6 +26,7 @@ constexpr int CS_PLANE = CS_SLOTS * 16;                          // bytes of one
 constexpr int CS_BUF = 2 * CS_PLANE;
 constexpr int CS_LDS_BYTES = 2 * CS_BUF;                         // 64,000
 constexpr float CS_ACT_SCALE = 1.0f / 16, CS_W_SCALE = 16.0f, CS_LO = 2048.0f;
+constexpr bool CS_S4_WIDE = true;
 }   // namespace
 
 // ------------------------------------------------------------------------------------------------------------ weight image
@@ -417,14 +418,17 @@ constexpr int S4_PLANE = S4_SLOTS * 16;                          // 27,648 bytes
 constexpr int S4_LDS_BYTES = 2 * S4_PLANE;                       // 55,296: one chunk image; two workgroups per CU
 }   // namespace
 
-__global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
+// NB n-blocks per workgroup: 1 (four waves per SIMD; every 16-cout block of a layer stages and converts the samples again) or all of a 32 / 64-cout
+// layer's (two waves per SIMD, up to 256 VGPRs: staged once)
+template <int NB>
+__global__ __launch_bounds__(512, NB == 1 ? 4 : 2) void k_conv3_split_s4(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cin = a.c0, nC = cin >> 3;
     const unsigned lblock = rf_xcd_contiguous(blockIdx.x, gridDim.x);
     const int n0 = (int)lblock * 8;
-    const int cob = blockIdx.y * 16;
+    const int cob = blockIdx.y * (NB * 16);
     const int ns = n0 + wave < a.n ? n0 + wave : a.n - 1;         // ragged last group: re-reads the last sample, the epilogue masks its stores
     const float4* __restrict__ aff = a.affine + (size_t)ns * cin;
     const float* __restrict__ s0 = a.src0 + (size_t)ns * cin * 64 + lane;             // this thread's voxel (z, y, x) = (lane >> 4, (lane >> 2) & 3, lane & 3)
@@ -460,14 +464,17 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
         const int tp = 4 * s + g < 27 ? 4 * s + g : 26;             // tap 27: zero weights
         atap[s] = ((tp / 9 - 1) * 36 + ((tp / 3) % 3 - 1) * 6 + (tp % 3 - 1)) * 16;
     }
-    f32x4 hi[4][1], lo[4][1];
+    f32x4 hi[4][NB], lo[4][NB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { hi[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int nbt = a.cout16 >> 4;
-    const h8* __restrict__ wn = reinterpret_cast<const h8*>(a.wp) + (size_t)blockIdx.y * 128 + lane;       // next k-step to fetch
+    const h8* __restrict__ wn = reinterpret_cast<const h8*>(a.wp) + (size_t)blockIdx.y * NB * 128 + lane;       // next k-step to fetch
     const int wstep = nbt * 128;
-    h8 bh[1], bl[1], nh[1], nl[1];
-    bh[0] = wn[0]; bl[0] = wn[64];
+    h8 bh[NB], bl[NB], nh[NB], nl[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { bh[nb] = wn[nb * 128]; bl[nb] = wn[nb * 128 + 64]; }
     wn += wstep;
     __syncthreads();                                                // the zero fill is complete
     stage_store(xr, 0);
@@ -478,7 +485,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
         if (more) stage_load(xr, ca + 1);                           // lands under this chunk's MFMAs
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
-            nh[0] = wn[0]; nl[0] = wn[64];                          // next k-step's weights (the image has one k-step of slack)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { nh[nb] = wn[nb * 128]; nl[nb] = wn[nb * 128 + 64]; }      // next k-step's weights (the image has one k-step of slack)
             wn += wstep;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -486,9 +494,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
                 if ((m == 0 && s < 2) || (m == 3 && s >= 5)) continue;      // every tap of the k-step reads the plane below / above the volume: zeros
                 const h8 ah = *reinterpret_cast<const h8*>(abase + m * 576 + atap[s]);
                 const h8 al = *reinterpret_cast<const h8*>(abase + m * 576 + atap[s] + S4_PLANE);
-                cs_mfma_block<1>(hi[m], lo[m], ah, al, bh, bl);
+                cs_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
             }
-            bh[0] = nh[0]; bl[0] = nl[0];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
         }
         __syncthreads();                                            // everyone left the image
         if (more) {
@@ -497,12 +506,14 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_s4(ConvArgs a) {
         }
     }
 
-    f32x4 acc[4][1];
+    f32x4 acc[4][NB];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][0][r] = fmaf(lo[m][0][r], 1.0f / CS_LO, hi[m][0][r]);
-    conv_box_epilogue<4, 4, 4, 8, 8, 4, 1, (size_t)S4_LDS_BYTES>(a, acc, reinterpret_cast<float*>(lds), tid, lane, wave, n0, 0, 0, 0, cob, lblock);
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nb][r] = fmaf(lo[m][nb][r], 1.0f / CS_LO, hi[m][nb][r]);
+    conv_box_epilogue<4, 4, 4, 8, 8, 4, NB, (size_t)S4_LDS_BYTES>(a, acc, reinterpret_cast<float*>(lds), tid, lane, wave, n0, 0, 0, 0, cob, lblock);
 }
 
 // ------------------------------------------------------------------------------------------- pre-split activations: a producer
@@ -723,7 +734,10 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
     if (edge == 4) {
         RF_REQUIRE(!pool_out, RF_E_UNSUPPORTED, "rf_conv3d_split_k3_gn_relu: the 4^3 form has no fused max-pool (pool its output with rf_maxpool3d_2_stats)");
-        hipLaunchKernelGGL(k_conv3_split_s4, dim3((unsigned)((n + 7) / 8), (unsigned)(a.cout16 / 16)), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        // all couts of a 32 / 64-cout layer in one workgroup (samples staged once; 4^3 levels of the retrieval backbone: 32 -> 32, 32 -> 64, 64 -> 64)
+        if (CS_S4_WIDE && a.cout16 == 64) hipLaunchKernelGGL(k_conv3_split_s4<4>, dim3((unsigned)((n + 7) / 8), 1u), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        else if (CS_S4_WIDE && a.cout16 == 32) hipLaunchKernelGGL(k_conv3_split_s4<2>, dim3((unsigned)((n + 7) / 8), 1u), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_conv3_split_s4<1>, dim3((unsigned)((n + 7) / 8), (unsigned)(a.cout16 / 16)), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
         RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
         return RF_OK;
     }
