@@ -735,9 +735,11 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     if (edge == 4) {
         RF_REQUIRE(!pool_out, RF_E_UNSUPPORTED, "rf_conv3d_split_k3_gn_relu: the 4^3 form has no fused max-pool (pool its output with rf_maxpool3d_2_stats)");
         // all couts of a 32 / 64-cout layer in one workgroup (samples staged once; 4^3 levels of the retrieval backbone: 32 -> 32, 32 -> 64, 64 -> 64)
-        if (CS_S4_WIDE && a.cout16 == 64) hipLaunchKernelGGL(k_conv3_split_s4<4>, dim3((unsigned)((n + 7) / 8), 1u), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
-        else if (CS_S4_WIDE && a.cout16 == 32) hipLaunchKernelGGL(k_conv3_split_s4<2>, dim3((unsigned)((n + 7) / 8), 1u), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(k_conv3_split_s4<1>, dim3((unsigned)((n + 7) / 8), (unsigned)(a.cout16 / 16)), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        const unsigned gx = (unsigned)((n + 7) / 8), nbt = (unsigned)(a.cout16 / 16);
+        if (CS_S4_WIDE && nbt % 4 == 0) hipLaunchKernelGGL(k_conv3_split_s4<4>, dim3(gx, nbt / 4), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        else if (CS_S4_WIDE && nbt % 3 == 0) hipLaunchKernelGGL(k_conv3_split_s4<3>, dim3(gx, nbt / 3), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);      // nf = 12: 48 / 96 couts
+        else if (CS_S4_WIDE && nbt % 2 == 0) hipLaunchKernelGGL(k_conv3_split_s4<2>, dim3(gx, nbt / 2), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_conv3_split_s4<1>, dim3(gx, nbt), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
         RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
         return RF_OK;
     }

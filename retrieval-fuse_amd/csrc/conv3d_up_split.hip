@@ -1075,13 +1075,18 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
     }
     if (edge == 4) {
         const int nbt = rf_round_up(cout, 16) / 16;
-        if (US_S4_WIDE && nbt == 4) {
-            // all 64 couts in one workgroup (256 VGPRs, 132 KB LDS, one workgroup per CU -- the shape of the 8^3 kernel): the samples are staged and
-            // converted ONCE instead of once per 16-cout block
-            static RfLdsOptIn opt_wide;
-            const int lds_wide = 64 * U4_E_STRIDE * 4;
-            if (int rc = opt_wide.ensure(reinterpret_cast<const void*>(k_conv3_up_split_s4<4, true>), lds_wide, "rf_conv3d_up_split_k3_gn_relu")) return rc;
-            hipLaunchKernelGGL((k_conv3_up_split_s4<4, true>), dim3((unsigned)((n + 7) / 8), 1u), dim3(512), lds_wide, (hipStream_t)stream, a);
+        if (US_S4_WIDE && (nbt == 4 || nbt == 3)) {
+            // all 64 (48: nf = 12) couts in one workgroup (256 VGPRs, 132 KB LDS, one workgroup per CU -- the shape of the 8^3 kernel): the samples are
+            // staged and converted ONCE instead of once per 16-cout block
+            static RfLdsOptIn opt_wide4, opt_wide3;
+            const int lds_wide = nbt * 16 * U4_E_STRIDE * 4;
+            if (nbt == 4) {
+                if (int rc = opt_wide4.ensure(reinterpret_cast<const void*>(k_conv3_up_split_s4<4, true>), lds_wide, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+                hipLaunchKernelGGL((k_conv3_up_split_s4<4, true>), dim3((unsigned)((n + 7) / 8), 1u), dim3(512), lds_wide, (hipStream_t)stream, a);
+            } else {
+                if (int rc = opt_wide3.ensure(reinterpret_cast<const void*>(k_conv3_up_split_s4<3, true>), lds_wide, "rf_conv3d_up_split_k3_gn_relu")) return rc;
+                hipLaunchKernelGGL((k_conv3_up_split_s4<3, true>), dim3((unsigned)((n + 7) / 8), 1u), dim3(512), lds_wide, (hipStream_t)stream, a);
+            }
             RF_CHECK_LAUNCH("rf_conv3d_up_split_k3_gn_relu");
             return RF_OK;
         }

@@ -186,6 +186,9 @@ SPLIT_BOX_CASES = [
     (1024, 64, 4, 64, 8),
     (2050, 8, 4, 12, 4),       # one chunk, cout < 16
     (1100, 32, 4, 32, 8),
+    (1030, 24, 4, 48, 6),      # nf = 12 (C5): 48 couts in one workgroup (NB 3)
+    (1026, 48, 4, 96, 6),      # ... 96 couts: two workgroups of 48
+    (1025, 16, 4, 44, 4),      # padded couts in the NB 3 instance
 ]
 
 
@@ -271,6 +274,7 @@ SPLIT_UP_CASES = [
     (1024, 0, 16, 4, 32, 8),    # no skip source, one partial group
     (2050, 8, 8, 4, 60, 4),     # one chunk each, padded couts
     (1100, 32, 72, 4, 32, 8),   # nine low-res chunks: groups of 4 + 4 + 1
+    (1030, 48, 96, 4, 48, 6),   # C5's dec0: 48 couts in one workgroup (NB 3 wide instance)
     (4, 0, 16, 64, 16, 8),      # 8^3 boxes of a large volume, no skip source (k_conv3_up_split_box): the final decoder's first conv, 512 boxes per sample
     (33, 0, 32, 32, 16, 8),     # the U-Net backbone's 32 -> 16 @32^3: four channel groups, ragged sample count
     (130, 0, 8, 16, 32, 4),     # one channel group, two n-blocks
