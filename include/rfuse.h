@@ -250,11 +250,25 @@ int rf_conv3d_k3_gn(const float* src0, int c0, const float* src1, int c1, int n,
                     const float* gn_affine, const float* w_packed, int cout, int relu, float* out, void* stream);
 /* out = dy where y > 0 else 0 (count floats, a multiple of 4): the ReLU of SingleConv 'gcr' (model/unet.py:45) backwards */
 int rf_relu_backward(const float* dy, const float* y, size_t count, float* out, void* stream);
+/* The data-gradient conv on the F16 matrix cores (split operands need their input inside the f16 pair's range, a gradient can be anywhere):
+ *   rf_relu_backward_amax   rf_relu_backward that also leaves max |out| as the maximum over amax_slots[rf_relu_backward_amax_slots()] (device
+ *                           floats, one per workgroup, all of them written: no atomics, no zeroing);
+ *   rf_dgrad_scale_affine   from those slots: the identity GroupNorm affine with scale s = the power of two that puts the maximum into [512, 1024)
+ *                           (rows x (0, s, 0, 0), the gn_affine layout) and scales = (s, 1 / s) -- exact scaling, no host sync;
+ *   rf_conv3d_split_k3_gn   rf_conv3d_split_k3_gn_relu as a plain operator: any cout (16 or 32 per workgroup), ReLU optional, no statistics.
+ * d xn = rf_conv3d_split_k3_gn(dz, affine of rf_dgrad_scale_affine, W^T with flipped taps, relu = 0) / s; rfuse/autograd.py takes 1 / s out in
+ * the GroupNorm backward that follows (gamma / s; dgamma, dbeta / s). */
+int rf_relu_backward_amax_slots(void);
+int rf_relu_backward_amax(const float* dy, const float* y, size_t count, float* out, float* amax_slots, void* stream);
+int rf_dgrad_scale_affine(const float* amax_slots, int rows, float* affine, float* scales, void* stream);
+int rf_conv3d_split_k3_gn_supported(int cin, int n, int edge, int cout);
+int rf_conv3d_split_k3_gn(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout, int relu,
+                          float* out, void* stream);
 /* GroupNorm backward (model/unet.py:54-66; torch.nn.GroupNorm semantics, biased variance): x, dxn [n][c][edge^3], gamma [c] ->
  * dx [n][c][edge^3] and per-(n, c) float64 pieces of dgamma / dbeta (sum them over n). */
 int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, float* dx,
                    double* dgamma_parts, double* dbeta_parts, void* ws, size_t ws_bytes, void* stream);
-size_t rf_gn_backward_ws_bytes(int n, int c);
+size_t rf_gn_backward_ws_bytes(int n, int c, int edge);
 /* Weight gradient of the 3x3x3 conv: dw[co][ci][tap] = sum_{n,v} dz[n][co][v] * GN(x)[n][ci][v + tap - 1] (zero padded), fp32 MFMA
  * with K = voxels; edge a power of two >= 8.  gn_affine as in the forward. */
 int rf_conv3d_k3_wgrad(const float* x, int cin, int n, int edge, const float* gn_affine, const float* dz, int cout, float* dw, void* ws,

@@ -28,120 +28,254 @@ extern "C" int rf_relu_backward(const float* dy, const float* y, size_t count, f
     return RF_OK;
 }
 
-// ------------------------------------------------------------------------------------------- GroupNorm backward
-// pass 1: per (sample, channel): mean / rstd of its group (recomputed: sum, sum of squares over the group), then
-// a1 = sum_v dxn, a2 = sum_v dxn * xh.  One workgroup per (n, c); every workgroup of a group recomputes the group moments
-// (cpg <= 16 re-reads of x: the backward pass is not the hot path).
-__global__ __launch_bounds__(256) void k_gnb_reduce(const float* __restrict__ x, const float* __restrict__ dxn, int C, int cpg, size_t vol, double eps,
-                                                    double2* __restrict__ moments, double* __restrict__ a1_out, double* __restrict__ a2_out) {
-    const int nc = blockIdx.x, nn = nc / C, c = nc % C, g = c / cpg;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ double red[8];
-    const float* xg = x + ((size_t)nn * C + (size_t)g * cpg) * vol;
-    const size_t glen = (size_t)cpg * vol;
-    double s = 0.0, q = 0.0;
-    if ((vol & 3) == 0) {                                           // 16-byte loads (every volume but 1^3)
-        const float4* xg4 = reinterpret_cast<const float4*>(xg);
-        for (size_t i = tid; i < glen / 4; i += 256) {
-            const float4 t = xg4[i];
-            const double v0 = t.x, v1 = t.y, v2 = t.z, v3 = t.w;
-            s += (v0 + v1) + (v2 + v3); q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-        }
-    } else {
-        for (size_t i = tid; i < glen; i += 256) { const double v = xg[i]; s += v; q += v * v; }
+// The same mask, and max |out| beside it: workgroup b leaves its maximum in slot b of RF_AMAX_SLOTS floats (and zeroes the slots b + gridDim.x, ...
+// nobody owns), the consumer takes the maximum of the slots.  (One atomicMax per workgroup on a single word was 10 ns each: 0.16 ms for 16 384
+// workgroups beside 0.03 ms of copying.)  The data-gradient conv on the F16 matrix cores wants its input scaled into the split forms' range.
+namespace { constexpr int RF_AMAX_SLOTS = 1024; }
+
+__global__ __launch_bounds__(256) void k_relu_bwd_amax(const float4* __restrict__ dy, const float4* __restrict__ y, size_t n4, float4* __restrict__ out,
+                                                       float* __restrict__ slots) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 g = dy[i], v = y[i];
+        const float4 o = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+        out[i] = o;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    s = wave_sum(s); q = wave_sum(q);
-    if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = q; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    double S = 0.0, Q = 0.0;
-    for (int w = 0; w < 4; ++w) { S += red[w * 2]; Q += red[w * 2 + 1]; }
-    __syncthreads();
-    const double mean = S / (double)glen;
-    double var = Q / (double)glen - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + eps);
-    const float* xc = x + (size_t)nc * vol;
-    const float* dc = dxn + (size_t)nc * vol;
-    double a1 = 0.0, a2 = 0.0;
-    if ((vol & 3) == 0) {
-        const float4* xc4 = reinterpret_cast<const float4*>(xc);
-        const float4* dc4 = reinterpret_cast<const float4*>(dc);
-        for (size_t i = tid; i < vol / 4; i += 256) {
-            const float4 xv = xc4[i], dv = dc4[i];
-            const double d0 = dv.x, d1 = dv.y, d2 = dv.z, d3 = dv.w;
-            a1 += (d0 + d1) + (d2 + d3);
-            a2 += (d0 * (((double)xv.x - mean) * rstd) + d1 * (((double)xv.y - mean) * rstd)) +
-                  (d2 * (((double)xv.z - mean) * rstd) + d3 * (((double)xv.w - mean) * rstd));
-        }
-    } else {
-        for (size_t i = tid; i < vol; i += 256) { const double d = dc[i]; a1 += d; a2 += d * ((double)xc[i] - mean) * rstd; }
-    }
-    a1 = wave_sum(a1); a2 = wave_sum(a2);
-    if (lane == 0) { red[wave * 2] = a1; red[wave * 2 + 1] = a2; }
-    __syncthreads();
-    if (tid == 0) {
-        double A1 = 0.0, A2 = 0.0;
-        for (int w = 0; w < 4; ++w) { A1 += red[w * 2]; A2 += red[w * 2 + 1]; }
-        a1_out[nc] = A1;
-        a2_out[nc] = A2;
-        moments[nc] = make_double2(mean, rstd);
+    if (threadIdx.x == 0) {
+        slots[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        for (unsigned k = blockIdx.x + gridDim.x; k < (unsigned)RF_AMAX_SLOTS; k += gridDim.x) slots[k] = 0.f;
     }
 }
 
-// pass 2: dx; and per (n, c) the pieces of dgamma / dbeta (summed over n by the caller in float64)
-__global__ __launch_bounds__(256) void k_gnb_apply(const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ gamma, int C,
-                                                   int cpg, size_t vol, const double2* __restrict__ moments, const double* __restrict__ a1,
-                                                   const double* __restrict__ a2, float* __restrict__ dx) {
-    const int nc = blockIdx.x, nn = nc / C, c = nc % C, g = c / cpg;
-    double G1 = 0.0, G2 = 0.0;                                       // sum over the group of gamma * a1, gamma * a2
-    for (int k = 0; k < cpg; ++k) {
-        const int cc = g * cpg + k;
-        G1 += (double)gamma[cc] * a1[(size_t)nn * C + cc];
-        G2 += (double)gamma[cc] * a2[(size_t)nn * C + cc];
+extern "C" int rf_relu_backward_amax_slots(void) { return RF_AMAX_SLOTS; }
+
+extern "C" int rf_relu_backward_amax(const float* dy, const float* y, size_t count, float* out, float* amax_slots, void* stream) {
+    RF_REQUIRE(dy && y && out && amax_slots && count > 0 && (count & 3) == 0, RF_E_INVALID, "rf_relu_backward_amax: bad arguments (count must be a multiple of 4)");
+    const size_t want = (count / 4 + 255) / 256;
+    hipLaunchKernelGGL(k_relu_bwd_amax, dim3((unsigned)(want < (size_t)RF_AMAX_SLOTS ? want : (size_t)RF_AMAX_SLOTS)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, (const float4*)y, count / 4, (float4*)out, amax_slots);
+    RF_CHECK_LAUNCH("rf_relu_backward_amax");
+    return RF_OK;
+}
+
+// identity GroupNorm affine (mean 0, shift 0) with scale s = the power of two that puts max |dz| into [512, 1024): rows x (0, s, 0, 0), and
+// scales = (s, 1 / s).  A zero, infinite or NaN maximum gives s = 1.  Everything stays on the device: no host sync in the backward pass.
+__global__ __launch_bounds__(256) void k_dgrad_affine(const float* __restrict__ slots, int rows, float4* __restrict__ affine, float* __restrict__ scales) {
+    float m = 0.f;
+    for (int k = threadIdx.x; k < RF_AMAX_SLOTS; k += 256) m = fmaxf(m, slots[k]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float s = 1.f;
+    if (m > 0.f && m < INFINITY) {
+        int e = 9 - ilogbf(m);
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        s = ldexpf(1.f, e);
     }
-    const double2 mo = moments[nc];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) affine[i] = make_float4(0.f, s, 0.f, 0.f);
+    if (i == 0) { scales[0] = s; scales[1] = 1.f / s; }
+}
+
+extern "C" int rf_dgrad_scale_affine(const float* amax_slots, int rows, float* affine, float* scales, void* stream) {
+    RF_REQUIRE(amax_slots && affine && scales && rows > 0, RF_E_INVALID, "rf_dgrad_scale_affine: bad arguments");
+    hipLaunchKernelGGL(k_dgrad_affine, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, amax_slots, rows, reinterpret_cast<float4*>(affine), scales);
+    RF_CHECK_LAUNCH("rf_dgrad_scale_affine");
+    return RF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- GroupNorm backward
+// Three launches, every tensor read once per pass and every launch wide enough for the chip whatever the shape ([4][16][64^3] of the final
+// decoder = 64 (sample, channel) pairs; [1024][8][16^3] of the retrieval backbone = 8192):
+//   pass 1  k_gnb_partial   per (sample, channel, slice of the volume): sum x, sum x^2, sum d, sum d * x  (d = d xn) in float64 -- raw sums, so
+//                           the pass needs no moments and reads x and d exactly once (a product of two floats is exact in float64);
+//   pass 2  k_gnb_finalize  per (sample, group): slices and channels summed in a fixed order -> mean, rstd, a1_c = sum d, a2_c = sum d * xh =
+//                           rstd * (sum d x - mean * sum d), G1 / G2 = the group's gamma-weighted sums -> the coefficients of pass 3 and the
+//                           per-sample pieces of dgamma / dbeta;
+//   pass 3  k_gnb_apply     dx = k0 * d - k1 - xh * k2   (float64 per element, rounded once).
+// (The first form recomputed the group moments in every channel's workgroup -- cpg re-reads of x -- with one workgroup per (sample, channel):
+// 3.9 ms of a 26.7 ms training step for 0.5 ms of traffic.)
+namespace {
+inline int gnb_slices(size_t vol) {                               // >= 4096 elements per workgroup of pass 1, at most 64 slices per channel
+    const size_t p = vol / 4096;
+    return p < 1 ? 1 : (p > 64 ? 64 : (int)p);
+}
+}
+
+// L = lanes per (sample, channel) row = 256 for volumes of >= 1024 elements, else the power of two >= the row's units (16-byte units; elements for
+// 1^3), at least 1: a workgroup takes 256 / L rows (a 4^3 row is 16 units: one row per workgroup left 240 of 256 threads idle -- 0.42 ms for
+// [1024][192][4^3]).  Sums: butterflies inside the row's lanes, then across its waves in order.
+__global__ __launch_bounds__(256) void k_gnb_partial(const float* __restrict__ x, const float* __restrict__ dxn, size_t vol, int P, int L, int rows,
+                                                     double4* __restrict__ part) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x * (256 / L) + tid / L, li = tid % L, p = blockIdx.y;
+    __shared__ double red[4][4];
+    double sx = 0.0, sq = 0.0, sd = 0.0, sdx = 0.0;
+    if (row < rows) {
+        const float* xc = x + (size_t)row * vol;
+        const float* dc = dxn + (size_t)row * vol;
+        if ((vol & 3) == 0) {                                       // 16-byte loads (every volume but 1^3)
+            const size_t u = vol / 4, i0 = u * p / P, i1 = u * (p + 1) / P;
+            const float4* xc4 = reinterpret_cast<const float4*>(xc);
+            const float4* dc4 = reinterpret_cast<const float4*>(dc);
+            for (size_t i = i0 + li; i < i1; i += L) {
+                const float4 xv = xc4[i], dv = dc4[i];
+                const double x0 = xv.x, x1 = xv.y, x2 = xv.z, x3 = xv.w, d0 = dv.x, d1 = dv.y, d2 = dv.z, d3 = dv.w;
+                sx += (x0 + x1) + (x2 + x3);
+                sq += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+                sd += (d0 + d1) + (d2 + d3);
+                sdx += (d0 * x0 + d1 * x1) + (d2 * x2 + d3 * x3);
+            }
+        } else {
+            const size_t i0 = vol * p / P, i1 = vol * (p + 1) / P;
+            for (size_t i = i0 + li; i < i1; i += L) {
+                const double xv = xc[i], dv = dc[i];
+                sx += xv; sq += xv * xv; sd += dv; sdx += dv * xv;
+            }
+        }
+    }
+    const int span = L < 64 ? L : 64;
+    for (int d = span >> 1; d >= 1; d >>= 1) {
+        sx += __shfl_xor(sx, d, 64); sq += __shfl_xor(sq, d, 64); sd += __shfl_xor(sd, d, 64); sdx += __shfl_xor(sdx, d, 64);
+    }
+    if (L <= 64) {
+        if (li == 0 && row < rows) part[(size_t)row * P + p] = make_double4(sx, sq, sd, sdx);
+        return;
+    }
+    if (lane == 0) { red[wave][0] = sx; red[wave][1] = sq; red[wave][2] = sd; red[wave][3] = sdx; }
+    __syncthreads();
+    if (li == 0 && row < rows) {                                    // L = 128 (two rows per workgroup: waves 0-1, 2-3) or 256
+        const int w0 = wave, nw = L / 64;
+        double4 o = make_double4(0.0, 0.0, 0.0, 0.0);
+        for (int w = w0; w < w0 + nw; ++w) { o.x += red[w][0]; o.y += red[w][1]; o.z += red[w][2]; o.w += red[w][3]; }
+        part[(size_t)row * P + p] = o;
+    }
+}
+
+// one 64-thread workgroup per (sample, group); thread k sums the slices of channel k (k, k + 64, ...) in slice order, thread 0 the channels in order
+__global__ __launch_bounds__(64) void k_gnb_finalize(const double4* __restrict__ part, const float* __restrict__ gamma, int C, int cpg, size_t vol, int P,
+                                                     double eps, double2* __restrict__ moments, double4* __restrict__ coef,
+                                                     double* __restrict__ a1_out, double* __restrict__ a2_out) {
+    const int groups = C / cpg, nn = blockIdx.x / groups, g = blockIdx.x % groups, tid = threadIdx.x;
+    __shared__ double4 ch[64];
+    __shared__ double grp[4];                                       // mean, rstd, G1, G2
     const double m = (double)cpg * (double)vol;
-    const double k0 = mo.y * (double)gamma[c], k1 = mo.y * G1 / m, k2 = mo.y * G2 / m;
-    const float* xc = x + (size_t)nc * vol;
-    const float* dc = dxn + (size_t)nc * vol;
-    float* o = dx + (size_t)nc * vol;
+    double S = 0.0, Q = 0.0;
+    for (int k0 = 0; k0 < cpg; k0 += 64) {                          // moments first: the channels' a2 need the mean
+        if (k0 + tid < cpg) {
+            const double4* pp = part + ((size_t)nn * C + (size_t)g * cpg + k0 + tid) * P;
+            double4 o = make_double4(0.0, 0.0, 0.0, 0.0);
+            for (int p = 0; p < P; ++p) { const double4 v = pp[p]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+            ch[tid] = o;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < 64 && k0 + k < cpg; ++k) { S += ch[k].x; Q += ch[k].y; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double mean = S / m;
+        double var = Q / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        grp[0] = mean; grp[1] = 1.0 / sqrt(var + eps); grp[2] = 0.0; grp[3] = 0.0;
+    }
+    __syncthreads();
+    const double mean = grp[0], rstd = grp[1];
+    for (int k0 = 0; k0 < cpg; k0 += 64) {
+        const int cc = g * cpg + k0 + tid;
+        if (k0 + tid < cpg) {
+            double4 o = ch[tid];
+            if (cpg > 64) {                                         // more than one round: the sums were overwritten, take them again
+                const double4* pp = part + ((size_t)nn * C + cc) * P;
+                o = make_double4(0.0, 0.0, 0.0, 0.0);
+                for (int p = 0; p < P; ++p) { const double4 v = pp[p]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+            }
+            const double a1 = o.z, a2 = rstd * (o.w - mean * o.z);
+            a1_out[(size_t)nn * C + cc] = a1;
+            a2_out[(size_t)nn * C + cc] = a2;
+            ch[tid] = make_double4((double)gamma[cc] * a1, (double)gamma[cc] * a2, 0.0, 0.0);
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < 64 && k0 + k < cpg; ++k) { grp[2] += ch[k].x; grp[3] += ch[k].y; }
+        __syncthreads();
+    }
+    const double G1 = grp[2], G2 = grp[3];
+    for (int k = tid; k < cpg; k += 64) {
+        const int cc = g * cpg + k;
+        moments[(size_t)nn * C + cc] = make_double2(mean, rstd);
+        coef[(size_t)nn * C + cc] = make_double4(rstd * (double)gamma[cc], rstd * G1 / m, rstd * G2 / m, 0.0);
+    }
+}
+
+// flat over the tensor's 16-byte units (elements for 1^3): a row's coefficients come through the cache, rows of any length fill the workgroups
+__global__ __launch_bounds__(256) void k_gnb_apply(const float* __restrict__ x, const float* __restrict__ dxn, size_t vol, size_t rows, const double2* __restrict__ moments,
+                                                   const double4* __restrict__ coef, float* __restrict__ dx) {
     if ((vol & 3) == 0) {
-        const float4* xc4 = reinterpret_cast<const float4*>(xc);
-        const float4* dc4 = reinterpret_cast<const float4*>(dc);
-        float4* o4 = reinterpret_cast<float4*>(o);
-        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < vol / 4; i += (size_t)gridDim.y * 256) {
-            const float4 xv = xc4[i], dv = dc4[i];
+        const size_t u = vol / 4, total = rows * u;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* d4 = reinterpret_cast<const float4*>(dxn);
+        float4* o4 = reinterpret_cast<float4*>(dx);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t nc = i / u;
+            const double2 mo = moments[nc];
+            const double4 kf = coef[nc];
+            const float4 xv = x4[i], dv = d4[i];
             float4 r;
-            r.x = (float)(k0 * (double)dv.x - k1 - (((double)xv.x - mo.x) * mo.y) * k2);
-            r.y = (float)(k0 * (double)dv.y - k1 - (((double)xv.y - mo.x) * mo.y) * k2);
-            r.z = (float)(k0 * (double)dv.z - k1 - (((double)xv.z - mo.x) * mo.y) * k2);
-            r.w = (float)(k0 * (double)dv.w - k1 - (((double)xv.w - mo.x) * mo.y) * k2);
+            r.x = (float)(kf.x * (double)dv.x - kf.y - (((double)xv.x - mo.x) * mo.y) * kf.z);
+            r.y = (float)(kf.x * (double)dv.y - kf.y - (((double)xv.y - mo.x) * mo.y) * kf.z);
+            r.z = (float)(kf.x * (double)dv.z - kf.y - (((double)xv.z - mo.x) * mo.y) * kf.z);
+            r.w = (float)(kf.x * (double)dv.w - kf.y - (((double)xv.w - mo.x) * mo.y) * kf.z);
             o4[i] = r;
         }
     } else {
-        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < vol; i += (size_t)gridDim.y * 256) {
-            const double xh = ((double)xc[i] - mo.x) * mo.y;
-            o[i] = (float)(k0 * (double)dc[i] - k1 - xh * k2);
+        const size_t total = rows * vol;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t nc = i / vol;
+            const double2 mo = moments[nc];
+            const double4 kf = coef[nc];
+            const double xh = ((double)x[i] - mo.x) * mo.y;
+            dx[i] = (float)(kf.x * (double)dxn[i] - kf.y - xh * kf.z);
         }
     }
 }
 
-extern "C" size_t rf_gn_backward_ws_bytes(int n, int c) { return (size_t)n * c * sizeof(double2); }
+extern "C" size_t rf_gn_backward_ws_bytes(int n, int c, int edge) {
+    const size_t vol = (size_t)edge * edge * edge;
+    return (size_t)n * c * ((size_t)gnb_slices(vol) * sizeof(double4) + sizeof(double2) + sizeof(double4));
+}
 
 // x, dxn [n][c][edge^3]; gamma [c]; out: dx [n][c][edge^3], dgamma_parts / dbeta_parts [n][c] float64 (the caller sums over n)
 extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, float* dx,
                               double* dgamma_parts, double* dbeta_parts, void* ws, size_t ws_bytes, void* stream) {
     RF_REQUIRE(x && dxn && gamma && dx && dgamma_parts && dbeta_parts && ws && n > 0 && c > 0 && edge > 0 && groups > 0 && c % groups == 0, RF_E_INVALID,
                "rf_gn_backward: bad arguments");
-    RF_REQUIRE(ws_bytes >= rf_gn_backward_ws_bytes(n, c), RF_E_WORKSPACE, "rf_gn_backward: workspace too small");
+    RF_REQUIRE(ws_bytes >= rf_gn_backward_ws_bytes(n, c, edge), RF_E_WORKSPACE, "rf_gn_backward: workspace too small");
     const size_t vol = (size_t)edge * edge * edge;
-    const int cpg = c / groups;
-    double2* moments = (double2*)ws;
+    const int cpg = c / groups, P = gnb_slices(vol);
+    double4* part = (double4*)ws;                                    // [n * c][P]
+    double4* coef = part + (size_t)n * c * P;                        // [n * c]
+    double2* moments = (double2*)(coef + (size_t)n * c);             // [n * c]
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gnb_reduce, dim3(n * c), dim3(256), 0, s, x, dxn, c, cpg, vol, (double)eps, moments, dbeta_parts, dgamma_parts);
-    RF_CHECK_LAUNCH("rf_gn_backward(reduce)");
-    const unsigned gy = (unsigned)((vol / 4 + 1023) / 1024);          // 1024 float4 per workgroup
-    hipLaunchKernelGGL(k_gnb_apply, dim3(n * c, gy < 1 ? 1 : gy), dim3(256), 0, s, x, dxn, gamma, c, cpg, vol, moments, dbeta_parts, dgamma_parts, dx);
+    const size_t units = (vol & 3) == 0 ? vol / 4 : vol;
+    int L = 1;
+    while (L < 256 && (size_t)L < units) L <<= 1;                   // lanes per row: the power of two >= its units, at most a workgroup
+    const int rows = n * c, rpw = 256 / L;
+    hipLaunchKernelGGL(k_gnb_partial, dim3((unsigned)((rows + rpw - 1) / rpw), P), dim3(256), 0, s, x, dxn, vol, P, L, rows, part);
+    RF_CHECK_LAUNCH("rf_gn_backward(partial)");
+    hipLaunchKernelGGL(k_gnb_finalize, dim3(n * groups), dim3(64), 0, s, part, gamma, c, cpg, vol, P, (double)eps, moments, coef, dbeta_parts, dgamma_parts);
+    RF_CHECK_LAUNCH("rf_gn_backward(finalize)");
+    const size_t want = ((size_t)rows * units + 255) / 256;
+    hipLaunchKernelGGL(k_gnb_apply, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, s, x, dxn, vol, (size_t)rows, moments, coef, dx);
     RF_CHECK_LAUNCH("rf_gn_backward(apply)");
     return RF_OK;
 }

@@ -709,6 +709,35 @@ static int launch_split(const ConvArgs& a, hipStream_t stream, const SplitPreOut
     return RF_OK;
 }
 
+static int split_run(const ConvArgs& a, void* stream) {
+    // 32 couts: one workgroup with two n-blocks per box (158 VGPRs: every A operand read from LDS feeds six MFMAs instead of three -- the
+    // 16-cout instance asks the LDS for 170 B/clk of A operands and gets 128).  Round 2 ran 32 couts as two 16-cout workgroups because this
+    // instance leaves room for other kernels' waves on its SIMDs and fp32 kernels of another stream then returned different bits beside its
+    // F16 MFMAs; that was an unsafe packed-fp32 instruction form in THOSE kernels (DESIGN 4.7), gone since round 3.
+    // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
+    // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and
+    // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
+    const int cin = a.c0, n = a.n, edge = a.edge;
+    if (edge == 4) {
+        RF_REQUIRE(!a.pool_out, RF_E_UNSUPPORTED, "rf_conv3d_split_k3_gn_relu: the 4^3 form has no fused max-pool (pool its output with rf_maxpool3d_2_stats)");
+        // all couts of a 32 / 64-cout layer in one workgroup (samples staged once; 4^3 levels of the retrieval backbone: 32 -> 32, 32 -> 64, 64 -> 64)
+        const unsigned gx = (unsigned)((n + 7) / 8), nbt = (unsigned)(a.cout16 / 16);
+        if (CS_S4_WIDE && nbt % 4 == 0) hipLaunchKernelGGL(k_conv3_split_s4<4>, dim3(gx, nbt / 4), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        else if (CS_S4_WIDE && nbt % 3 == 0) hipLaunchKernelGGL(k_conv3_split_s4<3>, dim3(gx, nbt / 3), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);      // nf = 12: 48 / 96 couts
+        else if (CS_S4_WIDE && nbt % 2 == 0) hipLaunchKernelGGL(k_conv3_split_s4<2>, dim3(gx, nbt / 2), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_conv3_split_s4<1>, dim3(gx, nbt), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
+        RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
+        return RF_OK;
+    }
+    if (cin % 8) {
+        if (cin < 8) return launch_split<1, 6, true, true>(a, (hipStream_t)stream);                   // 6 -> 12 of the nf = 12 U-Nets: one chunk, two zero slots
+        if (a.cout16 % 32 == 0) return launch_split<2, 2, false, true>(a, (hipStream_t)stream);
+        return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
+    }
+    if (cin > 8 && a.cout16 % 32 == 0) return launch_split<2, 2, false>(a, (hipStream_t)stream);
+    return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
+}
+
 extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                            float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
     RF_REQUIRE(rf_conv3d_split_supported(cin, 0, n, edge, cout), RF_E_UNSUPPORTED,
@@ -725,31 +754,30 @@ extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int 
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
     a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
     a.floor = 0.f;
-    // 32 couts: one workgroup with two n-blocks per box (158 VGPRs: every A operand read from LDS feeds six MFMAs instead of three -- the
-    // 16-cout instance asks the LDS for 170 B/clk of A operands and gets 128).  Round 2 ran 32 couts as two 16-cout workgroups because this
-    // instance leaves room for other kernels' waves on its SIMDs and fp32 kernels of another stream then returned different bits beside its
-    // F16 MFMAs; that was an unsafe packed-fp32 instruction form in THOSE kernels (DESIGN 4.7), gone since round 3.
-    // one 8-channel chunk (the retrieval backbone's 8 -> 16 @16^3 conv): no prefetch registers, one chunk buffer (32 KB), 80 VGPRs -> three
-    // workgroups = six waves per SIMD per CU; the layer is bound by the per-box latency chain (load -> stage -> 7 k-steps -> epilogue), and
-    // a third box in flight per CU is worth 13 % (1.60 -> 1.40 ms)
-    if (edge == 4) {
-        RF_REQUIRE(!pool_out, RF_E_UNSUPPORTED, "rf_conv3d_split_k3_gn_relu: the 4^3 form has no fused max-pool (pool its output with rf_maxpool3d_2_stats)");
-        // all couts of a 32 / 64-cout layer in one workgroup (samples staged once; 4^3 levels of the retrieval backbone: 32 -> 32, 32 -> 64, 64 -> 64)
-        const unsigned gx = (unsigned)((n + 7) / 8), nbt = (unsigned)(a.cout16 / 16);
-        if (CS_S4_WIDE && nbt % 4 == 0) hipLaunchKernelGGL(k_conv3_split_s4<4>, dim3(gx, nbt / 4), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
-        else if (CS_S4_WIDE && nbt % 3 == 0) hipLaunchKernelGGL(k_conv3_split_s4<3>, dim3(gx, nbt / 3), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);      // nf = 12: 48 / 96 couts
-        else if (CS_S4_WIDE && nbt % 2 == 0) hipLaunchKernelGGL(k_conv3_split_s4<2>, dim3(gx, nbt / 2), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(k_conv3_split_s4<1>, dim3(gx, nbt), dim3(512), S4_LDS_BYTES, (hipStream_t)stream, a);
-        RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
-        return RF_OK;
-    }
-    if (cin % 8) {
-        if (cin < 8) return launch_split<1, 6, true, true>(a, (hipStream_t)stream);                   // 6 -> 12 of the nf = 12 U-Nets: one chunk, two zero slots
-        if (a.cout16 == 32) return launch_split<2, 2, false, true>(a, (hipStream_t)stream);
-        return launch_split<1, 4, false, true>(a, (hipStream_t)stream);
-    }
-    if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false>(a, (hipStream_t)stream);
-    return cin == 8 ? launch_split<1, 6, true>(a, (hipStream_t)stream) : launch_split<1, 4, false>(a, (hipStream_t)stream);
+    return split_run(a, stream);
+}
+
+// The same conv as a plain operator for the training slice's data gradient (rfuse/autograd.py: d xn = conv3(dz, W^T with flipped taps)): any cout
+// (16 or 32 per workgroup, the cout blocks on grid.y), ReLU optional, no statistics, no pooling.  The caller scales dz into the split forms' range
+// through the affine (rf_dgrad_scale_affine: a power of two, exact) and takes the scale out again downstream.
+extern "C" int rf_conv3d_split_k3_gn_supported(int cin, int n, int edge, int cout) {
+    if (edge == 4) return rf_conv3d_split_supported(cin, 0, n, edge, cout);
+    if (cin < 6 || 4 * cin < 3 * rf_round_up(cin, 8) || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
+    return rf_conv_use_big(n, edge, 64);
+}
+
+extern "C" int rf_conv3d_split_k3_gn(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout, int relu,
+                                      float* out, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_k3_gn_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_k3_gn: takes cin >= 6 (at least 3/4 of the next multiple of 8), edge >= 8 with enough 8^3 boxes or whole 4^3 samples (got cin=%d n=%d edge=%d cout=%d)",
+               cin, n, edge, cout);
+    RF_REQUIRE(src && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_split_k3_gn: null pointer");
+    ConvArgs a;
+    a.src0 = src; a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const float*>(w_packed); a.out = out;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = rf_round_up(cout, 16);
+    a.stats = nullptr; a.stats_tiles = 0; a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0;
+    a.floor = relu ? 0.f : -INFINITY;
+    return split_run(a, stream);
 }
 
 // The same layer on a PRE-SPLIT input (already normalised for this layer's GroupNorm and split by its producer: rf_conv3d_cin1_presplit):

@@ -82,8 +82,13 @@ SIGNATURES = {
     'rf_conv3d_up_split_k3_gn_relu': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_p, c_p]),
     'rf_conv3d_k3_gn': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_p]),
     'rf_relu_backward': (c_i, [c_fp, c_fp, c_sz, c_fp, c_p]),
+    'rf_relu_backward_amax_slots': (c_i, []),
+    'rf_relu_backward_amax': (c_i, [c_fp, c_fp, c_sz, c_fp, c_fp, c_p]),
+    'rf_dgrad_scale_affine': (c_i, [c_fp, c_i, c_fp, c_fp, c_p]),
+    'rf_conv3d_split_k3_gn_supported': (c_i, [c_i, c_i, c_i, c_i]),
+    'rf_conv3d_split_k3_gn': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_i, c_fp, c_p]),
     'rf_gn_backward': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_i, c_f, c_fp, c_p, c_p, c_p, c_sz, c_p]),
-    'rf_gn_backward_ws_bytes': (c_sz, [c_i, c_i]),
+    'rf_gn_backward_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_k3_wgrad': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_sz, c_p]),
     'rf_conv3d_k3_wgrad_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'rf_unfold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),

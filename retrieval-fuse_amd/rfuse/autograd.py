@@ -41,6 +41,39 @@ def relu_backward(dy, y):
 
 
 @ops._device_scoped
+def relu_backward_amax(dy, y):
+    """relu_backward and max |result| (per-workgroup maxima on the device) beside it"""
+    out = torch.empty_like(y)
+    lib = _lib.load()
+    amax = torch.empty(lib.rf_relu_backward_amax_slots(), dtype=torch.float32, device=y.device)       # per-workgroup maxima, reduced by the consumer
+    _lib.check(lib.rf_relu_backward_amax(_p(dy), _p(y), y.numel(), _p(out), _p(amax), _stream()), 'rf_relu_backward_amax')
+    return out, amax
+
+
+@ops._device_scoped
+def dgrad_split(dz, amax, weight, cin):
+    """d xn * s = conv3(dz * s, W^T with flipped taps) on the F16 matrix cores (csrc/conv3d_split.hip, split operands): s = the power of two
+    that puts max |dz| into [512, 1024) (the split forms carry values as f16 pairs: a gradient has to be brought into their range first; a power
+    of two is exact), decided and applied on the device.  Returns (d xn * s, 1 / s as a device scalar)."""
+    n, cout, edge = dz.shape[0], dz.shape[1], dz.shape[2]
+    lib = _lib.load()
+    ident = torch.empty((n, cout, 4), dtype=torch.float32, device=dz.device)
+    scales = torch.empty(2, dtype=torch.float32, device=dz.device)
+    _lib.check(lib.rf_dgrad_scale_affine(_p(amax), n * cout, _p(ident), _p(scales), _stream()), 'rf_dgrad_scale_affine')
+    wt = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [cin, cout, 3,3,3]: the data-gradient conv's weight
+    out = torch.empty((n, cin, edge, edge, edge), dtype=torch.float32, device=dz.device)
+    _lib.check(lib.rf_conv3d_split_k3_gn(_p(dz), cout, n, edge, _p(ident), _p(ops.pack_conv3_split_weight(wt)), cin, 0, _p(out), _stream()),
+               'rf_conv3d_split_k3_gn')
+    return out, scales[1]
+
+
+def dgrad_split_supported(dz, weight, cin):
+    n, cout, edge = dz.shape[0], dz.shape[1], dz.shape[2]
+    return (ops.CONV_ARITH == 'split' and dz.numel() % 4 == 0 and bool(_lib.load().rf_conv3d_split_k3_gn_supported(cout, n, edge, cin))
+            and ops.split_range_ok(weight))
+
+
+@ops._device_scoped
 def conv3d_gn(x, aff, w_packed, cout, relu):
     n, c, edge = x.shape[0], x.shape[1], x.shape[2]
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=x.device)
@@ -55,7 +88,7 @@ def gn_backward(x, dxn, gamma, groups, eps):
     dx = torch.empty_like(x)
     dg = torch.empty((n, c), dtype=torch.float64, device=x.device)
     db = torch.empty((n, c), dtype=torch.float64, device=x.device)
-    ws = _ws(x.device, lib.rf_gn_backward_ws_bytes(n, c))
+    ws = _ws(x.device, lib.rf_gn_backward_ws_bytes(n, c, edge))
     _lib.check(lib.rf_gn_backward(_p(x), _p(dxn), n, c, edge, _p(gamma), groups, eps, _p(dx), _p(dg), _p(db), _p(ws), ws.numel(), _stream()), 'rf_gn_backward')
     return dx, dg.sum(0).float(), db.sum(0).float()
 
@@ -72,17 +105,27 @@ def conv3d_wgrad(x, aff, dz, cout):
 
 class ConvGnRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, groups, eps):
+    def forward(ctx, x, gamma, beta, weight, groups, eps, skip=None, low=None):
+        """``skip`` / ``low``: for a decoder layer, the two sources x was concatenated from (full-resolution skip or None, low-resolution source):
+        hints for the forward kernel only (the decoder form convolves the upsampled channels in low resolution), no gradient flows to them."""
         x = x.contiguous()
         n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
         cout = weight.shape[0]
         g = 1 if cin < groups else groups
         with torch.no_grad():
             aff = ops.gn_affine(x, None, gamma, beta, g, eps)
+            w = weight.contiguous()
+            # the inference kernels, chosen like model/unet.py:SingleConv.forward chooses them: the split-operand forms where the parameters are
+            # inside their range (one batched range check per optimiser step, ops._abs_max), the fp32 kernels otherwise
+            split_ok = edge > 1 and ops.CONV_ARITH == 'split' and ops.split_range_ok(weight, gamma, beta, (cin // g) * edge ** 3)
             if edge == 1:
-                y = ops.conv3d_gn_relu(x, None, aff, None, cout, direct_weight=weight.contiguous())
+                y = ops.conv3d_gn_relu(x, None, aff, None, cout, direct_weight=w)
+            elif split_ok and ops.conv_split_supported(x, None, cout):
+                y = ops.conv3d_split_gn_relu(x, aff, ops.pack_conv3_split_weight(w), cout)
+            elif split_ok and low is not None and ops.conv_up_split_supported(skip, low, cout):
+                y = ops.conv3d_up_split_gn_relu(skip, low, aff, ops.pack_conv3_up_split_weight(w, cin - low.shape[1]), cout)
             else:
-                y = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(weight.contiguous()), cout)
+                y = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(w), cout)
         ctx.save_for_backward(x, gamma, weight, aff, y)
         ctx.groups, ctx.eps = g, eps
         return y
@@ -93,8 +136,15 @@ class ConvGnRelu(torch.autograd.Function):
         n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
         cout = weight.shape[0]
         with torch.no_grad():
-            dz = relu_backward(dy.contiguous(), y) if y.numel() % 4 == 0 else dy * (y > 0)
-            if edge >= 2:
+            inv_s = None
+            if edge >= 4 and dgrad_split_supported(y, weight, cin):
+                dz, amax = relu_backward_amax(dy.contiguous(), y)
+                dxn, inv_s = dgrad_split(dz, amax, weight, cin)
+            else:
+                dz = relu_backward(dy.contiguous(), y) if y.numel() % 4 == 0 else dy * (y > 0)
+            if inv_s is not None:
+                pass
+            elif edge >= 2:
                 wt = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [cin, cout, 3,3,3]: the data-gradient conv's weight
                 ident = torch.zeros((n, cout, 4), dtype=torch.float32, device=x.device)
                 ident[..., 1] = 1.0
@@ -110,8 +160,12 @@ class ConvGnRelu(torch.autograd.Function):
                 cols = cols.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(n * edge ** 3, cin * 27)
                 dzf = dz.permute(0, 2, 3, 4, 1).reshape(n * edge ** 3, cout)
                 dw = ops.linear_wgrad(dzf.contiguous(), cols.contiguous()).reshape(cout, cin, 3, 3, 3)
-            dx, dgamma, dbeta = gn_backward(x, dxn.contiguous(), gamma, ctx.groups, ctx.eps)
-        return dx, dgamma, dbeta, dw, None, None
+            if inv_s is None:
+                dx, dgamma, dbeta = gn_backward(x, dxn.contiguous(), gamma, ctx.groups, ctx.eps)
+            else:                                                                   # d xn came scaled by s: GroupNorm backward is linear in it
+                dx, dgamma, dbeta = gn_backward(x, dxn, gamma * inv_s, ctx.groups, ctx.eps)
+                dgamma, dbeta = dgamma * inv_s, dbeta * inv_s
+        return dx, dgamma, dbeta, dw, None, None, None, None
 
 
 class Linear(torch.autograd.Function):
@@ -153,7 +207,9 @@ class _Upsample2(torch.autograd.Function):
 
 def conv_gn_relu(x, upsampled, gamma, beta, weight, groups, eps):
     """grad-mode SingleConv: two-source (decoder) layers are differentiated through a materialised nearest-x2 upsample + concat"""
+    skip = low = None
     if upsampled is not None:
+        skip, low = (x.detach().contiguous() if x is not None else None), upsampled.detach().contiguous()
         up = _Upsample2.apply(upsampled)
         x = up if x is None else torch.cat((x, up), dim=1)
-    return ConvGnRelu.apply(x, gamma, beta, weight, groups, eps)
+    return ConvGnRelu.apply(x, gamma, beta, weight, groups, eps, skip, low)

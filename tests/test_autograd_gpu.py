@@ -30,10 +30,17 @@ def rel_err(got, ref):
 
 
 @pytest.mark.parametrize('case', [(3, 8, 0, 16, 16, 8), (2, 16, 0, 8, 32, 8), (5, 6, 0, 8, 12, 6), (4, 32, 0, 4, 64, 8), (6, 64, 0, 2, 64, 8),
-                                  (3, 64, 0, 1, 128, 8), (2, 1, 0, 16, 8, 8), (2, 16, 32, 8, 24, 8), (1, 0, 16, 16, 16, 8)])
+                                  (3, 64, 0, 1, 128, 8), (2, 1, 0, 16, 8, 8), (2, 16, 32, 8, 24, 8), (1, 0, 16, 16, 16, 8),
+                                  # enough boxes for the split-operand routes: forward on the F16 cores, data gradient on them through a scaled dz
+                                  (130, 8, 0, 16, 16, 8), (1030, 16, 0, 8, 32, 8), (1030, 32, 0, 4, 64, 8), (1030, 8, 8, 8, 40, 4),
+                                  (4, 16, 0, 64, 16, 8),                  # few samples, large volumes: GroupNorm backward in 64 slices per channel
+                                  (1030, 16, 0, 8, 16, 8, 1e-9), (130, 8, 0, 16, 16, 8, 3e7)])     # tiny / huge upstream gradients
 def test_single_conv_gradients_match_float64_oracle(gpu, case):
-    """(n, c0, c1, edge, cout, groups): full-resolution source, optional low-res source (decoder layers), edges 16 .. 1"""
+    """(n, c0, c1, edge, cout, groups[, scale of the upstream gradient]): full-resolution source, optional low-res source (decoder layers),
+    edges 64 .. 1"""
     from model.unet import SingleConv
+    gscale = case[6] if len(case) > 6 else 1.0
+    case = case[:6]
     n, c0, c1, edge, cout, groups = case
     gen = torch.Generator().manual_seed(sum(case))
     cin = c0 + c1
@@ -45,10 +52,9 @@ def test_single_conv_gradients_match_float64_oracle(gpu, case):
     layer.to(gpu)
     x0 = torch.randn(n, c0, edge, edge, edge, generator=gen).relu() if c0 else None
     x1 = torch.randn(n, c1, edge // 2, edge // 2, edge // 2, generator=gen).relu() if c1 else None
-    r = torch.randn(n, cout, edge, edge, edge, generator=gen)
+    r = torch.randn(n, cout, edge, edge, edge, generator=gen) * gscale
     ins = [t.to(gpu).requires_grad_(True) if t is not None else None for t in (x0, x1)]
     y = layer(ins[0], ins[1])
-    (y * r.to(gpu)).sum().backward()
     # float64 oracle
     sd = {'p.groupnorm.weight': layer.groupnorm.weight.detach().cpu().double().requires_grad_(True),
           'p.groupnorm.bias': layer.groupnorm.bias.detach().cpu().double().requires_grad_(True),
@@ -57,6 +63,12 @@ def test_single_conv_gradients_match_float64_oracle(gpu, case):
     o1 = x1.double().requires_grad_(True) if c1 else None
     parts = ([o0] if c0 else []) + ([F.interpolate(o1, scale_factor=2, mode='nearest')] if c1 else [])
     yo = refpath.single_conv_gcr(torch.cat(parts, 1), sd, 'p', groups)
+    # an output within round-off of 0 can sit on different sides of the ReLU in fp32 and float64 (one such element among 21 M moves dx by 8e-3 of its
+    # maximum): no upstream gradient there, on either side -- the comparison is of the gradient arithmetic, not of that coin toss
+    flips = (y.detach().cpu() > 0) != (yo.detach() > 0)
+    assert int(flips.sum()) <= 4
+    r = r.masked_fill(flips, 0.0)
+    (y * r.to(gpu)).sum().backward()
     (yo * r.double()).sum().backward()
     assert rel_err(y, yo) < 1e-5
     errs = {'dW': rel_err(layer.conv.weight.grad, sd['p.conv.weight'].grad), 'dgamma': rel_err(layer.groupnorm.weight.grad, sd['p.groupnorm.weight'].grad),
