@@ -264,13 +264,21 @@ int rf_dgrad_scale_affine(const float* amax_slots, int rows, float* affine, floa
 int rf_conv3d_split_k3_gn_supported(int cin, int n, int edge, int cout);
 int rf_conv3d_split_k3_gn(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout, int relu,
                           float* out, void* stream);
+/* The pooling / upsampling ops of the training graph on [n][c][edge^3] tensors:
+ *   rf_maxpool3d_2_backward   MaxPool3d(2) backward (model/unet.py:159): dy [n][c][(edge/2)^3] goes to the FIRST maximum of each 2x2x2 cell of x in
+ *                             (z, y, x) order (torch's choice), zeros elsewhere -> dx [n][c][edge^3];
+ *   rf_upsample3d_2           nearest x2 upsample (model/unet.py:297-308) lo [n][c][edge_lo^3] -> hi [n][c][(2 edge_lo)^3];
+ *   rf_sumpool3d_2            its backward: the sum over each 2x2x2 cell in (z, y, x) order. */
+int rf_maxpool3d_2_backward(const float* x, const float* dy, int n, int c, int edge, float* dx, void* stream);
+int rf_upsample3d_2(const float* lo, int n, int c, int edge_lo, float* hi, void* stream);
+int rf_sumpool3d_2(const float* hi, int n, int c, int edge, float* lo, void* stream);
 /* GroupNorm backward (model/unet.py:54-66; torch.nn.GroupNorm semantics, biased variance): x, dxn [n][c][edge^3], gamma [c] ->
  * dx [n][c][edge^3] and per-(n, c) float64 pieces of dgamma / dbeta (sum them over n). */
 int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, float* dx,
                    double* dgamma_parts, double* dbeta_parts, void* ws, size_t ws_bytes, void* stream);
 size_t rf_gn_backward_ws_bytes(int n, int c, int edge);
 /* Weight gradient of the 3x3x3 conv: dw[co][ci][tap] = sum_{n,v} dz[n][co][v] * GN(x)[n][ci][v + tap - 1] (zero padded), fp32 MFMA
- * with K = voxels; edge a power of two >= 8.  gn_affine as in the forward. */
+ * with K = voxels; edge a power of two >= 4 (8^3 boxes; whole 4^3 samples eight at a time).  gn_affine as in the forward. */
 int rf_conv3d_k3_wgrad(const float* x, int cin, int n, int edge, const float* gn_affine, const float* dz, int cout, float* dw, void* ws,
                        size_t ws_bytes, void* stream);
 size_t rf_conv3d_k3_wgrad_ws_bytes(int cin, int cout, int n, int edge);

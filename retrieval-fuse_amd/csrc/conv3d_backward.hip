@@ -93,6 +93,92 @@ extern "C" int rf_dgrad_scale_affine(const float* amax_slots, int rows, float* a
     return RF_OK;
 }
 
+// ------------------------------------------------------------------------------------- pooling / upsampling of the training slice
+// MaxPool3d(2) backward (reference model/unet.py:159 pools between the encoder levels): the gradient of a pooled cell goes to the cell's FIRST
+// maximum in (z, y, x) order -- torch.nn.MaxPool3d's choice (its scan keeps the first of equal values), the other seven voxels get 0.
+// One thread per pooled cell: 4 float2 loads of x, 4 float2 stores.  rows = n * c volumes of edge^3.
+__global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ dy, size_t cells, int half, float* __restrict__ dx) {
+    const int edge = 2 * half;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / ((size_t)half * half * half);
+        const int q = (int)(i % ((size_t)half * half * half));
+        const int px = q % half, py = (q / half) % half, pz = q / (half * half);
+        const size_t base = row * (size_t)edge * edge * edge + ((size_t)(2 * pz) * edge + 2 * py) * edge + 2 * px;
+        float2 v[4];
+        int best = 0;
+        float m = -INFINITY;                                        // torch's scan: if (val > max || isnan(val)) { max = val; index = here; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = *reinterpret_cast<const float2*>(x + base + ((size_t)(k >> 1) * edge + (k & 1)) * edge);
+            if (v[k].x > m || v[k].x != v[k].x) { m = v[k].x; best = 2 * k; }
+            if (v[k].y > m || v[k].y != v[k].y) { m = v[k].y; best = 2 * k + 1; }
+        }
+        const float g = dy[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float2*>(dx + base + ((size_t)(k >> 1) * edge + (k & 1)) * edge) = make_float2(best == 2 * k ? g : 0.f, best == 2 * k + 1 ? g : 0.f);
+    }
+}
+
+extern "C" int rf_maxpool3d_2_backward(const float* x, const float* dy, int n, int c, int edge, float* dx, void* stream) {
+    RF_REQUIRE(x && dy && dx && n > 0 && c > 0 && edge >= 2 && edge % 2 == 0, RF_E_INVALID, "rf_maxpool3d_2_backward: bad arguments");
+    const int half = edge / 2;
+    const size_t cells = (size_t)n * c * half * half * half, want = (cells + 255) / 256;
+    hipLaunchKernelGGL(k_maxpool2_bwd, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream, x, dy, cells, half, dx);
+    RF_CHECK_LAUNCH("rf_maxpool3d_2_backward");
+    return RF_OK;
+}
+
+// nearest-neighbour x2 upsample (reference model/unet.py:297-308: F.interpolate(scale_factor = 2) ahead of a decoder's concat) and its backward, the sum
+// over each 2x2x2 cell in (z, y, x) order.  One thread per low-resolution voxel pair / voxel; rows = n * c volumes.
+__global__ __launch_bounds__(256) void k_upsample2(const float* __restrict__ lo, size_t pairs, int e, float* __restrict__ hi) {
+    const int hp = e / 2, E = 2 * e;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / ((size_t)hp * e * e);
+        const int q = (int)(i % ((size_t)hp * e * e));
+        const int xp = q % hp, y = (q / hp) % e, z = q / (hp * e);
+        const float2 v = *reinterpret_cast<const float2*>(lo + row * (size_t)e * e * e + ((size_t)z * e + y) * e + 2 * xp);
+        const float4 o = make_float4(v.x, v.x, v.y, v.y);
+        float* dst = hi + row * (size_t)E * E * E + ((size_t)(2 * z) * E + 2 * y) * E + 4 * xp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(dst + ((size_t)(k >> 1) * E + (k & 1)) * E) = o;
+    }
+}
+
+extern "C" int rf_upsample3d_2(const float* lo, int n, int c, int edge_lo, float* hi, void* stream) {
+    RF_REQUIRE(lo && hi && n > 0 && c > 0 && edge_lo >= 2 && edge_lo % 2 == 0, RF_E_INVALID, "rf_upsample3d_2: bad arguments (even low-resolution edge)");
+    const size_t pairs = (size_t)n * c * edge_lo * edge_lo * (edge_lo / 2), want = (pairs + 255) / 256;
+    hipLaunchKernelGGL(k_upsample2, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream, lo, pairs, edge_lo, hi);
+    RF_CHECK_LAUNCH("rf_upsample3d_2");
+    return RF_OK;
+}
+
+__global__ __launch_bounds__(256) void k_sumpool2(const float* __restrict__ hi, size_t cells, int half, float* __restrict__ lo) {
+    const int edge = 2 * half;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / ((size_t)half * half * half);
+        const int q = (int)(i % ((size_t)half * half * half));
+        const int px = q % half, py = (q / half) % half, pz = q / (half * half);
+        const size_t base = row * (size_t)edge * edge * edge + ((size_t)(2 * pz) * edge + 2 * py) * edge + 2 * px;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float2 v = *reinterpret_cast<const float2*>(hi + base + ((size_t)(k >> 1) * edge + (k & 1)) * edge);
+            sum += v.x; sum += v.y;
+        }
+        lo[i] = sum;
+    }
+}
+
+extern "C" int rf_sumpool3d_2(const float* hi, int n, int c, int edge, float* lo, void* stream) {
+    RF_REQUIRE(hi && lo && n > 0 && c > 0 && edge >= 2 && edge % 2 == 0, RF_E_INVALID, "rf_sumpool3d_2: bad arguments");
+    const int half = edge / 2;
+    const size_t cells = (size_t)n * c * half * half * half, want = (cells + 255) / 256;
+    hipLaunchKernelGGL(k_sumpool2, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, (hipStream_t)stream, hi, cells, half, lo);
+    RF_CHECK_LAUNCH("rf_sumpool3d_2");
+    return RF_OK;
+}
+
 // ------------------------------------------------------------------------------------------- GroupNorm backward
 // Three launches, every tensor read once per pass and every launch wide enough for the chip whatever the shape ([4][16][64^3] of the final
 // decoder = 64 (sample, channel) pairs; [1024][8][16^3] of the retrieval backbone = 8192):
@@ -287,7 +373,7 @@ extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, in
 // helps staging only).  A = dz tile [16][512] in LDS, B = the GroupNorm-applied halo box [4][10^3] in LDS read through a per-lane
 // column offset (channel * 1000 + tap offset).  A workgroup walks the boxes b = g, g + GB, ... of its (channel chunk, cout block)
 // and keeps its 16 x 108 partial in registers; partials [GB][cout][cin][27] are then reduced in float64 in a fixed order.
-// Edge >= 8 volumes only; 4^3 / 2^3 / 1^3 layers go through rf_linear on the unfolded input (rfuse/autograd.py).
+// Edge >= 4 volumes (4^3: eight whole samples per box); 2^3 / 1^3 layers go through rf_linear_wgrad on the unfolded input (rfuse/autograd.py).
 struct WgradArgs {
     const float* x;
     const float4* affine;
@@ -296,15 +382,18 @@ struct WgradArgs {
     int cin, cout, n, edge, gb;
 };
 
+// S4: whole 4^3 samples, 8 per "box" (512 voxels = sample * 64 + voxel; halo image 8 x 6^3 per channel): the 4^3 levels of the retrieval
+// backbone (192 -> 64, 64 -> 64, 32 -> 64 ... on 1024 samples) without the im2col detour (a [65536][5184] fp32 matrix written and read back).
+template <bool S4>
 __global__ __launch_bounds__(512) void k_conv3_wgrad(WgradArgs a) {
-    constexpr int HE = 10, CH = HE * HE * HE, DZS = 512 + 4;
+    constexpr int HE = S4 ? 6 : 10, CH = S4 ? 8 * 216 : 1000, DZS = 512 + 4;
     __shared__ float xs[4 * CH];
     __shared__ __attribute__((aligned(16))) float ds[16 * DZS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int cchunk = blockIdx.x, cob = blockIdx.y * 16, g = blockIdx.z;
-    const int edge = a.edge, bpe = edge / 8, boxes_per_sample = bpe * bpe * bpe;
-    const int nboxes = a.n * boxes_per_sample;
+    const int edge = a.edge, bpe = S4 ? 1 : edge / 8, boxes_per_sample = bpe * bpe * bpe;
+    const int nboxes = S4 ? (a.n + 7) / 8 : a.n * boxes_per_sample;
     const size_t vol = (size_t)edge * edge * edge;
     // this lane's B column: n-block = wave, column c = wave*16 + li -> (channel, tap)
     const int col = wave * 16 + li;
@@ -313,25 +402,38 @@ __global__ __launch_bounds__(512) void k_conv3_wgrad(WgradArgs a) {
     const int coloff = cch * CH + ((ctap / 9) * HE + (ctap / 3) % 3) * HE + ctap % 3;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int b = g; b < nboxes; b += a.gb) {
-        const int nn = b / boxes_per_sample, bb = b % boxes_per_sample;
+        const int nn = S4 ? b * 8 : b / boxes_per_sample, bb = S4 ? 0 : b % boxes_per_sample;
         const int x0 = (bb % bpe) * 8, y0 = ((bb / bpe) % bpe) * 8, z0 = (bb / (bpe * bpe)) * 8;
         __syncthreads();                                            // previous box fully consumed
         for (int i = tid; i < 4 * CH; i += 512) {                   // GroupNorm-applied halo box, zero outside the volume / past cin
-            const int c = i / CH, r = i % CH;
-            const int hx = r % HE, hy = (r / HE) % HE, hz = r / (HE * HE);
-            const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1, ci = cchunk * 4 + c;
+            const int c = i / CH, r = i % CH, ci = cchunk * 4 + c;
             float v = 0.f;
-            if (ci < a.cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge) {
-                const float4 af = a.affine[(size_t)nn * a.cin + ci];
-                v = fmaf(a.x[((size_t)nn * a.cin + ci) * vol + ((size_t)z * edge + y) * edge + x] - af.x, af.y, af.z);
+            if constexpr (S4) {
+                const int sm = r / 216, q = r % 216;
+                const int x = q % 6 - 1, y = (q / 6) % 6 - 1, z = q / 36 - 1;
+                if (ci < a.cin && nn + sm < a.n && (unsigned)z < 4u && (unsigned)y < 4u && (unsigned)x < 4u) {
+                    const float4 af = a.affine[(size_t)(nn + sm) * a.cin + ci];
+                    v = fmaf(a.x[((size_t)(nn + sm) * a.cin + ci) * 64 + (z * 4 + y) * 4 + x] - af.x, af.y, af.z);
+                }
+            } else {
+                const int hx = r % HE, hy = (r / HE) % HE, hz = r / (HE * HE);
+                const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+                if (ci < a.cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge) {
+                    const float4 af = a.affine[(size_t)nn * a.cin + ci];
+                    v = fmaf(a.x[((size_t)nn * a.cin + ci) * vol + ((size_t)z * edge + y) * edge + x] - af.x, af.y, af.z);
+                }
             }
             xs[i] = v;
         }
         for (int i = tid; i < 16 * 512; i += 512) {                 // dz tile [16 couts][512 voxels of the box]
             const int co = i >> 9, v = i & 511;
-            const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
             float d = 0.f;
-            if (cob + co < a.cout) d = a.dz[((size_t)nn * a.cout + cob + co) * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x)];
+            if constexpr (S4) {
+                if (cob + co < a.cout && nn + (v >> 6) < a.n) d = a.dz[((size_t)(nn + (v >> 6)) * a.cout + cob + co) * 64 + (v & 63)];
+            } else {
+                const int x = v & 7, y = (v >> 3) & 7, z = v >> 6;
+                if (cob + co < a.cout) d = a.dz[((size_t)nn * a.cout + cob + co) * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + (x0 + x)];
+            }
             ds[co * DZS + v] = d;
         }
         __syncthreads();
@@ -339,7 +441,8 @@ __global__ __launch_bounds__(512) void k_conv3_wgrad(WgradArgs a) {
 #pragma unroll 4
             for (int v0 = 0; v0 < 512; v0 += 4) {
                 const int v = v0 + kq;                              // this lane's voxel of the k-step
-                const int hb = (((v >> 6)) * HE + ((v >> 3) & 7)) * HE + (v & 7);
+                const int hb = S4 ? (v >> 6) * 216 + (((v >> 4) & 3) * HE + ((v >> 2) & 3)) * HE + (v & 3)
+                                  : (((v >> 6)) * HE + ((v >> 3) & 7)) * HE + (v & 7);
                 const float av = ds[li * DZS + v];
                 const float bv = xs[coloff + hb];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
@@ -366,7 +469,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 static int wgrad_groups(int n, int edge) {
-    const long long boxes = (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
+    const long long boxes = edge == 4 ? (n + 7) / 8 : (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
     return (int)(boxes < 256 ? boxes : 256);         // workgroups per (channel chunk, cout block): 64 left most CUs with one 8-wave workgroup
 }
 
@@ -378,13 +481,14 @@ extern "C" size_t rf_conv3d_k3_wgrad_ws_bytes(int cin, int cout, int n, int edge
 extern "C" int rf_conv3d_k3_wgrad(const float* x, int cin, int n, int edge, const float* gn_affine, const float* dz, int cout, float* dw, void* ws,
                                   size_t ws_bytes, void* stream) {
     RF_REQUIRE(x && gn_affine && dz && dw && ws && cin > 0 && cout > 0 && n > 0, RF_E_INVALID, "rf_conv3d_k3_wgrad: bad arguments");
-    RF_REQUIRE(rf_is_pow2(edge) && edge >= 8 && edge <= 128, RF_E_UNSUPPORTED, "rf_conv3d_k3_wgrad: edge %d (8^3 boxes: a power of two >= 8)", edge);
+    RF_REQUIRE(rf_is_pow2(edge) && edge >= 4 && edge <= 128, RF_E_UNSUPPORTED, "rf_conv3d_k3_wgrad: edge %d (8^3 boxes or whole 4^3 samples: a power of two >= 4)", edge);
     RF_REQUIRE(ws_bytes >= rf_conv3d_k3_wgrad_ws_bytes(cin, cout, n, edge), RF_E_WORKSPACE, "rf_conv3d_k3_wgrad: workspace too small");
     WgradArgs a;
     a.x = x; a.affine = reinterpret_cast<const float4*>(gn_affine); a.dz = dz; a.parts = (float*)ws;
     a.cin = cin; a.cout = cout; a.n = n; a.edge = edge; a.gb = wgrad_groups(n, edge);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_conv3_wgrad, dim3((cin + 3) / 4, (cout + 15) / 16, a.gb), dim3(512), 0, s, a);
+    if (edge == 4) hipLaunchKernelGGL(k_conv3_wgrad<true>, dim3((cin + 3) / 4, (cout + 15) / 16, a.gb), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(k_conv3_wgrad<false>, dim3((cin + 3) / 4, (cout + 15) / 16, a.gb), dim3(512), 0, s, a);
     RF_CHECK_LAUNCH("rf_conv3d_k3_wgrad");
     const size_t count = (size_t)cout * cin * 27;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const float*)ws, a.gb, count, dw);

@@ -118,7 +118,7 @@ class SingleConv(nn.Module):
             # training slice: the same kernels behind torch.autograd.Function, see rfuse/autograd.py
             from rfuse import autograd as rf_autograd
             out = rf_autograd.conv_gn_relu(x, upsampled, gn.weight, gn.bias, self.conv.weight, gn.num_groups, gn.eps)
-            return out if pool is None else (out, torch.nn.functional.max_pool3d(out, 2))
+            return out if pool is None else (out, rf_autograd.max_pool2(out))
         aff = ops.gn_affine(x, upsampled, gn.weight, gn.bias, gn.num_groups, gn.eps)
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
         # the split-operand (F16 matrix core) forms only where they cannot saturate: weights and GroupNorm outputs inside the f16 pair's range

@@ -8,7 +8,7 @@ retrieval_backbone / attention parameters, :295-306 phase hand-over).  Built her
       backward  rf_relu_backward -> rf_conv3d_k3_gn (relu = 0) on (dz, W^T with flipped taps)   = data gradient, same MFMA kernel
                 rf_conv3d_k3_wgrad (fp32 MFMA, K = voxels)                                     = weight gradient (edge >= 8)
                 rf_gn_backward                                                                  = dx, dgamma, dbeta
-                4^3 / 2^3 / 1^3 volumes: weight gradient as a split-K MFMA GEMM (rf_linear_wgrad) on the unfolded input, float64 slice sum
+                2^3 / 1^3 volumes: weight gradient as a split-K MFMA GEMM (rf_linear_wgrad) on the unfolded input, float64 slice sum
   Linear       y = act(x W^T + b)               the layers of AttentionFeatureEncoder (reference model/attention.py:29-46)
       backward  dx = rf_linear(dpre, W^T-as-weight),  dW = rf_linear(dpre^T, x^T-as-weight) in row chunks summed in float64
 
@@ -151,7 +151,7 @@ class ConvGnRelu(torch.autograd.Function):
                 dxn = conv3d_gn(dz, ident, ops.pack_conv3_weight(wt), cin, relu=False)
             else:                                                                   # 1^3 volume: only the centre tap touches data
                 dxn = ops.linear(dz.reshape(n, cout), ops.pack_linear_weight(weight[:, :, 1, 1, 1].t().contiguous()), None, cin).reshape(n, cin, 1, 1, 1)
-            if edge >= 8:
+            if edge >= 4:
                 dw = conv3d_wgrad(x, aff, dz, cout)
             else:
                 # small volumes: dW = dz^T . im2col(GN(x)) through rf_linear (the operands are re-laid by torch, the products run on rf_linear_wgrad's split-K MFMA GEMM)
@@ -192,17 +192,64 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+@ops._device_scoped
+def upsample2(x):
+    n, c, e = x.shape[0], x.shape[1], x.shape[2]
+    out = torch.empty((n, c, 2 * e, 2 * e, 2 * e), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rf_upsample3d_2(_p(x), n, c, e, _p(out), _stream()), 'rf_upsample3d_2')
+    return out
+
+
+@ops._device_scoped
+def sumpool2(g):
+    n, c, e = g.shape[0], g.shape[1], g.shape[2]
+    out = torch.empty((n, c, e // 2, e // 2, e // 2), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.load().rf_sumpool3d_2(_p(g), n, c, e, _p(out), _stream()), 'rf_sumpool3d_2')
+    return out
+
+
+@ops._device_scoped
+def maxpool2_backward(x, g):
+    n, c, e = x.shape[0], x.shape[1], x.shape[2]
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().rf_maxpool3d_2_backward(_p(x), _p(g), n, c, e, _p(dx), _stream()), 'rf_maxpool3d_2_backward')
+    return dx
+
+
 class _Upsample2(torch.autograd.Function):
-    """nearest x2 upsample whose backward is a 2x2x2 sum pool (avg_pool3d * 8): torch's upsample_nearest3d_backward takes 0.48 ms per call on a
-    [4,16,64^3] gradient (3.8 ms of a 33-38 ms training step)"""
+    """nearest x2 upsample (rf_upsample3d_2) whose backward is the 2x2x2 sum pool (rf_sumpool3d_2): torch's upsample_nearest3d_backward took 0.48 ms
+    per call on a [4,16,64^3] gradient, its avg_pool3d and upsample kernels launch 32 workgroups on the retrieval backbone's shapes"""
 
     @staticmethod
     def forward(ctx, x):
-        return F.interpolate(x, scale_factor=2, mode='nearest')
+        x = x.contiguous()
+        if x.shape[2] < 2 or x.shape[2] % 2:
+            return F.interpolate(x, scale_factor=2, mode='nearest')
+        return upsample2(x)
 
     @staticmethod
     def backward(ctx, g):
-        return F.avg_pool3d(g, 2) * 8.0
+        return sumpool2(g.contiguous())
+
+
+class _MaxPool2(torch.autograd.Function):
+    """MaxPool3d(2): forward rf_maxpool3d_2, backward rf_maxpool3d_2_backward (the gradient to the first maximum of a cell, like torch)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return ops.maxpool2(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return maxpool2_backward(x, g.contiguous())
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x) if x.shape[2] % 2 == 0 and x.shape[2] >= 2 else F.max_pool3d(x, 2)
 
 
 def conv_gn_relu(x, upsampled, gamma, beta, weight, groups, eps):

@@ -219,3 +219,25 @@ def test_forward_full_trains_like_the_oracle(gpu, cfg_name):
     cos = dot / np.sqrt(n1 * n2)
     print(f'\n{cfg_name}: loss {loss.item():.6f} (oracle {lo.item():.6f}); worst parameter gradient (hip vs f64, torch-fp32 vs f64): {worst}; cosine {cos:.8f}')
     assert cos > 0.9999
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 16), (1030, 3, 4), (2, 2, 64), (7, 1, 2)])
+def test_pool_and_upsample_ops_of_the_training_graph_equal_torch(gpu, shape):
+    """rf_maxpool3d_2_backward / rf_upsample3d_2 / rf_sumpool3d_2 (csrc/conv3d_backward.hip) against torch's MaxPool3d(2) backward (ReLU'd input: whole
+    cells of equal zeros, so the first-maximum rule is exercised), F.interpolate(scale_factor=2, 'nearest') and avg_pool3d * 8: bit for bit."""
+    from rfuse import autograd as rfa
+    n, c, e = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(n, c, e, e, e, generator=gen) - 0.8).relu().to(gpu)
+    g = torch.randn(n, c, e // 2, e // 2, e // 2, generator=gen).to(gpu)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 2)
+    yr.backward(g)
+    xm = x.clone().requires_grad_(True)
+    ym = rfa.max_pool2(xm)
+    ym.backward(g)
+    assert torch.equal(ym.detach(), yr.detach()) and torch.equal(xm.grad, xr.grad)
+    up = rfa._Upsample2.apply(x)
+    assert torch.equal(up, F.interpolate(x, scale_factor=2, mode='nearest'))
+    gh = torch.randn(n, c, e, e, e, generator=gen).to(gpu)
+    assert torch.equal(rfa.sumpool2(gh), F.avg_pool3d(gh, 2) * 8.0)
