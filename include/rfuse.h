@@ -282,6 +282,14 @@ size_t rf_gn_backward_ws_bytes(int n, int c, int edge);
 int rf_conv3d_k3_wgrad(const float* x, int cin, int n, int edge, const float* gn_affine, const float* dz, int cout, float* dw, void* ws,
                        size_t ws_bytes, void* stream);
 size_t rf_conv3d_k3_wgrad_ws_bytes(int cin, int cout, int n, int edge);
+/* The same weight gradient on the F16 matrix cores by operand splitting (csrc/conv3d_wgrad_split.hip): k = 32 voxels = four x-rows of an 8^3 box per
+ * MFMA, dz scaled by the power of two in scales = (s, 1 / s) of rf_dgrad_scale_affine (|dz| * s inside the f16 range) and GroupNorm(x) / 16 as f16
+ * pairs, exact products, fp32 accumulation per workgroup, float64 across workgroups.  cin >= 6 (at least 3/4 of the next multiple of 8), cout >= 8,
+ * edge a power of two >= 8; the caller keeps GroupNorm outputs inside the split forms' range (|xn| <= 65504 * 16, as for rf_conv3d_split_k3_gn_relu). */
+int rf_conv3d_k3_wgrad_split_supported(int cin, int cout, int n, int edge);
+size_t rf_conv3d_k3_wgrad_split_ws_bytes(int cin, int cout, int n, int edge);
+int rf_conv3d_k3_wgrad_split(const float* x, int cin, int n, int edge, const float* gn_affine, const float* dz, int cout, const float* scales,
+                             float* dw, void* ws, size_t ws_bytes, void* stream);
 
 /* --------------------------------------------------------------------------------------------- fold / unfold */
 

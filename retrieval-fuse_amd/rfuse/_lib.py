@@ -94,6 +94,9 @@ SIGNATURES = {
     'rf_gn_backward_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_k3_wgrad': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_sz, c_p]),
     'rf_conv3d_k3_wgrad_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'rf_conv3d_k3_wgrad_split_supported': (c_i, [c_i, c_i, c_i, c_i]),
+    'rf_conv3d_k3_wgrad_split_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'rf_conv3d_k3_wgrad_split': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_p, c_sz, c_p]),
     'rf_unfold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_fold3d': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_p]),
     'rf_linear_pack_weight': (c_i, [c_fp, c_i, c_i, c_fp, c_p]),

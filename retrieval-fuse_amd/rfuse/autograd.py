@@ -51,20 +51,37 @@ def relu_backward_amax(dy, y):
 
 
 @ops._device_scoped
-def dgrad_split(dz, amax, weight, cin):
-    """d xn * s = conv3(dz * s, W^T with flipped taps) on the F16 matrix cores (csrc/conv3d_split.hip, split operands): s = the power of two
-    that puts max |dz| into [512, 1024) (the split forms carry values as f16 pairs: a gradient has to be brought into their range first; a power
-    of two is exact), decided and applied on the device.  Returns (d xn * s, 1 / s as a device scalar)."""
+def dz_scale(amax, n, cout):
+    """from the maxima of relu_backward_amax: s = the power of two that puts max |dz| into [512, 1024) (the split forms carry values as f16 pairs: a
+    gradient has to be brought into their range first; a power of two is exact), decided and applied on the device.  Returns the identity GroupNorm
+    affine with scale s for [n][cout] and the device pair (s, 1 / s)."""
+    ident = torch.empty((n, cout, 4), dtype=torch.float32, device=amax.device)
+    scales = torch.empty(2, dtype=torch.float32, device=amax.device)
+    _lib.check(_lib.load().rf_dgrad_scale_affine(_p(amax), n * cout, _p(ident), _p(scales), _stream()), 'rf_dgrad_scale_affine')
+    return ident, scales
+
+
+@ops._device_scoped
+def dgrad_split(dz, ident, weight, cin):
+    """d xn * s = conv3(dz * s, W^T with flipped taps) on the F16 matrix cores (csrc/conv3d_split.hip, split operands)"""
     n, cout, edge = dz.shape[0], dz.shape[1], dz.shape[2]
-    lib = _lib.load()
-    ident = torch.empty((n, cout, 4), dtype=torch.float32, device=dz.device)
-    scales = torch.empty(2, dtype=torch.float32, device=dz.device)
-    _lib.check(lib.rf_dgrad_scale_affine(_p(amax), n * cout, _p(ident), _p(scales), _stream()), 'rf_dgrad_scale_affine')
     wt = weight.flip(2, 3, 4).transpose(0, 1).contiguous()          # [cin, cout, 3,3,3]: the data-gradient conv's weight
     out = torch.empty((n, cin, edge, edge, edge), dtype=torch.float32, device=dz.device)
-    _lib.check(lib.rf_conv3d_split_k3_gn(_p(dz), cout, n, edge, _p(ident), _p(ops.pack_conv3_split_weight(wt)), cin, 0, _p(out), _stream()),
+    _lib.check(_lib.load().rf_conv3d_split_k3_gn(_p(dz), cout, n, edge, _p(ident), _p(ops.pack_conv3_split_weight(wt)), cin, 0, _p(out), _stream()),
                'rf_conv3d_split_k3_gn')
-    return out, scales[1]
+    return out
+
+
+@ops._device_scoped
+def conv3d_wgrad_split(x, aff, dz, scales, cout):
+    """dW on the F16 matrix cores (csrc/conv3d_wgrad_split.hip): dz scaled by scales[0] inside the kernel, the result rescaled in its reduction"""
+    n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
+    lib = _lib.load()
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    ws = _ws(x.device, lib.rf_conv3d_k3_wgrad_split_ws_bytes(cin, cout, n, edge))
+    _lib.check(lib.rf_conv3d_k3_wgrad_split(_p(x), cin, n, edge, _p(aff), _p(dz), cout, _p(scales), _p(dw), _p(ws), ws.numel(), _stream()),
+               'rf_conv3d_k3_wgrad_split')
+    return dw
 
 
 def dgrad_split_supported(dz, weight, cin):
@@ -127,7 +144,7 @@ class ConvGnRelu(torch.autograd.Function):
             else:
                 y = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(w), cout)
         ctx.save_for_backward(x, gamma, weight, aff, y)
-        ctx.groups, ctx.eps = g, eps
+        ctx.groups, ctx.eps, ctx.split_ok = g, eps, bool(split_ok)
         return y
 
     @staticmethod
@@ -136,12 +153,16 @@ class ConvGnRelu(torch.autograd.Function):
         n, cin, edge = x.shape[0], x.shape[1], x.shape[2]
         cout = weight.shape[0]
         with torch.no_grad():
-            inv_s = None
-            if edge >= 4 and dgrad_split_supported(y, weight, cin):
+            inv_s = scales = None
+            use_dgrad = edge >= 4 and dgrad_split_supported(y, weight, cin)
+            use_wgrad = ctx.split_ok and y.numel() % 4 == 0 and bool(_lib.load().rf_conv3d_k3_wgrad_split_supported(cin, cout, n, edge))
+            if use_dgrad or use_wgrad:
                 dz, amax = relu_backward_amax(dy.contiguous(), y)
-                dxn, inv_s = dgrad_split(dz, amax, weight, cin)
+                ident, scales = dz_scale(amax, n, cout)
             else:
                 dz = relu_backward(dy.contiguous(), y) if y.numel() % 4 == 0 else dy * (y > 0)
+            if use_dgrad:
+                dxn, inv_s = dgrad_split(dz, ident, weight, cin), scales[1]
             if inv_s is not None:
                 pass
             elif edge >= 2:
@@ -151,7 +172,9 @@ class ConvGnRelu(torch.autograd.Function):
                 dxn = conv3d_gn(dz, ident, ops.pack_conv3_weight(wt), cin, relu=False)
             else:                                                                   # 1^3 volume: only the centre tap touches data
                 dxn = ops.linear(dz.reshape(n, cout), ops.pack_linear_weight(weight[:, :, 1, 1, 1].t().contiguous()), None, cin).reshape(n, cin, 1, 1, 1)
-            if edge >= 4:
+            if use_wgrad:
+                dw = conv3d_wgrad_split(x, aff, dz, scales, cout)
+            elif edge >= 4:
                 dw = conv3d_wgrad(x, aff, dz, cout)
             else:
                 # small volumes: dW = dz^T . im2col(GN(x)) through rf_linear (the operands are re-laid by torch, the products run on rf_linear_wgrad's split-K MFMA GEMM)
@@ -194,6 +217,7 @@ class Linear(torch.autograd.Function):
 
 @ops._device_scoped
 def upsample2(x):
+    ops._req(x, 'x')
     n, c, e = x.shape[0], x.shape[1], x.shape[2]
     out = torch.empty((n, c, 2 * e, 2 * e, 2 * e), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().rf_upsample3d_2(_p(x), n, c, e, _p(out), _stream()), 'rf_upsample3d_2')
@@ -202,6 +226,7 @@ def upsample2(x):
 
 @ops._device_scoped
 def sumpool2(g):
+    ops._req(g, 'g')
     n, c, e = g.shape[0], g.shape[1], g.shape[2]
     out = torch.empty((n, c, e // 2, e // 2, e // 2), dtype=torch.float32, device=g.device)
     _lib.check(_lib.load().rf_sumpool3d_2(_p(g), n, c, e, _p(out), _stream()), 'rf_sumpool3d_2')
@@ -210,6 +235,7 @@ def sumpool2(g):
 
 @ops._device_scoped
 def maxpool2_backward(x, g):
+    ops._req(x, 'x'), ops._req(g, 'g')
     n, c, e = x.shape[0], x.shape[1], x.shape[2]
     dx = torch.empty_like(x)
     _lib.check(_lib.load().rf_maxpool3d_2_backward(_p(x), _p(g), n, c, e, _p(dx), _stream()), 'rf_maxpool3d_2_backward')
