@@ -21,13 +21,12 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int WS_NC = 8;                                    // input channels per workgroup
-constexpr int WS_ROWS_B = 6 * 10;                           // halo rows (z, y) of a z-half per channel
-constexpr int WS_B_SLOTS = WS_NC * WS_ROWS_B * 3;           // 1440 per plane
+constexpr int WS_B_SLOTS = 1440;                            // per plane: 8 channels x 60 halo rows x 3 shifts (4^3: 4 samples x 4 channels x 30 row pairs x 3)
 constexpr int WS_A_STRIDE = 33;                             // slots per cout: 32 rows + 1 (bank spread)
 constexpr int WS_A_SLOTS = 64 * WS_A_STRIDE;                // 2112 per plane
 constexpr int WS_LDS_BYTES = (WS_B_SLOTS + WS_A_SLOTS) * 2 * 16;       // 113,664
 constexpr float WS_ACT_SCALE = 1.0f / 16, WS_LO = 2048.0f;
+constexpr int ws_nc(bool s4) { return s4 ? 4 : 8; }         // input channels per workgroup
 }
 
 struct WgradSplitArgs {
@@ -45,7 +44,12 @@ __device__ __forceinline__ void ws_split(float v, _Float16& h, _Float16& l) {
     l = (_Float16)fmaf(-WS_LO, (float)h, v * WS_LO);
 }
 
+// S4: whole 4^3 samples, eight per "box", four per half.  A slot is two x-rows of a sample (z, y = 2 yp, 2 yp + 1; 8 contiguous floats of dz); the B image
+// holds, per (sample, channel), the row PAIRS starting at every halo row hy0 = 0 .. 4 of every halo plane, x-shifted three ways (the x halo of a whole
+// sample is always zero padding): [sample 4][channel 4][hz 6][hy0 5][shift 3] = the same 1440 slots; 108 columns = 7 n-blocks over the 4 n-groups.
+template <bool S4>
 __global__ __launch_bounds__(512, 2) void k_conv3_wgrad_split(WgradSplitArgs a) {
+    constexpr int NC = ws_nc(S4), NT = S4 ? 7 : 14, JM = S4 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     h8* Bh = reinterpret_cast<h8*>(lds_raw);
     h8* Bl = Bh + WS_B_SLOTS;
@@ -56,65 +60,97 @@ __global__ __launch_bounds__(512, 2) void k_conv3_wgrad_split(WgradSplitArgs a) 
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, kg = lane >> 4;
     const int cchunk = blockIdx.x, cob = blockIdx.y * 64, g = blockIdx.z;
-    const int edge = a.edge, bpe = edge / 8, bps = bpe * bpe * bpe;
-    const int nboxes = a.n * bps;
+    const int edge = a.edge, bpe = S4 ? 1 : edge / 8, bps = bpe * bpe * bpe;
+    const int nboxes = S4 ? (a.n + 7) / 8 : a.n * bps;
     const size_t vol = (size_t)edge * edge * edge;
     const int cin = a.cin, cout = a.cout;
 
-    // this lane's B columns: n-block nt = wn + 4 j, column = nt * 16 + li -> (channel, tap); per k-step s the row adds ((s >> 1) * 10 + 4 (s & 1)) * 3
-    int bbase[4];
+    // this lane's B columns: n-block nt = wn + 4 j, column = nt * 16 + li -> (channel, tap); the k-step adds a compile-time row offset
+    int bbase[JM];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JM; ++j) {
         const int col = (wn + 4 * j) * 16 + li;
-        const bool ok = col < WS_NC * 27;
+        const bool ok = col < NC * 27;
         const int ci = ok ? col / 27 : 0, tap = ok ? col % 27 : 0;
-        bbase[j] = ((ci * 6 + tap / 9) * 10 + (tap / 3) % 3 + kg) * 3 + tap % 3;
+        bbase[j] = S4 ? ((ci * 6 + tap / 9 + (kg >> 1)) * 5 + (tap / 3) % 3 + 2 * (kg & 1)) * 3 + tap % 3
+                      : ((ci * 6 + tap / 9) * 10 + (tap / 3) % 3 + kg) * 3 + tap % 3;
     }
-    const int nj = wn < 2 ? 4 : 3;                                  // 14 n-blocks: n-groups 0, 1 hold four, 2, 3 hold three
+    const int nj = (NT - wn + 3) / 4;                               // n-blocks wn, wn + 4, ... < NT
     int abase[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = ((2 * wm + i) * 16 + li) * WS_A_STRIDE + kg;
     const bool m_live = cob + 32 * wm < cout;                       // the wave's 32 couts exist (wave-uniform)
 
-    f32x4 hi[2][4], lo[2][4];
+    f32x4 hi[2][JM], lo[2][JM];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < JM; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float sdz = a.scales[0];
 
     for (int b = g; b < nboxes; b += a.gb) {
-        const int nn = b / bps, bb = b % bps;
+        const int nn = S4 ? b * 8 : b / bps, bb = S4 ? 0 : b % bps;
         const int x0 = (bb % bpe) * 8, y0 = ((bb / bpe) % bpe) * 8, z0 = (bb / (bpe * bpe)) * 8;
         for (int zh = 0; zh < 2; ++zh) {
             __syncthreads();                                        // the previous half fully consumed
-            // ---- B: one thread per (channel, halo row): 10 values -> normalise, scale, split -> three shifted 8-voxel operands
-            if (tid < WS_NC * WS_ROWS_B) {
-                const int c = tid / WS_ROWS_B, r = tid % WS_ROWS_B;
-                const int hz = r / 10, hy = r % 10;
-                const int z = z0 + 4 * zh + hz - 1, y = y0 + hy - 1, ci = cchunk * WS_NC + c;
-                _Float16 h[10], l[10];
-                if (ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge) {
-                    const float4 af = a.affine[(size_t)nn * cin + ci];
-                    const float* row = a.x + ((size_t)nn * cin + ci) * vol + ((size_t)z * edge + y) * edge + x0;
-                    const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
-                    const float vm = x0 > 0 ? row[-1] : 0.f, vp = x0 + 8 < edge ? row[8] : 0.f;
-                    const float raw[10] = {vm, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, vp};
+            if constexpr (S4) {
+                // ---- B: one thread per (sample, channel, halo plane, first halo row of a pair): two rows of 4 -> normalise, scale, split -> three shifts
+                if (tid < 4 * NC * 30) {
+                    const int sl = tid / (NC * 30), c = (tid / 30) % NC, r = tid % 30;
+                    const int hz = r / 5, hy0 = r % 5;
+                    const int sm = nn + 4 * zh + sl, z = hz - 1, ci = cchunk * NC + c;
+                    _Float16 h[2][6], l[2][6];
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) ws_split(fmaf(raw[k] - af.x, af.y, af.z) * WS_ACT_SCALE, h[k], l[k]);
-                    if (x0 == 0) { h[0] = (_Float16)0.f; l[0] = (_Float16)0.f; }                  // zero padding is of xn, not of x
-                    if (x0 + 8 >= edge) { h[9] = (_Float16)0.f; l[9] = (_Float16)0.f; }
-                } else {
+                    for (int yy = 0; yy < 2; ++yy) {
+                        const int y = hy0 + yy - 1;
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) { h[k] = (_Float16)0.f; l[k] = (_Float16)0.f; }
+                        for (int k = 0; k < 6; ++k) { h[yy][k] = (_Float16)0.f; l[yy][k] = (_Float16)0.f; }
+                        if (ci < cin && sm < a.n && (unsigned)z < 4u && (unsigned)y < 4u) {
+                            const float4 af = a.affine[(size_t)sm * cin + ci];
+                            const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)sm * cin + ci) * 64 + (z * 4 + y) * 4);
+                            const float raw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) ws_split(fmaf(raw[k] - af.x, af.y, af.z) * WS_ACT_SCALE, h[yy][k + 1], l[yy][k + 1]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        h8 oh, ol;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { oh[k] = h[k >> 2][t + (k & 3)]; ol[k] = l[k >> 2][t + (k & 3)]; }
+                        Bh[tid * 3 + t] = oh;
+                        Bl[tid * 3 + t] = ol;
+                    }
                 }
+            } else {
+                // ---- B: one thread per (channel, halo row): 10 values -> normalise, scale, split -> three shifted 8-voxel operands
+                if (tid < NC * 60) {
+                    const int c = tid / 60, r = tid % 60;
+                    const int hz = r / 10, hy = r % 10;
+                    const int z = z0 + 4 * zh + hz - 1, y = y0 + hy - 1, ci = cchunk * NC + c;
+                    _Float16 h[10], l[10];
+                    if (ci < cin && (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge) {
+                        const float4 af = a.affine[(size_t)nn * cin + ci];
+                        const float* row = a.x + ((size_t)nn * cin + ci) * vol + ((size_t)z * edge + y) * edge + x0;
+                        const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
+                        const float vm = x0 > 0 ? row[-1] : 0.f, vp = x0 + 8 < edge ? row[8] : 0.f;
+                        const float raw[10] = {vm, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, vp};
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    h8 oh, ol;
+                        for (int k = 0; k < 10; ++k) ws_split(fmaf(raw[k] - af.x, af.y, af.z) * WS_ACT_SCALE, h[k], l[k]);
+                        if (x0 == 0) { h[0] = (_Float16)0.f; l[0] = (_Float16)0.f; }              // zero padding is of xn, not of x
+                        if (x0 + 8 >= edge) { h[9] = (_Float16)0.f; l[9] = (_Float16)0.f; }
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { oh[k] = h[t + k]; ol[k] = l[t + k]; }
-                    Bh[tid * 3 + t] = oh;
-                    Bl[tid * 3 + t] = ol;
+                        for (int k = 0; k < 10; ++k) { h[k] = (_Float16)0.f; l[k] = (_Float16)0.f; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        h8 oh, ol;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { oh[k] = h[t + k]; ol[k] = l[t + k]; }
+                        Bh[tid * 3 + t] = oh;
+                        Bl[tid * 3 + t] = ol;
+                    }
                 }
             }
             // ---- A: (cout, row) items, four per thread: the row's 8 gradients, scaled, split
@@ -122,8 +158,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_wgrad_split(WgradSplitArgs a) 
             for (int k = 0; k < 4; ++k) {
                 const int it = tid + k * 512, co = it >> 5, r = it & 31;
                 h8 oh, ol;
-                if (cob + co < cout) {
-                    const float* row = a.dz + ((size_t)nn * cout + cob + co) * vol + ((size_t)(z0 + 4 * zh + (r >> 3)) * edge + (y0 + (r & 7))) * edge + x0;
+                const bool live = cob + co < cout && (!S4 || nn + 4 * zh + (r >> 3) < a.n);
+                if (live) {
+                    const float* row = S4 ? a.dz + ((size_t)(nn + 4 * zh + (r >> 3)) * cout + cob + co) * 64 + (r & 7) * 8
+                                          : a.dz + ((size_t)nn * cout + cob + co) * vol + ((size_t)(z0 + 4 * zh + (r >> 3)) * edge + (y0 + (r & 7))) * edge + x0;
                     const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
                     const float raw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -139,12 +177,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3_wgrad_split(WgradSplitArgs a) 
             if (m_live) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const int roff = ((s >> 1) * 10 + 4 * (s & 1)) * 3;
+                    // row r = 4 s + kg of the half.  Boxes: z = s >> 1, y = 4 (s & 1) + kg.  4^3: sample s >> 1, z = 2 (s & 1) + (kg >> 1), y pair kg & 1.
+                    const int roff = S4 ? ((s >> 1) * NC * 30 + 2 * (s & 1) * 5) * 3 : ((s >> 1) * 10 + 4 * (s & 1)) * 3;
                     h8 ah[2], al[2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) { ah[i] = Ah[abase[i] + 4 * s]; al[i] = Al[abase[i] + 4 * s]; }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < JM; ++j) {
                         if (j < nj) {
                             const h8 bh = Bh[bbase[j] + roff], bl = Bl[bbase[j] + roff];
 #pragma unroll
@@ -162,10 +201,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_wgrad_split(WgradSplitArgs a) 
     // D[row = cout 4 kg + r of the tile][col = li]
     if (m_live) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < JM; ++j) {
             const int col = (wn + 4 * j) * 16 + li;
-            if (j < nj && col < WS_NC * 27) {
-                const int ci = cchunk * WS_NC + col / 27, tap = col % 27;
+            if (j < nj && col < NC * 27) {
+                const int ci = cchunk * NC + col / 27, tap = col % 27;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -178,26 +217,35 @@ __global__ __launch_bounds__(512, 2) void k_conv3_wgrad_split(WgradSplitArgs a) 
     }
 }
 
+// 64 outputs x 4 slices of the groups per workgroup: a thread sums its groups (g = slice, slice + 4, ...) in float64, the four partial sums are then
+// added in slice order -- a fixed order whatever the launch (the first form, one thread per output walking all the groups, ran 27 workgroups for a
+// 16 -> 16 layer and took as long as the MFMA kernel)
 __global__ __launch_bounds__(256) void k_wgrad_split_reduce(const float* __restrict__ parts, int gb, size_t count, const float* __restrict__ scales,
                                                             float* __restrict__ dw) {
+    __shared__ double red[4][64];
     const double back = (double)scales[1] / (double)WS_ACT_SCALE;   // 16 / s
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int g = 0; g < gb; ++g) s += (double)parts[(size_t)g * count + i];
-        dw[i] = (float)(s * back);
-    }
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + o;
+    double s = 0.0;
+    if (i < count)
+        for (int g = sl; g < gb; g += 4) s += (double)parts[(size_t)g * count + i];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < count) dw[i] = (float)((((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]) * back);
 }
 
 static int wgrad_split_groups(int cin, int cout, int n, int edge) {
-    const long long boxes = (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
-    const long long units = (long long)((cin + WS_NC - 1) / WS_NC) * ((cout + 63) / 64);
-    long long gb = (2048 + units - 1) / units;                      // about 2048 workgroups in all (256 CUs x 1 workgroup, 8 rounds)
+    const int nc = ws_nc(edge == 4);
+    const long long boxes = edge == 4 ? (n + 7) / 8 : (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
+    const long long units = (long long)((cin + nc - 1) / nc) * ((cout + 63) / 64);
+    long long gb = (768 + units - 1) / units;                       // about 768 workgroups in all: three rounds of one workgroup per CU
     if (gb > boxes) gb = boxes;
-    return (int)(gb < 1 ? 1 : (gb > 1024 ? 1024 : gb));
+    return (int)(gb < 1 ? 1 : (gb > 256 ? 256 : gb));
 }
 
 extern "C" int rf_conv3d_k3_wgrad_split_supported(int cin, int cout, int n, int edge) {
-    return cin >= 6 && 4 * cin >= 3 * rf_round_up(cin, WS_NC) && cout >= 8 && n > 0 && rf_is_pow2(edge) && edge >= 8 && edge <= 128;
+    if (edge == 4) return cin >= 3 && 4 * cin >= 3 * rf_round_up(cin, 4) && cout >= 8 && n >= 8;
+    return cin >= 6 && 4 * cin >= 3 * rf_round_up(cin, 8) && cout >= 8 && n > 0 && rf_is_pow2(edge) && edge >= 8 && edge <= 128;
 }
 
 extern "C" size_t rf_conv3d_k3_wgrad_split_ws_bytes(int cin, int cout, int n, int edge) {
@@ -210,19 +258,26 @@ extern "C" int rf_conv3d_k3_wgrad_split(const float* x, int cin, int n, int edge
                                         float* dw, void* ws, size_t ws_bytes, void* stream) {
     RF_REQUIRE(x && gn_affine && dz && scales && dw && ws, RF_E_INVALID, "rf_conv3d_k3_wgrad_split: null pointer");
     RF_REQUIRE(rf_conv3d_k3_wgrad_split_supported(cin, cout, n, edge), RF_E_UNSUPPORTED,
-               "rf_conv3d_k3_wgrad_split: takes cin >= 6 (at least 3/4 of the next multiple of 8), cout >= 8, edge a power of two >= 8 (got cin=%d cout=%d n=%d edge=%d)",
+               "rf_conv3d_k3_wgrad_split: takes cin >= 6 (at least 3/4 of the next multiple of 8; 4^3: of 4), cout >= 8, edge a power of two >= 8 or 8+ whole 4^3 samples (got cin=%d cout=%d n=%d edge=%d)",
                cin, cout, n, edge);
     RF_REQUIRE(ws_bytes >= rf_conv3d_k3_wgrad_split_ws_bytes(cin, cout, n, edge), RF_E_WORKSPACE, "rf_conv3d_k3_wgrad_split: workspace too small");
-    static RfLdsOptIn opt;
-    if (int rc = opt.ensure(reinterpret_cast<const void*>(k_conv3_wgrad_split), WS_LDS_BYTES, "rf_conv3d_k3_wgrad_split")) return rc;
+    static RfLdsOptIn opt_box, opt_s4;
     WgradSplitArgs a;
     a.x = x; a.affine = reinterpret_cast<const float4*>(gn_affine); a.dz = dz; a.scales = scales; a.parts = (float*)ws;
     a.cin = cin; a.cout = cout; a.n = n; a.edge = edge; a.gb = wgrad_split_groups(cin, cout, n, edge);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_conv3_wgrad_split, dim3((cin + WS_NC - 1) / WS_NC, (cout + 63) / 64, a.gb), dim3(512), WS_LDS_BYTES, s, a);
+    const int nc = ws_nc(edge == 4);
+    const dim3 grid((cin + nc - 1) / nc, (cout + 63) / 64, a.gb);
+    if (edge == 4) {
+        if (int rc = opt_s4.ensure(reinterpret_cast<const void*>(k_conv3_wgrad_split<true>), WS_LDS_BYTES, "rf_conv3d_k3_wgrad_split")) return rc;
+        hipLaunchKernelGGL(k_conv3_wgrad_split<true>, grid, dim3(512), WS_LDS_BYTES, s, a);
+    } else {
+        if (int rc = opt_box.ensure(reinterpret_cast<const void*>(k_conv3_wgrad_split<false>), WS_LDS_BYTES, "rf_conv3d_k3_wgrad_split")) return rc;
+        hipLaunchKernelGGL(k_conv3_wgrad_split<false>, grid, dim3(512), WS_LDS_BYTES, s, a);
+    }
     RF_CHECK_LAUNCH("rf_conv3d_k3_wgrad_split");
     const size_t count = (size_t)cout * cin * 27;
-    hipLaunchKernelGGL(k_wgrad_split_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (const float*)ws, a.gb, count, scales, dw);
+    hipLaunchKernelGGL(k_wgrad_split_reduce, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, (const float*)ws, a.gb, count, scales, dw);
     RF_CHECK_LAUNCH("rf_conv3d_k3_wgrad_split(reduce)");
     return RF_OK;
 }
