@@ -4,22 +4,24 @@ The reference trains THROUGH the drop-in modules (trainer/train_refinement.py:41
 retrieval_backbone / attention parameters, :295-306 phase hand-over).  Built here:
 
   ConvGnRelu   y = ReLU(conv3(GroupNorm(x)))   one SingleConv 'gcr' layer (reference model/unet.py:19-76) -- 97 % of the FLOPs
-      forward   rf_gn_stats / rf_gn_from_stats + rf_conv3d_k3_gn_relu*         (the inference kernels)
-      backward  rf_relu_backward -> rf_conv3d_k3_gn (relu = 0) on (dz, W^T with flipped taps)   = data gradient, same MFMA kernel
-                rf_conv3d_k3_wgrad (fp32 MFMA, K = voxels)                                     = weight gradient (edge >= 8)
-                rf_gn_backward                                                                  = dx, dgamma, dbeta
+      forward   rf_gn_stats / rf_gn_from_stats + the inference kernels, chosen like SingleConv.forward chooses them (split-operand F16 forms where
+                the parameters are inside their range: one batched range check per optimiser step)
+      backward  rf_relu_backward[_amax] -> d xn = conv3(dz, W^T with flipped taps), no ReLU: rf_conv3d_split_k3_gn on dz scaled by a power of two
+                into the f16 pairs' range (rf_dgrad_scale_affine; the scale leaves again in the GroupNorm backward), else rf_conv3d_k3_gn (fp32 MFMA)
+                rf_conv3d_k3_wgrad_split (F16 matrix cores, split operands; edge >= 8 boxes and whole 4^3 samples) / rf_conv3d_k3_wgrad (fp32 MFMA)
+                rf_gn_backward (three passes, every tensor read once per pass)                  = dx, dgamma, dbeta
                 2^3 / 1^3 volumes: weight gradient as a split-K MFMA GEMM (rf_linear_wgrad) on the unfolded input, float64 slice sum
   Linear       y = act(x W^T + b)               the layers of AttentionFeatureEncoder (reference model/attention.py:29-46)
-      backward  dx = rf_linear(dpre, W^T-as-weight),  dW = rf_linear(dpre^T, x^T-as-weight) in row chunks summed in float64
+      backward  dx = rf_linear(dpre, W^T-as-weight),  dW = rf_linear_wgrad(dpre, x) in row chunks summed in float64
+  MaxPool3d(2) / nearest x2 upsample             rf_maxpool3d_2 + rf_maxpool3d_2_backward, rf_upsample3d_2 + rf_sumpool3d_2 (bit-equal to torch's)
 
-torch does the bookkeeping and the light per-row work: transposes / flips / unfolds of operands, the activation mask of Linear,
-sums over the batch of per-sample float64 pieces, max-pool (F.max_pool3d), the 16 -> 1 pointwise conv + tanh of the final decoder,
-fold / unfold as views, and the patch attention's per-row normalise / scores / softmax or straight-through Gumbel-hard / blend
-(model/attention.py:_forward_autograd) -- together < 1 % of the FLOPs.  With that the whole training graph of the reference
-(trainer/train_refinement.py:108-116 forward_full, all four networks trainable = phase 3) runs through the drop-in modules in grad
-mode; loss and every parameter gradient are checked against float64 autograd of the oracle in tests/test_autograd_gpu.py.
-Not built: backward of the fused kernels' fast routes (parity-split decoder conv, fused attention MLP, fused max-pool epilogue --
-grad mode takes the plain routes), the patch encoders (trained by trainer/train_retrieval.py, outside the refinement path).
+torch does the bookkeeping and the light per-row work: transposes / flips of weights, the activation mask of Linear, sums over the batch of
+per-sample float64 pieces, the 16 -> 1 pointwise conv + tanh of the final decoder, fold / unfold as views, and the patch attention's per-row
+normalise / scores / softmax or straight-through Gumbel-hard / blend (model/attention.py:_forward_autograd) -- together < 1 % of the FLOPs.  With
+that the whole training graph of the reference (trainer/train_refinement.py:108-116 forward_full, all four networks trainable = phase 3) runs
+through the drop-in modules in grad mode; loss and every parameter gradient are checked against float64 autograd of the oracle in
+tests/test_autograd_gpu.py.  Not built: backward of the pre-split pair routes and the fused attention MLP (grad mode takes the plain routes), the
+patch encoders (trained by trainer/train_retrieval.py, outside the refinement path).
 """
 import torch
 import torch.nn.functional as F

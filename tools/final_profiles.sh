@@ -15,3 +15,7 @@ python bench.py --config C4 --batch 16 --no-cpu-baseline > gpurun_out/bench_r3_C
 python bench.py --config C1 --batch 16 --no-cpu-baseline > gpurun_out/bench_r3_C1.json 2> gpurun_out/bench_r3_C1.err
 python bench.py --config C3 --db 1000000 --no-cpu-baseline > gpurun_out/bench_r3_C3_1M.json 2> gpurun_out/bench_r3_C3_1M.err
 python tools/dbbuild_bench.py > gpurun_out/dbbuild_r3.log 2>&1
+python tools/train_bench.py C3 4 10 > gpurun_out/train_r3.json 2> gpurun_out/train_r3.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final_train -o train -- python $R/tools/train_bench.py C3 4 5 > $R/gpurun_out/prof_final_train.log 2>&1
+cd $R
