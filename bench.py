@@ -180,6 +180,44 @@ def parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev, chunks=(0, 17
             'bar': 1e-4}
 
 
+def time_launch_alone(entry, c0, c1, n, edge, cout, device, reps=10):
+    """mean duration (ms) of one launch of a heavy conv entry point on random tensors of the given shape, nothing else on the GPU"""
+    import torch
+    from rfuse import ops
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    s0 = torch.rand(n, c0, edge, edge, edge, device=device) if c0 else None
+    w = (torch.randn(cout, c0 + c1, 3, 3, 3, generator=gen) * 0.05).to(device)
+    aff = torch.zeros(n, c0 + c1, 4, device=device)
+    aff[..., 1] = 1.0
+    if 'up_split' in entry:
+        s1 = torch.rand(n, c1, edge // 2, edge // 2, edge // 2, device=device)
+        if not ops.conv_up_split_supported(s0, s1, cout):
+            return None
+        wp = ops.pack_conv3_up_split_weight(w, c0)
+        run = lambda: ops.conv3d_up_split_gn_relu(s0, s1, aff, wp, cout)
+    elif 'split' in entry and c1 == 0:
+        if not ops.conv_split_supported(s0, None, cout):
+            return None
+        wp = ops.pack_conv3_split_weight(w)
+        run = lambda: ops.conv3d_split_gn_relu(s0, aff, wp, cout)
+    else:
+        return None
+    saved, ops.conv_event_filter = ops.conv_event_filter, None
+    try:
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    finally:
+        ops.conv_event_filter = saved
+
+
 def kernel_work(name, a, cfg):
     """(bound, work per launch, unit) of one C-ABI launch from its integer arguments, or None when the launch is bookkeeping"""
     if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_k3_gn_relu_direct'):
@@ -516,6 +554,16 @@ def main():
                     'fp32_equivalent_tflops': useful / (kern_ms * 1e-3) / 1e12,
                     'algorithmic_bytes_per_launch': src_bytes,
                     'heavy_launches_ms': {'%s %s' % (lab[0], list(lab[2])): float(np.mean([t for t, _ in v])) for lab, v in sorted(by_launch.items(), key=lambda kv: -np.mean([t for t, _ in kv[1]]))}}
+            if not args.no_extras:
+                # the same launch ALONE (random tensors of its shape, 10 launches back to back on an idle GPU): inside the step the launch shares the
+                # CUs with the other streams' kernels (C2: top-k and the small U-Net backbone; C5: the query encoder's convs on the 128^3 grid, as
+                # heavy as the launch itself), so `launch_ms` -- what the step pays -- can be several times this.  (Dense random operands: the chip clocks
+                # lower under them than under the step's ReLU'd activations -- C2's dominant launch 1.73 ms alone, 1.60 ms in the step.)
+                alone = time_launch_alone(entry, c0_, c1_, n_, edge_, cout_, device)
+                if alone is not None:
+                    roof['launch_ms_alone'] = alone
+                    roof['frac_alone'] = kern_flops / (alone * 1e-3) / 1e12 / peak
+                    assert roof['frac_alone'] <= 1.0, roof
             assert roof['frac'] <= 1.0 and roof['useful_frac'] <= 1.0, roof
         out = {
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',

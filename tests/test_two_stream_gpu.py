@@ -178,9 +178,9 @@ def victims(ops):
     v['attention weights, softmax (4096 rows, K = 4)'] = weights_case(ops.ATTN_SOFTMAX, 1024.0, None)
     # the training slice's backward kernels (rfuse/autograd.py): data / weight gradient on the split forms, GroupNorm backward, pooling ops
     from rfuse import autograd as rfa
-    xt = rnd(g, 64, 16, 16, 16, 16).relu_().to(DEV)
-    yt = rnd(g, 64, 24, 16, 16, 16).relu_().to(DEV)
-    dyt = rnd(g, 64, 24, 16, 16, 16, scale=1e-3).to(DEV)
+    xt = rnd(g, 128, 16, 16, 16, 16).relu_().to(DEV)
+    yt = rnd(g, 128, 24, 16, 16, 16).relu_().to(DEV)
+    dyt = rnd(g, 128, 24, 16, 16, 16, scale=1e-3).to(DEV)
     gt, bt = (1 + 0.2 * rnd(g, 16)).to(DEV), rnd(g, 16, scale=0.2).to(DEV)
     wt_ = rnd(g, 24, 16, 3, 3, 3, scale=0.05).to(DEV)
     afft = ops.gn_affine(xt, None, gt, bt, 8)
@@ -188,22 +188,22 @@ def victims(ops):
     def backward_case(which):
         def run():
             dz, amax = rfa.relu_backward_amax(dyt, yt)
-            ident, scales = rfa.dz_scale(amax, 64, 24)
+            ident, scales = rfa.dz_scale(amax, 128, 24)
             if which == 'dgrad':
                 return rfa.dgrad_split(dz, ident, wt_, 16)
             if which == 'wgrad':
                 return rfa.conv3d_wgrad_split(xt, afft, dz, scales, 24)
             return dz
         return run
-    v['ReLU backward + max |dz| (64 x 24 x 16^3)'] = backward_case('relu')
-    if bool(lib_supported(ops, 'rf_conv3d_split_k3_gn_supported', 24, 64, 16, 16)):
-        v['split data-gradient conv (24->16 @16^3 x 64, scaled dz)'] = backward_case('dgrad')
-    v['split weight gradient (16->24 @16^3 x 64)'] = backward_case('wgrad')
-    v['fp32 weight gradient (16->24 @16^3 x 64)'] = lambda: rfa.conv3d_wgrad(xt, afft, rfa.relu_backward(dyt, yt), 24)
-    dxn_t = rnd(g, 64, 16, 16, 16, 16).to(DEV)
-    v['GroupNorm backward (64 x 16 x 16^3)'] = lambda: torch.cat([t.reshape(-1).double() for t in rfa.gn_backward(xt, dxn_t, gt, 8, 1e-5)])
-    v['max-pool backward (64 x 16 x 16^3)'] = lambda: rfa.maxpool2_backward(xt, dyt[:, :16, ::2, ::2, ::2].contiguous())
-    v['nearest x2 upsample / 2^3 sum pool (64 x 16 x 16^3)'] = lambda: rfa.sumpool2(rfa.upsample2(xt)) + rfa.sumpool2(xt).mean()
+    v['ReLU backward + max |dz| (128 x 24 x 16^3)'] = backward_case('relu')
+    if bool(lib_supported(ops, 'rf_conv3d_split_k3_gn_supported', 24, 128, 16, 16)):
+        v['split data-gradient conv (24->16 @16^3 x 128, scaled dz)'] = backward_case('dgrad')
+    v['split weight gradient (16->24 @16^3 x 128)'] = backward_case('wgrad')
+    v['fp32 weight gradient (16->24 @16^3 x 128)'] = lambda: rfa.conv3d_wgrad(xt, afft, rfa.relu_backward(dyt, yt), 24)
+    dxn_t = rnd(g, 128, 16, 16, 16, 16).to(DEV)
+    v['GroupNorm backward (128 x 16 x 16^3)'] = lambda: torch.cat([t.reshape(-1).double() for t in rfa.gn_backward(xt, dxn_t, gt, 8, 1e-5)])
+    v['max-pool backward (128 x 16 x 16^3)'] = lambda: rfa.maxpool2_backward(xt, dyt[:, :16, ::2, ::2, ::2].contiguous())
+    v['nearest x2 upsample / 2^3 sum pool (128 x 16 x 16^3)'] = lambda: rfa.sumpool2(rfa.upsample2(xt)) + rfa.sumpool2(xt).mean()
     xb = rnd(g, 2, 16, 32, 32, 32).to(DEV)
     rb = rnd(g, 2 * K, 16, 32, 32, 32).to(DEV)
     wts = torch.softmax(rnd(g, 2 * 4096, K), dim=1).to(DEV)
