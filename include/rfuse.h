@@ -204,6 +204,16 @@ int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int cout);
 int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
 
+/* The same layer on whole 2^3 volumes as ONE dense GEMM on the F16 matrix cores (csrc/conv3d_e2_split.hip): in a 2^3 volume every input voxel is a
+ * neighbour of every output voxel, so out[n][(co, v)] = GN(x)[n][(ci, u)] . B[(ci, u)][(co, v)] with B[(ci, u)][(co, v)] = W[co][ci][tap(u - v)] -- x and
+ * out ARE those row-major matrices.  Split operands like rf_conv3d_split_k3_gn_relu.  edge = 2, cin a multiple of 4 (>= 8), n >= 256; stats
+ * [n][cout][1][2] float64 (sum, sum of squares) or null.  Deepest level of the retrieval backbone: reference model/unet.py:125-144 on 2^3. */
+size_t rf_conv3_e2_split_packed_bytes(int cout, int cin);
+int rf_conv3_e2_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream);
+int rf_conv3d_e2_split_supported(int cin, int n, int edge, int cout);
+int rf_conv3d_e2_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
+                                  float* out, double* stats, void* stream);
+
 /* Activations in split form end to end ("pre-split" tensors).  Layout of C channels on edge^3 voxels: [n][cg = ceil(C/8)][plane h | plane l]
  * [voxel][8 halves] -- per (sample, 8-channel group) the LDS image of the split box kernel in global memory (rf_split_act_bytes bytes, as
  * many as the fp32 tensor), ALREADY normalised by the consumer's GroupNorm, scaled by 2^-4 and split into f16 pairs, so that the consumer

@@ -96,7 +96,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight, 'convvs': pack_convv_split_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight, 'conv3e2': pack_conv3_e2_split_weight, 'convvs': pack_convv_split_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -422,6 +422,39 @@ def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
     if pstats is not None:
         pooled._rf_stats = (pstats, tiles, pooled._version)
     return out if pool is None else (out, pooled)
+
+
+def pack_conv3_e2_split_weight(w):
+    """f16 fragment-order image of the dense GEMM form of a 3x3x3 conv on whole 2^3 volumes (csrc/conv3d_e2_split.hip)."""
+    _req(w.detach(), 'conv weight')
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError('pack_conv3_e2_split_weight: expected an OIDHW 3x3x3 weight, got %s' % (tuple(w.shape),))
+    lib = _lib.load()
+    out = torch.empty(lib.rf_conv3_e2_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.rf_conv3_e2_split_pack_weight(_p(w.detach()), cout, cin, _p(out), _stream()), 'rf_conv3_e2_split_pack_weight')
+    return out
+
+
+def conv_e2_split_supported(src, cout):
+    """True when the 2^3 GEMM form (rf_conv3d_e2_split_k3_gn_relu) takes this source and is switched on."""
+    if src is None or CONV_ARITH != 'split':
+        return False
+    n, c0, _, edge = _src_dims(src, None)
+    return bool(_lib.load().rf_conv3d_e2_split_supported(c0, n, edge, cout))
+
+
+def conv3d_e2_split_gn_relu(src, aff, w_e2_packed, cout):
+    """ReLU(conv3(GN(src))) on whole 2^3 volumes as one dense GEMM on the F16 matrix cores; the output's statistics ride along."""
+    n, cin, _, edge = _src_dims(src, None)
+    dev = _check_affine(aff, n, cin)
+    out = torch.empty((n, cout, 2, 2, 2), dtype=torch.float32, device=dev)
+    stats = torch.empty((n, cout, 1, 2), dtype=torch.float64, device=dev) if USE_FUSED_STATS else None
+    _lib.check(_lib.load().rf_conv3d_e2_split_k3_gn_relu(_p(src), cin, n, edge, _p(aff), _p(w_e2_packed), cout, _p(out), _p(stats), _stream()),
+               'rf_conv3d_e2_split_k3_gn_relu')
+    if stats is not None:
+        out._rf_stats = (stats, 1, out._version)
+    return out
 
 
 USE_PRESPLIT = True             # False: every layer normalises and splits its own input (the round-2 routes; kept for cross-checks)

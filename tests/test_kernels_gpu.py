@@ -232,6 +232,48 @@ def test_conv3d_split_operand_box_kernel(ops, case):
         same_affine(ops.gn_affine(t, None, g2, b2, g), ops.gn_affine(t.clone(), None, g2, b2, g), 'scale from fused stats')
 
 
+E2_CASES = [
+    # (n, cin, cout, groups): whole 2^3 volumes as one dense GEMM (rf_conv3d_e2_split_k3_gn_relu)
+    (8192, 64, 64, 8),         # retrieval backbone enc3, first conv (C1-C4, B = 32)
+    (1030, 64, 128, 8),        # ... second conv: four n-chunks, ragged sample count
+    (300, 48, 96, 6),          # nf = 12 (C5): 768 columns = three n-chunks
+    (260, 8, 6, 4),            # two k-steps, one partial n-chunk (48 of 256 columns)
+    (513, 20, 40, 4),          # cin a multiple of 4 only, partial second chunk
+]
+
+
+@pytest.mark.parametrize('case', E2_CASES)
+def test_conv3d_e2_split_gemm_form(ops, case):
+    """rf_conv3d_e2_split_k3_gn_relu (csrc/conv3d_e2_split.hip: SingleConv 'gcr' of model/unet.py:19-76 on whole 2^3 volumes as one dense GEMM on the F16
+    matrix cores) vs float64 torch and vs the fp32 position-major kernel: the same bar, and no further from float64 than it; fused statistics."""
+    n, cin, cout, groups = case
+    gen = torch.Generator().manual_seed(sum(case) + 5)
+    src = rnd(gen, n, cin, 2, 2, 2).relu_()
+    gamma, beta = 1 + 0.2 * rnd(gen, cin), 0.2 * rnd(gen, cin)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(8 * cin))
+    x = src.to(DEV)
+    assert ops.conv_e2_split_supported(x, cout)
+    aff = ops.gn_affine(x, None, gamma.to(DEV), beta.to(DEV), groups)
+    wd = w.to(DEV)
+    got = ops.conv3d_e2_split_gn_relu(x, aff, ops.pack_conv3_e2_split_weight(wd), cout)
+    saved, ops.CONV_ARITH = ops.CONV_ARITH, 'fp32'
+    try:
+        fp32 = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(wd), cout)
+    finally:
+        ops.CONV_ARITH = saved
+    close(got, fp32, 1e-5, '2^3 GEMM form vs the fp32 kernel')
+    ref = ref_gcr(src.double(), None, gamma.double(), beta.double(), groups, w.double())
+    close(got, ref.float(), 1e-5, '2^3 GEMM form vs float64 torch')
+    e_split, e_fp32 = (got.cpu().double() - ref).flatten(), (fp32.cpu().double() - ref).flatten()
+    rms_s, rms_f = e_split.pow(2).mean().sqrt().item(), e_fp32.pow(2).mean().sqrt().item()
+    print(f'\n{case}: error vs float64  split rms {rms_s:.3e} max {e_split.abs().max().item():.3e} | fp32 rms {rms_f:.3e} max {e_fp32.abs().max().item():.3e}')
+    assert rms_s <= 1.05 * rms_f and e_split.abs().max().item() <= 1.25 * e_fp32.abs().max().item()
+    g = groups if cout % groups == 0 else 1
+    g2, b2 = (1 + 0.2 * rnd(gen, cout)).to(DEV), (0.2 * rnd(gen, cout)).to(DEV)
+    assert getattr(got, '_rf_stats', None) is not None
+    same_affine(ops.gn_affine(got, None, g2, b2, g), ops.gn_affine(got.clone(), None, g2, b2, g), 'scale from fused stats')
+
+
 @pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (8, 16)])
 def test_split_box_kernel_leaves_concurrent_kernels_alone(ops, cin, cout):
     """Two-stream regression (the engine runs the U-Net backbone on a side stream): small fp32 convs on a second stream must return
