@@ -206,10 +206,11 @@ int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const
 
 /* The same layer on whole 2^3 volumes as ONE dense GEMM on the F16 matrix cores (csrc/conv3d_e2_split.hip): in a 2^3 volume every input voxel is a
  * neighbour of every output voxel, so out[n][(co, v)] = GN(x)[n][(ci, u)] . B[(ci, u)][(co, v)] with B[(ci, u)][(co, v)] = W[co][ci][tap(u - v)] -- x and
- * out ARE those row-major matrices.  Split operands like rf_conv3d_split_k3_gn_relu.  edge = 2, cin a multiple of 4 (>= 8), n >= 256; stats
- * [n][cout][1][2] float64 (sum, sum of squares) or null.  Deepest level of the retrieval backbone: reference model/unet.py:125-144 on 2^3. */
-size_t rf_conv3_e2_split_packed_bytes(int cout, int cin);
-int rf_conv3_e2_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream);
+ * out ARE those row-major matrices.  Split operands like rf_conv3d_split_k3_gn_relu.  edge = 2 (cin a multiple of 4) or edge = 1 (only the centre tap
+ * touches data: K = cin, N = cout), cin >= 8, n >= 16; the weight image is packed for one edge; stats [n][cout][1][2] float64 (sum, sum of squares) or
+ * null.  Deepest levels of the U-Nets: reference model/unet.py:125-144 on 2^3 / 1^3. */
+size_t rf_conv3_e2_split_packed_bytes(int cout, int cin, int edge);
+int rf_conv3_e2_split_pack_weight(const float* w_oidhw, int cout, int cin, int edge, void* w_packed, void* stream);
 int rf_conv3d_e2_split_supported(int cin, int n, int edge, int cout);
 int rf_conv3d_e2_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                   float* out, double* stats, void* stream);

@@ -1,4 +1,5 @@
 // rf_conv3d_e2_split_k3_gn_relu: SingleConv 'gcr' (reference model/unet.py:19-76: GroupNorm -> 3x3x3 conv, pad 1, no bias -> ReLU) on whole 2^3 volumes
+// (and 1^3 volumes: the same GEMM with K = cin, N = cout, the centre tap)
 // (the deepest level of the retrieval backbone: 64 -> 64 and 64 -> 128 on 8192 patches per step of C2) as ONE DENSE GEMM on the F16 matrix cores.
 //
 // In a 2^3 volume every input voxel u is a neighbour of every output voxel v (|u - v| <= 1 in each dimension), so
@@ -27,26 +28,36 @@ constexpr int E2_LDS_BYTES = 2 * E2_STEP_H8 * 16;            // 65,536
 constexpr float E2_ACT_SCALE = 1.0f / 16, E2_W_SCALE = 16.0f, E2_LO = 2048.0f;
 }
 
-extern "C" size_t rf_conv3_e2_split_packed_bytes(int cout, int cin) {
-    const size_t chunks = ((size_t)cout * 8 + E2_NC - 1) / E2_NC, ksteps = (size_t)(cin + 3) / 4;
-    return chunks * ksteps * E2_STEP_H8 * 16;
+// edge = 2: K = 8 cin, N = 8 cout (k-step = 4 channels x 8 voxels).  edge = 1: only the centre tap touches data: K = cin, N = cout (k-step = 32 channels).
+__host__ __device__ static inline size_t e2_chunks(int cout, int edge) { return ((size_t)cout * (edge == 2 ? 8 : 1) + E2_NC - 1) / E2_NC; }
+__host__ __device__ static inline size_t e2_ksteps(int cin, int edge) { return edge == 2 ? (size_t)(cin + 3) / 4 : (size_t)(cin + 31) / 32; }
+
+extern "C" size_t rf_conv3_e2_split_packed_bytes(int cout, int cin, int edge) {
+    return e2_chunks(cout, edge) * e2_ksteps(cin, edge) * E2_STEP_H8 * 16;
 }
 
-// wp[chunk][k-step s][n-block t][piece][lane]: lane (li, kg) holds K = 32 s + 8 kg + j -> (ci = 4 s + kg, u = j) of column (chunk * 256 + t * 16 + li) -> (co, v)
-__global__ void k_conv3_e2_split_pack(const float* __restrict__ w, int cout, int cin, h8* __restrict__ wp, size_t total) {
-    const int ksteps = (cin + 3) / 4;
+// wp[chunk][k-step s][n-block t][piece][lane]: lane (li, kg) holds K = 32 s + 8 kg + j of column chunk * 256 + t * 16 + li.
+// edge 2: K -> (ci = 4 s + kg, u = j), column -> (co, v);  edge 1: K -> ci = 32 s + 8 kg + j, column -> co
+__global__ void k_conv3_e2_split_pack(const float* __restrict__ w, int cout, int cin, int edge, h8* __restrict__ wp, size_t total) {
+    const int ksteps = (int)e2_ksteps(cin, edge);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63), piece = (int)((i >> 6) & 1), t = (int)((i >> 7) & 15);
         const size_t st = i >> 11;
         const int s = (int)(st % ksteps), chunk = (int)(st / ksteps);
-        const int col = chunk * E2_NC + t * 16 + (lane & 15), co = col >> 3, v = col & 7, ci = 4 * s + (lane >> 4);
+        const int col = chunk * E2_NC + t * 16 + (lane & 15);
         h8 out;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             double val = 0.0;
-            if (co < cout && ci < cin) {
-                const int dz = (u >> 2) - (v >> 2), dy = ((u >> 1) & 1) - ((v >> 1) & 1), dx = (u & 1) - (v & 1);
-                val = (double)w[((size_t)co * cin + ci) * 27 + ((dz + 1) * 3 + dy + 1) * 3 + dx + 1];
+            if (edge == 2) {
+                const int co = col >> 3, v = col & 7, ci = 4 * s + (lane >> 4);
+                if (co < cout && ci < cin) {
+                    const int dz = (u >> 2) - (v >> 2), dy = ((u >> 1) & 1) - ((v >> 1) & 1), dx = (u & 1) - (v & 1);
+                    val = (double)w[((size_t)co * cin + ci) * 27 + ((dz + 1) * 3 + dy + 1) * 3 + dx + 1];
+                }
+            } else {
+                const int co = col, ci = 32 * s + 8 * (lane >> 4) + u;
+                if (co < cout && ci < cin) val = (double)w[((size_t)co * cin + ci) * 27 + 13];
             }
             val *= (double)E2_W_SCALE;
             val = val > 65504.0 ? 65504.0 : (val < -65504.0 ? -65504.0 : val);
@@ -57,10 +68,10 @@ __global__ void k_conv3_e2_split_pack(const float* __restrict__ w, int cout, int
     }
 }
 
-extern "C" int rf_conv3_e2_split_pack_weight(const float* w_oidhw, int cout, int cin, void* w_packed, void* stream) {
-    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && cin > 0, RF_E_INVALID, "rf_conv3_e2_split_pack_weight: bad arguments");
-    const size_t total = rf_conv3_e2_split_packed_bytes(cout, cin) / 16, want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_conv3_e2_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin,
+extern "C" int rf_conv3_e2_split_pack_weight(const float* w_oidhw, int cout, int cin, int edge, void* w_packed, void* stream) {
+    RF_REQUIRE(w_oidhw && w_packed && cout > 0 && cin > 0 && (edge == 1 || edge == 2), RF_E_INVALID, "rf_conv3_e2_split_pack_weight: bad arguments");
+    const size_t total = rf_conv3_e2_split_packed_bytes(cout, cin, edge) / 16, want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_conv3_e2_split_pack, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, w_oidhw, cout, cin, edge,
                        reinterpret_cast<h8*>(w_packed), total);
     RF_CHECK_LAUNCH("rf_conv3_e2_split_pack_weight");
     return RF_OK;
@@ -75,6 +86,7 @@ struct E2Args {
     int cin, cout, n;
 };
 
+template <int V>      // voxels per volume: 8 (edge 2) or 1 (edge 1)
 __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     h8* bufs = reinterpret_cast<h8*>(lds_raw);
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * E2_MT, chunk = blockIdx.y;
-    const int cin = a.cin, cout = a.cout, ksteps = cin >> 2;
+    const int cin = a.cin, cout = a.cout, ksteps = V == 8 ? cin >> 2 : (cin + 31) >> 5;
     const h8* __restrict__ wsrc = a.wp + (size_t)chunk * ksteps * E2_STEP_H8 + tid;
 
     // this lane's two A rows (samples); rows past n read sample n - 1 and are never stored
@@ -93,8 +105,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
     for (int i = 0; i < 2; ++i) {
         int sm = n0 + (2 * wm + i) * 16 + li;
         sm = sm < a.n ? sm : a.n - 1;
-        xrow[i] = a.src + ((size_t)sm * cin + kg) * 8;
-        arow[i] = a.affine + (size_t)sm * cin + kg;
+        xrow[i] = a.src + (V == 8 ? ((size_t)sm * cin + kg) * 8 : (size_t)sm * cin + kg * 8);
+        arow[i] = a.affine + (V == 8 ? (size_t)sm * cin + kg : (size_t)sm * cin + kg * 8);
     }
     f32x4 hi[2][8], lo[2][8];
 #pragma unroll
@@ -102,14 +114,23 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    float4 xa[2][2], af[2];
+    float4 xa[2][2], af[2][V == 8 ? 1 : 8];
     h8 wreg[8];
     auto load_step = [&](int s) {                                  // raw A rows and the B block of k-step s
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            xa[i][0] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)s * 32);
-            xa[i][1] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)s * 32 + 4);
-            af[i] = arow[i][(size_t)s * 4];
+            if constexpr (V == 8) {
+                xa[i][0] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)s * 32);
+                xa[i][1] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)s * 32 + 4);
+                af[i][0] = arow[i][(size_t)s * 4];
+            } else {                                                // 8 channels of the one voxel; channels past cin: zeros (their weights are zero too)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = 32 * s + 8 * kg + j < cin;
+                    reinterpret_cast<float*>(&xa[i][0])[j] = ok ? xrow[i][(size_t)s * 32 + j] : 0.f;
+                    af[i][j] = ok ? arow[i][(size_t)s * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) wreg[q] = wsrc[(size_t)s * E2_STEP_H8 + q * 256];
@@ -127,7 +148,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
             const float raw[8] = {xa[i][0].x, xa[i][0].y, xa[i][0].z, xa[i][0].w, xa[i][1].x, xa[i][1].y, xa[i][1].z, xa[i][1].w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = __builtin_amdgcn_fmed3f(fmaf(raw[j] - af[i].x, af[i].y, af[i].z) * E2_ACT_SCALE, -65504.f, 65504.f);
+                const float4 t = af[i][V == 8 ? 0 : j];
+                const float v = __builtin_amdgcn_fmed3f(fmaf(raw[j] - t.x, t.y, t.z) * E2_ACT_SCALE, -65504.f, 65504.f);
                 const _Float16 hh = (_Float16)v;
                 ah[i][j] = hh;
                 al[i][j] = (_Float16)fmaf(-E2_LO, (float)hh, v * E2_LO);
@@ -158,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
         __syncthreads();
     }
 
-    // D[row = sample 4 kg + r of the m-block][col = li]: column = chunk * 256 + (wn * 8 + j) * 16 + li -> (co, v)
-    const int ncols = cout * 8;
+    // D[row = sample 4 kg + r of the m-block][col = li]: column = chunk * 256 + (wn * 8 + j) * 16 + li -> (co, v) (edge 1: co)
+    const int ncols = cout * V;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -173,32 +195,41 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
                 if (live) a.out[(size_t)sm * ncols + col] = y;
                 if (a.stats) {                                      // the 8 voxels of a cout: lanes li & 7 = 0 .. 7 of the same row (wave-uniform branch)
                     double sv = (double)y, sq = (double)y * (double)y;
+                    if constexpr (V == 8) {
 #pragma unroll
-                    for (int d = 1; d <= 4; d <<= 1) { sv += __shfl_xor(sv, d, 64); sq += __shfl_xor(sq, d, 64); }
-                    if (live && (li & 7) == 0) a.stats[(size_t)sm * cout + (col >> 3)] = make_double2(sv, sq);
+                        for (int d = 1; d <= 4; d <<= 1) { sv += __shfl_xor(sv, d, 64); sq += __shfl_xor(sq, d, 64); }
+                    }
+                    if (live && (V == 1 || (li & 7) == 0)) a.stats[(size_t)sm * cout + (V == 8 ? col >> 3 : col)] = make_double2(sv, sq);
                 }
             }
         }
 }
 
 extern "C" int rf_conv3d_e2_split_supported(int cin, int n, int edge, int cout) {
-    return edge == 2 && cin >= 8 && cin % 4 == 0 && cout >= 2 && n >= 256;
+    // from 16 samples on: below that a workgroup's 64 rows are nearly all padding and the fp32 position-major / direct kernels take the call
+    if (edge == 1) return cin >= 8 && cout >= 2 && n >= 16;
+    return edge == 2 && cin >= 8 && cin % 4 == 0 && cout >= 2 && n >= 16;
 }
 
-// src [n][cin][2^3], gn_affine [n][cin][4] (mean, scale, shift, -), w_packed from rf_conv3_e2_split_pack_weight -> out [n][cout][2^3] (ReLU'd) and,
-// optionally, stats [n][cout][1 tile][2] float64 (sum, sum of squares) -- the layout of the other conv entry points' statistics with one tile
+// src [n][cin][edge^3], gn_affine [n][cin][4] (mean, scale, shift, -), w_packed from rf_conv3_e2_split_pack_weight (same edge) -> out [n][cout][edge^3]
+// (ReLU'd) and, optionally, stats [n][cout][1 tile][2] float64 (sum, sum of squares) -- the layout of the other conv entry points' statistics with one tile
 extern "C" int rf_conv3d_e2_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                               float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_e2_split_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_e2_split_k3_gn_relu: takes whole 2^3 volumes, cin a multiple of 4 (>= 8), at least 256 samples (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
+               "rf_conv3d_e2_split_k3_gn_relu: takes whole 2^3 volumes (cin a multiple of 4) or 1^3 volumes, cin >= 8, at least 16 samples (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
     RF_REQUIRE(src && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_e2_split_k3_gn_relu: null pointer");
-    static RfLdsOptIn opt;
-    if (int rc = opt.ensure(reinterpret_cast<const void*>(k_conv3_e2_split), E2_LDS_BYTES, "rf_conv3d_e2_split_k3_gn_relu")) return rc;
+    static RfLdsOptIn opt8, opt1;
     E2Args a;
     a.src = src; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed); a.out = out;
     a.stats = reinterpret_cast<double2*>(stats); a.cin = cin; a.cout = cout; a.n = n;
-    hipLaunchKernelGGL(k_conv3_e2_split, dim3((unsigned)((n + E2_MT - 1) / E2_MT), (unsigned)((cout * 8 + E2_NC - 1) / E2_NC)), dim3(256), E2_LDS_BYTES,
-                       (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((n + E2_MT - 1) / E2_MT), (unsigned)e2_chunks(cout, edge));
+    if (edge == 2) {
+        if (int rc = opt8.ensure(reinterpret_cast<const void*>(k_conv3_e2_split<8>), E2_LDS_BYTES, "rf_conv3d_e2_split_k3_gn_relu")) return rc;
+        hipLaunchKernelGGL(k_conv3_e2_split<8>, grid, dim3(256), E2_LDS_BYTES, (hipStream_t)stream, a);
+    } else {
+        if (int rc = opt1.ensure(reinterpret_cast<const void*>(k_conv3_e2_split<1>), E2_LDS_BYTES, "rf_conv3d_e2_split_k3_gn_relu")) return rc;
+        hipLaunchKernelGGL(k_conv3_e2_split<1>, grid, dim3(256), E2_LDS_BYTES, (hipStream_t)stream, a);
+    }
     RF_CHECK_LAUNCH("rf_conv3d_e2_split_k3_gn_relu");
     return RF_OK;
 }

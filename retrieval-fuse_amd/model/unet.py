@@ -86,9 +86,9 @@ class Conv3dParams(nn.Module):
         """f16 fragment image of the split-operand box conv (csrc/conv3d_split.hip)"""
         return self._packed_split.get(self.weight)
 
-    def packed_e2_split(self):
-        """f16 fragment image of the dense GEMM form on whole 2^3 volumes (csrc/conv3d_e2_split.hip)"""
-        return self._packed_e2.get(self.weight)
+    def packed_e2_split(self, edge):
+        """f16 fragment image of the dense GEMM form on whole 2^3 / 1^3 volumes (csrc/conv3d_e2_split.hip)"""
+        return self._packed_e2.get(self.weight, edge)
 
     def packed_up_split(self, c0):
         """f16 fragment image of the split-operand decoder form (csrc/conv3d_up_split.hip)"""
@@ -133,8 +133,8 @@ class SingleConv(nn.Module):
             return self._forward_fp32(x, upsampled, aff, cout, edge, _direct, pool)
         if upsampled is None and not _direct and ops.conv_split_supported(x, None, cout):
             return ops.conv3d_split_gn_relu(x, aff, self.conv.packed_split(), cout, pool=pool)
-        if upsampled is None and not _direct and edge == 2 and ops.conv_e2_split_supported(x, cout):
-            out = ops.conv3d_e2_split_gn_relu(x, aff, self.conv.packed_e2_split(), cout)
+        if upsampled is None and not _direct and edge <= 2 and ops.conv_e2_split_supported(x, cout):
+            out = ops.conv3d_e2_split_gn_relu(x, aff, self.conv.packed_e2_split(edge), cout)
             return out if pool is None else (out, ops.maxpool2(out))
         if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
             return ops.conv3d_gn_relu_pool(x, None, aff, self.conv.packed(), cout, keep_full=(pool == 'also'))

@@ -64,8 +64,8 @@ SIGNATURES = {
     'rf_conv3_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_p, c_p]),
     'rf_conv3d_split_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_k3_gn_relu': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_p, c_fp, c_p, c_p]),
-    'rf_conv3_e2_split_packed_bytes': (c_sz, [c_i, c_i]),
-    'rf_conv3_e2_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_p, c_p]),
+    'rf_conv3_e2_split_packed_bytes': (c_sz, [c_i, c_i, c_i]),
+    'rf_conv3_e2_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_p, c_p]),
     'rf_conv3d_e2_split_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'rf_conv3d_e2_split_k3_gn_relu': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_p, c_p]),
     'rf_split_act_bytes': (c_sz, [c_i, c_i, c_i]),

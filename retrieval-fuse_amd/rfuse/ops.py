@@ -424,15 +424,15 @@ def conv3d_split_gn_relu(src, aff, w_split_packed, cout, pool=None):
     return out if pool is None else (out, pooled)
 
 
-def pack_conv3_e2_split_weight(w):
-    """f16 fragment-order image of the dense GEMM form of a 3x3x3 conv on whole 2^3 volumes (csrc/conv3d_e2_split.hip)."""
+def pack_conv3_e2_split_weight(w, edge=2):
+    """f16 fragment-order image of the dense GEMM form of a 3x3x3 conv on whole 2^3 (edge 2) or 1^3 (edge 1) volumes (csrc/conv3d_e2_split.hip)."""
     _req(w.detach(), 'conv weight')
     cout, cin = w.shape[0], w.shape[1]
-    if tuple(w.shape[2:]) != (3, 3, 3):
-        raise ValueError('pack_conv3_e2_split_weight: expected an OIDHW 3x3x3 weight, got %s' % (tuple(w.shape),))
+    if tuple(w.shape[2:]) != (3, 3, 3) or edge not in (1, 2):
+        raise ValueError('pack_conv3_e2_split_weight: expected an OIDHW 3x3x3 weight and edge 1 or 2, got %s, edge %r' % (tuple(w.shape), edge))
     lib = _lib.load()
-    out = torch.empty(lib.rf_conv3_e2_split_packed_bytes(cout, cin), dtype=torch.uint8, device=w.device)
-    _lib.check(lib.rf_conv3_e2_split_pack_weight(_p(w.detach()), cout, cin, _p(out), _stream()), 'rf_conv3_e2_split_pack_weight')
+    out = torch.empty(lib.rf_conv3_e2_split_packed_bytes(cout, cin, edge), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.rf_conv3_e2_split_pack_weight(_p(w.detach()), cout, cin, edge, _p(out), _stream()), 'rf_conv3_e2_split_pack_weight')
     return out
 
 
@@ -445,10 +445,10 @@ def conv_e2_split_supported(src, cout):
 
 
 def conv3d_e2_split_gn_relu(src, aff, w_e2_packed, cout):
-    """ReLU(conv3(GN(src))) on whole 2^3 volumes as one dense GEMM on the F16 matrix cores; the output's statistics ride along."""
+    """ReLU(conv3(GN(src))) on whole 2^3 / 1^3 volumes as one dense GEMM on the F16 matrix cores; the output's statistics ride along."""
     n, cin, _, edge = _src_dims(src, None)
     dev = _check_affine(aff, n, cin)
-    out = torch.empty((n, cout, 2, 2, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev)
     stats = torch.empty((n, cout, 1, 2), dtype=torch.float64, device=dev) if USE_FUSED_STATS else None
     _lib.check(_lib.load().rf_conv3d_e2_split_k3_gn_relu(_p(src), cin, n, edge, _p(aff), _p(w_e2_packed), cout, _p(out), _p(stats), _stream()),
                'rf_conv3d_e2_split_k3_gn_relu')

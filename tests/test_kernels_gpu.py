@@ -233,37 +233,42 @@ def test_conv3d_split_operand_box_kernel(ops, case):
 
 
 E2_CASES = [
-    # (n, cin, cout, groups): whole 2^3 volumes as one dense GEMM (rf_conv3d_e2_split_k3_gn_relu)
-    (8192, 64, 64, 8),         # retrieval backbone enc3, first conv (C1-C4, B = 32)
-    (1030, 64, 128, 8),        # ... second conv: four n-chunks, ragged sample count
-    (300, 48, 96, 6),          # nf = 12 (C5): 768 columns = three n-chunks
-    (260, 8, 6, 4),            # two k-steps, one partial n-chunk (48 of 256 columns)
-    (513, 20, 40, 4),          # cin a multiple of 4 only, partial second chunk
+    # (n, cin, cout, groups, edge): whole 2^3 / 1^3 volumes as one dense GEMM (rf_conv3d_e2_split_k3_gn_relu)
+    (8192, 64, 64, 8, 2),      # retrieval backbone enc3, first conv (C1-C4, B = 32)
+    (1030, 64, 128, 8, 2),     # ... second conv: four n-chunks, ragged sample count
+    (300, 48, 96, 6, 2),       # nf = 12 (C5): 768 columns = three n-chunks
+    (260, 8, 6, 4, 2),         # two k-steps, one partial n-chunk (48 of 256 columns)
+    (513, 20, 40, 4, 2),       # cin a multiple of 4 only, partial second chunk
+    (32, 32, 64, 8, 2),        # the U-Net backbone's 2^3 level at B = 32: half a workgroup of samples
+    (32, 64, 128, 8, 1),       # ... its 1^3 level: K = cin, N = cout, centre tap
+    (300, 72, 40, 8, 1),       # cin not a multiple of 32: zero-filled k-step tail
+    (16, 128, 300, 8, 1),      # two n-chunks
 ]
 
 
 @pytest.mark.parametrize('case', E2_CASES)
 def test_conv3d_e2_split_gemm_form(ops, case):
-    """rf_conv3d_e2_split_k3_gn_relu (csrc/conv3d_e2_split.hip: SingleConv 'gcr' of model/unet.py:19-76 on whole 2^3 volumes as one dense GEMM on the F16
-    matrix cores) vs float64 torch and vs the fp32 position-major kernel: the same bar, and no further from float64 than it; fused statistics."""
-    n, cin, cout, groups = case
+    """rf_conv3d_e2_split_k3_gn_relu (csrc/conv3d_e2_split.hip: SingleConv 'gcr' of model/unet.py:19-76 on whole 2^3 / 1^3 volumes as one dense GEMM on
+    the F16 matrix cores) vs float64 torch and vs the fp32 kernels (position-major / direct): the same bar, and no further from float64 than they; fused
+    statistics."""
+    n, cin, cout, groups, edge = case
     gen = torch.Generator().manual_seed(sum(case) + 5)
-    src = rnd(gen, n, cin, 2, 2, 2).relu_()
+    src = rnd(gen, n, cin, edge, edge, edge).relu_()
     gamma, beta = 1 + 0.2 * rnd(gen, cin), 0.2 * rnd(gen, cin)
-    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(8 * cin))
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=1.0 / np.sqrt(edge ** 3 * cin))
     x = src.to(DEV)
     assert ops.conv_e2_split_supported(x, cout)
     aff = ops.gn_affine(x, None, gamma.to(DEV), beta.to(DEV), groups)
     wd = w.to(DEV)
-    got = ops.conv3d_e2_split_gn_relu(x, aff, ops.pack_conv3_e2_split_weight(wd), cout)
+    got = ops.conv3d_e2_split_gn_relu(x, aff, ops.pack_conv3_e2_split_weight(wd, edge), cout)
     saved, ops.CONV_ARITH = ops.CONV_ARITH, 'fp32'
     try:
-        fp32 = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(wd), cout)
+        fp32 = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(wd) if edge > 1 else None, cout, direct_weight=wd if edge == 1 else None)
     finally:
         ops.CONV_ARITH = saved
-    close(got, fp32, 1e-5, '2^3 GEMM form vs the fp32 kernel')
+    close(got, fp32, 1e-5, 'GEMM form vs the fp32 kernel')
     ref = ref_gcr(src.double(), None, gamma.double(), beta.double(), groups, w.double())
-    close(got, ref.float(), 1e-5, '2^3 GEMM form vs float64 torch')
+    close(got, ref.float(), 1e-5, 'GEMM form vs float64 torch')
     e_split, e_fp32 = (got.cpu().double() - ref).flatten(), (fp32.cpu().double() - ref).flatten()
     rms_s, rms_f = e_split.pow(2).mean().sqrt().item(), e_fp32.pow(2).mean().sqrt().item()
     print(f'\n{case}: error vs float64  split rms {rms_s:.3e} max {e_split.abs().max().item():.3e} | fp32 rms {rms_f:.3e} max {e_fp32.abs().max().item():.3e}')

@@ -17,7 +17,7 @@ for n, cin, cout in [(8192, 64, 64), (8192, 64, 128), (4096, 48, 96), (16384, 64
     x = torch.rand(n, cin, 2, 2, 2, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
     aff = torch.zeros(n, cin, 4, device=dev); aff[..., 1] = 1.0
-    wp, we = ops.pack_conv3_weight(w), ops.pack_conv3_e2_split_weight(w)
+    wp, we = ops.pack_conv3_weight(w), ops.pack_conv3_e2_split_weight(w, 2)
     a = t(lambda: ops.conv3d_e2_split_gn_relu(x, aff, we, cout))
     saved, ops.CONV_ARITH = ops.CONV_ARITH, 'fp32'
     b = t(lambda: ops.conv3d_gn_relu(x, None, aff, wp, cout))
