@@ -1,6 +1,7 @@
+"""Dev tool (GPU box): the pipelined step of a config with the 2^3 / 1^3 GEMM form on and off, alternating in one process."""
 import sys, time
 from pathlib import Path
-REPO = Path(__file__).resolve().parents[2]
+REPO = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(REPO), str(REPO / 'retrieval-fuse_amd')]
 import numpy as np, torch
 import bench

@@ -1,6 +1,7 @@
+"""Dev tool (GPU box): the 2^3 GEMM form (rf_conv3d_e2_split_k3_gn_relu) against the fp32 position-major kernel, launch by launch (HIP events)."""
 import sys
 from pathlib import Path
-REPO = Path(__file__).resolve().parents[2]
+REPO = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(REPO / 'retrieval-fuse_amd')]
 import torch
 from rfuse import ops

@@ -1,3 +1,7 @@
+"""Dev tool: per-kernel totals of a rocprofv3 run kept in rocpd format (the default output, <dir>/<name>_results.db).
+
+    python tools/rocpd_summary.py results.db [steps] [rows]
+"""
 import sqlite3, collections, sys, re
 db=sqlite3.connect(sys.argv[1]); steps=int(sys.argv[2]) if len(sys.argv)>2 else 8
 c=db.cursor()

@@ -1,7 +1,7 @@
 """A config's step under three schedules: pipelined refine_stream, refine() with the side stream, refine() serial."""
 import sys, time
 from pathlib import Path
-REPO = Path(__file__).resolve().parents[2]
+REPO = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(REPO), str(REPO / 'retrieval-fuse_amd')]
 import numpy as np, torch
 import bench
