@@ -136,8 +136,10 @@ class ConvGnRelu(torch.autograd.Function):
             w = weight.contiguous()
             # the inference kernels, chosen like model/unet.py:SingleConv.forward chooses them: the split-operand forms where the parameters are
             # inside their range (one batched range check per optimiser step, ops._abs_max), the fp32 kernels otherwise
-            split_ok = edge > 1 and ops.CONV_ARITH == 'split' and ops.split_range_ok(weight, gamma, beta, (cin // g) * edge ** 3)
-            if edge == 1:
+            split_ok = ops.CONV_ARITH == 'split' and ops.split_range_ok(weight, gamma, beta, (cin // g) * edge ** 3)
+            if split_ok and edge <= 2 and ops.conv_e2_split_supported(x, cout):
+                y = ops.conv3d_e2_split_gn_relu(x, aff, ops.pack_conv3_e2_split_weight(w, edge), cout)
+            elif edge == 1:
                 y = ops.conv3d_gn_relu(x, None, aff, None, cout, direct_weight=w)
             elif split_ok and ops.conv_split_supported(x, None, cout):
                 y = ops.conv3d_split_gn_relu(x, aff, ops.pack_conv3_split_weight(w), cout)
@@ -146,7 +148,7 @@ class ConvGnRelu(torch.autograd.Function):
             else:
                 y = ops.conv3d_gn_relu(x, None, aff, ops.pack_conv3_weight(w), cout)
         ctx.save_for_backward(x, gamma, weight, aff, y)
-        ctx.groups, ctx.eps, ctx.split_ok = g, eps, bool(split_ok)
+        ctx.groups, ctx.eps, ctx.split_ok = g, eps, bool(split_ok) and edge > 1
         return y
 
     @staticmethod

@@ -32,7 +32,7 @@ def rel_err(got, ref):
 @pytest.mark.parametrize('case', [(3, 8, 0, 16, 16, 8), (2, 16, 0, 8, 32, 8), (5, 6, 0, 8, 12, 6), (4, 32, 0, 4, 64, 8), (6, 64, 0, 2, 64, 8),
                                   (3, 64, 0, 1, 128, 8), (2, 1, 0, 16, 8, 8), (2, 16, 32, 8, 24, 8), (1, 0, 16, 16, 16, 8),
                                   # enough boxes for the split-operand routes: forward on the F16 cores, data gradient on them through a scaled dz
-                                  (130, 8, 0, 16, 16, 8), (1030, 16, 0, 8, 32, 8), (1030, 32, 0, 4, 64, 8), (1030, 8, 8, 8, 40, 4), (12, 20, 0, 4, 24, 4),
+                                  (130, 8, 0, 16, 16, 8), (1030, 16, 0, 8, 32, 8), (1030, 32, 0, 4, 64, 8), (1030, 8, 8, 8, 40, 4), (12, 20, 0, 4, 24, 4), (300, 16, 0, 2, 24, 8), (40, 64, 0, 1, 32, 8),
                                   (4, 16, 0, 64, 16, 8),                  # few samples, large volumes: GroupNorm backward in 64 slices per channel
                                   (1030, 16, 0, 8, 16, 8, 1e-9), (130, 8, 0, 16, 16, 8, 3e7)])     # tiny / huge upstream gradients
 def test_single_conv_gradients_match_float64_oracle(gpu, case):
