@@ -267,8 +267,8 @@ int rf_relu_backward(const float* dy, const float* y, size_t count, float* out, 
  *   rf_dgrad_scale_affine   from those slots: the identity GroupNorm affine with scale s = the power of two that puts the maximum into [512, 1024)
  *                           (rows x (0, s, 0, 0), the gn_affine layout) and scales = (s, 1 / s) -- exact scaling, no host sync;
  *   rf_conv3d_split_k3_gn   rf_conv3d_split_k3_gn_relu as a plain operator: any cout (16 or 32 per workgroup), ReLU optional, no statistics.
- * d xn = rf_conv3d_split_k3_gn(dz, affine of rf_dgrad_scale_affine, W^T with flipped taps, relu = 0) / s; rfuse/autograd.py takes 1 / s out in
- * the GroupNorm backward that follows (gamma / s; dgamma, dbeta / s). */
+ * d xn = rf_conv3d_split_k3_gn(dz, affine of rf_dgrad_scale_affine, W^T with flipped taps, relu = 0) / s; the GroupNorm backward that follows takes
+ * 1 / s out (rf_gn_backward's dxn_inv_scale = scales + 1). */
 int rf_relu_backward_amax_slots(void);
 int rf_relu_backward_amax(const float* dy, const float* y, size_t count, float* out, float* amax_slots, void* stream);
 int rf_dgrad_scale_affine(const float* amax_slots, int rows, float* affine, float* scales, void* stream);
@@ -284,9 +284,10 @@ int rf_maxpool3d_2_backward(const float* x, const float* dy, int n, int c, int e
 int rf_upsample3d_2(const float* lo, int n, int c, int edge_lo, float* hi, void* stream);
 int rf_sumpool3d_2(const float* hi, int n, int c, int edge, float* lo, void* stream);
 /* GroupNorm backward (model/unet.py:54-66; torch.nn.GroupNorm semantics, biased variance): x, dxn [n][c][edge^3], gamma [c] ->
- * dx [n][c][edge^3] and per-(n, c) float64 pieces of dgamma / dbeta (sum them over n). */
-int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, float* dx,
-                   double* dgamma_parts, double* dbeta_parts, void* ws, size_t ws_bytes, void* stream);
+ * dx [n][c][edge^3], dgamma [c], dbeta [c] (float64 sums in a fixed order, rounded once).  dxn_inv_scale: null, or a device float when d xn arrives
+ * multiplied by 1 / *dxn_inv_scale (rf_dgrad_scale_affine's power of two): the three outputs are multiplied by it (they are linear in d xn). */
+int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, const float* dxn_inv_scale,
+                   float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 size_t rf_gn_backward_ws_bytes(int n, int c, int edge);
 /* Weight gradient of the 3x3x3 conv: dw[co][ci][tap] = sum_{n,v} dz[n][co][v] * GN(x)[n][ci][v + tap - 1] (zero padded), fp32 MFMA
  * with K = voxels; edge a power of two >= 4 (8^3 boxes; whole 4^3 samples eight at a time).  gn_affine as in the forward. */

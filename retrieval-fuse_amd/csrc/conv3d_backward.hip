@@ -180,14 +180,15 @@ extern "C" int rf_sumpool3d_2(const float* hi, int n, int c, int edge, float* lo
 }
 
 // ------------------------------------------------------------------------------------------- GroupNorm backward
-// Three launches, every tensor read once per pass and every launch wide enough for the chip whatever the shape ([4][16][64^3] of the final
+// Four launches, every tensor read once per pass and every launch wide enough for the chip whatever the shape ([4][16][64^3] of the final
 // decoder = 64 (sample, channel) pairs; [1024][8][16^3] of the retrieval backbone = 8192):
 //   pass 1  k_gnb_partial   per (sample, channel, slice of the volume): sum x, sum x^2, sum d, sum d * x  (d = d xn) in float64 -- raw sums, so
 //                           the pass needs no moments and reads x and d exactly once (a product of two floats is exact in float64);
 //   pass 2  k_gnb_finalize  per (sample, group): slices and channels summed in a fixed order -> mean, rstd, a1_c = sum d, a2_c = sum d * xh =
 //                           rstd * (sum d x - mean * sum d), G1 / G2 = the group's gamma-weighted sums -> the coefficients of pass 3 and the
 //                           per-sample pieces of dgamma / dbeta;
-//   pass 3  k_gnb_apply     dx = k0 * d - k1 - xh * k2   (float64 per element, rounded once).
+//   pass 3  k_gnb_apply     dx = k0 * d - k1 - xh * k2   (float64 per element, rounded once);
+//   pass 4  k_gnb_sum_n     dgamma, dbeta = the per-sample pieces summed over the batch (float64, fixed order).
 // (The first form recomputed the group moments in every channel's workgroup -- cpg re-reads of x -- with one workgroup per (sample, channel):
 // 3.9 ms of a 26.7 ms training step for 0.5 ms of traffic.)
 namespace {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void k_gnb_partial(const float* __restrict__ x
 
 // one 64-thread workgroup per (sample, group); thread k sums the slices of channel k (k, k + 64, ...) in slice order, thread 0 the channels in order
 __global__ __launch_bounds__(64) void k_gnb_finalize(const double4* __restrict__ part, const float* __restrict__ gamma, int C, int cpg, size_t vol, int P,
-                                                     double eps, double2* __restrict__ moments, double4* __restrict__ coef,
+                                                     double eps, const float* __restrict__ inv_scale, double2* __restrict__ moments, double4* __restrict__ coef,
                                                      double* __restrict__ a1_out, double* __restrict__ a2_out) {
     const int groups = C / cpg, nn = blockIdx.x / groups, g = blockIdx.x % groups, tid = threadIdx.x;
     __shared__ double4 ch[64];
@@ -296,10 +297,11 @@ __global__ __launch_bounds__(64) void k_gnb_finalize(const double4* __restrict__
         __syncthreads();
     }
     const double G1 = grp[2], G2 = grp[3];
+    const double inv = inv_scale ? (double)*inv_scale : 1.0;       // d xn arrived multiplied by 1 / inv (a power of two): dx is linear in it
     for (int k = tid; k < cpg; k += 64) {
         const int cc = g * cpg + k;
         moments[(size_t)nn * C + cc] = make_double2(mean, rstd);
-        coef[(size_t)nn * C + cc] = make_double4(rstd * (double)gamma[cc], rstd * G1 / m, rstd * G2 / m, 0.0);
+        coef[(size_t)nn * C + cc] = make_double4(inv * rstd * (double)gamma[cc], inv * rstd * G1 / m, inv * rstd * G2 / m, 0.0);
     }
 }
 
@@ -335,15 +337,35 @@ __global__ __launch_bounds__(256) void k_gnb_apply(const float* __restrict__ x, 
     }
 }
 
-extern "C" size_t rf_gn_backward_ws_bytes(int n, int c, int edge) {
-    const size_t vol = (size_t)edge * edge * edge;
-    return (size_t)n * c * ((size_t)gnb_slices(vol) * sizeof(double4) + sizeof(double2) + sizeof(double4));
+// dgamma_c = sum_n a2[n][c], dbeta_c = sum_n a1[n][c] (x inv): 64 threads per channel, thread t sums samples t, t + 64, ... in float64, the 64 partial
+// sums are added in thread order -- a fixed order
+__global__ __launch_bounds__(64) void k_gnb_sum_n(const double* __restrict__ a1, const double* __restrict__ a2, int n, int C, const float* __restrict__ inv_scale,
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    __shared__ double r1[64], r2[64];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = t; i < n; i += 64) { s1 += a1[(size_t)i * C + c]; s2 += a2[(size_t)i * C + c]; }
+    r1[t] = s1; r2[t] = s2;
+    __syncthreads();
+    if (t == 0) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int k = 0; k < 64; ++k) { S1 += r1[k]; S2 += r2[k]; }
+        const double inv = inv_scale ? (double)*inv_scale : 1.0;
+        dbeta[c] = (float)(S1 * inv);
+        dgamma[c] = (float)(S2 * inv);
+    }
 }
 
-// x, dxn [n][c][edge^3]; gamma [c]; out: dx [n][c][edge^3], dgamma_parts / dbeta_parts [n][c] float64 (the caller sums over n)
-extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, float* dx,
-                              double* dgamma_parts, double* dbeta_parts, void* ws, size_t ws_bytes, void* stream) {
-    RF_REQUIRE(x && dxn && gamma && dx && dgamma_parts && dbeta_parts && ws && n > 0 && c > 0 && edge > 0 && groups > 0 && c % groups == 0, RF_E_INVALID,
+extern "C" size_t rf_gn_backward_ws_bytes(int n, int c, int edge) {
+    const size_t vol = (size_t)edge * edge * edge;
+    return (size_t)n * c * ((size_t)gnb_slices(vol) * sizeof(double4) + sizeof(double2) + sizeof(double4) + 2 * sizeof(double));
+}
+
+// x, dxn [n][c][edge^3]; gamma [c]; dxn_inv_scale: null, or a device float: d xn arrives multiplied by 1 / *dxn_inv_scale (the split data-gradient conv
+// works on a power-of-two scaled dz, rf_dgrad_scale_affine) and everything that leaves is multiplied by it; out: dx [n][c][edge^3], dgamma [c], dbeta [c]
+extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, int edge, const float* gamma, int groups, float eps, const float* dxn_inv_scale,
+                              float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    RF_REQUIRE(x && dxn && gamma && dx && dgamma && dbeta && ws && n > 0 && c > 0 && edge > 0 && groups > 0 && c % groups == 0, RF_E_INVALID,
                "rf_gn_backward: bad arguments");
     RF_REQUIRE(ws_bytes >= rf_gn_backward_ws_bytes(n, c, edge), RF_E_WORKSPACE, "rf_gn_backward: workspace too small");
     const size_t vol = (size_t)edge * edge * edge;
@@ -351,6 +373,8 @@ extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, in
     double4* part = (double4*)ws;                                    // [n * c][P]
     double4* coef = part + (size_t)n * c * P;                        // [n * c]
     double2* moments = (double2*)(coef + (size_t)n * c);             // [n * c]
+    double* a1 = (double*)(moments + (size_t)n * c);                 // [n][c] sum d xn          (per-sample pieces of dbeta)
+    double* a2 = a1 + (size_t)n * c;                                 // [n][c] sum d xn * xh     (... of dgamma)
     hipStream_t s = (hipStream_t)stream;
     const size_t units = (vol & 3) == 0 ? vol / 4 : vol;
     int L = 1;
@@ -358,11 +382,13 @@ extern "C" int rf_gn_backward(const float* x, const float* dxn, int n, int c, in
     const int rows = n * c, rpw = 256 / L;
     hipLaunchKernelGGL(k_gnb_partial, dim3((unsigned)((rows + rpw - 1) / rpw), P), dim3(256), 0, s, x, dxn, vol, P, L, rows, part);
     RF_CHECK_LAUNCH("rf_gn_backward(partial)");
-    hipLaunchKernelGGL(k_gnb_finalize, dim3(n * groups), dim3(64), 0, s, part, gamma, c, cpg, vol, P, (double)eps, moments, coef, dbeta_parts, dgamma_parts);
+    hipLaunchKernelGGL(k_gnb_finalize, dim3(n * groups), dim3(64), 0, s, part, gamma, c, cpg, vol, P, (double)eps, dxn_inv_scale, moments, coef, a1, a2);
     RF_CHECK_LAUNCH("rf_gn_backward(finalize)");
     const size_t want = ((size_t)rows * units + 255) / 256;
     hipLaunchKernelGGL(k_gnb_apply, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, s, x, dxn, vol, (size_t)rows, moments, coef, dx);
     RF_CHECK_LAUNCH("rf_gn_backward(apply)");
+    hipLaunchKernelGGL(k_gnb_sum_n, dim3(c), dim3(64), 0, s, a1, a2, n, c, dxn_inv_scale, dgamma, dbeta);
+    RF_CHECK_LAUNCH("rf_gn_backward(sum)");
     return RF_OK;
 }
 

@@ -94,7 +94,7 @@ SIGNATURES = {
     'rf_maxpool3d_2_backward': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_upsample3d_2': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
     'rf_sumpool3d_2': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_p]),
-    'rf_gn_backward': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_i, c_f, c_fp, c_p, c_p, c_p, c_sz, c_p]),
+    'rf_gn_backward': (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_fp, c_p, c_sz, c_p]),
     'rf_gn_backward_ws_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3d_k3_wgrad': (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_sz, c_p]),
     'rf_conv3d_k3_wgrad_ws_bytes': (c_sz, [c_i, c_i, c_i, c_i]),

@@ -101,15 +101,17 @@ def conv3d_gn(x, aff, w_packed, cout, relu):
 
 
 @ops._device_scoped
-def gn_backward(x, dxn, gamma, groups, eps):
+def gn_backward(x, dxn, gamma, groups, eps, inv_scale=None):
+    """dx, dgamma, dbeta of GroupNorm; ``inv_scale``: a device scalar when dxn arrives multiplied by 1 / inv_scale (the scaled split data gradient)"""
     n, c, edge = x.shape[0], x.shape[1], x.shape[2]
     lib = _lib.load()
     dx = torch.empty_like(x)
-    dg = torch.empty((n, c), dtype=torch.float64, device=x.device)
-    db = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = _ws(x.device, lib.rf_gn_backward_ws_bytes(n, c, edge))
-    _lib.check(lib.rf_gn_backward(_p(x), _p(dxn), n, c, edge, _p(gamma), groups, eps, _p(dx), _p(dg), _p(db), _p(ws), ws.numel(), _stream()), 'rf_gn_backward')
-    return dx, dg.sum(0).float(), db.sum(0).float()
+    _lib.check(lib.rf_gn_backward(_p(x), _p(dxn), n, c, edge, _p(gamma), groups, eps, _p(inv_scale), _p(dx), _p(dg), _p(db), _p(ws), ws.numel(), _stream()),
+               'rf_gn_backward')
+    return dx, dg, db
 
 
 @ops._device_scoped
@@ -166,7 +168,7 @@ class ConvGnRelu(torch.autograd.Function):
             else:
                 dz = relu_backward(dy.contiguous(), y) if y.numel() % 4 == 0 else dy * (y > 0)
             if use_dgrad:
-                dxn, inv_s = dgrad_split(dz, ident, weight, cin), scales[1]
+                dxn, inv_s = dgrad_split(dz, ident, weight, cin), scales[1:]
             if inv_s is not None:
                 pass
             elif edge >= 2:
@@ -187,11 +189,8 @@ class ConvGnRelu(torch.autograd.Function):
                 cols = cols.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(n * edge ** 3, cin * 27)
                 dzf = dz.permute(0, 2, 3, 4, 1).reshape(n * edge ** 3, cout)
                 dw = ops.linear_wgrad(dzf.contiguous(), cols.contiguous()).reshape(cout, cin, 3, 3, 3)
-            if inv_s is None:
-                dx, dgamma, dbeta = gn_backward(x, dxn.contiguous(), gamma, ctx.groups, ctx.eps)
-            else:                                                                   # d xn came scaled by s: GroupNorm backward is linear in it
-                dx, dgamma, dbeta = gn_backward(x, dxn, gamma * inv_s, ctx.groups, ctx.eps)
-                dgamma, dbeta = dgamma * inv_s, dbeta * inv_s
+            # (d xn of the split data gradient came scaled by s: GroupNorm backward is linear in it and takes 1 / s out)
+            dx, dgamma, dbeta = gn_backward(x, dxn.contiguous(), gamma, ctx.groups, ctx.eps, inv_s)
         return dx, dgamma, dbeta, dw, None, None, None, None
 
 
