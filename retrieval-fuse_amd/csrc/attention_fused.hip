@@ -321,7 +321,9 @@ __device__ __forceinline__ void ams_layer(const float* wbuf, int tn, const am_h8
     }
 }
 
-__global__ __launch_bounds__(AM_WAVES * 64) void k_attn_mlp_split(AmArgs a) {
+// 12 waves (three per SIMD: 168 registers each) instead of the fp32 kernel's 16: at 128 registers the layer loop spilled 22 of them (270 -> 250 us on 524 288 rows)
+#define AMS_WAVES 12
+__global__ __launch_bounds__(AMS_WAVES * 64) void k_attn_mlp_split(AmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];     // two weight buffers of AM_BUF_FLOATS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,15 +335,15 @@ __global__ __launch_bounds__(AM_WAVES * 64) void k_attn_mlp_split(AmArgs a) {
         const int npiece = ams_steps(a.n_in, layer) * ams_ibn(layer) * 2;
         const float* src = a.img2 + ams_layer_off(a.n_in, layer);
         float* dst = smem + (layer & 1) * AM_BUF_FLOATS;
-        for (int q = wave; q < npiece; q += AM_WAVES)
+        for (int q = wave; q < npiece; q += AMS_WAVES)
             __builtin_amdgcn_global_load_lds((rf_gptr)(src + q * 256 + lane * 4), (rf_lptr)(dst + q * 256), 16, 0, 0);
     };
     const float4* bias4 = reinterpret_cast<const float4*>(a.img + am_layer_off(a.n_in, 4));     // [layer][32 float4s]
 
     dma_layer(0);
-    const int nwt = (a.ntiles + AM_WAVES - 1) / AM_WAVES;             // workgroup tiles of 16 waves x 16 rows
+    const int nwt = (a.ntiles + AMS_WAVES - 1) / AMS_WAVES;             // workgroup tiles of 12 waves x 16 rows
     for (int wt = blockIdx.x; wt < nwt; wt += gridDim.x) {
-        const int rt = wt * AM_WAVES + wave;
+        const int rt = wt * AMS_WAVES + wave;
         const bool live = rt < a.ntiles;
         int row = rt * 16 + j;
         if (row >= a.nrows) row = a.nrows - 1;                        // clamp: computed, never stored
@@ -423,7 +425,8 @@ static int am_launch(const AmArgs& a, hipStream_t st) {
     if (a.img2) {
         static RfLdsOptIn opt_in2;
         if (int rc = opt_in2.ensure(reinterpret_cast<const void*>(k_attn_mlp_split), lds, "rf_attn_mlp")) return rc;
-        hipLaunchKernelGGL(k_attn_mlp_split, dim3(nwt < 256 ? nwt : 256), dim3(AM_WAVES * 64), lds, st, a);
+        const int nwt2 = (a.ntiles + AMS_WAVES - 1) / AMS_WAVES;
+        hipLaunchKernelGGL(k_attn_mlp_split, dim3(nwt2 < 256 ? nwt2 : 256), dim3(AMS_WAVES * 64), lds, st, a);
     } else {
         hipLaunchKernelGGL(k_attn_mlp, dim3(nwt < 256 ? nwt : 256), dim3(AM_WAVES * 64), lds, st, a);
     }
