@@ -349,6 +349,7 @@ __global__ __launch_bounds__(64) void k_gnb_sum_n(const double* __restrict__ a1,
     __syncthreads();
     if (t == 0) {
         double S1 = 0.0, S2 = 0.0;
+#pragma unroll 4
         for (int k = 0; k < 64; ++k) { S1 += r1[k]; S2 += r2[k]; }
         const double inv = inv_scale ? (double)*inv_scale : 1.0;
         dbeta[c] = (float)(S1 * inv);

@@ -114,21 +114,30 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    float4 xa[2][2], af[2][V == 8 ? 1 : 8];
+    float4 xa[2][2], af[2];                                       // edge 2: the raw row and its affine, converted after the MFMAs they were loaded under
+    h8 nah[2], nal[2];                                             // edge 1: converted at once (8 affines per row would not fit beside the accumulators)
     h8 wreg[8];
-    auto load_step = [&](int s) {                                  // raw A rows and the B block of k-step s
+    auto split1 = [](float y, _Float16& hh, _Float16& ll) {
+        const float v = __builtin_amdgcn_fmed3f(y * E2_ACT_SCALE, -65504.f, 65504.f);
+        hh = (_Float16)v;
+        ll = (_Float16)fmaf(-E2_LO, (float)hh, v * E2_LO);
+    };
+    auto load_step = [&](int s) {                                  // A rows and the B block of k-step s
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if constexpr (V == 8) {
                 xa[i][0] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)s * 32);
                 xa[i][1] = *reinterpret_cast<const float4*>(xrow[i] + (size_t)s * 32 + 4);
-                af[i][0] = arow[i][(size_t)s * 4];
+                af[i] = arow[i][(size_t)s * 4];
             } else {                                                // 8 channels of the one voxel; channels past cin: zeros (their weights are zero too)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool ok = 32 * s + 8 * kg + j < cin;
-                    reinterpret_cast<float*>(&xa[i][0])[j] = ok ? xrow[i][(size_t)s * 32 + j] : 0.f;
-                    af[i][j] = ok ? arow[i][(size_t)s * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float x = ok ? xrow[i][(size_t)s * 32 + j] : 0.f;
+                    const float4 t = ok ? arow[i][(size_t)s * 32 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    _Float16 hh, ll;
+                    split1(fmaf(x - t.x, t.y, t.z), hh, ll);
+                    nah[i][j] = hh; nal[i][j] = ll;
                 }
             }
         }
@@ -145,14 +154,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
     auto convert = [&] {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float raw[8] = {xa[i][0].x, xa[i][0].y, xa[i][0].z, xa[i][0].w, xa[i][1].x, xa[i][1].y, xa[i][1].z, xa[i][1].w};
+            if constexpr (V == 8) {
+                const float raw[8] = {xa[i][0].x, xa[i][0].y, xa[i][0].z, xa[i][0].w, xa[i][1].x, xa[i][1].y, xa[i][1].z, xa[i][1].w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 t = af[i][V == 8 ? 0 : j];
-                const float v = __builtin_amdgcn_fmed3f(fmaf(raw[j] - t.x, t.y, t.z) * E2_ACT_SCALE, -65504.f, 65504.f);
-                const _Float16 hh = (_Float16)v;
-                ah[i][j] = hh;
-                al[i][j] = (_Float16)fmaf(-E2_LO, (float)hh, v * E2_LO);
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 hh, ll;
+                    split1(fmaf(raw[j] - af[i].x, af[i].y, af[i].z), hh, ll);
+                    ah[i][j] = hh; al[i][j] = ll;
+                }
+            } else {
+                ah[i] = nah[i]; al[i] = nal[i];
             }
         }
     };
