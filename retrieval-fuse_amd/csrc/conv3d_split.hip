@@ -195,11 +195,26 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a, SplitPreOu
     // ---- per-lane operand addressing (BoxOrder: x = i & 7, y = 4 (wave & 1) + 2 (mb >> 1) + (i >> 3), z = 2 (wave >> 1) + (mb & 1))
     const int g = lane >> 4, ri = lane & 15;
     const int abase = ((2 * (wave >> 1) + 1) * CS_SZ + (4 * (wave & 1) + (ri >> 3) + 1) * CS_SY + (ri & 7) + 1) * 16;
-    int atap[7];
+    // tap offset of k-step s for this lane's tap 4 s + g.  Multi-chunk instances keep the seven offsets in registers; the one-chunk instances
+    // (80 registers for three workgroups per CU; the seven offsets were exactly the seven registers they spilled, reloaded from scratch between the
+    // MFMAs of the k-steps) recompute an offset in the shadow of the previous k-step's MFMAs, from a copy of g the compiler cannot see through
+    int atap[ONE ? 1 : 7];
+    auto tap_off = [&](int s) -> int {
+        if constexpr (ONE) {
+            int gg = g;
+            asm volatile("" : "+v"(gg));
+            const int tq = 4 * s + gg, tp = tq < 27 ? tq : 26;
+            return ((tp / 9 - 1) * CS_SZ + ((tp / 3) % 3 - 1) * CS_SY + (tp % 3 - 1)) * 16;
+        } else {
+            return atap[s];
+        }
+    };
+    if constexpr (!ONE) {
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const int tp = 4 * s + g < 27 ? 4 * s + g : 26;
-        atap[s] = ((tp / 9 - 1) * CS_SZ + ((tp / 3) % 3 - 1) * CS_SY + (tp % 3 - 1)) * 16;
+        for (int s = 0; s < 7; ++s) {
+            const int tp = 4 * s + g < 27 ? 4 * s + g : 26;
+            atap[s] = ((tp / 9 - 1) * CS_SZ + ((tp / 3) % 3 - 1) * CS_SY + (tp % 3 - 1)) * 16;
+        }
     }
 
     f32x4 hi[4][NB], lo[4][NB];
@@ -268,11 +283,13 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a, SplitPreOu
         auto xload = [&] { if constexpr (!ONE) stage_load(x, cx); };
         auto no_hook = [](int) {};
         const unsigned char* buf = lds + (ca & 1) * CS_BUF + abase;
-        ah[0] = *reinterpret_cast<const h8*>(buf + atap[0]);
-        al[0] = *reinterpret_cast<const h8*>(buf + atap[0] + CS_PLANE);
+        int tcur = tap_off(0);
+        ah[0] = *reinterpret_cast<const h8*>(buf + tcur);
+        al[0] = *reinterpret_cast<const h8*>(buf + tcur + CS_PLANE);
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
-            const unsigned char* ap = buf + atap[s];
+            const unsigned char* ap = buf + tcur;
+            const int tnext = s < 6 ? tap_off(s + 1) : tcur;
             auto conv_hook = [&](int m) {
                 if constexpr (!ONE && !PRE) {
                     const int e = (s - 2) * 4 + m, r = e >> 3, j = e & 7;
@@ -283,11 +300,12 @@ __global__ __launch_bounds__(512, WPS) void k_conv3_split(ConvArgs a, SplitPreOu
                     lq[r][j] = (_Float16)fmaf(-CS_LO, (float)hh, v * CS_LO);
                 }
             };
-            if (s == 0) kstep(std::true_type{}, xload, no_hook, ap, buf + atap[s + 1], ch, cl, nh, nl);
+            if (s == 0) kstep(std::true_type{}, xload, no_hook, ap, buf + tnext, ch, cl, nh, nl);
             else if (s == 6) kstep(std::false_type{}, no_x, no_hook, ap, ap, ch, cl, nh, nl);
-            else if (s == 1) kstep(std::true_type{}, no_x, no_hook, ap, buf + atap[s + 1], nh, nl, ch, cl);
-            else if (s & 1) kstep(std::true_type{}, no_x, conv_hook, ap, buf + atap[s + 1], nh, nl, ch, cl);
-            else kstep(std::true_type{}, no_x, conv_hook, ap, buf + atap[s + 1], ch, cl, nh, nl);
+            else if (s == 1) kstep(std::true_type{}, no_x, no_hook, ap, buf + tnext, nh, nl, ch, cl);
+            else if (s & 1) kstep(std::true_type{}, no_x, conv_hook, ap, buf + tnext, nh, nl, ch, cl);
+            else kstep(std::true_type{}, no_x, conv_hook, ap, buf + tnext, ch, cl, nh, nl);
+            tcur = tnext;
         }
         if constexpr (!ONE) {
             if constexpr (PRE) {
