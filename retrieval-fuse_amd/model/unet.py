@@ -136,6 +136,13 @@ class SingleConv(nn.Module):
         if upsampled is None and not _direct and edge <= 2 and ops.conv_e2_split_supported(x, cout):
             out = ops.conv3d_e2_split_gn_relu(x, aff, self.conv.packed_e2_split(edge), cout)
             return out if pool is None else (out, ops.maxpool2(out))
+        if upsampled is not None and edge == 2 and not _direct and pool is None:
+            # decoder stage on 2^3 volumes (skip @2^3 + a 1^3 source): the eight copies of the low-resolution voxel written out (a [n][c0 + c1][8] tensor, a
+            # few KB per sample) and the layer run as the dense GEMM -- the affine table is per channel of the concatenation either way
+            up = upsampled.reshape(upsampled.shape[0], upsampled.shape[1], 1, 1, 1).expand(-1, -1, 2, 2, 2)
+            xc = torch.cat((x, up), dim=1) if x is not None else up.contiguous()
+            if ops.conv_e2_split_supported(xc, cout):
+                return ops.conv3d_e2_split_gn_relu(xc, aff, self.conv.packed_e2_split(2), cout)
         if pool is not None and upsampled is None and not _direct and edge >= 4 and ops.conv_pool_supported(x, None, cout):
             return ops.conv3d_gn_relu_pool(x, None, aff, self.conv.packed(), cout, keep_full=(pool == 'also'))
         if _direct or edge == 1:
