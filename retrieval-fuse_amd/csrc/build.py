@@ -17,7 +17,24 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # wave's F16 MFMA runs on the SIMD (check_isa below).  The scalar v_fma_f32 form gives the same bits and is immune.
 EXTRA_FLAGS = {'attention.hip': ['-ffp-contract=off'], 'attention_fused.hip': ['-ffp-contract=off'], 'retrieval.hip': ['-ffp-contract=off'],
                'conv3d_mfma.hip': ['-fno-slp-vectorize'], 'conv3d_up.hip': ['-fno-slp-vectorize']}
-LLVM_BIN = Path('/opt/rocm/lib/llvm/bin')
+
+
+def _hipcc():
+    return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+def _llvm_bin():
+    """llvm-objdump of the ROCm tree the compiler in use belongs to (HIPCC may point at another ROCm root than /opt/rocm)."""
+    import shutil
+    roots = [Path(os.path.realpath(_hipcc())).parents[1], Path(os.environ.get('ROCM_PATH', '/opt/rocm')), Path('/opt/rocm')]
+    for r in roots:
+        for sub in ('lib/llvm/bin', 'llvm/bin'):
+            if (r / sub / 'llvm-objdump').exists():
+                return r / sub
+    found = shutil.which('llvm-objdump')
+    if found:
+        return Path(found).parent
+    raise RuntimeError('check_isa: llvm-objdump not found under %s' % ', '.join(str(r) for r in roots))
 
 
 def _stale(obj, deps):
@@ -40,20 +57,21 @@ def unsafe_packed_fp32(asm_text):
     return bad
 
 
-def check_isa(so=OUT):
+def check_isa(so=OUT, name=None):
     """Disassembles every gfx950 code object of the library and raises if an unsafe packed-fp32 form is in it (see unsafe_packed_fp32)."""
     import shutil
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
-        lib = Path(tmp) / so.name
+        lib = Path(tmp) / (name or so.name)
         shutil.copy(so, lib)
-        subprocess.run([str(LLVM_BIN / 'llvm-objdump'), '--offloading', str(lib)], check=True, stdout=subprocess.DEVNULL, cwd=tmp)
-        cos = sorted(Path(tmp).glob(so.name + '.*gfx950*'))
+        llvm_bin = _llvm_bin()
+        subprocess.run([str(llvm_bin / 'llvm-objdump'), '--offloading', str(lib)], check=True, stdout=subprocess.DEVNULL, cwd=tmp)
+        cos = sorted(Path(tmp).glob(lib.name + '.*gfx950*'))
         if not cos:
             raise RuntimeError('check_isa: no gfx950 code object found in %s' % so)
         bad = []
         for co in cos:
-            asm = subprocess.run([str(LLVM_BIN / 'llvm-objdump'), '-d', str(co)], check=True, capture_output=True, text=True).stdout
+            asm = subprocess.run([str(llvm_bin / 'llvm-objdump'), '-d', str(co)], check=True, capture_output=True, text=True).stdout
             bad += unsafe_packed_fp32(asm)
     if bad:
         raise RuntimeError('check_isa: %d packed-fp32 instructions with op_sel on src1/src2 (wrong results beside F16 MFMAs on gfx950), e.g.\n  %s'
@@ -62,7 +80,7 @@ def check_isa(so=OUT):
 
 
 def build(force=False, verbose=False):
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hipcc = _hipcc()
     objdir = HERE / 'build'
     objdir.mkdir(exist_ok=True)
     headers = [HERE / 'common.h', HERE / 'conv_box.h', HERE / 'attn_row.h', HERE.parents[1] / 'include' / 'rfuse.h']
@@ -79,11 +97,20 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(OUT, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(OUT)] + [str(o) for o in objs]
+        # link beside the target, check the ISA of THAT file, and only then move it into place: a library the check rejects (or that could not be
+        # checked) never becomes rfuse/librfuse_hip.so, and a stale accepted one is removed rather than left to be loaded
+        tmp_out = OUT.with_name(OUT.name + '.unchecked')
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(tmp_out)] + [str(o) for o in objs]
         if verbose:
             print(' '.join(cmd))
-        subprocess.run(cmd, check=True)
-        check_isa(OUT)
+        try:
+            subprocess.run(cmd, check=True)
+            check_isa(tmp_out, name=OUT.name)
+        except BaseException:
+            tmp_out.unlink(missing_ok=True)
+            OUT.unlink(missing_ok=True)
+            raise
+        os.replace(tmp_out, OUT)
     return OUT
 
 
@@ -94,8 +121,7 @@ TESTKIT_OUT = TESTKIT_SRC.parent / 'librfuse_testkit.so'
 def build_testkit(force=False):
     """tests/testkit/librfuse_testkit.so: the test harness's own kernels (NaN poisoning of LDS / VGPRs, an F16-MFMA load).  Kept out of the product ABI."""
     if force or _stale(TESTKIT_OUT, [TESTKIT_SRC, HERE / 'build.py']):
-        hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', str(TESTKIT_OUT), str(TESTKIT_SRC)], check=True)
+        subprocess.run([_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', str(TESTKIT_OUT), str(TESTKIT_SRC)], check=True)
     return TESTKIT_OUT
 
 

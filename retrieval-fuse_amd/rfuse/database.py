@@ -25,39 +25,77 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-_host_groups = {}
-
-
-def _host_group(group):
-    """A gloo twin of ``group`` for host-side agreement checks (no GPU work, no device synchronisation).  Created collectively the first
-    time every rank reaches the sharded search; a gloo group is its own twin."""
+def make_host_group(group=None):
+    """A gloo twin of ``group`` for host-side agreement checks (no GPU work, no device synchronisation).  ``dist.new_group`` is COLLECTIVE OVER THE
+    DEFAULT GROUP: every rank of the world must call this at the same point of its program (``PatchDatabase.__init__`` does, for world > 1).
+    A gloo group is its own twin."""
     import torch.distributed as dist
-    key = id(group)
-    hg = _host_groups.get(key)
-    if hg is None:
-        if dist.get_backend(group) == 'gloo':
-            hg = group
-        else:
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            hg = dist.new_group(ranks=ranks, backend='gloo')
-        _host_groups[key] = hg
-    return hg
+    if dist.get_backend(group) == 'gloo':
+        return group if group is not None else dist.group.WORLD
+    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+    return dist.new_group(ranks=ranks, backend='gloo')
 
 
-def _check_equal_query_counts(nq, group):
-    """all_gather_into_tensor needs the same number of queries on every rank (chunk batches are split evenly); unequal counts would hang
-    or mis-slice silently.  Checked on EVERY call, symmetrically on every rank (a per-rank cache let one rank skip the check the
-    other entered), over the gloo twin of the group: a host-only exchange of one integer, no device synchronisation -- it overlaps the GPU
-    work already enqueued."""
-    import torch.distributed as dist
-    hg = _host_group(group)
-    counts = [None] * dist.get_world_size(hg)
-    dist.all_gather_object(counts, int(nq), group=hg)
-    if len(set(counts)) != 1:
-        raise ValueError('sharded search: every rank must pass the same number of queries, got %s' % (counts,))
+class QueryCountCheck:
+    """all_gather_into_tensor needs the same number of queries on every rank (chunk batches are split evenly); unequal counts would hang or
+    mis-slice silently.  Every call of the sharded search posts ONE non-blocking gloo all-gather of its count (a CPU int64, no device
+    synchronisation) -- the same collective sequence on every rank, whatever each rank has seen before -- and
+
+      * the FIRST time this rank passes a given count it waits for the exchange and raises before any device collective is issued;
+      * otherwise it does not wait: the exchange of call i is examined at call i + 1 (or at ``flush()``), when it has long completed.  In steady
+        state no rank's enqueue thread blocks on the slowest rank (round 3 did one blocking ``all_gather_object`` per step).
+
+    A mismatch a rank could not see on its own (its count is one it has used before, a peer's is not) is therefore raised by the peer at once and by
+    this rank one call later -- the peer never enters the mismatched device collectives."""
+
+    def __init__(self, host_group):
+        import torch.distributed as dist
+        self.host_group = host_group
+        self.world = dist.get_world_size(host_group)
+        self.seen = set()
+        self.pending = None            # (work, counts tensors, mine tensor) of the previous call
+
+    @staticmethod
+    def _verify(counts):
+        vals = [int(c.item()) for c in counts]
+        if len(set(vals)) != 1:
+            raise ValueError('sharded search: every rank must pass the same number of queries, got %s' % (vals,))
+
+    def flush(self):
+        """Wait for and examine the exchange of the previous call (raises ValueError on a mismatch)."""
+        if self.pending is not None:
+            work, counts, _ = self.pending
+            self.pending = None
+            work.wait()
+            self._verify(counts)
+
+    def post(self, nq, defer=True):
+        """``defer=False``: always wait (used when the data-path collectives block the host anyway -- a gloo / CPU data path -- so that no rank
+        walks into a collective its peer has refused)."""
+        import torch.distributed as dist
+        self.flush()
+        mine = torch.tensor([int(nq)], dtype=torch.int64)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        work = dist.all_gather(counts, mine, group=self.host_group, async_op=True)
+        self.pending = (work, counts, mine)
+        if nq not in self.seen or not defer:
+            self.flush()
+            self.seen.add(nq)
 
 
-def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings=None):
+_fallback_checks = []                  # (group, QueryCountCheck) for direct callers of sharded_search that pass no checker
+
+
+def _fallback_check(group):
+    for g, c in _fallback_checks:
+        if g is group:
+            return c
+    c = QueryCountCheck(make_host_group(group))
+    _fallback_checks.append((group, c))
+    return c
+
+
+def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings=None, count_check=None):
     """The sharded search protocol, independent of how the local scan / merge are computed (so it runs on
     gloo/CPU in tests with numpy stand-ins of the same contract, and on RCCL with the HIP kernels):
 
@@ -69,12 +107,15 @@ def sharded_search(q_local, local_topk_keys, merge_keys, k2, group=None, timings
       4. merge_keys(the W candidate lists of this rank's own queries) -> (dist [nq, k2], idx [nq, k2])
 
     The unsigned order of the keys is the (distance, row id) order, so the merge of W shard lists equals a single scan
-    bit for bit.  ``timings``: optional list; (start, end) CUDA event pairs of the two collectives are appended."""
+    bit for bit.  ``timings``: optional list; (start, end) CUDA event pairs of the two collectives are appended.  ``count_check``: the
+    caller's QueryCountCheck (PatchDatabase owns one per database); without it a per-group one is created on first use, which is collective over
+    the world for a non-gloo group (see make_host_group)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq = q_local.shape[0]
-    _check_equal_query_counts(nq, group)
+    # device data path: the collectives below are only enqueued, so the check may trail by one call; host (gloo) data path: they block, check first
+    (count_check if count_check is not None else _fallback_check(group)).post(nq, defer=q_local.is_cuda)
     q_local = q_local.contiguous()
     ev = None
     if timings is not None and q_local.is_cuda:
@@ -174,10 +215,17 @@ class PatchDatabase:
         emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
         return cls(emb, meta, volumes, device, rank, world, group)
 
-    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend):
+    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend, host_group=None):
         """emb [N+1,64] float32 (unit rows), meta [N+1,7] int32, volumes [S,64,64,64] float32 -- host or device tensors /
-        numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes."""
+        numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes.
+
+        With world > 1 (or an initialised process group) the constructor is COLLECTIVE: unless ``host_group`` (a gloo group over the ranks of
+        ``group``) is passed, it creates the gloo twin of ``group`` for the query-count check, and ``dist.new_group`` must be entered by every
+        rank of the default group -- construct the database on all ranks at the same point of the program."""
         emb = torch.as_tensor(emb)
+        self.count_check = None
+        if world > 1:
+            self.count_check = QueryCountCheck(host_group if host_group is not None else make_host_group(group))
         self.backend = backend
         self.collective_events = None    # bench.py: a list to collect (start, end) event pairs of the two collectives
         self.n_rows = emb.shape[0]
@@ -235,7 +283,15 @@ class PatchDatabase:
         U-Net backbone the engine forked onto its side stream keeps the GPU busy while they are in flight."""
         if self.world == 1 and not self.force_collectives:
             return self.local_topk(q, k2)
-        return sharded_search(q, lambda qa: self.local_topk_keys(qa, k2), self.backend.merge_keys, k2, self.group, self.collective_events)
+        if self.count_check is None:                               # one rank with the protocol forced (bench.py --force-collectives, tests)
+            self.count_check = QueryCountCheck(make_host_group(self.group))
+        return sharded_search(q, lambda qa: self.local_topk_keys(qa, k2), self.backend.merge_keys, k2, self.group, self.collective_events,
+                              self.count_check)
+
+    def check(self):
+        """Examine the query-count exchange of the last search now (it is otherwise examined at the next search); raises ValueError on a mismatch."""
+        if self.count_check is not None:
+            self.count_check.flush()
 
     def retrieve(self, q, K, query_scene=None, query_keep=None):
         """flann_knn_worker semantics (util/retrieval.py:92-100): top-2K, same-scene demotion, keep K.

@@ -123,10 +123,11 @@ def _worker(rank, world, port, n_rows, nq_local, K, out_dir, unequal):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_rows,nq_local,K', [(2, 1001, 64, 4), (2, 13, 5, 4), (2, 1, 3, 4), (4, 1003, 16, 8)])
+@pytest.mark.parametrize('world,n_rows,nq_local,K', [(2, 1001, 64, 4), (2, 13, 5, 4), (2, 1, 3, 4), (4, 1003, 16, 8), (8, 1003, 8, 8), (8, 5, 2, 4)])
 def test_sharded_search_equals_single_process(tmp_path, world, n_rows, nq_local, K):
     """(1 row, 2 ranks): rank 1's shard is EMPTY -- it contributes all-NONE lists.  (4 ranks, 1003 rows, K = 8): shards of unequal size
-    (n % W != 0), the C4 list length."""
+    (n % W != 0), the C4 list length.  (8 ranks): the node size of BASELINE configs[2] -- 1003 % 8 = 3 rows go to the low ranks; 5 rows on 8 ranks
+    leave three shards empty."""
     mp.spawn(_worker, args=(world, _free_port(), n_rows, nq_local, K, str(tmp_path), False), nprocs=world, join=True)
     sys.path.insert(0, str(REPO / 'retrieval-fuse_amd'))
     emb, meta, q_all, qscene = _problem(n_rows, world, nq_local)
@@ -156,6 +157,43 @@ def test_unequal_query_counts_are_refused(tmp_path, mode):
     mp.spawn(_worker, args=(world, _free_port(), 100, 6, 4, str(tmp_path), mode), nprocs=world, join=True)
     for rank in range(world):
         assert 'same number of queries' in (tmp_path / f'rank{rank}.txt').read_text()
+
+
+def _deferred_worker(rank, world, port, out_dir):
+    for p in (str(REPO), str(REPO / 'retrieval-fuse_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rfuse.database import QueryCountCheck, make_host_group
+    chk = QueryCountCheck(make_host_group(None))
+    log = []
+    try:
+        chk.post(6)                                  # first use of 6 everywhere: checked at once, equal
+        log.append('a')
+        chk.post(6)                                  # seen: not waited for
+        log.append('b' if chk.pending is not None else 'b-waited')
+        chk.post(5 if rank == 0 else 6)              # rank 0: a new count -> waits, sees (5, 6, ...) and raises; the others defer
+        log.append('c')
+        chk.post(6)                                  # ... and raise here, one call later, when they examine the previous exchange
+        log.append('d')
+    except ValueError as e:
+        log.append('refused: ' + str(e))
+    Path(out_dir, f'rank{rank}.txt').write_text('|'.join(log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_count_check_deferred_mode(tmp_path):
+    """The device data path's mode (collectives only enqueued): a seen count is not waited for, the rank with the new count refuses at once and
+    its peers one call later; every rank posts the same sequence of host exchanges whatever it has seen (no rank skips one the other enters)."""
+    world = 3
+    mp.spawn(_deferred_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [(tmp_path / f'rank{k}.txt').read_text() for k in range(world)]
+    assert r[0].startswith('a|b|refused') and 'same number of queries' in r[0] and '[5, 6, 6]' in r[0]
+    for k in (1, 2):
+        assert r[k].startswith('a|b|c|refused') and '[5, 6, 6]' in r[k]
 
 
 def test_shard_bounds_cover_rows_exactly():
