@@ -250,6 +250,10 @@ int rf_conv3d_up_split_presplit(const float* src0, int c0, const float* src1, in
                                 int cout, const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit,
                                 double* stats, void* stream);
 int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout);
+/* tiles per (sample, cout) of the statistics rf_conv3d_split_pre_k3_relu writes ([n][cout][tiles] (sum, sum of squares)): one per 8^3 box, or ONE per
+ * sample where the persistent z-column form takes the layer (csrc/conv3d_split_zc.hip: 8 -> <= 16 channels on 16^3 samples, the second conv of the
+ * retrieval backbone's level 0, model/unet.py:125-144 -- a workgroup walks whole samples and sums their boxes itself) */
+int rf_conv3d_split_pre_stats_tiles(int cin, int n, int edge, int cout);
 int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout,
                                 float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
 

@@ -16,24 +16,8 @@
 // global -> VGPR one k-step ahead.  Register use is small (NB 1: 32 accumulator VGPRs), two workgroups per CU.
 #include "common.h"
 #include "conv_box.h"
+#include "conv_split_common.h"
 #include <type_traits>
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-namespace {
-// halo box [10][10][10] in 16-byte slots, Y-MAJOR with a padded y stride: slot(z, y, x) = y * 104 + z * 10 + x.  An A operand is a ds_read_b128 of
-// an m-block = 8 x by 2 y voxels, served in four fixed 16-lane groups (MI355X_MICROARCH.md, LDS): lanes {0-3, 12-15} of one tap and {4-11} of the
-// next, i.e. x 0-3 of row y, x 4-7 of row y + 1 and the other halves one tap on.  With slot(z, y, x) = z * 100 + y * 10 + x (rounds 2-3) row y + 1
-// sat 10 slots on: x = 6, 7 of it on the slots (mod 16) of x = 0, 1 of row y -- two LDS cycles per group for every A operand of every box kernel
-// (SQ_LDS_BANK_CONFLICT: 0.36-0.46 of the active LDS cycles).  With the rows of a tile 104 = 8 (mod 16) slots apart the group covers 16 different
-// slots except where two taps meet: 1.29 cycles per group over the 7 k-steps (model: tools/lds_bank_model.py).
-constexpr int CS_SY = 104, CS_SZ = 10, CS_VOX = 1000, CS_SLOTS = 1040;
-constexpr int CS_PLANE = CS_SLOTS * 16;                          // bytes of one (h or l) plane
-constexpr int CS_BUF = 2 * CS_PLANE;
-constexpr int CS_LDS_BYTES = 2 * CS_BUF;                         // 66,560
-constexpr float CS_ACT_SCALE = 1.0f / 16, CS_W_SCALE = 16.0f, CS_LO = 2048.0f;
-constexpr bool CS_S4_WIDE = true;
-}   // namespace
 
 // ------------------------------------------------------------------------------------------------------------ weight image
 extern "C" size_t rf_conv3_split_packed_bytes(int cout, int cin) {
@@ -74,26 +58,6 @@ extern "C" int rf_conv3_split_pack_weight(const float* w_oidhw, int cout, int ci
 }
 
 // ------------------------------------------------------------------------------------------------------------------- kernel
-__device__ __forceinline__ void cs_split8(const float (&y)[8], h8& h, h8& l) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = __builtin_amdgcn_fmed3f(y[j] * CS_ACT_SCALE, -65504.f, 65504.f);
-        const _Float16 hh = (_Float16)v;
-        h[j] = hh;
-        l[j] = (_Float16)fmaf(-CS_LO, (float)hh, v * CS_LO);          // (v - h) * 2^11: exact either way, one v_fma_mix instead of cvt + sub + mul
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], const h8& ah, const h8& al, const h8 (&bh)[NB], const h8 (&bl)[NB]) {
-#pragma unroll
-    for (int n = 0; n < NB; ++n) hi[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], hi[n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], lo[n], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], lo[n], 0, 0, 0);
-}
-
 // ONE: the layer has a single 8-channel chunk (no prefetch of a next chunk, one chunk buffer)
 // PADC: cin is not a multiple of 8 -- the last chunk's missing channels are staged as zeros (they re-read channel cin-1 with a zero affine
 // triple; their weights are zero too)
@@ -815,6 +779,17 @@ extern "C" int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout)
     return cin >= 8 && cin % 8 == 0 && edge >= 8 && rf_conv3d_split_supported(cin, 0, n, edge, cout);
 }
 
+// conv3d_split_zc.hip: the persistent z-column form of the one-chunk pre-split layer (8 -> 16 @16^3: level 0 of the retrieval backbone)
+bool rf_split_zc_takes(int cin, int n, int edge, int cout);
+int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream);
+
+// tiles per (sample, cout) of the statistics rf_conv3d_split_pre_k3_relu writes for this shape ([n][cout][tiles] double2): one per 8^3 box, or one per
+// sample where the persistent form (which sums a sample's boxes itself) takes the layer
+extern "C" int rf_conv3d_split_pre_stats_tiles(int cin, int n, int edge, int cout) {
+    if (rf_split_zc_takes(cin, n, edge, cout)) return 1;
+    return (edge / 8) * (edge / 8) * (edge / 8);
+}
+
 extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout,
                                            float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
     RF_REQUIRE(rf_conv3d_split_pre_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
@@ -830,6 +805,10 @@ extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, in
     a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
     a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
     a.floor = 0.f;
+    if (rf_split_zc_takes(cin, n, edge, cout)) {
+        a.stats_tiles = 1;
+        return rf_split_zc_launch(a, (hipStream_t)stream);
+    }
     if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false, false, true>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true, false, true>(a, (hipStream_t)stream) : launch_split<1, 4, false, false, true>(a, (hipStream_t)stream);
 }

@@ -1,0 +1,300 @@
+// k_conv3_split_zc: SingleConv 'gcr' (reference model/unet.py:19-76) of a level-0 DoubleConv's SECOND conv -- 8 -> 16 channels on 16^3 samples, input
+// pre-split by its producer (rf_conv3d_cin1_presplit) -- as a PERSISTENT workgroup that walks whole samples, box by box, with the operand
+// reads and the weight traffic of the box kernel (conv3d_split.hip) cut down.  Same arithmetic contract: exact f16 x f16 products of split operands,
+// fp32 accumulation in separate hi / lo accumulators, combined once.
+//
+// What is different from k_conv3_split<1, 6, true, false, true> (round 3: 0.75 ms alone, 1.06-1.18 ms in the step, MFMA pipe 26-40 % busy):
+//  * Z-COLUMNS with operand reuse.  A wave owns 4 z-planes of a 2 (y) x 8 (x) footprint (m-block = one plane) and the 27 taps are ordered so that a
+//    k-step is four taps of ONE dz: k-step (dz, q) = taps (dz, j = 4q + g), j = (dy + 1) * 3 + dx + 1 < 8, lane group g; the ninth (dy, dx) = (1, 1) of the
+//    three dz make k-step 6.  The A operand "image plane P, half q" then serves m-block P (as dz = -1), P - 1 (dz = 0) and P - 2 (dz = +1): 16 operand
+//    reads per wave and box instead of 28, each feeding up to nine MFMAs instead of three (the 16-cout box kernel asked the LDS for an A fragment per
+//    48 matrix-pipe cycles of every SIMD).  The weight image is the box kernel's; the workgroup permutes it into this tap order while copying it to LDS.
+//  * PERSISTENT: a workgroup keeps the layer's weight fragments (14 KB) in LDS for its whole life -- no weight load in the box loop, so no s_waitcnt vmcnt
+//    between MFMAs that would also wait for the next box's voxels (vmcnt retires in order) -- and stages box i + 1 (two halo voxels per thread, copies of
+//    16-byte slots) into the other image buffer while box i multiplies.
+//  * x-adjacent box PAIRS share one epilogue: the pooled rows of both boxes go through an LDS tile and leave as 128-byte runs (the box kernel wrote
+//    16-byte fragments: 4.2x write amplification on the pooled-only layer); GroupNorm statistics are accumulated per wave over the eight
+//    boxes of a sample and reduced once per sample (stats_tiles = 1).
+#include "common.h"
+#include "conv_box.h"
+#include "conv_split_common.h"
+
+namespace {
+constexpr int ZC_W_BYTES = 7 * 2 * 64 * 16;                       // 14,336: [k-step][h | l][lane][8 halves]
+constexpr int ZC_LDS_BYTES = ZC_W_BYTES + 2 * CS_BUF;             // 80,896: two workgroups per CU
+constexpr int ZC_TILE_STRIDE = 132;                               // floats per cout row of the pooled tile (128 + 4: conflict-free float2 writes)
+constexpr int ZC_TILE_BYTES = 16 * ZC_TILE_STRIDE * 4;            // 8,448
+constexpr int ZC_RED_BYTES = 8 * 16 * 16;                         // [wave][cout] double2
+static_assert(ZC_TILE_BYTES + 2 * ZC_RED_BYTES <= CS_BUF, "epilogue scratch lives in a dead image buffer");
+
+__device__ __forceinline__ void lds_barrier() {                   // LDS-only: global loads of the next box stay in flight across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+struct ZcStage { h8 ph[2], pl[2]; bool in[2]; };
+}   // namespace
+
+template <bool FULL>                                                // FULL: the full-resolution output (and its statistics) too; false: pooled only
+__global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, int samples_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int E = 16, VOL = E * E * E, PE = 8, PVOL = PE * PE * PE;
+    const int n_first = blockIdx.x * samples_per_wg;
+    const int n_last = min(a.n, n_first + samples_per_wg);
+    if (n_first >= n_last) return;
+
+    // ---- weights: the box kernel's image [k-step s][n-block][h | l][lane = 16 g + cout][8 halves] with tap 4 s + g, copied to LDS in THIS kernel's order
+    {
+        const int nbt = a.cout16 >> 4;
+        const h8* __restrict__ wsrc = reinterpret_cast<const h8*>(a.wp) + (size_t)blockIdx.y * 128;
+        for (int f = tid; f < 7 * 128; f += 512) {
+            const int k = f >> 7, piece = (f >> 6) & 1, g = (f >> 4) & 3, co = f & 15;
+            int tap;
+            if (k < 6) tap = (k >> 1) * 9 + 4 * (k & 1) + g;
+            else tap = g < 3 ? g * 9 + 8 : 27;                      // tap 27: the box image's zero dummy
+            reinterpret_cast<h8*>(lds)[f] = wsrc[((size_t)(tap >> 2) * nbt * 2 + piece) * 64 + (tap & 3) * 16 + co];
+        }
+    }
+
+    // ---- staging: thread t owns halo voxels t and t + 512 (the second only for t < 488) of every box
+    int hpos[2], vslot[2];                                          // halo position (hz, hy, hx) packed 8 bits each; byte offset of the slot in a plane
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int v = tid + r * 512;
+        const int hx = v % 10, hy = (v / 10) % 10, hz = v / 100;
+        hpos[r] = hz << 16 | hy << 8 | hx;
+        vslot[r] = (hz * CS_SZ + hy * CS_SY + hx) * 16;
+    }
+    const unsigned char* __restrict__ spre = reinterpret_cast<const unsigned char*>(a.src0);
+    auto stage_load = [&](ZcStage& st, int box) {                   // box = sample * 8 + (bz, by, bx)
+        const int n0 = box >> 3, z0 = ((box >> 2) & 1) * 8 - 1, y0 = ((box >> 1) & 1) * 8 - 1, x0 = (box & 1) * 8 - 1;
+        const unsigned char* p = spre + (size_t)n0 * (2 * VOL * 16);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int z = z0 + (hpos[r] >> 16), y = y0 + ((hpos[r] >> 8) & 255), x = x0 + (hpos[r] & 255);
+            st.in[r] = (unsigned)z < (unsigned)E && (unsigned)y < (unsigned)E && (unsigned)x < (unsigned)E && (r == 0 || tid < CS_VOX - 512);
+            const int off = st.in[r] ? ((z * E + y) * E + x) * 16 : 0;
+            st.ph[r] = *reinterpret_cast<const h8*>(p + off);
+            st.pl[r] = *reinterpret_cast<const h8*>(p + VOL * 16 + off);
+        }
+    };
+    auto stage_store = [&](const ZcStage& st, unsigned char* img) {  // zeros outside the volume (the padding of the NORMALISED tensor)
+        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (r == 0 || tid < CS_VOX - 512) {
+                *reinterpret_cast<h8*>(img + vslot[r]) = st.in[r] ? st.ph[r] : zero;
+                *reinterpret_cast<h8*>(img + vslot[r] + CS_PLANE) = st.in[r] ? st.pl[r] : zero;
+            }
+    };
+
+    // ---- operand addressing.  wave = (zh, yq): planes z = 4 zh + mb, rows y = 2 yq + (ri >> 3), x = ri & 7; halo slot (z + 1, y + 1, x + 1)
+    const int g = lane >> 4, ri = lane & 15, zh = wave >> 2, yq = wave & 3;
+    int aq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = 4 * q + g, dy = j / 3 - 1, dx = j % 3 - 1;
+        aq[q] = ((4 * zh) * CS_SZ + (2 * yq + (ri >> 3) + dy + 1) * CS_SY + (ri & 7) + dx + 1) * 16;      // + P * CS_SZ * 16: image plane 4 zh + P
+    }
+    const int a6 = ((4 * zh + (g < 3 ? g : 2)) * CS_SZ + (2 * yq + (ri >> 3) + 2) * CS_SY + (ri & 7) + 2) * 16;   // + mb * CS_SZ * 16; lane group 3: zero weights
+    const unsigned char* const wl = lds + lane * 16;
+    constexpr int PSTEP = CS_SZ * 16;
+
+    auto mf = [](const h8& x, const h8& y, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0); };
+    // all MFMAs of one box for this wave: acc = hi + lo / 2^11 of the four planes
+    auto compute = [&](const unsigned char* img, f32x4 (&acc)[4]) {
+        f32x4 hi[4], lo[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { hi[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        h8 fh[2], fl[2];
+        h8 wh[3], wlo[3];
+        {
+            const unsigned char* ap = img + aq[0];
+            fh[0] = *reinterpret_cast<const h8*>(ap);
+            fl[0] = *reinterpret_cast<const h8*>(ap + CS_PLANE);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            wh[d] = *reinterpret_cast<const h8*>(wl + (2 * d) * 2048);
+            wlo[d] = *reinterpret_cast<const h8*>(wl + (2 * d) * 2048 + 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned char* ap = img + aq[q];
+#pragma unroll
+            for (int P = 0; P < 6; ++P) {
+                const int cur = (q * 6 + P) & 1, nxt = cur ^ 1;
+                // next operand: plane P + 1 of this half, the first plane of the other half, or the first operand of k-step 6
+                const unsigned char* np = P < 5 ? ap + (P + 1) * PSTEP : (q == 0 ? img + aq[1] : img + a6);
+                fh[nxt] = *reinterpret_cast<const h8*>(np);
+                fl[nxt] = *reinterpret_cast<const h8*>(np + CS_PLANE);
+                __builtin_amdgcn_sched_barrier(0);
+                // plane P is tap dz = -1 of m-block P, dz = 0 of m-block P - 1, dz = +1 of m-block P - 2 (weights d = dz + 1)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { const int m = P - d; if (m >= 0 && m < 4) hi[m] = mf(fh[cur], wh[d], hi[m]); }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { const int m = P - d; if (m >= 0 && m < 4) lo[m] = mf(fh[cur], wlo[d], lo[m]); }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { const int m = P - d; if (m >= 0 && m < 4) lo[m] = mf(fl[cur], wh[d], lo[m]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // weights of the other half / of k-step 6 into the registers whose k-step has had its last use
+                if (q == 0 && P >= 3) {
+                    const int d = P - 3;
+                    wh[d] = *reinterpret_cast<const h8*>(wl + (2 * d + 1) * 2048);
+                    wlo[d] = *reinterpret_cast<const h8*>(wl + (2 * d + 1) * 2048 + 1024);
+                }
+                if (q == 1 && P == 3) {
+                    wh[0] = *reinterpret_cast<const h8*>(wl + 6 * 2048);
+                    wlo[0] = *reinterpret_cast<const h8*>(wl + 6 * 2048 + 1024);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {                                 // k-step 6: (dy, dx) = (1, 1) of the three dz of m-block m
+            const int cur = m & 1, nxt = cur ^ 1;
+            if (m < 3) {
+                fh[nxt] = *reinterpret_cast<const h8*>(img + a6 + (m + 1) * PSTEP);
+                fl[nxt] = *reinterpret_cast<const h8*>(img + a6 + (m + 1) * PSTEP + CS_PLANE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            hi[m] = mf(fh[cur], wh[0], hi[m]);
+            lo[m] = mf(fh[cur], wlo[0], lo[m]);
+            lo[m] = mf(fl[cur], wh[0], lo[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][r] = fmaf(lo[m][r], 1.0f / CS_LO, hi[m][r]);
+    };
+
+    // ---- outputs of one box from the accumulators.  D tile: col = lane & 15 = cout, rows 4 (lane >> 4) + r = voxel i: x = i & 7, y = 2 yq + (i >> 3)
+    const int col = lane & 15, kq = lane >> 4;
+    const bool want_full = FULL, want_pool = a.pool_mode != 0;
+    double fsm = 0.0, fsq = 0.0, psm = 0.0, psq = 0.0;              // this lane's share of the sample's statistics (full output / pooled output)
+    auto box_outputs = [&](const f32x4 (&acc)[4], int box, float2 (&pooled)[2]) {
+        const int n0 = box >> 3, z0 = ((box >> 2) & 1) * 8, y0 = ((box >> 1) & 1) * 8, x0 = (box & 1) * 8;
+        if (want_full) {
+            if (col < a.cout) {
+                float* o = a.out + ((size_t)n0 * a.cout + col) * VOL + (size_t)(y0 + 2 * yq + (kq >> 1)) * E + x0 + 4 * (kq & 1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 v = acc[m];
+                    *reinterpret_cast<float4*>(o + (size_t)(z0 + 4 * zh + m) * E * E) =
+                        make_float4(fmaxf(v[0], a.floor), fmaxf(v[1], a.floor), fmaxf(v[2], a.floor), fmaxf(v[3], a.floor));
+                }
+            }
+            if (a.stats) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const double v = (double)fmaxf(acc[m][r], 0.f); fsm += v; fsq += v * v; }
+            }
+        }
+        if (want_pool) {                                              // z pair = planes (2 zp, 2 zp + 1), x pairs in r, y pair in lane ^ 32
+#pragma unroll
+            for (int zp = 0; zp < 2; ++zp) {
+                const f32x4 u = acc[2 * zp], v = acc[2 * zp + 1];
+                float p0 = fmaxf(fmaxf(u[0], u[1]), fmaxf(v[0], v[1]));
+                float p1 = fmaxf(fmaxf(u[2], u[3]), fmaxf(v[2], v[3]));
+                p0 = fmaxf(p0, __shfl_xor(p0, 32, 64));
+                p1 = fmaxf(p1, __shfl_xor(p1, 32, 64));
+                p0 = fmaxf(p0, 0.f);                                  // max and ReLU commute
+                p1 = fmaxf(p1, 0.f);
+                pooled[zp] = make_float2(p0, p1);
+                if (kq < 2) { psm += (double)p0 + (double)p1; psq += (double)p0 * (double)p0 + (double)p1 * (double)p1; }
+            }
+        }
+    };
+
+    // ---- the box loop: pairs of x-adjacent boxes; the image buffers swap roles every pair
+    unsigned char* bufA = lds + ZC_W_BYTES;                         // holds box A of the current pair
+    unsigned char* bufB = lds + ZC_W_BYTES + CS_BUF;
+    ZcStage st;
+    stage_load(st, n_first * 8);
+    stage_store(st, bufA);
+    lds_barrier();                                                  // weights and the first image are in place
+    const int pair_end = n_last * 4;
+    for (int pair = n_first * 4; pair < pair_end; ++pair) {
+        const int boxA = 2 * pair, boxB = boxA + 1;
+        f32x4 acc[4];
+        float2 poolA[2], poolB[2];
+        stage_load(st, boxB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(bufA, acc);
+        box_outputs(acc, boxA, poolA);
+        stage_store(st, bufB);
+        lds_barrier();                                              // 1: box B's image complete, box A's image dead
+        const int next = pair + 1 < pair_end ? boxB + 1 : boxB;     // (the last pair re-loads its own box: no branch around the loads)
+        stage_load(st, next);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(bufB, acc);
+        box_outputs(acc, boxB, poolB);
+        const bool sample_end = (pair & 3) == 3;
+        float* tile = reinterpret_cast<float*>(bufA);
+        double2* red = reinterpret_cast<double2*>(bufA + ZC_TILE_BYTES);
+        if (want_pool && kq < 2) {
+#pragma unroll
+            for (int zp = 0; zp < 2; ++zp) {
+                float* t = tile + col * ZC_TILE_STRIDE + ((2 * zh + zp) * 4 + yq) * 8 + 2 * kq;
+                *reinterpret_cast<float2*>(t) = poolA[zp];
+                *reinterpret_cast<float2*>(t + 4) = poolB[zp];
+            }
+        }
+        if (sample_end) {
+            if (a.pool_stats) {
+                const double s1 = psm + __shfl_xor(psm, 16, 64), s2 = psq + __shfl_xor(psq, 16, 64);      // the two x halves (lane groups 0 and 1)
+                if (lane < 16) red[wave * 16 + lane] = make_double2(s1, s2);
+            }
+            if (FULL && a.stats) {
+                double s1 = fsm + __shfl_xor(fsm, 16, 64), s2 = fsq + __shfl_xor(fsq, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 16) red[128 + wave * 16 + lane] = make_double2(s1, s2);
+            }
+            fsm = fsq = psm = psq = 0.0;
+        }
+        lds_barrier();                                              // 2: tile (and the sample's partial sums) complete; box B's image dead
+        if (want_pool) {
+            const int co = tid >> 5, pz = (tid >> 3) & 3, w4 = tid & 7;
+            if (co < a.cout) {
+                const int n0 = boxA >> 3, z0 = ((boxA >> 2) & 1) * 4, y0 = ((boxA >> 1) & 1) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(tile + co * ZC_TILE_STRIDE + pz * 32 + w4 * 4);
+                *reinterpret_cast<float4*>(a.pool_out + ((size_t)n0 * a.cout + co) * PVOL + (size_t)(z0 + pz) * 64 + y0 * 8 + w4 * 4) = v;
+            }
+        }
+        if (sample_end && tid < 32) {
+            const int which = tid >> 4, co = tid & 15;
+            double2* dst = which ? a.stats : a.pool_stats;
+            if ((FULL || !which) && dst && co < a.cout) {
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { const double2 v = red[which * 128 + w * 16 + co]; sm += v.x; sq += v.y; }
+                dst[(size_t)(boxA >> 3) * a.cout + co] = make_double2(sm, sq);
+            }
+        }
+        stage_store(st, bufB);                                      // the next pair's box A into the buffer box B has left
+        lds_barrier();                                              // 3: ... complete; the tile has been read
+        unsigned char* t = bufA; bufA = bufB; bufB = t;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------- host
+// Taken by rf_conv3d_split_pre_k3_relu (conv3d_split.hip) for the shapes this kernel is built for.
+bool rf_split_zc_takes(int cin, int n, int edge, int cout) {
+    return cin == 8 && edge == 16 && cout > 0 && cout <= 16 && n >= 512;
+}
+
+int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream) {
+    const bool full = a.pool_mode != 2;
+    auto kern = full ? k_conv3_split_zc<true> : k_conv3_split_zc<false>;
+    static RfLdsOptIn opt[2];
+    if (int rc = opt[full].ensure(reinterpret_cast<const void*>(kern), ZC_LDS_BYTES, "rf_conv3d_split_pre_k3_relu")) return rc;
+    const int wgs = a.n < 512 ? a.n : 512;                            // two workgroups per CU, whole samples each
+    const int per = (a.n + wgs - 1) / wgs;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.n + per - 1) / per)), dim3(512), ZC_LDS_BYTES, stream, a, per);
+    RF_CHECK_LAUNCH("rf_conv3d_split_pre_k3_relu");
+    return RF_OK;
+}

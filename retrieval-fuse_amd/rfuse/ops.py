@@ -556,7 +556,7 @@ def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None):
     lib = _lib.load()
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if pool != 'only' else None
     pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev) if pool is not None else None
-    tiles = max(1, (edge // 8) ** 3)
+    tiles = lib.rf_conv3d_split_pre_stats_tiles(cin, n, edge, cout)      # one per 8^3 box, or one per sample (persistent form)
     stats = pstats = None
     if USE_FUSED_STATS:
         stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if out is not None else None
