@@ -466,6 +466,20 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
  * its all-trunc sentinel patch (util/retrieval.py:21-26,45). */
 int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t m, int width, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------- mesh export */
+
+/* Marching cubes on the device: the last step of the reference's inference loop (util/visualization.py:34-37 visualize_sdf_as_mesh:
+ * marching_cubes(sdf, 0.75) -> vertices, triangles -> .obj; trainer/train_refinement.py:170-173).  The reference's `marching_cubes` package is third-party
+ * and not pinned: PARITY UNPINNED -- contract = the construction itself (rfuse/mesh.py, csrc/mesh.hip).  sdf [x][y][z] fp32, inside = value < level.
+ * Two passes around exclusive scans the caller makes (torch.cumsum):
+ *   rf_mc_classify: cube_ntri [x*y*z] int32 triangles of the cube whose corner 0 is that voxel; edge_flag [x*y*z*3] int32: the level crosses the grid
+ *                   edge that starts at that voxel along axis 0 / 1 / 2.  tri_count int8 [256]: triangles per corner configuration.
+ *   rf_mc_emit:     verts [V][3] fp32 (voxel-index coordinates, one per crossed grid edge at edge_off), tris [T][3] int32 (vertex indices, cube by cube at
+ *                   cube_off).  tri_table int8 [256][16]: cube-edge numbers (axis * 4 + u + 2 v), -1 terminated (rfuse/mesh.py:build_tables). */
+int rf_mc_classify(const float* sdf, int x, int y, int z, float level, const signed char* tri_count, int* cube_ntri, int* edge_flag, void* stream);
+int rf_mc_emit(const float* sdf, int x, int y, int z, float level, const signed char* tri_table, const long long* cube_off, const long long* edge_off,
+               const int* cube_ntri, const int* edge_flag, float* verts, int* tris, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,12 +36,17 @@ namespace { constexpr int RF_AMAX_SLOTS = 1024; }
 __global__ __launch_bounds__(256) void k_relu_bwd_amax(const float4* __restrict__ dy, const float4* __restrict__ y, size_t n4, float4* __restrict__ out,
                                                        float* __restrict__ slots) {
     float m = 0.f;
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 g = dy[i], v = y[i];
         const float4 o = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
         out[i] = o;
         m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        // fmaxf drops a NaN and the split forms clamp: an upstream gradient that is not finite must stay visible (overflow / anomaly detection of the
+        // training loop), so it is recorded as an infinite maximum, which rf_dgrad_scale_affine turns into NaN gradients
+        bad |= !(fabsf(o.x) < INFINITY) | !(fabsf(o.y) < INFINITY) | !(fabsf(o.z) < INFINITY) | !(fabsf(o.w) < INFINITY);
     }
+    if (bad) m = INFINITY;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
     __shared__ float wm[4];
@@ -65,7 +70,10 @@ extern "C" int rf_relu_backward_amax(const float* dy, const float* y, size_t cou
 }
 
 // identity GroupNorm affine (mean 0, shift 0) with scale s = the power of two that puts max |dz| into [512, 1024): rows x (0, s, 0, 0), and
-// scales = (s, 1 / s).  A zero, infinite or NaN maximum gives s = 1.  Everything stays on the device: no host sync in the backward pass.
+// scales = (s, 1 / s).  A zero maximum gives s = 1; a maximum that is not finite (rf_relu_backward_amax records inf / NaN gradients as +inf) gives s = 1 and
+// 1 / s = NaN: the data gradient (rf_gn_backward's dxn_inv_scale) and the weight gradient (the split wgrad's reduction) are multiplied by it and come out
+// NaN everywhere -- the fp32 route and the reference propagate inf / NaN, and a clamped, finite gradient would hide an overflow from the training loop.
+// Everything stays on the device: no host sync in the backward pass.
 __global__ __launch_bounds__(256) void k_dgrad_affine(const float* __restrict__ slots, int rows, float4* __restrict__ affine, float* __restrict__ scales) {
     float m = 0.f;
     for (int k = threadIdx.x; k < RF_AMAX_SLOTS; k += 256) m = fmaxf(m, slots[k]);
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void k_dgrad_affine(const float* __restrict__ 
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < rows) affine[i] = make_float4(0.f, s, 0.f, 0.f);
-    if (i == 0) { scales[0] = s; scales[1] = 1.f / s; }
+    if (i == 0) { scales[0] = s; scales[1] = (m < INFINITY) ? 1.f / s : __builtin_nanf(""); }
 }
 
 extern "C" int rf_dgrad_scale_affine(const float* amax_slots, int rows, float* affine, float* scales, void* stream) {

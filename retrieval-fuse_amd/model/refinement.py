@@ -5,7 +5,7 @@ import math
 import torch
 from torch import nn
 
-from model.unet import UNet3D, DecoderNoJoining
+from model.unet import UNet3D, DecoderNoJoining, _group_elements
 from rfuse import ops
 
 
@@ -104,7 +104,7 @@ class Superresolution08FinalDecoder(nn.Module):
         g2 = c2.groupnorm
         cout, edge = c2.conv.out_channels, y1.shape[2]
         if (ops.conv_split_pointwise_supported(y1, cout)
-                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (g2.num_channels // max(1, min(g2.num_groups, g2.num_channels))) * edge ** 3)):
+                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, _group_elements(g2, edge))):
             aff = ops.gn_affine(y1, None, g2.weight, g2.bias, g2.num_groups, g2.eps)
             return ops.conv3d_split_pointwise_tanh(y1, aff, c2.conv.packed_split(), cout, pw.weight, pw.bias, post_add, post_mul)
         return ops.conv1x1_tanh(c2(y1), pw.weight, pw.bias, post_add=post_add, post_mul=post_mul)

@@ -98,6 +98,16 @@ class Conv3dParams(nn.Module):
         return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}'
 
 
+def _groups_of(gn):
+    """the group count GroupNormParams really normalises with (reference model/unet.py:62-63: one group when there are fewer channels than groups)"""
+    return 1 if gn.num_channels < gn.num_groups else gn.num_groups
+
+
+def _group_elements(gn, edge):
+    """elements one GroupNorm group holds on an edge^3 volume (the bound on |GroupNorm output| that ops.split_range_ok checks is gamma * sqrt(that) + |beta|)"""
+    return (gn.num_channels // _groups_of(gn)) * edge ** 3
+
+
 class SingleConv(nn.Module):
     """GroupNorm -> Conv3d(k3, p1, no bias) -> ReLU, order 'gcr' (reference model/unet.py:19-76,79-100)."""
 
@@ -128,7 +138,7 @@ class SingleConv(nn.Module):
         edge = x.shape[2] if x is not None else 2 * upsampled.shape[2]
         # the split-operand (F16 matrix core) forms only where they cannot saturate: weights and GroupNorm outputs inside the f16 pair's range
         # (ops.split_range_ok, decided from the parameters once per version); otherwise the fp32 kernels, like the reference's fp32 path
-        split_ok = ops.CONV_ARITH == 'split' and ops.split_range_ok(self.conv.weight, gn.weight, gn.bias, (gn.num_channels // gn.num_groups) * edge ** 3)
+        split_ok = ops.CONV_ARITH == 'split' and ops.split_range_ok(self.conv.weight, gn.weight, gn.bias, _group_elements(gn, edge))
         if not split_ok:
             return self._forward_fp32(x, upsampled, aff, cout, edge, _direct, pool)
         if upsampled is None and not _direct and ops.conv_split_supported(x, None, cout):
@@ -170,9 +180,6 @@ class SingleConv(nn.Module):
         return out if pool is None else (out, ops.maxpool2(out))
 
 
-def _groups_of(gn):
-    """the group count GroupNormParams really normalises with (reference model/unet.py:62-63: one group when there are fewer channels than groups)"""
-    return 1 if gn.num_channels < gn.num_groups else gn.num_groups
 
 
 def _decoder_pair_presplit_ok(c1, c2, x, upsampled):
@@ -186,9 +193,8 @@ def _decoder_pair_presplit_ok(c1, c2, x, upsampled):
         return False
     if not bool(ops._lib.load().rf_conv3d_split_pre_supported(cmid, n, edge, c2.conv.out_channels)):
         return False
-    cin = (x.shape[1] if x is not None else 0) + upsampled.shape[1]
-    return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, (cin // g1.num_groups) * edge ** 3)
-            and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (cmid // g2.num_groups) * edge ** 3))
+    return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, _group_elements(g1, edge))
+            and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, _group_elements(g2, edge)))
 
 
 def _decoder_pair_presplit(c1, c2, x, upsampled):
@@ -239,9 +245,8 @@ class DoubleConv(nn.Module):
         cmid, n, edge = c1.conv.out_channels, x.shape[0], x.shape[2]
         if not ops.conv_split_presplit_supported(x, cmid, _groups_of(g2)) or not bool(ops._lib.load().rf_conv3d_split_pre_supported(cmid, n, edge, c2.conv.out_channels)):
             return False
-        g1n = 1 if x.shape[1] < g1.num_groups else g1.num_groups
-        return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, (x.shape[1] // g1n) * edge ** 3)
-                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (cmid // _groups_of(g2)) * edge ** 3))
+        return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, _group_elements(g1, edge))
+                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, _group_elements(g2, edge)))
 
     def _presplit_ok(self, x):
         c1, c2 = self.SingleConv1, self.SingleConv2
@@ -251,7 +256,7 @@ class DoubleConv(nn.Module):
         if not ops.cin1_presplit_supported(x, c1.conv.out_channels, g2.num_groups, c2.conv.out_channels):
             return False
         edge = x.shape[2]
-        return ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, (g2.num_channels // g2.num_groups) * edge ** 3)
+        return ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, _group_elements(g2, edge))
 
 
 class StepDownDoubleConv(nn.Module):

@@ -135,6 +135,8 @@ SIGNATURES = {
     'rf_topk_merge': (c_i, [c_fp, c_p, c_i, c_i, c_i, c_fp, c_p, c_p]),
     'rf_demote_same_scene': (c_i, [c_fp, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_fp, c_p, c_p]),
     'rf_gather_rows': (c_i, [c_fp, c_i64, c_p, c_i64, c_i, c_fp, c_p]),
+    'rf_mc_classify': (c_i, [c_fp, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'rf_mc_emit': (c_i, [c_fp, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_fp, c_p, c_p]),
     'rf_gather_patches': (c_i, [c_fp, c_i64, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_fp, c_p]),
 }
 
@@ -144,7 +146,7 @@ _lib = None
 class _Library:
     """The bound entry points as plain attributes (no indirection on the hot path).  ``start_profile`` swaps every stream-ordered
     entry point for a wrapper that brackets the call with HIP events on the launch stream and records
-    (name, integer arguments, start, end) -- bench.py's per-kernel table; ``stop_profile`` restores the direct bindings."""
+    (name, integer arguments, start, end, positions of the null pointer arguments) -- bench.py's per-kernel table; ``stop_profile`` restores the direct bindings."""
 
     def __init__(self, cdll):
         self._cdll = cdll
@@ -156,17 +158,20 @@ class _Library:
             self._direct[name] = fn
             setattr(self, name, fn)
 
-    def start_profile(self, records):
+    def start_profile(self, records, only=None):
+        """``only``: a set of entry-point names -- bracket just those (the timed region of bench.py times its one dominant entry point this way)."""
         def timed(name, fn):
             def call(*args):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(*args)
                 e1.record()
-                records.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1))
+                records.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1, tuple(i for i, a in enumerate(args) if a is None or (isinstance(a, ctypes.c_void_p) and not a.value))))
                 return rc
             return call
         for name, (res, args) in SIGNATURES.items():
+            if only is not None and name not in only:
+                continue
             if res is c_i and args and name not in ('rf_abi_version',):     # int-returning launches (all take the stream last)
                 setattr(self, name, timed(name, self._direct[name]))
 

@@ -170,15 +170,20 @@ class RefinementEngine:
         input -- depends on nothing of batch i, is VALU / HBM work of ~2 ms and is issued on a helper stream BEFORE the back end of batch i
         (retrieval backbone, attention, decoder: LDS / MFMA work of ~7 ms on the caller's stream), so the two overlap on the GPU instead of following
         each other.  Same kernels on the same data as ``refine``: results are bit-identical; only the latency of a batch grows by one front end."""
-        with torch.cuda.device(self.device), torch.no_grad():
-            main = torch.cuda.current_stream(self.device)
-            front = self._side_streams.get(('front', main.cuda_stream))
-            if front is None:
-                front = self._side_streams[('front', main.cuda_stream)] = torch.cuda.Stream(self.device)
-            pending = None
-            for i, raw in enumerate(batches):
-                qs = query_scenes[i] if query_scenes is not None else None
-                pm = patch_masks[i] if patch_masks is not None else None
+        # the device / no_grad contexts are entered around the WORK of an iteration only and left before every yield: both are thread-global state, and a
+        # generator that held them across its yields would run the consumer's loop body under no_grad on the engine's device (and keep them until it is
+        # collected if the consumer breaks out)
+        pending = None
+        main = None
+        for i, raw in enumerate(batches):
+            qs = query_scenes[i] if query_scenes is not None else None
+            pm = patch_masks[i] if patch_masks is not None else None
+            with torch.cuda.device(self.device), torch.no_grad():
+                if main is None:
+                    main = torch.cuda.current_stream(self.device)
+                front = self._side_streams.get(('front', main.cuda_stream))
+                if front is None:
+                    front = self._side_streams[('front', main.cuda_stream)] = torch.cuda.Stream(self.device)
                 ready = torch.cuda.Event()
                 ready.record(main)                                   # whatever produced `raw` on the caller's stream
                 front.wait_event(ready)
@@ -189,11 +194,14 @@ class RefinementEngine:
                     front.wait_stream(side)
                     done = torch.cuda.Event()
                     done.record(front)
-                if pending is not None:
-                    yield self._finish_pipelined(main, *pending)
+                out = self._finish_pipelined(main, *pending) if pending is not None else None
                 pending = (patches, x_back, done)
-            if pending is not None:
-                yield self._finish_pipelined(main, *pending)
+            if out is not None:
+                yield out
+        if pending is not None:
+            with torch.cuda.device(self.device), torch.no_grad():
+                out = self._finish_pipelined(main, *pending)
+            yield out
 
     def _finish_pipelined(self, main, patches, x_back, done):
         main.wait_event(done)

@@ -10,8 +10,8 @@ reaches; chunks are pasted in list order (a later chunk overwrites an earlier on
 ``refine_scene`` is the scene-level driver around the hot path: what the reference's inference loop does per visualisation dataset
 (trainer/train_refinement.py:158-169: batches of chunks -> forward_full -> network_pred_to_df -> .cpu().half() -> combine_retrievals(.., 0)).
 
-Host-side numpy scatter, not on the hot path.  Mesh export (util/visualization.py: marching cubes -> .obj) has no
-counterpart here: it needs the ``marching_cubes`` / ``trimesh`` packages, which this image does not have.
+The recomposition of refined chunks runs on the device (slice copies into a float64 canvas, one transfer per scene); ``combine_chunks`` is the
+host-side form the goldens pin.  Mesh export (util/visualization.py:34-37: marching cubes at level 0.75 -> .obj) is rfuse/mesh.py.
 """
 import numpy as np
 
@@ -73,13 +73,29 @@ def combine_predictions(chunk_names, predictions, dataset_name, trunc_val):
     return combine_chunks(chunk_names, [preds[i, 0] for i in range(len(chunk_names))], dataset_name, 1, 64, trunc_val)
 
 
-def refine_scene(engine, chunk_names, chunk_inputs, batch=32, query_scene=None, patch_mask=None, half=True):
+def _scene_layout(chunk_names, dataset_name, chunk_size=64):
+    """-> {superscene: (canvas shape, [(chunk index, (x, y, z))])}: where ``combine_chunks`` would paste every chunk, in list order"""
+    members = {}
+    for i, name in enumerate(chunk_names):
+        key, origin = superscene_and_position(name, dataset_name)
+        members.setdefault(key, []).append((i, tuple(int(v) for v in origin.astype(np.int32))))
+    return {key: (tuple(int(r) for r in (np.max([o for _, o in items], axis=0) + chunk_size)), items) for key, items in members.items()}
+
+
+def refine_scene(engine, chunk_names, chunk_inputs, batch=32, query_scene=None, patch_mask=None, half=True, assemble_on_device=True):
     """Scene-level inference: low-resolution chunks of one or several superscenes -> {superscene: refined TSDF volume (float64)}.
 
     chunk_inputs [n, s, s, s] raw (un-normalised) low-resolution chunks, ``chunk_names[i]`` the dataset's chunk name (it carries the position).
-    Chunks run through ``engine.refine`` in batches of ``batch`` (the last one ragged); predictions come back as float16 like the reference's
-    ``network_pred_to_df(pred_shape).cpu().half()`` (``half=False`` keeps fp32) and are pasted by ``combine_predictions``.  The device -> host
-    copy of batch i overlaps the refinement of batch i + 1 (pinned double buffer on a copy stream)."""
+    Chunks run through ``engine.refine_stream`` in batches of ``batch`` (the last one ragged; the front end of batch i + 1 beside the back end of batch i);
+    predictions are rounded to float16 like the reference's ``network_pred_to_df(pred_shape).cpu().half()`` (``half=False`` keeps fp32) and recomposed
+    as ``combine_predictions`` does (reference dataset/patched_scene_dataset.py:160-186: a float64 canvas filled with the target truncation, chunks
+    pasted in list order).
+
+    ``assemble_on_device`` (default): the canvases live on the device -- every batch is pasted by slice copies as soon as it is refined, and each finished
+    canvas crosses PCIe once, as float64, into pinned host memory (torch's caching host allocator hands the same pages out again once a previous
+    result is released).  Round 3 copied float16 chunks to the host and pasted them into a float64 numpy canvas on one thread: 8.4 M conversions per 32
+    chunks, four times the GPU time of the chunks themselves (bench.py `scene_driver`: 996 chunks/s against 4547 resident).  False: that host path,
+    kept as the cross-check (same values: float16 -> float64 is exact either way)."""
     import torch
     cfg = engine.config
     n = len(chunk_names)
@@ -87,20 +103,113 @@ def refine_scene(engine, chunk_names, chunk_inputs, batch=32, query_scene=None, 
     assert x.shape[0] == n, 'one input chunk per name'
     dev = engine.device
     out_dtype = torch.float16 if half else torch.float32
-    host = torch.empty((n, 1, 64, 64, 64), dtype=out_dtype).pin_memory() if dev.type == 'cuda' else torch.empty((n, 1, 64, 64, 64), dtype=out_dtype)
-    copy = torch.cuda.Stream(dev)
-    main = torch.cuda.current_stream(dev)
-    for lo in range(0, n, batch):
-        hi = min(lo + batch, n)
-        qs = query_scene[lo * 64:hi * 64] if query_scene is not None else None
-        pm = patch_mask[lo:hi] if patch_mask is not None else None
-        df = engine.refine(x[lo:hi].to(dev, non_blocking=True), query_scene=qs, patch_mask=pm)
-        df = df.to(out_dtype)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(copy):
-            copy.wait_event(ready)
-            host[lo:hi].copy_(df, non_blocking=True)
-            df.record_stream(copy)
-    copy.synchronize()
-    return combine_predictions(chunk_names, host.numpy(), cfg['dataset_train']['dataset_name'], float(engine.target_trunc))
+    dataset_name, trunc = cfg['dataset_train']['dataset_name'], float(engine.target_trunc)
+    spans = [(lo, min(lo + batch, n)) for lo in range(0, n, batch)]
+    scenes_q = [query_scene[lo * 64:hi * 64] if query_scene is not None else None for lo, hi in spans]
+    masks = [patch_mask[lo:hi] if patch_mask is not None else None for lo, hi in spans]
+    x_pin = x.pin_memory() if dev.type == 'cuda' and not x.is_pinned() else x
+    batches = (x_pin[lo:hi].to(dev, non_blocking=True) for lo, hi in spans)
+    stream = engine.refine_stream(batches, scenes_q if query_scene is not None else None, masks if patch_mask is not None else None)
+    if not assemble_on_device:
+        host = torch.empty((n, 1, 64, 64, 64), dtype=out_dtype).pin_memory()
+        copy = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        for (lo, hi), df in zip(spans, stream):
+            df = df.to(out_dtype)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(copy):
+                copy.wait_event(ready)
+                host[lo:hi].copy_(df, non_blocking=True)
+                df.record_stream(copy)
+        copy.synchronize()
+        return combine_predictions(chunk_names, host.numpy(), dataset_name, trunc)
+    layout = _scene_layout(chunk_names, dataset_name)
+    sizes = [int(np.prod(shape)) for shape, _ in layout.values()]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    with torch.cuda.device(dev):
+        # ONE device buffer and ONE pinned host buffer hold every canvas of the call (a ShapeNet-style dataset has a canvas per chunk: 64 allocations and
+        # 64 transfers per 64 chunks otherwise); the returned arrays are views of the host buffer
+        flat = torch.full((int(starts[-1]),), trunc, dtype=torch.float64, device=dev)
+        canvases = {key: flat[starts[k]:starts[k + 1]].view(shape) for k, (key, (shape, _)) in enumerate(layout.items())}
+        one_chunk_each = all(shape == (64, 64, 64) and len(items) == 1 for shape, items in layout.values()) and \
+            [items[0][0] for _, items in layout.values()] == list(range(n))
+        plans = None
+        if not one_chunk_each:
+            # per canvas: the chunks that survive (a later chunk at the same origin overwrites an earlier one) with their grid cell, as device index
+            # tensors -- a batch pastes its members of a canvas with ONE indexed copy into the canvas seen as [gx, gy, gz, 64, 64, 64]
+            plans = {}
+            for key, (shape, items) in layout.items():
+                if any(d % 64 for d in shape) or any(c % 64 for _, o in items for c in o):
+                    plans[key] = None                                 # origins off the 64-grid: slice copies in list order
+                    continue
+                last = {}
+                for i, o in items:
+                    last[o] = i
+                keep = sorted((i, o) for o, i in last.items())
+                ids = np.array([i for i, _ in keep], dtype=np.int64)
+                cells = torch.tensor([[c // 64 for c in o] for _, o in keep], dtype=torch.int64, device=dev)
+                grid = canvases[key].view(shape[0] // 64, 64, shape[1] // 64, 64, shape[2] // 64, 64).permute(0, 2, 4, 1, 3, 5)
+                plans[key] = (ids, cells, grid)
+        # transfer regions: x-slabs of 64 voxels of the planned canvases (contiguous in memory; split_scene lists chunks x-outermost, so slabs complete in
+        # order), whole canvases otherwise.  A region goes to the pinned host buffer on a copy stream as soon as its last chunk has been pasted -- under
+        # the refinement of the next batch -- and only the regions the last batch completes are waited for.
+        host = torch.empty(flat.shape, dtype=torch.float64, pin_memory=True)
+        copy = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        regions = []                                                 # [start, end, chunks still to come]
+        region_of = {}                                               # chunk index -> region
+        for k, (key, (shape, items)) in enumerate(layout.items()):
+            if one_chunk_each or plans[key] is None:
+                regions.append([int(starts[k]), int(starts[k + 1]), len(items)])
+                for i, _ in items:
+                    region_of[i] = len(regions) - 1
+                continue
+            slab = 64 * shape[1] * shape[2]
+            first = len(regions)
+            regions += [[int(starts[k]) + ix * slab, int(starts[k]) + (ix + 1) * slab, 0] for ix in range(shape[0] // 64)]
+            for i, cell in zip(plans[key][0], plans[key][1][:, 0].tolist()):
+                region_of[int(i)] = first + cell
+                regions[first + cell][2] += 1
+
+        def ship(done):
+            if not done:
+                return
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(copy):
+                copy.wait_event(ready)
+                for r in done:
+                    host[regions[r][0]:regions[r][1]].copy_(flat[regions[r][0]:regions[r][1]], non_blocking=True)
+
+        ship([r for r, reg in enumerate(regions) if reg[2] == 0])    # regions no chunk lands in: the truncation fill
+        for (lo, hi), df in zip(spans, stream):
+            rounded = df.to(out_dtype)                               # the reference's float16 round trip
+            done = []
+            for i in range(lo, hi):
+                r = region_of.get(i)                                 # (None: a chunk that a later one at the same origin overwrites)
+                if r is not None:
+                    regions[r][2] -= 1
+                    if regions[r][2] == 0:
+                        done.append(r)
+            if one_chunk_each:
+                flat.view(n, 64, 64, 64)[lo:hi].copy_(rounded[:, 0])   # (the copy widens to the canvas' float64: exact)
+                ship(done)
+                continue
+            vals = rounded.to(torch.float64)
+            for key, (shape, items) in layout.items():
+                if plans[key] is None:
+                    for i, (ox, oy, oz) in items:
+                        if lo <= i < hi:
+                            canvases[key][ox:ox + 64, oy:oy + 64, oz:oz + 64] = vals[i - lo, 0]
+                    continue
+                ids, cells, grid = plans[key]
+                a, b = np.searchsorted(ids, lo), np.searchsorted(ids, hi)
+                if b > a:
+                    sel = torch.as_tensor(ids[a:b] - lo, device=dev)
+                    grid[cells[a:b, 0], cells[a:b, 1], cells[a:b, 2]] = vals[sel, 0]
+            ship(done)
+        copy.synchronize()
+        flat.record_stream(copy)
+    host_np = host.numpy()
+    return {key: host_np[starts[k]:starts[k + 1]].reshape(shape) for k, (key, (shape, _)) in enumerate(layout.items())}

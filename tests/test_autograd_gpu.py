@@ -81,6 +81,25 @@ def test_single_conv_gradients_match_float64_oracle(gpu, case):
     assert max(errs.values()) < 2e-4, errs
 
 
+@pytest.mark.parametrize('poison', [float('inf'), float('nan')])
+def test_nonfinite_upstream_gradient_stays_visible(gpu, poison):
+    """The split-operand backward clamps its operands into the f16 pairs' range and takes a maximum with fmaxf (which drops NaN): an upstream gradient
+    that is not finite would come out as a FINITE data / weight gradient and hide an overflow from the training loop (GradScaler, anomaly detection).
+    rf_relu_backward_amax records it, rf_dgrad_scale_affine turns the rescaling factor into NaN: both gradients are non-finite, like the fp32 route's."""
+    from model.unet import SingleConv
+    n, cin, edge, cout, groups = 1030, 16, 8, 32, 8                  # enough boxes for the split-operand routes
+    torch.manual_seed(5)
+    layer = SingleConv(cin, cout, num_groups=groups).to(gpu)
+    x = torch.randn(n, cin, edge, edge, edge, device=gpu).relu().requires_grad_(True)
+    y = layer(x)
+    r = torch.randn_like(y)
+    idx = (y[3, 5] > 0).nonzero()[0]                                  # a position the ReLU lets through
+    r[3, 5, idx[0], idx[1], idx[2]] = poison
+    (y * r).sum().backward()
+    assert not torch.isfinite(x.grad).all(), 'the data gradient hides a non-finite upstream gradient'
+    assert not torch.isfinite(layer.conv.weight.grad).all(), 'the weight gradient hides a non-finite upstream gradient'
+
+
 def test_attention_feature_encoder_gradients(gpu):
     """4 Linear layers + LeakyReLU through rfuse.autograd.Linear against float64 autograd of the oracle.
     LeakyReLU has a kink at 0: a row with a pre-activation within fp32 round-off of zero takes the other slope in fp32 than in float64 and its
@@ -162,11 +181,12 @@ def test_retrieval_backbone_trains_like_the_oracle(gpu):
     assert loss2.item() < loss.item()
 
 
-@pytest.mark.parametrize('cfg_name', ['C3', 'C1'])
+@pytest.mark.parametrize('cfg_name', ['C3', 'C1', 'C4', 'C5'])
 def test_forward_full_trains_like_the_oracle(gpu, cfg_name):
     """The reference's training graph (trainer/train_refinement.py:108-116 forward_full -> an L1 loss on df, phase 3: every network
     trainable) through the drop-in modules in grad mode: loss value and the gradient of EVERY parameter of the four networks
-    against float64 autograd of the oracle.  C3 = softmax attention, C1 = straight-through Gumbel-hard with injected noise."""
+    against float64 autograd of the oracle.  C3 = softmax attention, C1 = straight-through Gumbel-hard with injected noise, C4 = K = 8 on a 16^3 input
+    (Matterport3D), C5 = the nf = 12 / five-level U-Net on a 128^3 grid (model/refinement.py:37-45) -- trainer/train_refinement.py:41-43 trains every config."""
     import model
     from model.attention import Unfold3D, Fold3D
     cfg = rf_configs.get_config(cfg_name)
@@ -180,7 +200,8 @@ def test_forward_full_trains_like_the_oracle(gpu, cfg_name):
         m.to(gpu).train()
     gen = torch.Generator().manual_seed(21)
     K, B = cfg['K'], 1
-    x_in = torch.randn(B, 1, 8, 8, 8, generator=gen)
+    s_in = cfg['dataset_train']['input_chunk_size']
+    x_in = torch.randn(B, 1, s_in, s_in, s_in, generator=gen)
     retr = torch.randn(B, K, 64, 64, 64, generator=gen)
     target = torch.rand(B, 1, 64, 64, 64, generator=gen) * trunc_t
     noise = -torch.empty(B * 4096, K).exponential_(generator=gen).log() * 4.0 if cfg['attn_retrieval_mode'] else None
@@ -199,7 +220,7 @@ def test_forward_full_trains_like_the_oracle(gpu, cfg_name):
         lo = (dfo - target.to(dt)).abs().mean()
         lo.backward()
         return lo, sdo
-    torch.set_num_threads(16)
+    torch.set_num_threads(32)
     lo, sd64 = oracle(torch.float64)
     _, sd32 = oracle(torch.float32)
     assert abs(loss.item() - lo.item()) < 1e-4 * abs(lo.item())

@@ -17,7 +17,7 @@ torch.manual_seed(0)
 emb, meta, vols = bench.synthetic_database(cfg, 50_000, dev)
 eng = RefinementEngine(cfg, dev, PatchDatabase(emb, meta, vols, dev))
 raw = torch.from_numpy(np.stack([synthetic.make_chunk(10_000 + b, cfg)['input_raw'] for b in range(B)])).to(dev)
-t = bench.kernel_table(eng, raw, cfg, steps=3, top=60)
+t, _ = bench.kernel_table(eng, raw, cfg, steps=3, top=60)
 print('serial ms/step %.3f' % t['serial_ms_per_step'])
 for r in t['top']:
     print('%-30s %-34s x%-3.0f %7.3f ms  %5.1f%%  %s' % (r['entry'], r['args'], r['launches_per_step'], r['ms_per_step'], 100 * r['share'],

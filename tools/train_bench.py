@@ -72,7 +72,7 @@ step()
 torch.cuda.synchronize()
 lib.stop_profile()
 agg = {}
-for entry, _, a0, a1 in records:
+for entry, _, a0, a1, _nulls in records:
     agg[entry] = agg.get(entry, 0.0) + a0.elapsed_time(a1)
 top = sorted(agg.items(), key=lambda kv: -kv[1])[:8]
 
