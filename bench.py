@@ -314,7 +314,7 @@ def kernel_work(name, a, cfg):
     return None
 
 
-def kernel_table(eng, raw_dev, cfg, steps=3, top=5):
+def kernel_table(eng, raw_dev, cfg, steps=3, top=8):
     """per entry point (and shape) HIP-event time over ``steps`` serial steps (backbone on the main stream: no overlap)"""
     from rfuse import _lib
     lib = _lib.load()

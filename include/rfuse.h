@@ -466,6 +466,20 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
  * its all-trunc sentinel patch (util/retrieval.py:21-26,45). */
 int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t m, int width, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------- channel-interleaved hand-over (the final decoder's 64^3 pair) */
+
+/* "ch8": an fp32 activation tensor stored [n][c / 8][edge^3][8 channels] instead of NCDHW.  The final decoder's conv pair (reference model/refinement.py:48-61:
+ * DecoderNoJoining(16, 16) on 64^3, then Conv3d(16, 1, 1) + tanh) cannot hand over pre-split -- a 64^3 sample is 512 boxes, no workgroup has the statistics
+ * the second GroupNorm needs -- but the second conv stages 8 channels of a voxel at a time, and from an NCDHW tensor that is eight 4-byte gathers in 40-byte
+ * runs per voxel (bound by the address path, not by HBM).  The producer therefore writes its output ch8 (256 contiguous bytes per box row), the consumer
+ * loads two 16-byte pieces per voxel.  Values and statistics are those of rf_conv3d_up_split_k3_gn_relu / rf_conv3d_split_k3_gn_relu_pointwise_tanh. */
+int rf_conv3d_up_split_ch8_supported(int c0, int c1, int n, int edge, int cout);
+int rf_conv3d_up_split_k3_gn_relu_ch8(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
+                                      const void* w_packed, int cout, float* out_ch8, double* stats, void* stream);
+int rf_conv3d_split_pointwise_ch8_supported(int cin, int n, int edge, int cout);
+int rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8(const float* src_ch8, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
+                                                  const float* pw_w, const float* pw_b, float post_add, float post_mul, float* out1, void* stream);
+
 /* ------------------------------------------------------------------------------- mesh export */
 
 /* Marching cubes on the device: the last step of the reference's inference loop (util/visualization.py:34-37 visualize_sdf_as_mesh:

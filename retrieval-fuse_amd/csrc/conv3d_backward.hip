@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_relu_bwd_amax(const float4* __restrict_
         m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         // fmaxf drops a NaN and the split forms clamp: an upstream gradient that is not finite must stay visible (overflow / anomaly detection of the
         // training loop), so it is recorded as an infinite maximum, which rf_dgrad_scale_affine turns into NaN gradients
-        bad |= !(fabsf(o.x) < INFINITY) | !(fabsf(o.y) < INFINITY) | !(fabsf(o.z) < INFINITY) | !(fabsf(o.w) < INFINITY);
+        bad = bad || !(fabsf(o.x) < INFINITY) || !(fabsf(o.y) < INFINITY) || !(fabsf(o.z) < INFINITY) || !(fabsf(o.w) < INFINITY);
     }
     if (bad) m = INFINITY;
 #pragma unroll

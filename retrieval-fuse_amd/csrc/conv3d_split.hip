@@ -19,6 +19,14 @@
 #include "conv_split_common.h"
 #include <type_traits>
 
+// conv3d_split_zc.hip: the persistent z-column forms.  zc: the one-chunk pre-split layer on 16^3 samples (8 -> 16: level 0 of the retrieval backbone);
+// zcm: layers of two or more whole chunks with up to 16 couts, any output form of this file (full / pooled / pointwise head / pre-split)
+bool rf_split_zc_takes(int cin, int n, int edge, int cout);
+int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream);
+bool rf_split_zcm_takes(int cin, int n, int edge, int cout);
+int rf_split_zcm_launch(const ConvArgs& a, const SplitPreOut& po, bool pre, hipStream_t stream, const char* who);
+int rf_split_zcm_launch_ch8_pointwise(const ConvArgs& a, const SplitPreOut& po, hipStream_t stream, const char* who);
+
 // ------------------------------------------------------------------------------------------------------------ weight image
 extern "C" size_t rf_conv3_split_packed_bytes(int cout, int cin) {
     return ((size_t)((cin + 7) / 8) * 7 + 1) * (size_t)(rf_round_up(cout, 16) / 16) * 2 * 64 * 16;
@@ -63,21 +71,6 @@ extern "C" int rf_conv3_split_pack_weight(const float* w_oidhw, int cout, int ci
 // triple; their weights are zero too)
 // PRE: the input is a PRE-SPLIT tensor (rf_split_act_bytes: per (sample, 8-channel group) an h plane and an l plane of 16-byte voxel slots) that
 // its producer already normalised for THIS layer's GroupNorm and split -- staging is a copy of slots, no affine table, no conversion
-// pre-split OUTPUT (whole 8^3 samples, 16 couts in one workgroup): the NEXT layer's GroupNorm -- its gamma / beta / groups / eps over this layer's couts --
-// is applied in the epilogue from the sample's own statistics and the result written as that layer's pre-split input; null: off
-struct SplitPreOut {
-    h8* out;
-    const float* gamma;
-    const float* beta;
-    int groups;
-    float eps;
-    // ... or the final decoder's pointwise head (reference model/refinement.py:48-61: Conv3d(nf, 1, 1) + bias -> tanh -> network_pred_to_df) applied to the
-    // ReLU'd output in the epilogue: pw_out [n][1][edge^3] = (tanh(sum_c w[c] y[c] + b) + post_add) * post_mul, the nf-channel tensor is never written
-    float* pw_out;
-    const float* pw_w;
-    const float* pw_b;
-    float post_add, post_mul;
-};
 constexpr int CS_PO_STRIDE = 517;                                   // tile row (floats), odd: conflict-free scalar writes
 constexpr int CS_PO_STATS = 16 * CS_PO_STRIDE * 4, CS_PO_TRIPLES = CS_PO_STATS + 16 * 16;      // behind the tile: 16 x double2, 16 x float4
 static_assert(CS_PO_TRIPLES + 16 * 16 <= CS_LDS_BYTES, "pre-split epilogue must fit the multi-chunk instance's LDS");
@@ -722,6 +715,8 @@ static int split_run(const ConvArgs& a, void* stream) {
         RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
         return RF_OK;
     }
+    if (a.cout16 == 16 && rf_split_zcm_takes(cin, n, edge, a.cout))
+        return rf_split_zcm_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, false, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu");
     if (cin % 8) {
         if (cin < 8) return launch_split<1, 6, true, true>(a, (hipStream_t)stream);                   // 6 -> 12 of the nf = 12 U-Nets: one chunk, two zero slots
         if (a.cout16 % 32 == 0) return launch_split<2, 2, false, true>(a, (hipStream_t)stream);
@@ -779,9 +774,6 @@ extern "C" int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout)
     return cin >= 8 && cin % 8 == 0 && edge >= 8 && rf_conv3d_split_supported(cin, 0, n, edge, cout);
 }
 
-// conv3d_split_zc.hip: the persistent z-column form of the one-chunk pre-split layer (8 -> 16 @16^3: level 0 of the retrieval backbone)
-bool rf_split_zc_takes(int cin, int n, int edge, int cout);
-int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream);
 
 // tiles per (sample, cout) of the statistics rf_conv3d_split_pre_k3_relu writes for this shape ([n][cout][tiles] double2): one per 8^3 box, or one per
 // sample where the persistent form (which sums a sample's boxes itself) takes the layer
@@ -809,6 +801,8 @@ extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, in
         a.stats_tiles = 1;
         return rf_split_zc_launch(a, (hipStream_t)stream);
     }
+    if (a.cout16 == 16 && rf_split_zcm_takes(cin, n, edge, cout))
+        return rf_split_zcm_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, true, (hipStream_t)stream, "rf_conv3d_split_pre_k3_relu");
     if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false, false, true>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true, false, true>(a, (hipStream_t)stream) : launch_split<1, 4, false, false, true>(a, (hipStream_t)stream);
 }
@@ -831,6 +825,7 @@ extern "C" int rf_conv3d_split_presplit(const float* src, int cin, int n, int ed
     a.stats = reinterpret_cast<double2*>(stats); a.stats_tiles = stats ? 1 : 0;
     a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
     const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps, nullptr, nullptr, nullptr, 0.f, 0.f};
+    if (rf_split_zcm_takes(cin, n, edge, cout)) return rf_split_zcm_launch(a, po, false, (hipStream_t)stream, "rf_conv3d_split_presplit");
     return launch_split<1, 4, false>(a, (hipStream_t)stream, po);
 }
 
@@ -851,5 +846,25 @@ extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh(const float* src, int c
     a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
     a.stats = nullptr; a.stats_tiles = 0; a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
     const SplitPreOut po{nullptr, nullptr, nullptr, 0, 0.f, out1, pw_w, pw_b, post_add, post_mul};
+    if (rf_split_zcm_takes(cin, n, edge, cout)) return rf_split_zcm_launch(a, po, false, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu_pointwise_tanh");
     return cin % 8 ? launch_split<1, 4, false, true>(a, (hipStream_t)stream, po) : launch_split<1, 4, false>(a, (hipStream_t)stream, po);
+}
+
+// ... on the CHANNEL-INTERLEAVED output of rf_conv3d_up_split_k3_gn_relu_ch8 ([n][cin / 8][edge^3][8] fp32): same values bit for bit, the staging loads are
+// two 16-byte loads per voxel instead of eight 4-byte gathers.  The persistent z-column form only.
+extern "C" int rf_conv3d_split_pointwise_ch8_supported(int cin, int n, int edge, int cout) {
+    return rf_conv3d_split_pointwise_supported(cin, n, edge, cout) && cin % 8 == 0 && rf_split_zcm_takes(cin, n, edge, cout);
+}
+
+extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8(const float* src_ch8, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
+                                                             const float* pw_w, const float* pw_b, float post_add, float post_mul, float* out1, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_pointwise_ch8_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8: takes cin in eights (>= 16), up to 16 couts, edge >= 8 and at least 2048 boxes (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
+    RF_REQUIRE(src_ch8 && gn_affine && w_packed && pw_w && pw_b && out1, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8: null pointer");
+    ConvArgs a;
+    a.src0 = src_ch8; a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const float*>(w_packed); a.out = nullptr;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
+    a.stats = nullptr; a.stats_tiles = 0; a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
+    const SplitPreOut po{nullptr, nullptr, nullptr, 0, 0.f, out1, pw_w, pw_b, post_add, post_mul};
+    return rf_split_zcm_launch_ch8_pointwise(a, po, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8");
 }

@@ -135,6 +135,8 @@ struct UpSplitArgs {
     const float* nbeta;
     int ngroups;
     float neps;
+    // box kernel only: `out` is written channel-interleaved, [n][cout / 8][voxel][8 channels] fp32 (rf_conv3d_up_split_k3_gn_relu_ch8)
+    int out_ch8;
 };
 
 // 8 normalised channel values of one voxel -> the two f16 pieces (scaled by 2^-4; saturating, never inf)
@@ -765,8 +767,19 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_box(UpSplitArgs a, in
     __syncthreads();
     const int cout = a.cout;
     const size_t vol = (size_t)edge * edge * edge;
+    if (a.out_ch8) {
+        // channel-interleaved output for a consumer that stages 8 channels of a voxel at a time: a box row is 8 voxels x 32 bytes = 256 contiguous bytes
+        float* __restrict__ oc = a.out + (size_t)n * cout * vol;
+        for (int q = tid; q < (cout >> 3) * 1024; q += 512) {
+            const int cg = q >> 10, vox = (q >> 1) & 511, hf = q & 1;
+            const int z = vox >> 6, y = (vox >> 3) & 7, x = vox & 7;
+            const float* ep = e + (cg * 8 + hf * 4) * UB_E_STRIDE + vox;
+            *reinterpret_cast<float4*>(oc + (((size_t)cg * vol + ((size_t)(z0 + z) * edge + y0 + y) * edge + x0 + x) << 3) + hf * 4) =
+                make_float4(ep[0], ep[UB_E_STRIDE], ep[2 * UB_E_STRIDE], ep[3 * UB_E_STRIDE]);
+        }
+    }
     float* __restrict__ o = a.out + (size_t)n * cout * vol + ((size_t)z0 * edge + y0) * edge + x0;
-    for (int q = tid; q < cout * 128; q += 512) {
+    for (int q = tid; q < (a.out_ch8 ? 0 : cout * 128); q += 512) {
         const int co = q >> 7, l4 = q & 127;                          // l4: float4 index inside the box: (z, y, half row)
         const int z = l4 >> 4, y = (l4 >> 1) & 7, xh = l4 & 1;
         *reinterpret_cast<float4*>(o + (size_t)co * vol + ((size_t)z * edge + y) * edge + xh * 4) = *reinterpret_cast<const float4*>(e + co * UB_E_STRIDE + l4 * 4);
@@ -1030,6 +1043,8 @@ static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
     return RF_OK;
 }
 
+static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, int cout, void* stream);
+
 extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                               const void* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
@@ -1039,7 +1054,11 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = out; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
-    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f;
+    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f; a.out_ch8 = 0;
+    return up_split_dispatch(a, c0, c1, n, edge, cout, stream);
+}
+
+static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, int cout, void* stream) {
     if (up_split_box_takes(c0, c1, n, edge, cout)) {
         const unsigned boxes = (unsigned)n * (edge / 8) * (edge / 8) * (edge / 8);
         const int nbq = rf_round_up(cout, 16) / 16;
@@ -1120,6 +1139,28 @@ extern "C" int rf_conv3d_up_split_presplit(const float* src0, int c0, const floa
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = nullptr; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
-    a.pre_out = reinterpret_cast<h8*>(out_presplit); a.ngamma = next_gamma; a.nbeta = next_beta; a.ngroups = next_groups; a.neps = eps;
+    a.pre_out = reinterpret_cast<h8*>(out_presplit); a.ngamma = next_gamma; a.nbeta = next_beta; a.ngroups = next_groups; a.neps = eps; a.out_ch8 = 0;
     return rf_round_up(cout, 16) == 48 ? launch_up_split<3>(a, (hipStream_t)stream) : launch_up_split<4>(a, (hipStream_t)stream);
+}
+
+// rf_conv3d_up_split_k3_gn_relu with the output CHANNEL-INTERLEAVED, [n][cout / 8][edge^3][8 channels] fp32 ("ch8"), for a consumer that stages the 8 channels
+// of a voxel together (rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8: the final decoder's conv pair on 64^3, reference model/refinement.py:48-61 -- a
+// 64^3 sample is 512 boxes, no workgroup has its statistics, so the pair cannot hand over pre-split; but the consumer's staging of an NCDHW tensor is
+// 16 four-byte gathers per thread and chunk in 40-byte runs, bound by the address path, where this layout gives it four 16-byte loads).  Same values,
+// same statistics; the box form only (no skip source, <= 32 couts in eights).
+extern "C" int rf_conv3d_up_split_ch8_supported(int c0, int c1, int n, int edge, int cout) {
+    return up_split_box_takes(c0, c1, n, edge, cout) && cout % 8 == 0;
+}
+
+extern "C" int rf_conv3d_up_split_k3_gn_relu_ch8(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
+                                                  const void* w_packed, int cout, float* out_ch8, double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_up_split_ch8_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_up_split_k3_gn_relu_ch8: takes the box form of rf_conv3d_up_split_k3_gn_relu (no skip source, >= 1024 boxes) with cout in eights (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               c0, c1, n, edge, cout);
+    RF_REQUIRE(src1 && gn_affine && w_packed && out_ch8, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu_ch8: null pointer");
+    UpSplitArgs a;
+    a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
+    a.out = out_ch8; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f; a.out_ch8 = 1;
+    return up_split_dispatch(a, c0, c1, n, edge, cout, stream);
 }

@@ -40,3 +40,18 @@ __device__ __forceinline__ void cs_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], 
     for (int n = 0; n < NB; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], lo[n], 0, 0, 0);
 }
 
+// pre-split OUTPUT (whole 8^3 samples, 16 couts in one workgroup): the NEXT layer's GroupNorm -- its gamma / beta / groups / eps over this layer's couts --
+// is applied in the epilogue from the sample's own statistics and the result written as that layer's pre-split input; null: off
+struct SplitPreOut {
+    h8* out;
+    const float* gamma;
+    const float* beta;
+    int groups;
+    float eps;
+    // ... or the final decoder's pointwise head (reference model/refinement.py:48-61: Conv3d(nf, 1, 1) + bias -> tanh -> network_pred_to_df) applied to the
+    // ReLU'd output in the epilogue: pw_out [n][1][edge^3] = (tanh(sum_c w[c] y[c] + b) + post_add) * post_mul, the nf-channel tensor is never written
+    float* pw_out;
+    const float* pw_w;
+    const float* pw_b;
+    float post_add, post_mul;
+};

@@ -626,6 +626,53 @@ def conv3d_up_split_gn_relu(src0, src1, aff, w_split_packed, cout):
     return out
 
 
+USE_CH8 = True                  # False: the final decoder's conv pair hands over an NCDHW tensor (the round-3 route; kept for cross-checks)
+
+
+def conv_up_split_ch8_supported(src1, cout, next_cout):
+    """True when the final decoder's pair can hand over channel-interleaved: the box form of the decoder-form split conv writes ch8
+    (rf_conv3d_up_split_k3_gn_relu_ch8) and the persistent z-column form of the second conv + pointwise head reads it."""
+    if not USE_CH8 or not USE_FUSED_STATS or not USE_CONV_UP or CONV_ARITH != 'split' or src1 is None:
+        return False
+    n, c1, edge = src1.shape[0], src1.shape[1], 2 * src1.shape[2]
+    lib = _lib.load()
+    return bool(lib.rf_conv3d_up_split_ch8_supported(0, c1, n, edge, cout)) and bool(lib.rf_conv3d_split_pointwise_ch8_supported(cout, n, edge, next_cout))
+
+
+def conv3d_up_split_gn_relu_ch8(src1, aff, w_split_packed, cout):
+    """relu(conv3(GN(up2(src1)))) written channel-interleaved: -> (out [n, cout / 8, e, e, e, 8] fp32, stats [n, cout, tiles, 2] float64, tiles)"""
+    _req(src1, 'src1')
+    n, c1, edge = src1.shape[0], src1.shape[1], 2 * src1.shape[2]
+    dev = _check_affine(aff, n, c1)
+    lib = _lib.load()
+    out = torch.empty((n, cout // 8, edge, edge, edge, 8), dtype=torch.float32, device=dev)
+    tiles = lib.rf_conv3d_up_split_stats_tiles(0, c1, n, edge, cout)
+    stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev)
+    _lib.check(lib.rf_conv3d_up_split_k3_gn_relu_ch8(_p(None), 0, _p(src1), c1, n, edge, _p(aff), _p(w_split_packed), cout, _p(out), _p(stats), _stream()),
+               'rf_conv3d_up_split_k3_gn_relu_ch8')
+    return out, stats, tiles
+
+
+def gn_affine_from_stats(stats, tiles, n, c, edge, gamma, beta, groups, eps=1e-5):
+    """the GroupNorm triples of a tensor known only through its producer's per-tile sums (a ch8 tensor: gn_affine reads shapes as NCDHW)"""
+    if c < groups:
+        groups = 1
+    aff = torch.empty((n, c, 4), dtype=torch.float32, device=stats.device)
+    _lib.check(_lib.load().rf_gn_from_stats(_p(stats), c, tiles, _p(None), 0, 0, n, edge, _p(gamma.detach()), _p(beta.detach()), groups, eps, _p(aff), _stream()), 'rf_gn_from_stats')
+    return aff
+
+
+def conv3d_split_pointwise_tanh_ch8(x_ch8, gn_affine_t, w_split_packed, cout, pw_w, pw_b, post_add=0.0, post_mul=1.0):
+    """conv3d_split_pointwise_tanh on a channel-interleaved input [n, cin / 8, e, e, e, 8]"""
+    _req(x_ch8, 'x_ch8')
+    n, cin, edge = x_ch8.shape[0], x_ch8.shape[1] * 8, x_ch8.shape[2]
+    _check_affine(gn_affine_t, n, cin)
+    out = torch.empty((n, 1, edge, edge, edge), dtype=torch.float32, device=x_ch8.device)
+    _lib.check(_lib.load().rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8(_p(x_ch8), cin, n, edge, _p(gn_affine_t), _p(w_split_packed), cout, _p(pw_w.detach()), _p(pw_b.detach()),
+                                                                         post_add, post_mul, _p(out), _stream()), 'rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8')
+    return out
+
+
 def conv_up_split_issued_flops(c0, c1, n, edge, cout):
     """f16 multiply-adds (x2 = flop) rf_conv3d_up_split_k3_gn_relu ISSUES: three MFMAs per k-step of 32, k-steps = 7 per 8 skip
     channels (28 tap slots for 27 taps) + 2 per 8 upsampled channels, on round_up(cout, 16) columns, minus the z-border MFMAs the

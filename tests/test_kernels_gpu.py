@@ -174,6 +174,10 @@ SPLIT_BOX_CASES = [
     (1025, 56, 8, 16, 8),      # seven chunks (odd), GroupNorm groups of 7 channels
     (3, 16, 64, 16, 8),        # final decoder: 512 boxes per sample
     (1040, 24, 8, 12, 6),      # nf = 12 family: cout < 16
+    (2100, 24, 8, 12, 6),      # ... with enough boxes for the persistent z-column form (k_conv3_split_zcm): three chunks, 12 couts
+    (2049, 16, 8, 16, 8),      # ... two chunks, ragged box count over the workgroups
+    (5, 16, 64, 16, 8),        # ... 2560 boxes of five 64^3 samples: halos from the neighbouring boxes, statistics per box
+    (40, 56, 32, 16, 8),       # ... seven chunks, 2560 boxes
     (33, 32, 32, 24, 8),
     (1040, 12, 8, 12, 6),      # cin not a multiple of 8: the last chunk's missing channels are zero slots (nf = 12: C5's U-Net)
     (1030, 42, 8, 12, 6),      # 42 -> 48 slots, six chunks
@@ -1221,7 +1225,7 @@ def test_presplit_route_of_a_level0_double_conv(ops, n, pool):
             assert torch.allclose(sf, sp, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('shape', [(32, 64, 56, 16, 1030), (32, 48, 48, 16, 1025)])
+@pytest.mark.parametrize('shape', [(32, 64, 56, 16, 1030), (32, 48, 48, 16, 1025), (32, 64, 56, 16, 2100)])     # 2100 samples: the consumer on the persistent z-column form
 def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
     """StepDownDoubleConv of the retrieval backbone's last decoder (96 -> 56 -> 16 @8^3, reference model/unet.py:149-159): the first conv hands the second
     its input pre-split (rf_conv3d_up_split_presplit -> rf_conv3d_split_pre_k3_relu, the multi-chunk consumer) -- against float64 torch and against the
@@ -1254,7 +1258,8 @@ def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
     assert (got - plain).abs().max().item() <= 2e-6 * max(1.0, scale)
 
 
-def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops):
+@pytest.mark.parametrize('n', [1030, 2070])
+def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops, n):
     """DoubleConv of an encoder level on whole 8^3 samples (the retrieval backbone's 16 -> 16 -> 32 @8^3, fused pool): the split box kernel hands the second
     conv its input pre-split (rf_conv3d_split_presplit) -- bit-equal to the plain route, close to float64"""
     from model.unet import DoubleConv
@@ -1264,7 +1269,7 @@ def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops):
         for g in (blk.SingleConv1.groupnorm, blk.SingleConv2.groupnorm):
             g.weight.add_(0.2 * torch.randn_like(g.weight)); g.bias.add_(0.2 * torch.randn_like(g.bias))
     gen = torch.Generator().manual_seed(4)
-    x = rnd(gen, 1030, 16, 8, 8, 8).relu_()
+    x = rnd(gen, n, 16, 8, 8, 8).relu_()                            # 2070: the producer on the persistent z-column form (k_conv3_split_zcm, pre-split epilogue)
     with torch.no_grad():
         assert blk._box_pair_presplit_ok(x.to(DEV))
         outs = {}
@@ -1283,15 +1288,15 @@ def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops):
     assert torch.equal(outs[True][1][1], F.max_pool3d(outs[True][0], 2))
 
 
-@pytest.mark.parametrize('nf', [16, 12])
-def test_final_decoder_head_in_the_conv_epilogue(ops, nf):
+@pytest.mark.parametrize('nf,batch', [(16, 3), (12, 3), (16, 5)])
+def test_final_decoder_head_in_the_conv_epilogue(ops, nf, batch):
     """Superresolution08FinalDecoder (reference model/refinement.py:48-61): the 1x1x1 conv + tanh (+ network_pred_to_df) run in the epilogue of the up
     stage's second conv (rf_conv3d_split_k3_gn_relu_pointwise_tanh) -- the same bits as the conv followed by rf_conv1x1_tanh, and the float64 value"""
     import model as rf_model
     torch.manual_seed(nf)
     dec = rf_model.Superresolution08FinalDecoder(nf, 'gcr').to(DEV).eval()
     gen = torch.Generator().manual_seed(8)
-    x = rnd(gen, 3, nf, 32, 32, 32).relu_()
+    x = rnd(gen, batch, nf, 32, 32, 32).relu_()                     # batch 5: 2560 boxes, the persistent z-column form takes both routes
     with torch.no_grad():
         dc = dec.network[0].basic_module
         y1 = dc.SingleConv1(None, x.to(DEV))
@@ -1307,6 +1312,15 @@ def test_final_decoder_head_in_the_conv_epilogue(ops, nf):
         ref = torch.tanh(F.conv3d(x64, dec.network[1].weight.double().cpu(), dec.network[1].bias.double().cpu()))
     assert torch.equal(fused, plain) and torch.equal(fused_df, plain_df)
     close(fused, ref.float(), 1e-5, 'final decoder with the fused head')
+    # the channel-interleaved hand-over between the two convs (taken from 2048 boxes on) changes the layout of the intermediate, not a bit of the result
+    took_ch8 = ops.conv_up_split_ch8_supported(x.to(DEV), nf, nf)
+    assert took_ch8 == (batch >= 4 and nf % 8 == 0)
+    saved, ops.USE_CH8 = ops.USE_CH8, False
+    try:
+        with torch.no_grad():
+            assert torch.equal(dec(x.to(DEV)), fused) and torch.equal(dec.forward_df(x.to(DEV), 0.375), fused_df)
+    finally:
+        ops.USE_CH8 = saved
 
 
 def test_in_kernel_gumbel_sampler(ops):
