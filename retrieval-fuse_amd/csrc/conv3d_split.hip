@@ -715,7 +715,7 @@ static int split_run(const ConvArgs& a, void* stream) {
         RF_CHECK_LAUNCH("rf_conv3d_split_k3_gn_relu");
         return RF_OK;
     }
-    if (a.cout16 == 16 && rf_split_zcm_takes(cin, n, edge, a.cout))
+    if (a.cout16 <= 32 && rf_split_zcm_takes(cin, n, edge, a.cout))
         return rf_split_zcm_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, false, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu");
     if (cin % 8) {
         if (cin < 8) return launch_split<1, 6, true, true>(a, (hipStream_t)stream);                   // 6 -> 12 of the nf = 12 U-Nets: one chunk, two zero slots
@@ -801,7 +801,7 @@ extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, in
         a.stats_tiles = 1;
         return rf_split_zc_launch(a, (hipStream_t)stream);
     }
-    if (a.cout16 == 16 && rf_split_zcm_takes(cin, n, edge, cout))
+    if (a.cout16 <= 32 && rf_split_zcm_takes(cin, n, edge, cout))
         return rf_split_zcm_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, true, (hipStream_t)stream, "rf_conv3d_split_pre_k3_relu");
     if (cin > 8 && a.cout16 == 32) return launch_split<2, 2, false, false, true>(a, (hipStream_t)stream);
     return cin == 8 ? launch_split<1, 6, true, false, true>(a, (hipStream_t)stream) : launch_split<1, 4, false, false, true>(a, (hipStream_t)stream);
@@ -825,7 +825,7 @@ extern "C" int rf_conv3d_split_presplit(const float* src, int cin, int n, int ed
     a.stats = reinterpret_cast<double2*>(stats); a.stats_tiles = stats ? 1 : 0;
     a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
     const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps, nullptr, nullptr, nullptr, 0.f, 0.f};
-    if (rf_split_zcm_takes(cin, n, edge, cout)) return rf_split_zcm_launch(a, po, false, (hipStream_t)stream, "rf_conv3d_split_presplit");
+    if (cout <= 16 && rf_split_zcm_takes(cin, n, edge, cout)) return rf_split_zcm_launch(a, po, false, (hipStream_t)stream, "rf_conv3d_split_presplit");
     return launch_split<1, 4, false>(a, (hipStream_t)stream, po);
 }
 
@@ -846,14 +846,14 @@ extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh(const float* src, int c
     a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
     a.stats = nullptr; a.stats_tiles = 0; a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
     const SplitPreOut po{nullptr, nullptr, nullptr, 0, 0.f, out1, pw_w, pw_b, post_add, post_mul};
-    if (rf_split_zcm_takes(cin, n, edge, cout)) return rf_split_zcm_launch(a, po, false, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu_pointwise_tanh");
+    if (cout <= 16 && rf_split_zcm_takes(cin, n, edge, cout)) return rf_split_zcm_launch(a, po, false, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu_pointwise_tanh");
     return cin % 8 ? launch_split<1, 4, false, true>(a, (hipStream_t)stream, po) : launch_split<1, 4, false>(a, (hipStream_t)stream, po);
 }
 
 // ... on the CHANNEL-INTERLEAVED output of rf_conv3d_up_split_k3_gn_relu_ch8 ([n][cin / 8][edge^3][8] fp32): same values bit for bit, the staging loads are
 // two 16-byte loads per voxel instead of eight 4-byte gathers.  The persistent z-column form only.
 extern "C" int rf_conv3d_split_pointwise_ch8_supported(int cin, int n, int edge, int cout) {
-    return rf_conv3d_split_pointwise_supported(cin, n, edge, cout) && cin % 8 == 0 && rf_split_zcm_takes(cin, n, edge, cout);
+    return rf_conv3d_split_pointwise_supported(cin, n, edge, cout) && cin % 8 == 0 && cout <= 16 && rf_split_zcm_takes(cin, n, edge, cout);
 }
 
 extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8(const float* src_ch8, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,

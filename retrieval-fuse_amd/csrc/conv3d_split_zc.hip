@@ -348,20 +348,21 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
         for (int r = 0; r < 2; ++r) {
             const int z = z0 - 1 + (hpos[r] >> 16), y = y0 - 1 + ((hpos[r] >> 8) & 255), x = x0 - 1 + (hpos[r] & 255);
             st.in[r] = (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge && (r == 0 || tid < CS_VOX - 512);
+            // uniform 64-bit base per (sample, chunk) + 32-bit lane offsets: address registers the compiler does not have to carry (or spill) as pairs
             const unsigned off = st.in[r] ? (unsigned)((z * edge + y) * edge + x) : 0u;
             if constexpr (PRE) {
                 const unsigned char* p = reinterpret_cast<const unsigned char*>(a.src0) + ((size_t)n0 * nC + ca) * 2 * vol * 16;
-                st.ph[r] = *reinterpret_cast<const h8*>(p + (size_t)off * 16);
-                st.pl[r] = *reinterpret_cast<const h8*>(p + (vol + off) * 16);
+                st.ph[r] = *reinterpret_cast<const h8*>(p + off * 16u);
+                st.pl[r] = *reinterpret_cast<const h8*>(p + ((unsigned)vol + off) * 16u);
             } else if constexpr (CH8) {
-                const float4* p = reinterpret_cast<const float4*>(a.src0 + ((((size_t)n0 * nC + ca) * vol + off) << 3));
+                const float4* p = reinterpret_cast<const float4*>(a.src0 + (((size_t)n0 * nC + ca) * vol << 3)) + off * 2u;
                 const float4 u = p[0], v = p[1];
                 st.x[r][0] = u.x; st.x[r][1] = u.y; st.x[r][2] = u.z; st.x[r][3] = u.w;
                 st.x[r][4] = v.x; st.x[r][5] = v.y; st.x[r][6] = v.z; st.x[r][7] = v.w;
             } else {
-                const float* p = a.src0 + ((size_t)n0 * cin + ca * 8) * vol + off;
+                const float* p = a.src0 + ((size_t)n0 * cin + ca * 8) * vol;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) st.x[r][j] = p[(size_t)j * vol];
+                for (int j = 0; j < 8; ++j) st.x[r][j] = p[(unsigned)j * (unsigned)vol + off];
             }
         }
     };
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
     lds_barrier();
 
     const int col = lane & 15, kq = lane >> 4;
+    const int cob = blockIdx.y * 16;                                 // this workgroup's 16 couts of the layer (EPI 0: up to two blocks, grid.y)
     int item = 0;                                                    // parity of the image buffer
     for (int box = b_first; box < b_last; ++box) {
 #pragma unroll
@@ -478,14 +480,14 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                 nbox = box + 1;
                 if (nbox == b_last) { nbox = box; nca = ca; }
             }
-            const h8 w1 = wsrc[(size_t)ca * wstride + wsrc1];        // R1 of this chunk: lands under pass 0
+            const h8 w1 = (wsrc + (size_t)ca * wstride)[(unsigned)wsrc1];     // R1 of this chunk: lands under pass 0
             __builtin_amdgcn_sched_barrier(0);
             stage_load(st, nbox, nca);
             __builtin_amdgcn_sched_barrier(0);
             half_pass(img, std::integral_constant<int, 0>{});
             *reinterpret_cast<h8*>(lds + ZM_R1 + tid * 16) = w1;
             lds_barrier();                                            // MID: R1 in place, R0 free
-            const h8 w0 = wsrc[(size_t)nca * wstride + wsrc0];       // R0 of the next chunk: lands under pass 1
+            const h8 w0 = (wsrc + (size_t)nca * wstride)[(unsigned)wsrc0];    // R0 of the next chunk: lands under pass 1
             __builtin_amdgcn_sched_barrier(0);
             half_pass(img, std::integral_constant<int, 1>{});
             kstep6(img);
@@ -500,13 +502,18 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                     for (int r = 0; r < 4; ++r) hi[m][r] = fmaxf(fmaf(lo[m][r], 1.0f / CS_LO, hi[m][r]), a.floor);      // the box's output values
             }
             if (EPI == 0 && last) {
-                // outputs straight from the accumulators: D tile col = lane & 15 = cout, rows 4 (lane >> 4) + r = voxel x = i & 7, y = 2 yq + (i >> 3)
+                // outputs straight from the accumulators: D tile col = lane & 15 = cout, rows 4 (lane >> 4) + r = voxel x = i & 7, y = 2 yq + (i >> 3).
+                // The store addresses depend on the box only, and hipcc hoists them out of the chunk loop as 64-bit pairs (six pairs held -- and spilled --
+                // across every k-step of the box): an opaque copy of the lane's coordinates keeps them here
+                int co_g = cob + col, kq = lane >> 4;
+                asm volatile("" : "+v"(co_g), "+v"(kq));
                 if (a.pool_mode != 2) {
-                    if (col < a.cout) {
-                        float* o = a.out + ((size_t)n0 * a.cout + col) * vol + (size_t)(y0 + 2 * yq + (kq >> 1)) * edge + x0 + 4 * (kq & 1);
+                    if (co_g < a.cout) {
+                        float* o = a.out + (size_t)n0 * a.cout * vol;                 // uniform; a sample is < 2^32 bytes (<= 32 couts x 128^3)
+                        const unsigned o0 = (unsigned)co_g * (unsigned)vol + (unsigned)((z0 + 4 * zh) * edge + y0 + 2 * yq + (kq >> 1)) * (unsigned)edge + (unsigned)(x0 + 4 * (kq & 1));
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
-                            *reinterpret_cast<float4*>(o + (size_t)(z0 + 4 * zh + m) * edge * edge) = make_float4(hi[m][0], hi[m][1], hi[m][2], hi[m][3]);
+                            *reinterpret_cast<float4*>(o + (o0 + (unsigned)(m * edge * edge))) = make_float4(hi[m][0], hi[m][1], hi[m][2], hi[m][3]);
                     }
                     if (a.stats) {
 #pragma unroll
@@ -529,9 +536,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                         if (kq < 2) {
                             psm += (double)p0 + (double)p1;
                             psq += (double)p0 * (double)p0 + (double)p1 * (double)p1;
-                            if (col < a.cout)
-                                *reinterpret_cast<float2*>(a.pool_out + ((size_t)n0 * a.cout + col) * ((size_t)hedge * hedge * hedge) +
-                                                           ((size_t)((z0 >> 1) + 2 * zh + zp) * hedge + (y0 >> 1) + yq) * hedge + (x0 >> 1) + 2 * kq) = make_float2(p0, p1);
+                            if (co_g < a.cout)
+                                *reinterpret_cast<float2*>(a.pool_out + (size_t)n0 * a.cout * ((size_t)hedge * hedge * hedge) +
+                                                           ((unsigned)co_g * (unsigned)(hedge * hedge * hedge) +
+                                                            (unsigned)(((z0 >> 1) + 2 * zh + zp) * hedge + (y0 >> 1) + yq) * (unsigned)hedge + (unsigned)((x0 >> 1) + 2 * kq))) = make_float2(p0, p1);
                         }
                     }
                 }
@@ -557,11 +565,11 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                     if (tid < 32) {
                         const int which = tid >> 4, co = tid & 15;
                         double2* dst = which ? a.pool_stats : a.stats;
-                        if (dst && co < a.cout) {
+                        if (dst && cob + co < a.cout) {
                             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                             for (int w = 0; w < 8; ++w) { const double2 v = red[which * 128 + w * 16 + co]; s1 += v.x; s2 += v.y; }
-                            dst[((size_t)n0 * a.cout + co) * a.stats_tiles + (box & ((1 << (3 * tsh)) - 1))] = make_double2(s1, s2);
+                            dst[((size_t)n0 * a.cout + cob + co) * a.stats_tiles + (box & ((1 << (3 * tsh)) - 1))] = make_double2(s1, s2);
                         }
                     }
                 }
@@ -578,10 +586,12 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                 lds_barrier();
                 if constexpr (EPI == 1) {
                     // pointwise head: per voxel the channel sum in the order of rf_conv1x1_tanh (bias first, channels ascending: the same bits)
+                    int tv = tid;
+                    asm volatile("" : "+v"(tv));                      // (keeps the output address out of the chunk loop's preheader, see EPI 0)
                     float accp = po.pw_b[0];
-                    for (int c = 0; c < a.cout; ++c) accp = fmaf(e[c * ZM_TILE_STRIDE + tid], po.pw_w[c], accp);
-                    const int z = tid >> 6, y = (tid >> 3) & 7, x = tid & 7;
-                    po.pw_out[(size_t)n0 * vol + ((size_t)(z0 + z) * edge + (y0 + y)) * edge + x0 + x] = (tanhf(accp) + po.post_add) * po.post_mul;
+                    for (int c = 0; c < a.cout; ++c) accp = fmaf(e[c * ZM_TILE_STRIDE + tv], po.pw_w[c], accp);
+                    const int z = tv >> 6, y = (tv >> 3) & 7, x = tv & 7;
+                    (po.pw_out + (size_t)n0 * vol)[(unsigned)(((z0 + z) * edge + (y0 + y)) * edge + x0 + x)] = (tanhf(accp) + po.post_add) * po.post_mul;
                 } else {
                     // pre-split output (whole 8^3 samples): statistics of the sample -> the next layer's GroupNorm triples -> normalise, split, slots
                     // (the arithmetic of k_conv3_split's pre-split epilogue, conv3d_split.hip)
@@ -613,13 +623,15 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                         trip[tid] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tid], po.beta[tid]);
                     }
                     lds_barrier();
-                    h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * 512 + tid;
+                    int tv = tid;
+                    asm volatile("" : "+v"(tv));
+                    h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * 512 + (unsigned)tv;
                     for (int sg = 0; sg < (a.cout >> 3); ++sg) {
                         float y[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float4 t4 = trip[sg * 8 + j];
-                            y[j] = fmaf(e[(sg * 8 + j) * ZM_TILE_STRIDE + tid] - t4.x, t4.y, t4.z);
+                            y[j] = fmaf(e[(sg * 8 + j) * ZM_TILE_STRIDE + tv] - t4.x, t4.y, t4.z);
                         }
                         h8 h, l;
                         cs_split8(y, h, l);
@@ -650,10 +662,12 @@ int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream) {
     return RF_OK;
 }
 
-// multi-chunk persistent form: 16 couts, cin in whole chunks (>= 2), edge a power of two >= 8, enough boxes to give every workgroup a few
+// multi-chunk persistent form: up to 32 couts (16 per workgroup: the full-output form runs a 17..32-cout layer as two cout blocks on grid.y, each staging
+// the boxes for itself -- with the operand reuse of the z-columns that is no more LDS traffic than one two-n-block workgroup of the box kernel and it keeps
+// four waves per SIMD; the other epilogues take <= 16 couts), cin in whole chunks (>= 2), edge a power of two >= 8, enough boxes
 bool rf_split_zcm_takes(int cin, int n, int edge, int cout) {
     const long long boxes = (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
-    return cin >= 16 && cin % 8 == 0 && cout > 0 && cout <= 16 && edge >= 8 && edge <= 128 && (edge & (edge - 1)) == 0 && boxes >= 2048;
+    return cin >= 16 && cin % 8 == 0 && cout > 0 && cout <= 32 && edge >= 8 && edge <= 128 && (edge & (edge - 1)) == 0 && boxes >= 2048;
 }
 
 template <bool PRE, int EPI, bool CH8 = false>
@@ -663,8 +677,9 @@ static int zcm_launch(const ConvArgs& a, const SplitPreOut& po, hipStream_t stre
     if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), ZM_LDS_BYTES, who)) return rc;
     const long long boxes = (long long)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
     const int wgs = 512;                                              // two workgroups per CU
-    const int per = (int)((boxes + wgs - 1) / wgs);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((boxes + per - 1) / per)), dim3(512), ZM_LDS_BYTES, stream, a, po, per, (int)boxes);
+    const unsigned cob_blocks = (unsigned)(a.cout16 / 16);
+    const int per = (int)((boxes * cob_blocks + wgs - 1) / wgs);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((boxes + per - 1) / per), cob_blocks), dim3(512), ZM_LDS_BYTES, stream, a, po, per, (int)boxes);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rf_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return RF_E_LAUNCH; }
     return RF_OK;

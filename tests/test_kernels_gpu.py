@@ -178,6 +178,8 @@ SPLIT_BOX_CASES = [
     (2049, 16, 8, 16, 8),      # ... two chunks, ragged box count over the workgroups
     (5, 16, 64, 16, 8),        # ... 2560 boxes of five 64^3 samples: halos from the neighbouring boxes, statistics per box
     (40, 56, 32, 16, 8),       # ... seven chunks, 2560 boxes
+    (2100, 16, 8, 32, 8),      # ... 32 couts: two cout blocks of the persistent form
+    (6, 32, 64, 24, 8),        # ... 24 couts (the second block half empty), four chunks, halos
     (33, 32, 32, 24, 8),
     (1040, 12, 8, 12, 6),      # cin not a multiple of 8: the last chunk's missing channels are zero slots (nf = 12: C5's U-Net)
     (1030, 42, 8, 12, 6),      # 42 -> 48 slots, six chunks

@@ -8,11 +8,12 @@ REPO = Path(__file__).resolve().parents[1]
 CSRC = REPO / 'retrieval-fuse_amd' / 'csrc'
 OUT = REPO / 'tools' / '_haz'
 ENTRY = '''
-extern "C" int zcm_run(const void* src, int pre, const float* aff, const void* wp, float* out, float* pw_out, const float* pw_w, const float* pw_b, int cin, int n, int edge, void* stream) {
+extern "C" int zcm_run(const void* src, int pre, const float* aff, const void* wp, float* out, float* pw_out, const float* pw_w, const float* pw_b, int cin, int n, int edge, void* stream,
+                       int cout, float* pool_out, double* stats, double* pool_stats) {
     ConvArgs a;
     a.src0 = reinterpret_cast<const float*>(src); a.src1 = nullptr; a.affine = reinterpret_cast<const float4*>(aff); a.wp = reinterpret_cast<const float*>(wp); a.out = out;
-    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = 16; a.cin4 = cin; a.cout16 = 16; a.stats = nullptr; a.stats_tiles = 0;
-    a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = (cout + 15) / 16 * 16; a.stats = reinterpret_cast<double2*>(stats); a.stats_tiles = 1;
+    a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats); a.pool_mode = pool_out ? 1 : 0; a.floor = 0.f;
     const SplitPreOut po{nullptr, nullptr, nullptr, 0, 0.f, pw_out, pw_w, pw_b, 1.0f, 0.5f};
     return rf_split_zcm_launch(a, po, pre != 0, (hipStream_t)stream, "zcm_run");
 }
@@ -36,12 +37,12 @@ SST = "            stage_store(st, nbox, nca, other);\n            if (tid < 384
 NO_SST = "            if (box < 0) stage_store(st, nbox, nca, other);\n            if (tid < 384)"
 EPI_ALL = "            if (!last) continue;"
 NO_EPI_ALL = "            if (!last || box >= 0) continue;"
-EPI_OUT = "                if (a.pool_mode != 2) {\n                    if (col < a.cout) {"
-NO_EPI_OUT = "                if (a.pool_mode != 2) {\n                    if (col < a.cout && hi[0][0] == 123.456f) {"
-DECL = "    const int col = lane & 15, kq = lane >> 4;\n    int item = 0;                                                    // parity of the image buffer"
-DECL_STAMP = "    const int col = lane & 15, kq = lane >> 4;\n    const long long dbg_t0 = __builtin_readcyclecounter();\n    int item = 0;"
+EPI_OUT = "                if (a.pool_mode != 2) {\n                    if (co_g < a.cout) {"
+NO_EPI_OUT = "                if (a.pool_mode != 2) {\n                    if (co_g < a.cout && hi[0][0] == 123.456f) {"
+DECL = "    int item = 0;                                                    // parity of the image buffer"
+DECL_STAMP = "    const long long dbg_t0 = __builtin_readcyclecounter();\n    int item = 0;"
 END = "                        o[(size_t)sg * 2 * 512 + 512] = l;\n                    }\n                }\n            }\n        }\n    }\n}"
-END_STAMP = "                        o[(size_t)sg * 2 * 512 + 512] = l;\n                    }\n                }\n            }\n        }\n    }\n    if (lane == 0 && dbg_out) dbg_out[blockIdx.x * 8 + wave] = (float)(__builtin_readcyclecounter() - dbg_t0);\n}"
+END_STAMP = "                        o[(size_t)sg * 2 * 512 + 512] = l;\n                    }\n                }\n            }\n        }\n    }\n    if (lane == 0 && dbg_out) { dbg_out[blockIdx.x * 8 + wave] = (float)(__builtin_readcyclecounter() - dbg_t0); if (wave == 0) { reinterpret_cast<long long*>(dbg_out + 4096)[(blockIdx.y * 512 + blockIdx.x) * 2] = dbg_t0; reinterpret_cast<long long*>(dbg_out + 4096)[(blockIdx.y * 512 + blockIdx.x) * 2 + 1] = __builtin_readcyclecounter(); } }\n}"
 VARIANTS = {'base': [], 'no_mfma': [(MF, NO_MF)], 'no_mid_barrier': [(MID, '')], 'no_loads': [(LOADS_PRE, NO_LOADS_PRE), (LOADS_F32, NO_LOADS_F32)],
             'no_conversion': [(CONV, NO_CONV)], 'no_weight_loads': [(W1, NO_W1), (W0, NO_W0)], 'no_staging': [(LOADS_PRE, NO_LOADS_PRE), (LOADS_F32, NO_LOADS_F32), (SST, NO_SST)],
             'no_epilogue': [(EPI_ALL, NO_EPI_ALL), (EPI_OUT, NO_EPI_OUT)],
@@ -78,17 +79,21 @@ def run():
     dev = torch.device('cuda:0')
     VP = ctypes.c_void_p
     names = [a for a in sys.argv[1:]] or list(VARIANTS)
-    for label, pre, cin, n, edge in (('56->16 @8^3 x 8192, pre-split in, full out', 1, 56, 8192, 8), ('16->16 @64^3 x 32, fp32 in, pointwise head', 0, 16, 32, 64)):
+    for label, pre, cin, n, edge, cout in (('56->16 @8^3 x 8192, pre-split in, full out', 1, 56, 8192, 8, 16), ('16->16 @64^3 x 32, fp32 in, pointwise head', 0, 16, 32, 64, 16),
+                                            ('16->32 @8^3 x 8192, pre-split in, full + pooled out, statistics', 1, 16, 8192, 8, 32)):
         if pre:
             src = torch.randint(0, 255, (n * (cin // 8) * 2 * edge ** 3 * 16,), dtype=torch.uint8, device=dev)
             src.view(torch.float16).clamp_(-4, 4); src.view(torch.float16).nan_to_num_(0.0)
         else:
             src = torch.randn(n, cin, edge, edge, edge, device=dev).relu_()
         aff = torch.zeros(n, cin, 4, device=dev); aff[..., 1] = 1.0
-        w = ops.pack_conv3_split_weight(torch.randn(16, cin, 3, 3, 3, device=dev) * 0.05)
-        out = torch.empty(n, 16, edge, edge, edge, device=dev)
+        w = ops.pack_conv3_split_weight(torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05)
+        out = torch.empty(n, cout, edge, edge, edge, device=dev)
+        pooled = torch.empty(n, cout, edge // 2, edge // 2, edge // 2, device=dev) if cout == 32 else None
+        st1 = torch.empty(n, cout, 1, 2, dtype=torch.float64, device=dev) if cout == 32 else None
+        st2 = torch.empty(n, cout, 1, 2, dtype=torch.float64, device=dev) if cout == 32 else None
         pw_out = torch.empty(n, 1, edge, edge, edge, device=dev); pw_w = torch.randn(16, device=dev); pw_b = torch.zeros(1, device=dev)
-        dbg = torch.zeros(512 * 8, device=dev)
+        dbg = torch.zeros(4096 + 4 * 2048, device=dev)
         print(label)
         for name in names:
             so = OUT / ('libzcm_%s.so' % name)
@@ -97,9 +102,10 @@ def run():
             lib = ctypes.CDLL(str(so))
             lib.zcm_dbg.argtypes = [VP]; lib.zcm_dbg(dbg.data_ptr())
             f = lib.zcm_run
-            f.argtypes = [VP, ctypes.c_int, VP, VP, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP]
+            f.argtypes = [VP, ctypes.c_int, VP, VP, VP, VP, VP, VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, VP, ctypes.c_int, VP, VP, VP]
             st = torch.cuda.current_stream().cuda_stream
-            call = lambda: f(src.data_ptr(), pre, aff.data_ptr(), w.data_ptr(), out.data_ptr(), None if pre else pw_out.data_ptr(), pw_w.data_ptr(), pw_b.data_ptr(), cin, n, edge, st)
+            call = lambda: f(src.data_ptr(), pre, aff.data_ptr(), w.data_ptr(), out.data_ptr(), None if (pre or cout == 32) else pw_out.data_ptr(), pw_w.data_ptr(), pw_b.data_ptr(), cin, n, edge, st,
+                             cout, pooled.data_ptr() if pooled is not None else None, st1.data_ptr() if st1 is not None else None, st2.data_ptr() if st2 is not None else None)
             for _ in range(5): assert call() == 0, name
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -107,7 +113,12 @@ def run():
             for _ in range(20): call()
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 50
-            print('   %-22s %8.1f us   %8.0f k cycles per wave  (%.2f GHz)' % (name, us, dbg.mean().item() / 1e3, dbg.mean().item() / us / 1e3), flush=True)
+            cyc = dbg[:4096][dbg[:4096] > 0].mean().item()
+            ts = dbg[4096:].view(torch.int64).view(-1, 2).cpu()
+            ts = ts[ts[:, 0] > 0]
+            span = (ts[:, 1].max() - ts[:, 0].min()).item()
+            late = (ts[:, 0] > ts[:, 0].min() + 0.25 * span).sum().item()
+            print('   %-22s %8.1f us   %8.0f k cycles per wave, kernel span %8.0f k cycles (%.2f GHz); %d of %d workgroups started after the first quarter' % (name, us, cyc / 1e3, span / 1e3, span / us / 1e3, late, len(ts)), flush=True)
 
 
 if __name__ == '__main__':
