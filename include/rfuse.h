@@ -466,6 +466,21 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
  * its all-trunc sentinel patch (util/retrieval.py:21-26,45). */
 int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t m, int width, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------- pre-split hand-over across the level-0 max-pool */
+
+/* The retrieval backbone's level 0 -> level 1 (reference model/unet.py:230-253: DoubleConv, MaxPool3d(2), DoubleConv) without an fp32 consumer in between:
+ * rf_conv3d_split_pre_k3_relu_pool_presplit = rf_conv3d_split_pre_k3_relu (pooled output only) whose persistent workgroups also write the pooled tensor
+ * pre-split for the NEXT level's first conv (that layer's GroupNorm applied from the sample's own statistics: next_gamma / next_beta [cout], next_groups, eps);
+ * rf_conv3d_split_pre_presplit = that first conv, pre-split in and pre-split out (whole 8^3 samples).  No rf_gn_from_stats launch, no conversion in either
+ * consumer.  pool_out fp32 is still written (the kernel reads it back through L2 once the sample's statistics are known). */
+int rf_conv3d_split_pre_pool_presplit_supported(int cin, int n, int edge, int cout, int next_groups);
+int rf_conv3d_split_pre_k3_relu_pool_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, float* pool_out,
+                                              double* pool_stats, const float* next_gamma, const float* next_beta, int next_groups, float eps,
+                                              void* out_presplit, void* stream);
+int rf_conv3d_split_pre_presplit_supported(int cin, int n, int edge, int cout, int next_groups);
+int rf_conv3d_split_pre_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, const float* next_gamma,
+                                 const float* next_beta, int next_groups, float eps, void* out_presplit, double* stats, void* stream);
+
 /* ------------------------------------------------------------------------------- channel-interleaved hand-over (the final decoder's 64^3 pair) */
 
 /* "ch8": an fp32 activation tensor stored [n][c / 8][edge^3][8 channels] instead of NCDHW.  The final decoder's conv pair (reference model/refinement.py:48-61:

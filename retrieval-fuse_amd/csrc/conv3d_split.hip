@@ -22,7 +22,7 @@
 // conv3d_split_zc.hip: the persistent z-column forms.  zc: the one-chunk pre-split layer on 16^3 samples (8 -> 16: level 0 of the retrieval backbone);
 // zcm: layers of two or more whole chunks with up to 16 couts, any output form of this file (full / pooled / pointwise head / pre-split)
 bool rf_split_zc_takes(int cin, int n, int edge, int cout);
-int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream);
+int rf_split_zc_launch(const ConvArgs& a, const SplitPreOut& po, hipStream_t stream);
 bool rf_split_zcm_takes(int cin, int n, int edge, int cout);
 int rf_split_zcm_launch(const ConvArgs& a, const SplitPreOut& po, bool pre, hipStream_t stream, const char* who);
 int rf_split_zcm_launch_ch8_pointwise(const ConvArgs& a, const SplitPreOut& po, hipStream_t stream, const char* who);
@@ -799,7 +799,7 @@ extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, in
     a.floor = 0.f;
     if (rf_split_zc_takes(cin, n, edge, cout)) {
         a.stats_tiles = 1;
-        return rf_split_zc_launch(a, (hipStream_t)stream);
+        return rf_split_zc_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, (hipStream_t)stream);
     }
     if (a.cout16 <= 32 && rf_split_zcm_takes(cin, n, edge, cout))
         return rf_split_zcm_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, true, (hipStream_t)stream, "rf_conv3d_split_pre_k3_relu");
@@ -867,4 +867,48 @@ extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8(const float* src_ch
     a.stats = nullptr; a.stats_tiles = 0; a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
     const SplitPreOut po{nullptr, nullptr, nullptr, 0, 0.f, out1, pw_w, pw_b, post_add, post_mul};
     return rf_split_zcm_launch_ch8_pointwise(a, po, (hipStream_t)stream, "rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8");
+}
+
+// rf_conv3d_split_pre_k3_relu of a level-0 second conv (pooled output only) that ALSO hands the pooled tensor to the next level's first conv pre-split: the
+// persistent form walks whole 16^3 samples, so at a sample's end it has the statistics of the pooled [cout][8^3] tensor, applies that layer's GroupNorm
+// (next_gamma / next_beta [cout], next_groups, eps), splits and writes rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_presplit /
+// rf_conv3d_split_pre_k3_relu.  pool_out (fp32, required: the values are read back through L2) and pool_stats (optional) as rf_conv3d_split_pre_k3_relu.
+extern "C" int rf_conv3d_split_pre_pool_presplit_supported(int cin, int n, int edge, int cout, int next_groups) {
+    return rf_split_zc_takes(cin, n, edge, cout) && cout % 8 == 0 && next_groups > 0 && cout % next_groups == 0;
+}
+
+extern "C" int rf_conv3d_split_pre_k3_relu_pool_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, float* pool_out,
+                                                         double* pool_stats, const float* next_gamma, const float* next_beta, int next_groups, float eps,
+                                                         void* out_presplit, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_pre_k3_relu_pool_presplit: takes 8 -> 8 or 16 channels on 16^3 samples (n >= 512) with the couts in whole groups (got cin=%d n=%d edge=%d cout=%d groups=%d)",
+               cin, n, edge, cout, next_groups);
+    RF_REQUIRE(src_presplit && w_packed && pool_out && next_gamma && next_beta && out_presplit, RF_E_INVALID, "rf_conv3d_split_pre_k3_relu_pool_presplit: null pointer");
+    ConvArgs a;
+    a.src0 = reinterpret_cast<const float*>(src_presplit); a.src1 = nullptr; a.affine = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.out = nullptr;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = rf_round_up(cout, 16);
+    a.stats = nullptr; a.stats_tiles = 1; a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats); a.pool_mode = 2; a.floor = 0.f;
+    const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps, nullptr, nullptr, nullptr, 0.f, 0.f};
+    return rf_split_zc_launch(a, po, (hipStream_t)stream);
+}
+
+// rf_conv3d_split_presplit on a PRE-SPLIT input: whole 8^3 samples in, whole 8^3 samples out, both as f16 pairs normalised for their consumer's GroupNorm
+// (the first conv of the retrieval backbone's level 1 between rf_conv3d_split_pre_k3_relu_pool_presplit and rf_conv3d_split_pre_k3_relu).  The persistent
+// z-column form only.  stats (optional): [n][cout] (sum, sum of squares) of the ReLU'd output.
+extern "C" int rf_conv3d_split_pre_presplit_supported(int cin, int n, int edge, int cout, int next_groups) {
+    return edge == 8 && cin >= 16 && cin % 8 == 0 && (cout == 8 || cout == 16) && next_groups > 0 && cout % next_groups == 0 && rf_split_zcm_takes(cin, n, edge, cout);
+}
+
+extern "C" int rf_conv3d_split_pre_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, const float* next_gamma,
+                                            const float* next_beta, int next_groups, float eps, void* out_presplit, double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_pre_presplit_supported(cin, n, edge, cout, next_groups), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_pre_presplit: takes whole 8^3 samples (n >= 2048), cin >= 16 in eights, 8 or 16 couts in whole groups (got cin=%d n=%d edge=%d cout=%d groups=%d)", cin, n, edge, cout, next_groups);
+    RF_REQUIRE(src_presplit && w_packed && next_gamma && next_beta && out_presplit, RF_E_INVALID, "rf_conv3d_split_pre_presplit: null pointer");
+    ConvArgs a;
+    a.src0 = reinterpret_cast<const float*>(src_presplit); a.src1 = nullptr; a.affine = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.out = nullptr;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = 16;
+    a.stats = reinterpret_cast<double2*>(stats); a.stats_tiles = stats ? 1 : 0;
+    a.pool_out = nullptr; a.pool_stats = nullptr; a.pool_mode = 0; a.floor = 0.f;
+    const SplitPreOut po{reinterpret_cast<h8*>(out_presplit), next_gamma, next_beta, next_groups, eps, nullptr, nullptr, nullptr, 0.f, 0.f};
+    return rf_split_zcm_launch(a, po, true, (hipStream_t)stream, "rf_conv3d_split_pre_presplit");
 }

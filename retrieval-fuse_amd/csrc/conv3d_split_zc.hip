@@ -22,7 +22,8 @@
 
 namespace {
 constexpr int ZC_W_BYTES = 7 * 2 * 64 * 16;                       // 14,336: [k-step][h | l][lane][8 halves]
-constexpr int ZC_LDS_BYTES = ZC_W_BYTES + 2 * CS_BUF;             // 80,896: two workgroups per CU
+constexpr int ZC_SCRATCH = ZC_W_BYTES + 2 * CS_BUF;               // 512 bytes behind the images: per-cout sums and GroupNorm triples of the pre-split hand-over
+constexpr int ZC_LDS_BYTES = ZC_SCRATCH + 512;                    // 81,408: two workgroups per CU
 constexpr int ZC_TILE_STRIDE = 132;                               // floats per cout row of the pooled tile (128 + 4: conflict-free float2 writes)
 constexpr int ZC_TILE_BYTES = 16 * ZC_TILE_STRIDE * 4;            // 8,448
 constexpr int ZC_RED_BYTES = 8 * 16 * 16;                         // [wave][cout] double2
@@ -38,7 +39,7 @@ struct ZcStage { h8 ph[2], pl[2]; bool in[2]; };
 }   // namespace
 
 template <bool FULL>                                                // FULL: the full-resolution output (and its statistics) too; false: pooled only
-__global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, int samples_per_wg) {
+__global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, SplitPreOut po, int samples_per_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,6 +275,43 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, int sampl
 #pragma unroll
                 for (int w = 0; w < 8; ++w) { const double2 v = red[which * 128 + w * 16 + co]; sm += v.x; sq += v.y; }
                 dst[(size_t)(boxA >> 3) * a.cout + co] = make_double2(sm, sq);
+                if (!which && po.out) reinterpret_cast<double2*>(lds + ZC_SCRATCH)[co] = make_double2(sm, sq);
+            }
+        }
+        if (sample_end && po.out) {
+            // the POOLED sample handed to the next level's first conv pre-split: the workgroup has walked the whole sample, so it has the
+            // statistics that layer's GroupNorm needs; the pooled values (32 KB, just written, L2-resident) are read back, normalised, split and stored as
+            // [2 channel groups][h | l][8^3][8 halves] -- the consumer stages copies and rf_gn_from_stats is not launched
+            double2* chst = reinterpret_cast<double2*>(lds + ZC_SCRATCH);
+            float4* trip = reinterpret_cast<float4*>(lds + ZC_SCRATCH + 256);
+            // this workgroup's pooled stores have reached L2 (stores retire through vmcnt); the read-back below goes to L2 past the L1 (device-scope relaxed
+            // atomic loads).  NOT a device-scope release / acquire fence pair: that writes back and invalidates whole caches -- measured 0.57 -> 3.4 ms per launch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (tid < a.cout) {                                        // as rf_gn_from_stats: group sums in channel order, float64
+                const int cpg = a.cout / po.groups, c0 = (tid / cpg) * cpg;
+                double sm = 0.0, sq = 0.0;
+                for (int c = c0; c < c0 + cpg; ++c) { sm += chst[c].x; sq += chst[c].y; }
+                const double count = (double)cpg * PVOL, mean = sm / count;
+                double var = sq / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                trip[tid] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tid], po.beta[tid]);
+            }
+            lds_barrier();
+            const int n0 = boxA >> 3;
+            const float* pv = a.pool_out + (size_t)n0 * a.cout * PVOL + tid;
+            h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * PVOL + tid;
+            for (int sg = 0; sg < (a.cout >> 3); ++sg) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 t4 = trip[sg * 8 + j];
+                    y[j] = fmaf(__hip_atomic_load(pv + (sg * 8 + j) * PVOL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t4.x, t4.y, t4.z);
+                }
+                h8 h, l;
+                cs_split8(y, h, l);
+                o[(size_t)sg * 2 * PVOL] = h;
+                o[(size_t)sg * 2 * PVOL + PVOL] = l;
             }
         }
         stage_store(st, bufB);                                      // the next pair's box A into the buffer box B has left
@@ -650,14 +688,14 @@ bool rf_split_zc_takes(int cin, int n, int edge, int cout) {
     return cin == 8 && edge == 16 && cout > 0 && cout <= 16 && n >= 512;
 }
 
-int rf_split_zc_launch(const ConvArgs& a, hipStream_t stream) {
+int rf_split_zc_launch(const ConvArgs& a, const SplitPreOut& po, hipStream_t stream) {
     const bool full = a.pool_mode != 2;
     auto kern = full ? k_conv3_split_zc<true> : k_conv3_split_zc<false>;
     static RfLdsOptIn opt[2];
     if (int rc = opt[full].ensure(reinterpret_cast<const void*>(kern), ZC_LDS_BYTES, "rf_conv3d_split_pre_k3_relu")) return rc;
     const int wgs = a.n < 512 ? a.n : 512;                            // two workgroups per CU, whole samples each
     const int per = (a.n + wgs - 1) / wgs;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((a.n + per - 1) / per)), dim3(512), ZC_LDS_BYTES, stream, a, per);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.n + per - 1) / per)), dim3(512), ZC_LDS_BYTES, stream, a, po, per);
     RF_CHECK_LAUNCH("rf_conv3d_split_pre_k3_relu");
     return RF_OK;
 }

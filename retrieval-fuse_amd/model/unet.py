@@ -219,14 +219,27 @@ class DoubleConv(nn.Module):
         self.SingleConv1 = SingleConv(c1_in, c1_out, kernel_size, order, num_groups)
         self.SingleConv2 = SingleConv(c2_in, c2_out, kernel_size, order, num_groups)
 
-    def forward(self, x, upsampled=None, pool=None):
+    def forward(self, x, upsampled=None, pool=None, next_block=None):
+        """``next_block``: the DoubleConv that will read MaxPool3d(2) of this block's output (the next encoder level), when the caller knows it -- with
+        pool='only' the pooled tensor can then be handed over pre-split (returned as an ops.PreSplit in place of the pooled tensor)."""
         c1, c2 = self.SingleConv1, self.SingleConv2
+        if isinstance(x, ops.PreSplit):
+            # the previous level handed its pooled output over pre-split for THIS block's first GroupNorm: both convs stage copies
+            g2 = c2.groupnorm
+            mid = ops.conv3d_split_pre_presplit(x, c1.conv.packed_split(), c1.conv.out_channels, g2.weight, g2.bias, _groups_of(g2), g2.eps)
+            return ops.conv3d_split_pre_relu(mid.data, mid.channels, mid.n, mid.edge, c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
         if upsampled is None and self._presplit_ok(x):
             # level 0 of a U-Net on 16^3 samples: the first conv hands the second its input already normalised (second GroupNorm) and split
             # into f16 pairs (ops.conv3d_cin1_presplit) -- the second conv stages it with copies (DESIGN 4.8)
             g1, g2 = c1.groupnorm, c2.groupnorm
-            pre = ops.conv3d_cin1_presplit(x, g1.weight, g1.bias, g1.eps, c1.conv.packed(), c1.conv.out_channels, g2.weight, g2.bias, g2.num_groups, g2.eps)
-            return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
+            n, edge, cmid, cout = x.shape[0], x.shape[2], c1.conv.out_channels, c2.conv.out_channels
+            pre = ops.conv3d_cin1_presplit(x, g1.weight, g1.bias, g1.eps, c1.conv.packed(), cmid, g2.weight, g2.bias, g2.num_groups, g2.eps)
+            if pool == 'only' and next_block is not None and next_block.accepts_prepooled(n, cout, edge // 2):
+                ng = next_block.SingleConv1.groupnorm
+                if ops.conv_split_pre_pool_presplit_supported(cmid, n, edge, cout, _groups_of(ng)):
+                    _, handed = ops.conv3d_split_pre_relu_pool_presplit(pre, cmid, n, edge, c2.conv.packed_split(), cout, ng.weight, ng.bias, _groups_of(ng), ng.eps)
+                    return None, handed
+            return ops.conv3d_split_pre_relu(pre, cmid, n, edge, c2.conv.packed_split(), cout, pool=pool)
         if upsampled is not None and pool is None and _decoder_pair_presplit_ok(c1, c2, x, upsampled):
             return _decoder_pair_presplit(c1, c2, x, upsampled)
         if upsampled is None and x is not None and self._box_pair_presplit_ok(x):
@@ -236,6 +249,21 @@ class DoubleConv(nn.Module):
             pre = ops.conv3d_split_presplit(x, aff, c1.conv.packed_split(), c1.conv.out_channels, g2.weight, g2.bias, _groups_of(g2), g2.eps)
             return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, x.shape[0], x.shape[2], c2.conv.packed_split(), c2.conv.out_channels, pool=pool)
         return c2(c1(x, upsampled), pool=pool)
+
+    def accepts_prepooled(self, n, cin, edge):
+        """this block's conv pair can take its input as an ops.PreSplit of [n, cin, edge^3] (normalised for SingleConv1's GroupNorm) -- decided from shapes and
+        parameters only, so that the PRODUCER can ask before it writes"""
+        c1, c2 = self.SingleConv1, self.SingleConv2
+        g1, g2 = c1.groupnorm, c2.groupnorm
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return False
+        if c1.conv.in_channels != cin:
+            return False
+        cmid = c1.conv.out_channels
+        if not ops.conv_split_pre_presplit_supported(cin, n, edge, cmid, _groups_of(g2)) or not bool(ops._lib.load().rf_conv3d_split_pre_supported(cmid, n, edge, c2.conv.out_channels)):
+            return False
+        return (ops.split_range_ok(c1.conv.weight, g1.weight, g1.bias, _group_elements(g1, edge))
+                and ops.split_range_ok(c2.conv.weight, g2.weight, g2.bias, _group_elements(g2, edge)))
 
     def _box_pair_presplit_ok(self, x):
         c1, c2 = self.SingleConv1, self.SingleConv2
@@ -287,8 +315,9 @@ class Encoder(nn.Module):
         self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
                                          order=conv_layer_order, num_groups=num_groups)
 
-    def forward(self, x, prepooled=None, pool=None):
-        """``prepooled``: MaxPool3d(2)(x) when the producer already emitted it (fused epilogue); ``pool``: see SingleConv.forward."""
+    def forward(self, x, prepooled=None, pool=None, next_block=None):
+        """``prepooled``: MaxPool3d(2)(x) when the producer already emitted it (fused epilogue; an ops.PreSplit when it was handed over pre-split);
+        ``pool``: see SingleConv.forward; ``next_block``: see DoubleConv.forward."""
         if self.apply_pooling:
             if prepooled is not None:
                 x = prepooled
@@ -296,7 +325,11 @@ class Encoder(nn.Module):
                 x = torch.nn.functional.max_pool3d(x, 2)            # grad mode: torch's max-pool carries the backward
             else:
                 x = ops.maxpool2(x)
-        return self.basic_module(x, pool=pool) if pool is not None else self.basic_module(x)
+        if pool is None:
+            return self.basic_module(x)
+        if next_block is not None and isinstance(self.basic_module, DoubleConv):
+            return self.basic_module(x, pool=pool, next_block=next_block)
+        return self.basic_module(x, pool=pool)
 
 
 class Decoder(nn.Module):
@@ -369,7 +402,8 @@ class UNet3D(nn.Module):
                 x, pooled = encoder(x, prepooled=pooled), None
             else:
                 is_skip = i >= n_enc - 1 - n_dec
-                x, pooled = encoder(x, prepooled=pooled, pool='also' if is_skip else 'only')
+                nxt = self.encoders[i + 1].basic_module
+                x, pooled = encoder(x, prepooled=pooled, pool='also' if is_skip else 'only', next_block=nxt if isinstance(nxt, DoubleConv) else None)
             feats.insert(0, x)
         feats = feats[1:]                                            # model/unet.py:500-504
         for decoder, skip in zip(self.decoders, feats):              # zip truncates, model/unet.py:507

@@ -550,6 +550,54 @@ def conv3d_up_split_presplit(x, upsampled, gn_affine_t, w_packed, cout, next_gam
     return out
 
 
+USE_PREPOOL = True              # False: the level-0 max-pool hands an fp32 tensor to the next level (the round-3 route; kept for cross-checks)
+
+
+class PreSplit:
+    """A pre-split activation tensor (rf_split_act_bytes: per (sample, 8-channel group) an h plane and an l plane of 16-byte voxel slots), already normalised
+    by its consumer's GroupNorm -- what the producers of DESIGN 4.8 hand to rf_conv3d_split_pre_*; the shape travels with the bytes."""
+
+    def __init__(self, data, n, channels, edge):
+        self.data, self.n, self.channels, self.edge = data, n, channels, edge
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def conv_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups):
+    return USE_PREPOOL and USE_PRESPLIT and CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups))
+
+
+def conv3d_split_pre_relu_pool_presplit(pre, cin, n, edge, w_split_packed, cout, next_gamma, next_beta, next_groups, eps):
+    """conv3d_split_pre_relu(pool='only') whose pooled output is ALSO emitted pre-split for the next level's first conv: -> (pooled fp32 with its
+    statistics attached, PreSplit of the pooled tensor)"""
+    dev = pre.device
+    lib = _lib.load()
+    half = edge // 2
+    pooled = torch.empty((n, cout, half, half, half), dtype=torch.float32, device=dev)
+    pstats = torch.empty((n, cout, 1, 2), dtype=torch.float64, device=dev) if USE_FUSED_STATS else None
+    out = torch.empty(lib.rf_split_act_bytes(n, cout, half), dtype=torch.uint8, device=dev)
+    _lib.check(lib.rf_conv3d_split_pre_k3_relu_pool_presplit(_p(pre), cin, n, edge, _p(w_split_packed), cout, _p(pooled), _p(pstats), _p(next_gamma.detach()),
+                                                             _p(next_beta.detach()), next_groups, eps, _p(out), _stream()), 'rf_conv3d_split_pre_k3_relu_pool_presplit')
+    if pstats is not None:
+        pooled._rf_stats = (pstats, 1, pooled._version)
+    return pooled, PreSplit(out, n, cout, half)
+
+
+def conv_split_pre_presplit_supported(cin, n, edge, cout, next_groups):
+    return USE_PRESPLIT and CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_split_pre_presplit_supported(cin, n, edge, cout, next_groups))
+
+
+def conv3d_split_pre_presplit(pre, w_split_packed, cout, next_gamma, next_beta, next_groups, eps):
+    """relu(conv(.)) of a PreSplit input (whole 8^3 samples), emitted as the PreSplit input of the NEXT layer"""
+    lib = _lib.load()
+    out = torch.empty(lib.rf_split_act_bytes(pre.n, cout, pre.edge), dtype=torch.uint8, device=pre.device)
+    _lib.check(lib.rf_conv3d_split_pre_presplit(_p(pre.data), pre.channels, pre.n, pre.edge, _p(w_split_packed), cout, _p(next_gamma.detach()), _p(next_beta.detach()),
+                                                next_groups, eps, _p(out), _p(None), _stream()), 'rf_conv3d_split_pre_presplit')
+    return PreSplit(out, pre.n, cout, pre.edge)
+
+
 def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None):
     """conv3d_split_gn_relu on a pre-split input (already normalised for this layer and split by its producer)."""
     dev = pre.device

@@ -1227,6 +1227,45 @@ def test_presplit_route_of_a_level0_double_conv(ops, n, pool):
             assert torch.allclose(sf, sp, rtol=1e-5, atol=1e-5)
 
 
+def test_prepooled_handover_between_the_first_two_levels(ops):
+    """The retrieval backbone's level 0 -> MaxPool3d(2) -> level 1 (reference model/unet.py:230-253) with the pooled tensor handed over pre-split
+    (rf_conv3d_split_pre_k3_relu_pool_presplit -> rf_conv3d_split_pre_presplit -> rf_conv3d_split_pre_k3_relu): against the route with an fp32 pooled tensor
+    (rf_gn_from_stats + a consumer that normalises and splits) and against float64 torch"""
+    from model.unet import UNet3D
+    torch.manual_seed(77)
+    net = UNet3D(1, 16, f_maps=[16, 32, 64, 128], num_groups=8, num_levels=4, is_segmentation=False, remove_n_final_layers=1).to(DEV).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, 'groupnorm'):
+                m.groupnorm.weight.add_(0.2 * torch.randn_like(m.groupnorm.weight)); m.groupnorm.bias.add_(0.2 * torch.randn_like(m.groupnorm.bias))
+    gen = torch.Generator().manual_seed(6)
+    x = rnd(gen, 2100, 1, 16, 16, 16)
+    e0, e1 = net.encoders[0], net.encoders[1]
+    with torch.no_grad():
+        assert e1.basic_module.accepts_prepooled(2100, 16, 8)
+        outs = {}
+        for flag in (True, False):
+            ops.USE_PREPOOL = flag
+            _, pooled = e0(x.to(DEV), pool='only', next_block=e1.basic_module)
+            assert isinstance(pooled, ops.PreSplit) == flag
+            outs[flag] = e1(None, prepooled=pooled, pool='also')
+        ops.USE_PREPOOL = True
+        x64 = x[:64].double()
+        for blk, pool_first in ((e0.basic_module, False), (e1.basic_module, True)):
+            if pool_first:
+                x64 = F.max_pool3d(x64, 2)
+            for sc in (blk.SingleConv1, blk.SingleConv2):
+                gn = sc.groupnorm
+                g = 1 if gn.num_channels < gn.num_groups else gn.num_groups
+                x64 = F.relu(F.conv3d(F.group_norm(x64, g, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), sc.conv.weight.double().cpu(), padding=1))
+    for k in (0, 1):
+        a_, b_ = outs[True][k], outs[False][k]
+        scale = float(b_.abs().max())
+        assert (a_ - b_).abs().max().item() <= 2e-6 * max(1.0, scale), 'routes differ by %.2e of %.2f' % ((a_ - b_).abs().max().item(), scale)
+    close(outs[True][0][:64], x64.float(), 1e-5, 'level 1 output, pre-split hand-over across the max-pool')
+    close(outs[True][1][:64], F.max_pool3d(x64, 2).float(), 1e-5, 'its fused pool')
+
+
 @pytest.mark.parametrize('shape', [(32, 64, 56, 16, 1030), (32, 48, 48, 16, 1025), (32, 64, 56, 16, 2100)])     # 2100 samples: the consumer on the persistent z-column form
 def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
     """StepDownDoubleConv of the retrieval backbone's last decoder (96 -> 56 -> 16 @8^3, reference model/unet.py:149-159): the first conv hands the second
