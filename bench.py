@@ -195,7 +195,7 @@ def kernel_bytes(name, a, nulls=()):
     """algorithmic HBM bytes of one launch -- every input element read once, every output element written once -- or None.
     ``nulls``: positions of the launch's null pointer arguments (an output that is not written is not counted)"""
     if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_k3_gn_relu_direct', 'rf_conv3d_up_k3_gn_relu',
-                'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit'):
+                'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit', 'rf_conv3d_up_split_k3_gn_relu_ch8'):
         c0, c1, n, edge, cout = a[:5]
         return 4.0 * n * (c0 * edge ** 3 + c1 * (edge // 2) ** 3 + cout * edge ** 3)
     if name in ('rf_conv3d_split_k3_gn_relu', 'rf_conv3d_split_pre_k3_relu', 'rf_conv3d_split_presplit'):
@@ -203,9 +203,15 @@ def kernel_bytes(name, a, nulls=()):
         out_pos, pool_pos = {'rf_conv3d_split_k3_gn_relu': (7, 9), 'rf_conv3d_split_pre_k3_relu': (6, 8), 'rf_conv3d_split_presplit': (None, None)}[name]
         written = (0.0 if out_pos in nulls else 1.0) + (0.125 if pool_pos is not None and pool_pos not in nulls else 0.0)      # full output / fused MaxPool3d(2) output
         return 4.0 * n * edge ** 3 * (cin + cout * written)
-    if name == 'rf_conv3d_split_k3_gn_relu_pointwise_tanh':
+    if name in ('rf_conv3d_split_k3_gn_relu_pointwise_tanh', 'rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8'):
         cin, n, edge, cout = a[:4]
         return 4.0 * n * edge ** 3 * (cin + 1)
+    if name == 'rf_conv3d_split_pre_k3_relu_pool_presplit':          # pre-split in, pooled fp32 out + the pooled tensor pre-split (as many bytes) out
+        cin, n, edge, cout = a[:4]
+        return 4.0 * n * edge ** 3 * (cin + 2 * cout / 8.0)
+    if name == 'rf_conv3d_split_pre_presplit':
+        cin, n, edge, cout = a[:4]
+        return 4.0 * n * edge ** 3 * (cin + cout)
     if name == 'rf_conv3d_cin1_presplit':
         n, edge, cout = a[:3]
         return 4.0 * n * edge ** 3 * (1 + cout)
@@ -223,9 +229,11 @@ def kernel_bytes(name, a, nulls=()):
 
 def conv_shape(name, a):
     """(c0, c1, n, edge, cout) of a 3x3x3 GroupNorm-conv launch, or None"""
-    if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_up_k3_gn_relu', 'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit'):
+    if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_up_k3_gn_relu', 'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit',
+                'rf_conv3d_up_split_k3_gn_relu_ch8'):
         return tuple(a[:5])
-    if name in ('rf_conv3d_split_k3_gn_relu', 'rf_conv3d_split_pre_k3_relu', 'rf_conv3d_split_presplit', 'rf_conv3d_split_k3_gn_relu_pointwise_tanh'):
+    if name in ('rf_conv3d_split_k3_gn_relu', 'rf_conv3d_split_pre_k3_relu', 'rf_conv3d_split_presplit', 'rf_conv3d_split_k3_gn_relu_pointwise_tanh', 'rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8',
+                'rf_conv3d_split_pre_k3_relu_pool_presplit', 'rf_conv3d_split_pre_presplit'):
         cin, n, edge, cout = a[:4]
         return (cin, 0, n, edge, cout)
     return None
@@ -242,7 +250,7 @@ def kernel_work(name, a, cfg):
         c0, c1, n, edge, cout = a[:5]
         from rfuse import ops
         return 'mfma', ops.conv_up_issued_flops(c0, c1, n, edge, cout), 'flop ISSUED (decoder form, 8 pre-summed taps for the upsampled channels, minus the skipped padding taps)'
-    if name in ('rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit'):
+    if name in ('rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit', 'rf_conv3d_up_split_k3_gn_relu_ch8'):
         c0, c1, n, edge, cout = a[:5]
         from rfuse import ops
         return 'mfma-f16', ops.conv_up_split_issued_flops(c0, c1, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; decoder form; 28 tap slots per 27 taps, couts padded to 16); '
@@ -250,7 +258,7 @@ def kernel_work(name, a, cfg):
     if name == 'rf_conv3d_cin1_presplit':
         n, edge, cout = a[:3]
         return 'hbm', 4.0 * n * edge ** 3 * (1 + cout), 'bytes'
-    if name in ('rf_conv3d_split_k3_gn_relu', 'rf_conv3d_split_pre_k3_relu'):
+    if name in ('rf_conv3d_split_k3_gn_relu', 'rf_conv3d_split_pre_k3_relu', 'rf_conv3d_split_pre_k3_relu_pool_presplit', 'rf_conv3d_split_pre_presplit', 'rf_conv3d_split_presplit'):
         cin, n, edge, cout = a[:4]
         from rfuse import ops
         return 'mfma-f16', ops.conv_split_issued_flops(cin, n, edge, cout), ('f16 flop ISSUED (operand splitting: 3 MFMAs per product tile; 28 tap slots per 27 taps, couts padded to 16); '
@@ -289,7 +297,7 @@ def kernel_work(name, a, cfg):
     if name == 'rf_linear':
         rows, nin, nout = a[:3]
         return 'mfma', 2.0 * rows * nin * nout, 'flop'
-    if name == 'rf_conv3d_split_k3_gn_relu_pointwise_tanh':
+    if name in ('rf_conv3d_split_k3_gn_relu_pointwise_tanh', 'rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8'):
         cin, n, edge, cout = a[:4]
         from rfuse import ops
         return 'mfma-f16', ops.conv_split_issued_flops(cin, n, edge, cout), 'f16 flop ISSUED (operand splitting; the pointwise head + tanh ride in the epilogue); fp32-equivalent %.1f GFLOP' % (2.0 * 27 * cin * cout * edge ** 3 * n / 1e9)
@@ -333,7 +341,7 @@ def kernel_table(eng, raw_dev, cfg, steps=3, top=8):
     agg = {}
     nulls_of = {}
     for name, ints, e0, e1, nulls in records:
-        key = (name, ints[:6])
+        key = (name, ints[:8])
         t = agg.setdefault(key, [0.0, 0])
         t[0] += e0.elapsed_time(e1)
         t[1] += 1
@@ -559,7 +567,7 @@ def main():
     block_ms = [1e3 * float(v) / args.steps for v in t.tolist()]
     assert torch.isfinite(df).all()
 
-    in_step = [e0.elapsed_time(e1) for name, ints, e0, e1, _ in dom_records if dominant is not None and ints[:6] == dominant[2]]
+    in_step = [e0.elapsed_time(e1) for name, ints, e0, e1, _ in dom_records if dominant is not None and ints[:8] == dominant[2]]
     per_rank_collectives = None
     if collective_events:
         mine = (float(np.mean([e[0].elapsed_time(e[1]) for e in collective_events])), float(np.mean([e[2].elapsed_time(e[3]) for e in collective_events])))

@@ -259,16 +259,20 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, SplitPreO
             fsm = fsq = psm = psq = 0.0;
         }
         lds_barrier();                                              // 2: tile (and the sample's partial sums) complete; box B's image dead
+        // everything below is addressed from an opaque copy of the thread index: the lane-dependent parts of these addresses do not depend on the pair, and
+        // hipcc otherwise forms them ahead of the loop and keeps them in scratch across the MFMAs (21 spilled registers, reloaded here one by one)
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
         if (want_pool) {
-            const int co = tid >> 5, pz = (tid >> 3) & 3, w4 = tid & 7;
+            const int co = tv >> 5, pz = (tv >> 3) & 3, w4 = tv & 7;
             if (co < a.cout) {
                 const int n0 = boxA >> 3, z0 = ((boxA >> 2) & 1) * 4, y0 = ((boxA >> 1) & 1) * 4;
                 const float4 v = *reinterpret_cast<const float4*>(tile + co * ZC_TILE_STRIDE + pz * 32 + w4 * 4);
                 *reinterpret_cast<float4*>(a.pool_out + ((size_t)n0 * a.cout + co) * PVOL + (size_t)(z0 + pz) * 64 + y0 * 8 + w4 * 4) = v;
             }
         }
-        if (sample_end && tid < 32) {
-            const int which = tid >> 4, co = tid & 15;
+        if (sample_end && tv < 32) {
+            const int which = tv >> 4, co = tv & 15;
             double2* dst = which ? a.stats : a.pool_stats;
             if ((FULL || !which) && dst && co < a.cout) {
                 double sm = 0.0, sq = 0.0;
@@ -288,19 +292,19 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, SplitPreO
             // atomic loads).  NOT a device-scope release / acquire fence pair: that writes back and invalidates whole caches -- measured 0.57 -> 3.4 ms per launch
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
-            if (tid < a.cout) {                                        // as rf_gn_from_stats: group sums in channel order, float64
-                const int cpg = a.cout / po.groups, c0 = (tid / cpg) * cpg;
+            if (tv < a.cout) {                                        // as rf_gn_from_stats: group sums in channel order, float64
+                const int cpg = a.cout / po.groups, c0 = (tv / cpg) * cpg;
                 double sm = 0.0, sq = 0.0;
                 for (int c = c0; c < c0 + cpg; ++c) { sm += chst[c].x; sq += chst[c].y; }
                 const double count = (double)cpg * PVOL, mean = sm / count;
                 double var = sq / count - mean * mean;
                 if (var < 0.0) var = 0.0;
-                trip[tid] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tid], po.beta[tid]);
+                trip[tv] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tv], po.beta[tv]);
             }
             lds_barrier();
             const int n0 = boxA >> 3;
-            const float* pv = a.pool_out + (size_t)n0 * a.cout * PVOL + tid;
-            h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * PVOL + tid;
+            const float* pv = a.pool_out + (size_t)n0 * a.cout * PVOL + (unsigned)tv;
+            h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * PVOL + (unsigned)tv;
             for (int sg = 0; sg < (a.cout >> 3); ++sg) {
                 float y[8];
 #pragma unroll
