@@ -506,7 +506,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
     stage_store(st, b_first, 0, lds + ZM_IMG);
     lds_barrier();
 
-    const int col = lane & 15, kq = lane >> 4;
+    const int col = lane & 15;
     const int cob = blockIdx.y * 16;                                 // this workgroup's 16 couts of the layer (EPI 0: up to two blocks, grid.y)
     int item = 0;                                                    // parity of the image buffer
     for (int box = b_first; box < b_last; ++box) {
@@ -618,13 +618,16 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
             } else {
                 // ReLU'd tile [couts][8^3] in the dead image
                 float* e = reinterpret_cast<float*>(img);
+                {
+                    int lv = lane;
+                    asm volatile("" : "+v"(lv));
+                    const int colv = lv & 15, kqv = lv >> 4;
+                    float* ew = e + colv * ZM_TILE_STRIDE + (4 * zh * 8 + 2 * yq + (kqv >> 1)) * 8 + 4 * (kqv & 1);
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * kq + r;
-                        e[col * ZM_TILE_STRIDE + ((4 * zh + m) * 8 + 2 * yq + (i >> 3)) * 8 + (i & 7)] = hi[m][r];
-                    }
+                        for (int r = 0; r < 4; ++r) ew[m * 64 + r] = hi[m][r];
+                }
                 lds_barrier();
                 if constexpr (EPI == 1) {
                     // pointwise head: per voxel the channel sum in the order of rf_conv1x1_tanh (bias first, channels ascending: the same bits)
@@ -639,8 +642,10 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                     // (the arithmetic of k_conv3_split's pre-split epilogue, conv3d_split.hip)
                     double2* chst = reinterpret_cast<double2*>(lds + ZM_SCRATCH);
                     float4* trip = reinterpret_cast<float4*>(lds + ZM_SCRATCH + 256);
+                    int tv = tid;
+                    asm volatile("" : "+v"(tv));                      // (keeps the addresses below out of the chunk loop's preheader, see EPI 0)
                     {
-                        const int co = tid >> 5, part = tid & 31;       // 32 threads per cout, 16 values each, then a butterfly (fixed order)
+                        const int co = tv >> 5, part = tv & 31;       // 32 threads per cout, 16 values each, then a butterfly (fixed order)
                         double sm = 0.0, sq = 0.0;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
@@ -655,18 +660,16 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
                         }
                     }
                     lds_barrier();
-                    if (tid < a.cout) {                                // as rf_gn_from_stats: group sums in channel order, float64
-                        const int cpg = a.cout / po.groups, c0 = (tid / cpg) * cpg;
+                    if (tv < a.cout) {                                // as rf_gn_from_stats: group sums in channel order, float64
+                        const int cpg = a.cout / po.groups, c0 = (tv / cpg) * cpg;
                         double sm = 0.0, sq = 0.0;
                         for (int c = c0; c < c0 + cpg; ++c) { sm += chst[c].x; sq += chst[c].y; }
                         const double count = (double)cpg * 512.0, mean = sm / count;
                         double var = sq / count - mean * mean;
                         if (var < 0.0) var = 0.0;
-                        trip[tid] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tid], po.beta[tid]);
+                        trip[tv] = gn_affine(mean, 1.0 / sqrt(var + (double)po.eps), po.gamma[tv], po.beta[tv]);
                     }
                     lds_barrier();
-                    int tv = tid;
-                    asm volatile("" : "+v"(tv));
                     h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * 512 + (unsigned)tv;
                     for (int sg = 0; sg < (a.cout >> 3); ++sg) {
                         float y[8];
