@@ -179,6 +179,9 @@ SPLIT_BOX_CASES = [
     (5, 16, 64, 16, 8),        # ... 2560 boxes of five 64^3 samples: halos from the neighbouring boxes, statistics per box
     (40, 56, 32, 16, 8),       # ... seven chunks, 2560 boxes
     (2100, 16, 8, 32, 8),      # ... 32 couts: two cout blocks of the persistent form
+    (2050, 12, 8, 12, 6),      # ... cin not a multiple of 8 (nf = 12): the last chunk's missing channels as zero slots
+    (2060, 42, 8, 24, 6),      # ... 42 -> 48 slots, six chunks, two cout blocks
+    (5, 12, 64, 12, 6),        # ... C5's final decoder at a batch that gives 2560 boxes
     (6, 32, 64, 24, 8),        # ... 24 couts (the second block half empty), four chunks, halos
     (33, 32, 32, 24, 8),
     (1040, 12, 8, 12, 6),      # cin not a multiple of 8: the last chunk's missing channels are zero slots (nf = 12: C5's U-Net)
