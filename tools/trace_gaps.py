@@ -33,9 +33,11 @@ for s, e in iv[1:]:
         cur_e = max(cur_e, e)
 covered += cur_e - cur_s
 print('some kernel running: %.1f %% of the window; nothing running: %.3f ms per step' % (100 * covered / (t1 - t0), (t1 - t0 - covered) / 1e6 / (steps - 1)))
-# per kernel name: mean duration in this window
-agg = collections.defaultdict(lambda: [0, 0.0])
-for r in rows:
-    a = agg[r['Kernel_Name'][:70]]; a[0] += 1; a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-for name, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
-    print('%7.1f us/step  %5.1f us x %5.1f  %s' % (us / (steps - 1), us / c, c / (steps - 1), name))
+# per queue and kernel name: mean duration in this window
+for q, rs in byq.items():
+    print('--- queue', q)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rs:
+        a = agg[r['Kernel_Name'][:70]]; a[0] += 1; a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    for name, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:26]:
+        print('%7.1f us/step  %5.1f us x %5.1f  %s' % (us / (steps - 1), us / c, c / (steps - 1), name))
