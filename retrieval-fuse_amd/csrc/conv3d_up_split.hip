@@ -804,6 +804,162 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_box(UpSplitArgs a, in
     }
 }
 
+// ------------------------------------------------------------------------------ the box kernel, persistent
+// k_conv3_up_split_box for the widest volumes (the final decoder's 16 -> 16 @64^3: 16,384 boxes per step of 32 chunks): the layer has 48 MFMAs per
+// wave and box, so a workgroup per box spends its life staging, storing and waiting at its own start and end.  Here a workgroup (512 threads, two per
+// CU) owns a run of consecutive boxes: each wave keeps its parity's weights in registers for the whole run, the low-res halo image is double-buffered
+// (box i + 2 is requested while box i's outputs are stored, box i + 1 converted while the other waves finish box i's MFMAs), and the epilogue tile is
+// drained while the next voxels are in flight.  Two barriers per box:
+//     MFMA(i) | A | tile(i) <- accumulators, image(i + 1) <- registers | B | request box i + 2, store tile(i), statistics(i)
+// Results are those of k_conv3_up_split_box bit for bit (same products, same accumulation order, same statistics order).
+// Measured (tools/upbox_bench.py, tools/upbox_ablation.py; 32 chunks): 0.315 -> 0.25 ms alone.  Without the voxel loads 0.17, without the stores 0.17,
+// with neither 0.09: a box's loads and stores go out in two bursts and only two workgroups per CU interleave them.  A rotated loop whose waits for
+// the voxels leave the stores in flight (vmcnt(4) instead of vmcnt(0)) and a two-boxes-deep request measured 0.259 / 0.268: not kept.
+namespace {
+constexpr int UP_IMG = 2 * 2 * US_B_PLANE;                         // one halo image: <= 2 channel groups x (h | l)            13,824
+constexpr int UP_TILE = 2 * UP_IMG;                                // epilogue tile [16][UB_E_STRIDE] fp32                      33,024
+constexpr int UP_AFF = UP_TILE + 16 * UB_E_STRIDE * 4;             // <= 16 GroupNorm triples of the sample being staged
+constexpr int UP_LDS_BYTES = UP_AFF + 16 * 16;                     // 60,928: two workgroups per CU
+}
+template <int NBG, int CGO>
+__global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, int edge, int boxes_per_wg, int total_boxes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    constexpr int c1 = NBG * 8;
+    const int half = edge >> 1, tpe = edge >> 3;
+    const int lt = 31 - __builtin_clz(tpe);                        // edge is a power of two
+    const int hvol = half * half * half;
+    constexpr int cout = CGO * 8;                                  // channel-interleaved output only: whole groups of 8
+    const int vol = edge * edge * edge;
+    const int b0 = blockIdx.x * boxes_per_wg, b1 = min(b0 + boxes_per_wg, total_boxes);
+    if (b0 >= b1) return;
+
+    // this thread's staging item: (channel group, halo voxel) -- one item per thread, NBG x 216 of the 512 threads have one
+    const bool stager = tid < NBG * US_BSLOTS;
+    const int scg = tid / US_BSLOTS, sv = tid % US_BSLOTS;
+    const int shz = sv / US_BZ - 1, shy = (sv / US_BY) % 6 - 1, shx = sv % 6 - 1;
+    float xr[8];
+    bool xin = false;
+    // raw voxels of box b -> registers.  The GroupNorm triples sit in an LDS table that is rewritten only when a run crosses into the next sample
+    // (refresh): a per-box load of them would put a vmcnt(0) -- the round trip of these loads AND of the previous box's stores -- into every box
+    auto request = [&](int b) {
+        const int n = b >> (3 * lt), t = b & ((1 << (3 * lt)) - 1);
+        const int z = ((t >> (2 * lt)) << 2) + shz, y = (((t >> lt) & (tpe - 1)) << 2) + shy, x = ((t & (tpe - 1)) << 2) + shx;
+        xin = stager && (unsigned)z < (unsigned)half && (unsigned)y < (unsigned)half && (unsigned)x < (unsigned)half;
+        const float* __restrict__ sb = a.src1 + (size_t)n * c1 * hvol;                  // uniform base, 32-bit lane offsets
+        const unsigned off = xin ? (unsigned)(scg * 8 * hvol + (z * half + y) * half + x) : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[j] = sb[off + (unsigned)(j * hvol)];
+    };
+    auto refresh = [&](int n) {
+        if (tid < c1) *reinterpret_cast<float4*>(lds + UP_AFF + tid * 16) = a.affine[(size_t)n * c1 + tid];
+    };
+    auto stage = [&](int buf) {                                     // registers -> normalised, split halo image
+        if (!stager) return;
+        float yv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 af = *reinterpret_cast<const float4*>(lds + UP_AFF + (scg * 8 + j) * 16);
+            yv[j] = xin ? fmaf(xr[j] - af.x, af.y, af.z) : 0.f;                          // zero padding of the NORMALISED tensor
+        }
+        h8 h, l;
+        us_split8(yv, h, l);
+        unsigned char* p = lds + buf * UP_IMG + scg * 2 * US_B_PLANE + sv * 16;
+        *reinterpret_cast<h8*>(p) = h;
+        *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
+    };
+
+    // ---- this parity's weights: [group][tz][h | l], 16 VGPRs per group, resident for the whole run
+    h8 wh[NBG][2], wl[NBG][2];
+    {
+        const h8* __restrict__ wn = a.wp + (size_t)wave * NBG * 2 * 128 + lane;
+#pragma unroll
+        for (int cb = 0; cb < NBG; ++cb)
+#pragma unroll
+            for (int tz = 0; tz < 2; ++tz) { wh[cb][tz] = wn[(cb * 2 + tz) * 128]; wl[cb][tz] = wn[(cb * 2 + tz) * 128 + 64]; }
+    }
+    const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
+    const int bbase = (pz * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;        // + (m + tz) BZ
+    float* const e = reinterpret_cast<float*>(lds + UP_TILE);
+
+    request(b0);
+    refresh(b0 >> (3 * lt));
+    __syncthreads();
+    stage(0);
+    if (b0 + 1 < b1) request(b0 + 1);
+    __syncthreads();
+
+    for (int b = b0; b < b1; ++b) {
+        const int cur = (b - b0) & 1;
+        f32x4 hi[4][1], lo[4][1];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { hi[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int cb = 0; cb < NBG; ++cb)
+#pragma unroll
+            for (int tz = 0; tz < 2; ++tz) {
+                const unsigned char* ap = lds + cur * UP_IMG + cb * 2 * US_B_PLANE + bbase + tz * US_BZ * 16;
+                const h8 (&bh)[1] = reinterpret_cast<const h8 (&)[1]>(wh[cb][tz]);
+                const h8 (&bl)[1] = reinterpret_cast<const h8 (&)[1]>(wl[cb][tz]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const h8 ah = *reinterpret_cast<const h8*>(ap + m * US_BZ * 16);
+                    const h8 al = *reinterpret_cast<const h8*>(ap + m * US_BZ * 16 + US_B_PLANE);
+                    us_mfma_block<1>(hi[m], lo[m], ah, al, bh, bl);
+                }
+            }
+        if (b + 1 < b1 && ((b + 1) & ((1 << (3 * lt)) - 1)) == 0) refresh((b + 1) >> (3 * lt));     // the next box opens a sample (the table was last read before B(b - 1))
+        __syncthreads();                                           // A: tile(b - 1) drained by every wave, image(cur ^ 1) free since MFMA(b - 1)
+        {
+            const int col = lane & 15, yj = lane >> 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lin = (2 * m + pz) * 64 + (2 * yj + py) * 8 + 2 * r + px;
+                    e[col * UB_E_STRIDE + lin] = fmaxf(fmaf(lo[m][0][r], 1.0f / US_LO, hi[m][0][r]), 0.f);
+                }
+        }
+        if (b + 1 < b1) stage(cur ^ 1);
+        __syncthreads();                                           // B: tile(b) and image(b + 1) complete
+        if (b + 2 < b1) request(b + 2);
+
+        const int n = b >> (3 * lt), tile = b & ((1 << (3 * lt)) - 1);
+        const int z0 = (tile >> (2 * lt)) << 3, y0 = ((tile >> lt) & (tpe - 1)) << 3, x0 = (tile & (tpe - 1)) << 3;
+        float* __restrict__ on = a.out + (size_t)n * cout * vol;                          // uniform; lane offsets are 32-bit (a sample is < 2^28 floats)
+        // channel-interleaved: a box row is 8 voxels x 32 bytes = 256 contiguous bytes.  A compile-time number of stores: the waits for the NEXT box's
+        // voxels (requested above, retired in order before these) can then leave the stores in flight
+#pragma unroll
+        for (int it = 0; it < 2 * CGO; ++it) {
+            const int q = tid + it * 512;
+            const int cg = q >> 10, vox = (q >> 1) & 511, hf = q & 1;
+            const int z = vox >> 6, y = (vox >> 3) & 7, x = vox & 7;
+            const float* ep = e + (cg * 8 + hf * 4) * UB_E_STRIDE + vox;
+            const unsigned o = ((unsigned)(cg * vol + ((z0 + z) * edge + y0 + y) * edge + x0 + x) << 3) + hf * 4;
+            *reinterpret_cast<float4*>(on + o) = make_float4(ep[0], ep[UB_E_STRIDE], ep[2 * UB_E_STRIDE], ep[3 * UB_E_STRIDE]);
+        }
+        if (a.stats) {
+            const int co = tid >> 3, part = tid & 7;
+            double sm = 0.0, sq = 0.0;
+            if (co < cout) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(e + co * UB_E_STRIDE + (part * 16 + i) * 4);
+                    sm += (double)v.x; sq += (double)v.x * v.x;
+                    sm += (double)v.y; sq += (double)v.y * v.y;
+                    sm += (double)v.z; sq += (double)v.z * v.z;
+                    sm += (double)v.w; sq += (double)v.w * v.w;
+                }
+            }
+#pragma unroll
+            for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
+            if (part == 0 && co < cout) a.stats[((size_t)n * cout + co) * (size_t)(1 << (3 * lt)) + tile] = make_double2(sm, sq);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ 8^3 boxes of a large volume WITH a skip source
 // The decoder form for the U-Nets' decoder stages on 16^3 ... 128^3 volumes (C5's 48 + 96 -> 78 @32^3, reference model/refinement.py:37-45 +
 // model/unet.py:297-308): phase A as k_conv3_up_split (27 taps on the full-res halo box, 7 k-steps per 8-channel chunk) with the halo read from the
@@ -1063,7 +1219,21 @@ static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, in
         const unsigned boxes = (unsigned)n * (edge / 8) * (edge / 8) * (edge / 8);
         const int nbq = rf_round_up(cout, 16) / 16;
         const size_t lds_bytes = (size_t)(nbq * 16) * UB_E_STRIDE * 4 > (size_t)(c1 / 8) * 2 * US_B_PLANE ? (size_t)(nbq * 16) * UB_E_STRIDE * 4 : (size_t)(c1 / 8) * 2 * US_B_PLANE;
-        if (nbq == 1) {
+        if (a.out_ch8 && (c1 == 8 || c1 == 16) && (cout == 8 || cout == 16) && boxes >= 2048 && (long long)cout * edge * edge * edge < (1ll << 28)) {
+            // persistent form (channel-interleaved output only): two workgroups per CU, each a run of consecutive boxes
+            const unsigned wgs = 512, per = (boxes + wgs - 1) / wgs;
+            static RfLdsOptIn opt_p[4];
+#define RF_BOXP(I_, NBG_, CGO_)                                                                                                      \
+            do {                                                                                                                     \
+                if (int rc = opt_p[I_].ensure(reinterpret_cast<const void*>(k_conv3_up_split_boxp<NBG_, CGO_>), UP_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu_ch8")) return rc; \
+                hipLaunchKernelGGL((k_conv3_up_split_boxp<NBG_, CGO_>), dim3((boxes + per - 1) / per), dim3(512), UP_LDS_BYTES, (hipStream_t)stream, a, edge, (int)per, (int)boxes); \
+            } while (0)
+            if (c1 == 16 && cout == 16) RF_BOXP(0, 2, 2);
+            else if (c1 == 16) RF_BOXP(1, 2, 1);
+            else if (cout == 16) RF_BOXP(2, 1, 2);
+            else RF_BOXP(3, 1, 1);
+#undef RF_BOXP
+        } else if (nbq == 1) {
             hipLaunchKernelGGL(k_conv3_up_split_box<1>, dim3(boxes), dim3(512), lds_bytes, (hipStream_t)stream, a, edge);
         } else {
             static RfLdsOptIn opt_in;

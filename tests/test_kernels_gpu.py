@@ -387,6 +387,39 @@ def test_conv3d_up_split_operand_kernel(ops, case):
     same_affine(fused, plain, 'scale from fused stats')
 
 
+UP_CH8_CASES = [
+    # (n, c1, edge, cout): rf_conv3d_up_split_k3_gn_relu_ch8 -- from 2048 boxes on the persistent kernel (k_conv3_up_split_boxp), below that one workgroup per box
+    (5, 16, 64, 16),      # the final decoder's first conv: 2560 boxes, five per workgroup
+    (3, 16, 64, 16),      # 1536 boxes: one workgroup per box
+    (300, 8, 16, 8),      # one channel group in, one out: 2400 boxes = 480 workgroups x 5, a run crosses samples every 8 boxes
+    (37, 16, 32, 8),      # 2368 boxes: the last workgroup's run is short
+    (41, 8, 32, 16),      # one group in, two out
+]
+
+
+@pytest.mark.parametrize('case', UP_CH8_CASES)
+def test_conv3d_up_split_channel_interleaved_output(ops, case):
+    """The channel-interleaved ([n][cout / 8][voxel][8]) form of the decoder box conv (model/unet.py:297-308 without a skip source) holds exactly the
+    values and the statistics of the NCDHW form: the persistent kernel changes the schedule of a box, not its arithmetic."""
+    n, c1, edge, cout = case
+    gen = torch.Generator().manual_seed(sum(case) + 11)
+    src1 = rnd(gen, n, c1, edge // 2, edge // 2, edge // 2).relu_().to(DEV)
+    gamma, beta = (1 + 0.2 * rnd(gen, c1)).to(DEV), (0.2 * rnd(gen, c1)).to(DEV)
+    w = rnd(gen, cout, c1, 3, 3, 3, scale=1.0 / np.sqrt(27 * c1)).to(DEV)
+    aff = ops.gn_affine(None, src1, gamma, beta, 8 if c1 % 8 == 0 else 1)
+    wp = ops.pack_conv3_up_split_weight(w, 0)
+    from rfuse import _lib
+    assert _lib.load().rf_conv3d_up_split_ch8_supported(0, c1, n, edge, cout)
+    plain = ops.conv3d_up_split_gn_relu(None, src1, aff, wp, cout)
+    got, stats, tiles = ops.conv3d_up_split_gn_relu_ch8(src1, aff, wp, cout)
+    back = got.permute(0, 1, 5, 2, 3, 4).reshape(n, cout, edge, edge, edge)
+    assert torch.equal(back, plain), 'ch8 output differs from the NCDHW output: max %.3e' % (back - plain).abs().max().item()
+    pst, ptiles = plain._rf_stats[:2]
+    assert tiles == ptiles and torch.equal(stats, pst), 'per-box statistics differ'
+    ref = ref_gcr(None, src1[:1].cpu().double(), gamma.cpu().double(), beta.cpu().double(), 8 if c1 % 8 == 0 else 1, w.cpu().double())
+    close(back[:1], ref.float(), 1e-5, 'ch8 vs float64 torch')
+
+
 def test_conv3d_up_split_saturates_instead_of_overflowing(ops):
     """activations beyond the f16 range of the split (|GroupNorm output| > 65504 * 16) saturate; nothing becomes inf / nan"""
     n, c0, c1, cout = 256, 8, 8, 40
