@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--feature-cache', action='store_true', help='also time the optional cached-retrieval-features serving mode (reported separately)')
     ap.add_argument('--repeats', type=int, default=4, help='further blocks of K steps timed after the contract\'s K (reported as `blocks`: min / median; never `value`)')
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
+    ap.add_argument('--kernels-top', type=int, default=8, help='rows of the serial per-kernel table')
     ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank under torch.distributed.run, still run the all-gather + merge protocol')
     return ap.parse_args()
 
@@ -521,7 +522,7 @@ def main():
     # definition), `frac_serial` the same against its duration in the serial pass.
     from rfuse import _lib
     lib = _lib.load()
-    kernels, dominant = kernel_table(eng, raw_dev, cfg)
+    kernels, dominant = kernel_table(eng, raw_dev, cfg, top=args.kernels_top)
     for df in eng.refine_stream(raw_dev for _ in range(args.warmup)):
         pass
     torch.cuda.synchronize()
