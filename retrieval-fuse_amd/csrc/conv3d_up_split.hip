@@ -463,8 +463,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------- 4^3 volumes
 // The decoder form on whole 4^3 samples (retrieval backbone dec0: 64 skip channels @4^3 + 128 channels upsampled from 2^3 -> 64): 8 samples
-// per workgroup, wave = output parity (pz, py, px) as above, m-block m = the parity class (8 voxels each) of samples 2m and 2m + 1, 16 couts
-// per workgroup (grid.y).  Phase A (skip channels, 27 taps): 8 halo cubes of 6^3 slots, one voxel staged per thread and chunk.  Phase B
+// per workgroup, wave = output parity (pz, py, px) as above, m-block m = one z plane (4 voxels) of the parity class of samples 4 (m >> 1) .. + 3
+// (see the kernel), 16 couts per workgroup (grid.y).  Phase A (skip channels, 27 taps): 8 halo cubes of 6^3 slots, one voxel staged per thread and chunk.  Phase B
 // (upsampled channels, the 8 pre-summed low-res taps of the weight image's B region): 8 halo cubes of 4^3 slots per chunk, four chunks
 // staged at a time into the same LDS (the phase-A image is dead by then).  Epilogue through an LDS tile [cout][sample][64] as above.
 namespace {
@@ -498,20 +498,33 @@ __global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSp
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { hi[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    // weight fragments: A region [chunk][7 steps][nbt][h|l][64], B region of this parity [chunk][2 steps][nbt][h|l][64]; one k-step ahead
+    // ---- m-blocks and skipped k-steps (round 4).  Row ri of m-block m: sample 4 (m >> 1) + (ri >> 2), parity-class voxel (qz, qy, qx) with (qy, qx) =
+    // ((ri >> 1) & 1, ri & 1): an m-block lies in ONE z plane.  m & 1 = 0 is the parity class's BORDER plane (z = 0 for pz = 0, z = 3 for pz = 1: qz = pz),
+    // m & 1 = 1 its interior plane (z = 2 / z = 1).  The border plane's taps that point out of the volume read padding: two of a chunk's seven k-steps
+    // in phase A, one of the two in phase B -- skipped, 18 % of dec0's MFMAs.  WHICH k-steps depends on pz; two compiled variants behind a branch on pz
+    // cost 70-140 spilled registers in this 256-VGPR kernel (hipcc hoists and sinks the variants' common code across the diamond), so there is one
+    // variant and the waves with pz = 1 walk the taps in z-MIRRORED order (k-step s, lane group g: tap mirror(4 s + g), its weights gathered from the
+    // fragment image per lane group; phase B: k-steps in the order tz = 1, 0): for every wave the padding k-steps of the border plane are the first ones.
+    static_assert(PRE, "k_conv3_up_split_s4: the one-k-step-ahead weight prefetch is the only form kept");
     const int wstep = nbt * 128;
-    const h8* const wA = a.wp + (size_t)nb0 * 128 + lane;
-    const h8* const wB = wA + ((size_t)nA * 7 + (size_t)wave * nB * 2) * wstep;
-    const int TA = nA * 7;
-    auto wptr = [&](int t) { return t < TA ? wA + (size_t)t * wstep : wB + (size_t)(t - TA) * wstep; };   // t == TA + TB: the next parity's region / the slack step
+    const h8* const wA0 = a.wp + (size_t)nb0 * 128;
+    const h8* const wB0 = wA0 + ((size_t)nA * 7 + (size_t)wave * nB * 2) * wstep;
+    auto mirror = [](int i) { return i < 27 ? (2 - i / 9) * 9 + i % 9 : 27; };
+    auto sel4 = [&](int v0, int v1, int v2, int v3) { const int a01 = g & 1 ? v1 : v0, a23 = g & 1 ? v3 : v2; return g & 2 ? a23 : a01; };
+    // this lane's weight fragment of phase-A k-step (ca, s): [h | l at + 64]
+    auto pA = [&](int ca, int s) -> const h8* {
+        const h8* cb = wA0 + (size_t)(ca * 7) * wstep;
+        const int t0 = mirror(4 * s), t1 = mirror(4 * s + 1), t2 = mirror(4 * s + 2), t3 = mirror(4 * s + 3);
+        const int offm = sel4((t0 >> 2) * wstep + (t0 & 3) * 16, (t1 >> 2) * wstep + (t1 & 3) * 16, (t2 >> 2) * wstep + (t2 & 3) * 16, (t3 >> 2) * wstep + (t3 & 3) * 16) + ri;
+        return cb + (pz ? offm : s * wstep + lane);
+    };
+    auto pB = [&](int cgi, int tzp) -> const h8* { return wB0 + (size_t)(cgi * 2 + (tzp ^ pz)) * wstep + lane; };
     h8 bh[NB], bl[NB], nh[NB], nl[NB];
-    auto load_b = [&](int t, h8 (&h)[NB], h8 (&l)[NB]) {
-        const h8* p = wptr(t);
+    auto load_p = [&](const h8* p, h8 (&h)[NB], h8 (&l)[NB]) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { h[nb] = p[nb * 128]; l[nb] = p[nb * 128 + 64]; }
     };
-    load_b(0, bh, bl);
-    int t = 0;                                                      // k-step counter over both phases
+    load_p(nA ? pA(0, 0) : pB(0, 0), bh, bl);
 
     // ---------------------------------------------------------------- phase A
     {
@@ -536,10 +549,10 @@ __global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSp
             *reinterpret_cast<h8*>(myslot) = h;
             *reinterpret_cast<h8*>(myslot + U4_A_PLANE) = l;
         };
-        // row ri of m-block m: sample 2m + (ri >> 3), parity-class voxel j = ri & 7 -> (z, y, x) = (2 (j >> 2) + pz, 2 ((j >> 1) & 1) + py, 2 (j & 1) + px)
-        const int j = ri & 7;
-        const unsigned char* const abase = lds + ((ri >> 3) * 216 + (2 * (j >> 2) + pz + 1) * 36 + (2 * ((j >> 1) & 1) + py + 1) * 6 + 2 * (j & 1) + px + 1) * 16;
-        auto tapoff = [](int tp) { return ((tp / 9 - 1) * 36 + ((tp / 3) % 3 - 1) * 6 + (tp % 3 - 1)) * 16; };       // tap 27: zero weights, reads tap 26
+        // (z, y, x) = (2 qz + pz, 2 qy + py, 2 qx + px) in the sample's 6^3 halo cube (+1): the border plane is z = 3 pz, the interior plane z = 2 - pz
+        const unsigned char* const abase = lds + ((ri >> 2) * 216 + (2 * ((ri >> 1) & 1) + py + 1) * 6 + 2 * (ri & 1) + px + 1) * 16;
+        const int zplane[2] = {(3 * pz + 1) * 36 * 16, (3 - pz) * 36 * 16};
+        auto tapoff = [](int tp) { tp = tp < 27 ? tp : 26; return ((tp / 9 - 1) * 36 + ((tp / 3) % 3 - 1) * 6 + (tp % 3 - 1)) * 16; };       // tap 27: zero weights, reads tap 26
         float xr[8];
         if (nA) stage_load(xr, 0);
         zero_lds(2 * U4_A_PLANE);                                   // the rings are the zero padding and are written once
@@ -551,22 +564,22 @@ __global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSp
             if (more) stage_load(xr, ca + 1);
 #pragma unroll
             for (int s = 0; s < 7; ++s) {
-                if constexpr (PRE) load_b(++t, nh, nl);
-                else if (t++ > 0) load_b(t - 1, bh, bl);
-                // the lane group's tap offset of this k-step: four compile-time constants, selected by g (7 registers less than a table)
-                const int o01 = g & 1 ? tapoff(4 * s + 1) : tapoff(4 * s), o23 = g & 1 ? tapoff(4 * s + 3 < 27 ? 4 * s + 3 : 26) : tapoff(4 * s + 2);
-                const int at = g & 2 ? o23 : o01;
+                load_p(s < 6 ? pA(ca, s + 1) : (more ? pA(ca + 1, 0) : pB(0, 0)), nh, nl);
+                // the lane group's tap offset of this k-step: compile-time constants selected by g and pz
+                const int atn = sel4(tapoff(4 * s), tapoff(4 * s + 1), tapoff(4 * s + 2), tapoff(4 * s + 3));
+                const int atm = sel4(tapoff(mirror(4 * s)), tapoff(mirror(4 * s + 1)), tapoff(mirror(4 * s + 2)), tapoff(mirror(4 * s + 3)));
+                const int at = pz ? atm : atn;
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const h8 ah = *reinterpret_cast<const h8*>(abase + m * (2 * 216 * 16) + at);
-                    const h8 al = *reinterpret_cast<const h8*>(abase + m * (2 * 216 * 16) + at + U4_A_PLANE);
+                    if ((m & 1) == 0 && s < 2) continue;            // border plane, taps 0..7 of this wave's order: all out of the volume
+                    const unsigned char* ap = abase + (m >> 1) * (4 * 216 * 16) + zplane[m & 1] + at;
+                    const h8 ah = *reinterpret_cast<const h8*>(ap);
+                    const h8 al = *reinterpret_cast<const h8*>(ap + U4_A_PLANE);
                     us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
                 }
-                if constexpr (PRE) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
-                }
+                for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
             }
             __syncthreads();
             if (more) {
@@ -584,9 +597,10 @@ __global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSp
         const float4* __restrict__ aff = a.affine + (size_t)ns * cin + c0;
         const float* __restrict__ s1 = a.src1 + (size_t)ns * c1 * 8 + sv;
         unsigned char* const myslot = lds + scg * 2 * U4_B_PLANE + (ssm * 64 + ((sv >> 2) + 1) * 16 + (((sv >> 1) & 1) + 1) * 4 + (sv & 1) + 1) * 16;
-        // row (sample 2m + (ri >> 3), q = ri & 7), k-step tz, lane group (ty, tx): low-res halo voxel (qz + tz + pz, qy + ty + py, qx + tx + px)
-        const int q = ri & 7;
-        const unsigned char* const bbase = lds + ((ri >> 3) * 64 + ((q >> 2) + pz) * 16 + (((q >> 1) & 1) + py + (g >> 1)) * 4 + (q & 1) + px + (g & 1)) * 16;
+        // k-step tz, lane group (ty, tx): low-res halo voxel (qz + tz + pz, qy + ty + py, qx + tx + px); halo planes 0 and 3 are padding.  Border plane
+        // (qz = pz): halo z = 2 pz + tz, padding for tz = pz -- this wave's first k-step (tz = tzp ^ pz); interior plane (qz = 1 - pz): halo z = 1 + tz
+        const unsigned char* const bbase = lds + ((ri >> 2) * 64 + (((ri >> 1) & 1) + py + (g >> 1)) * 4 + (ri & 1) + px + (g & 1)) * 16;
+        const int zb[2][2] = {{(2 * pz + pz) * 256, (1 + pz) * 256}, {(2 * pz + (1 ^ pz)) * 256, (1 + (1 ^ pz)) * 256}};      // [tzp][m & 1]
         zero_lds(U4_BG * 2 * U4_B_PLANE);                           // (phase A ended on a barrier)
         __syncthreads();
         for (int cb0 = 0; cb0 < nB; cb0 += U4_BG) {
@@ -606,22 +620,21 @@ __global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSp
             }
             __syncthreads();
             for (int cg = 0; cg < ng; ++cg) {
+                const int cgi = cb0 + cg;
 #pragma unroll
-                for (int tz = 0; tz < 2; ++tz) {
-                    if constexpr (PRE) load_b(++t, nh, nl);
-                    else if (t++ > 0) load_b(t - 1, bh, bl);
+                for (int tzp = 0; tzp < 2; ++tzp) {
+                    load_p(tzp == 0 ? pB(cgi, 1) : pB(cgi + 1 < nB ? cgi + 1 : cgi, 0), nh, nl);       // (after the last k-step: any fragment of the image)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        const unsigned char* p = bbase + cg * 2 * U4_B_PLANE + m * (2 * 64 * 16) + tz * (16 * 16);
+                        if ((m & 1) == 0 && tzp == 0) continue;     // border plane, the k-step whose low-res plane is outside
+                        const unsigned char* p = bbase + cg * 2 * U4_B_PLANE + (m >> 1) * (4 * 64 * 16) + zb[tzp][m & 1];
                         const h8 ah = *reinterpret_cast<const h8*>(p);
                         const h8 al = *reinterpret_cast<const h8*>(p + U4_B_PLANE);
                         us_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
                     }
-                    if constexpr (PRE) {
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
-                    }
+                    for (int nb = 0; nb < NB; ++nb) { bh[nb] = nh[nb]; bl[nb] = nl[nb]; }
                 }
             }
         }
@@ -638,8 +651,9 @@ __global__ __launch_bounds__(512, NB >= 3 ? 2 : 4) void k_conv3_up_split_s4(UpSp
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * g + r, sm = 2 * m + (row >> 3), jq = row & 7;
-                    const int lin = sm * 64 + (2 * (jq >> 2) + pz) * 16 + (2 * ((jq >> 1) & 1) + py) * 4 + 2 * (jq & 1) + px;
+                    const int row = 4 * g + r, sm = 4 * (m >> 1) + (row >> 2);
+                    const int z = m & 1 ? 2 - pz : 3 * pz;
+                    const int lin = sm * 64 + z * 16 + (2 * ((row >> 1) & 1) + py) * 4 + 2 * (row & 1) + px;
                     e[(nb * 16 + col) * U4_E_STRIDE + lin] = fmaxf(fmaf(lo[m][nb][r], 1.0f / US_LO, hi[m][nb][r]), 0.f);
                 }
     }
@@ -807,7 +821,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_box(UpSplitArgs a, in
 // ------------------------------------------------------------------------------ the box kernel, persistent
 // k_conv3_up_split_box for the widest volumes (the final decoder's 16 -> 16 @64^3: 16,384 boxes per step of 32 chunks): the layer has 48 MFMAs per
 // wave and box, so a workgroup per box spends its life staging, storing and waiting at its own start and end.  Here a workgroup (512 threads, two per
-// CU) owns a run of consecutive boxes: each wave keeps its parity's weights in registers for the whole run, the low-res halo image is double-buffered
+// CU) owns a run of boxes (every 64th of its XCD's range, see the kernel): each wave keeps its parity's weights in registers for the whole run, the low-res halo image is double-buffered
 // (box i + 2 is requested while box i's outputs are stored, box i + 1 converted while the other waves finish box i's MFMAs), and the epilogue tile is
 // drained while the next voxels are in flight.  Two barriers per box:
 //     MFMA(i) | A | tile(i) <- accumulators, image(i + 1) <- registers | B | request box i + 2, store tile(i), statistics(i)
@@ -822,7 +836,7 @@ constexpr int UP_AFF = UP_TILE + 16 * UB_E_STRIDE * 4;             // <= 16 Grou
 constexpr int UP_LDS_BYTES = UP_AFF + 16 * 16;                     // 60,928: two workgroups per CU
 }
 template <int NBG, int CGO>
-__global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, int edge, int boxes_per_wg, int total_boxes) {
+__global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, int edge, int total_boxes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -833,7 +847,13 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, i
     const int hvol = half * half * half;
     constexpr int cout = CGO * 8;                                  // channel-interleaved output only: whole groups of 8
     const int vol = edge * edge * edge;
-    const int b0 = blockIdx.x * boxes_per_wg, b1 = min(b0 + boxes_per_wg, total_boxes);
+    // Which boxes: XCD k (workgroups k, k + 8, ...: the dispatcher deals workgroups round-robin over the 8 XCDs) owns the k-th eighth of the boxes, and its
+    // workgroups walk that range TOGETHER -- workgroup j of the XCD takes boxes j, j + bs, j + 2 bs, ... of it (bs = workgroups per XCD).  At any time an
+    // XCD therefore works on ~bs consecutive boxes (a z slab of a sample): the low-res rows (128-byte lines that 8 x-neighbours and the y / z halos
+    // share) are fetched into its L2 once.  With a contiguous run per workgroup they were fetched again for nearly every box (the workgroup's own
+    // output stream had evicted them): 849 MB read per launch for a 67 MB source (PMC, profiles/r04_pmc_bench_C2_B32.csv).
+    const int bs = (int)(gridDim.x >> 3), per_xcd = (total_boxes + 7) >> 3;
+    const int b0 = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3), b1 = min(((int)(blockIdx.x & 7u) + 1) * per_xcd, total_boxes);
     if (b0 >= b1) return;
 
     // this thread's staging item: (channel group, halo voxel) -- one item per thread, NBG x 216 of the 512 threads have one
@@ -888,11 +908,12 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, i
     refresh(b0 >> (3 * lt));
     __syncthreads();
     stage(0);
-    if (b0 + 1 < b1) request(b0 + 1);
+    if (b0 + bs < b1) request(b0 + bs);
     __syncthreads();
 
-    for (int b = b0; b < b1; ++b) {
-        const int cur = (b - b0) & 1;
+    int cur = 1;
+    for (int b = b0; b < b1; b += bs) {
+        cur ^= 1;
         f32x4 hi[4][1], lo[4][1];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { hi[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -910,7 +931,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, i
                     us_mfma_block<1>(hi[m], lo[m], ah, al, bh, bl);
                 }
             }
-        if (b + 1 < b1 && ((b + 1) & ((1 << (3 * lt)) - 1)) == 0) refresh((b + 1) >> (3 * lt));     // the next box opens a sample (the table was last read before B(b - 1))
+        if (b + bs < b1 && ((b + bs) >> (3 * lt)) != (b >> (3 * lt))) refresh((b + bs) >> (3 * lt));   // the next box is in another sample (the table was last read before B(b - 1))
         __syncthreads();                                           // A: tile(b - 1) drained by every wave, image(cur ^ 1) free since MFMA(b - 1)
         {
             const int col = lane & 15, yj = lane >> 4;
@@ -922,9 +943,9 @@ __global__ __launch_bounds__(512, 4) void k_conv3_up_split_boxp(UpSplitArgs a, i
                     e[col * UB_E_STRIDE + lin] = fmaxf(fmaf(lo[m][0][r], 1.0f / US_LO, hi[m][0][r]), 0.f);
                 }
         }
-        if (b + 1 < b1) stage(cur ^ 1);
+        if (b + bs < b1) stage(cur ^ 1);
         __syncthreads();                                           // B: tile(b) and image(b + 1) complete
-        if (b + 2 < b1) request(b + 2);
+        if (b + 2 * bs < b1) request(b + 2 * bs);
 
         const int n = b >> (3 * lt), tile = b & ((1 << (3 * lt)) - 1);
         const int z0 = (tile >> (2 * lt)) << 3, y0 = ((tile >> lt) & (tpe - 1)) << 3, x0 = (tile & (tpe - 1)) << 3;
@@ -1221,12 +1242,11 @@ static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, in
         const size_t lds_bytes = (size_t)(nbq * 16) * UB_E_STRIDE * 4 > (size_t)(c1 / 8) * 2 * US_B_PLANE ? (size_t)(nbq * 16) * UB_E_STRIDE * 4 : (size_t)(c1 / 8) * 2 * US_B_PLANE;
         if (a.out_ch8 && (c1 == 8 || c1 == 16) && (cout == 8 || cout == 16) && boxes >= 2048 && (long long)cout * edge * edge * edge < (1ll << 28)) {
             // persistent form (channel-interleaved output only): two workgroups per CU, each a run of consecutive boxes
-            const unsigned wgs = 512, per = (boxes + wgs - 1) / wgs;
             static RfLdsOptIn opt_p[4];
 #define RF_BOXP(I_, NBG_, CGO_)                                                                                                      \
             do {                                                                                                                     \
                 if (int rc = opt_p[I_].ensure(reinterpret_cast<const void*>(k_conv3_up_split_boxp<NBG_, CGO_>), UP_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu_ch8")) return rc; \
-                hipLaunchKernelGGL((k_conv3_up_split_boxp<NBG_, CGO_>), dim3((boxes + per - 1) / per), dim3(512), UP_LDS_BYTES, (hipStream_t)stream, a, edge, (int)per, (int)boxes); \
+                hipLaunchKernelGGL((k_conv3_up_split_boxp<NBG_, CGO_>), dim3(512), dim3(512), UP_LDS_BYTES, (hipStream_t)stream, a, edge, (int)boxes); \
             } while (0)
             if (c1 == 16 && cout == 16) RF_BOXP(0, 2, 2);
             else if (c1 == 16) RF_BOXP(1, 2, 1);
