@@ -351,13 +351,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
     const int edge = a.edge, cin = a.c0, nC = cin >> 3;
     const int tsh = __builtin_ctz(edge >> 3);                       // boxes per axis = 1 << tsh
     const size_t vol = (size_t)edge * edge * edge;
-    // Which boxes: XCD k (workgroups with blockIdx.x & 7 = k: the dispatcher deals workgroups round-robin over the 8 XCDs; gridDim.x is a multiple of 8) owns
-    // the k-th eighth of the boxes and its workgroups walk that range together, workgroup j taking boxes j, j + bs, j + 2 bs, ... of it: at any time an XCD
-    // works on ~bs neighbouring boxes, so the halo lines that neighbours share are fetched into its L2 once.  With one contiguous run per workgroup a
-    // box's halo had left the L2 again (evicted by the outputs) before the neighbour came by: the pointwise-head layer fetched 1.38 GB for a 0.54 GB input.
-    const int bs = (int)(gridDim.x >> 3), per_xcd = (total_boxes + 7) >> 3;
-    const int b_first = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    const int b_last = min(total_boxes, ((int)(blockIdx.x & 7u) + 1) * per_xcd);
+    const int b_first = blockIdx.x * boxes_per_wg;
+    const int b_last = min(total_boxes, b_first + boxes_per_wg);
     if (b_first >= b_last) return;
     auto box_origin = [&](int box, int& n0, int& z0, int& y0, int& x0) {
         const int m = (1 << tsh) - 1;
@@ -514,7 +509,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
     const int col = lane & 15;
     const int cob = blockIdx.y * 16;                                 // this workgroup's 16 couts of the layer (EPI 0: up to two blocks, grid.y)
     int item = 0;                                                    // parity of the image buffer
-    for (int box = b_first; box < b_last; box += bs) {
+    for (int box = b_first; box < b_last; ++box) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) { hi[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         for (int ca = 0; ca < nC; ++ca, item ^= 1) {
@@ -524,8 +519,8 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
             int nbox = box, nca = ca + 1;
             if (nca == nC) {
                 nca = 0;
-                nbox = box + bs;
-                if (nbox >= b_last) { nbox = box; nca = ca; }
+                nbox = box + 1;
+                if (nbox == b_last) { nbox = box; nca = ca; }
             }
             const h8 w1 = (wsrc + (size_t)ca * wstride)[(unsigned)wsrc1];     // R1 of this chunk: lands under pass 0
             __builtin_amdgcn_sched_barrier(0);
@@ -726,9 +721,10 @@ static int zcm_launch(const ConvArgs& a, const SplitPreOut& po, hipStream_t stre
     static RfLdsOptIn opt;
     if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), ZM_LDS_BYTES, who)) return rc;
     const long long boxes = (long long)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
+    const int wgs = 512;                                              // two workgroups per CU
     const unsigned cob_blocks = (unsigned)(a.cout16 / 16);
-    const unsigned gx = cob_blocks >= 2 ? 256u : 512u;                // two workgroups per CU in all; a multiple of 8 (the kernel's box order)
-    hipLaunchKernelGGL(kern, dim3(gx, cob_blocks), dim3(512), ZM_LDS_BYTES, stream, a, po, 0, (int)boxes);
+    const int per = (int)((boxes * cob_blocks + wgs - 1) / wgs);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((boxes + per - 1) / per), cob_blocks), dim3(512), ZM_LDS_BYTES, stream, a, po, per, (int)boxes);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rf_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return RF_E_LAUNCH; }
     return RF_OK;
