@@ -468,6 +468,11 @@ def host_io_rate(eng, raws_host, device, steps=10):
 
 def main():
     args = parse()
+    # The contract is ONE line on stdout.  RCCL and gloo print banners to the C-level stdout of every rank ("RCCL version : ...", "[Gloo] Rank 0 is connected
+    # ..."): keep a private handle on the real stdout for the JSON line and point file descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -698,7 +703,8 @@ def main():
             out['cpu_baseline'] = None
             if world == 1 and not host_db_ok:
                 out['cpu_baseline_note'] = 'skipped: the oracle needs the %d-patch voxel store on the host' % n_patches
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out)
+        json_out.flush()
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
