@@ -509,6 +509,12 @@ int rf_mc_classify(const float* sdf, int x, int y, int z, float level, const sig
 int rf_mc_emit(const float* sdf, int x, int y, int z, float level, const signed char* tri_table, const long long* cube_off, const long long* edge_off,
                const int* cube_ntri, const int* edge_flag, float* verts, int* tris, void* stream);
 
+/* Scene recomposition on the device (reference dataset/patched_scene_dataset.py:160-186 combine_predictions after trainer/train_refinement.py:160-167's
+ * `.cpu().half()`): m chunks of a refined batch df [b][64^3] fp32 -> float16 rounding (round_half != 0) -> float64 -> pasted into `flat` at element
+ * offsets dst[i] (chunk sel[i] of the batch) with canvas strides sx, sy (elements; z contiguous; offsets and strides even: 16-byte stores). */
+int rf_paste_chunks(const float* df, int b, const int* sel, const long long* dst, int m, long long sx, long long sy, int round_half, double* flat,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,34 @@ extern "C" int rf_mc_emit(const float* sdf, int x, int y, int z, float level, co
     RF_CHECK_LAUNCH("rf_mc_emit");
     return RF_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ scene recomposition
+// combine_predictions on the device (reference dataset/patched_scene_dataset.py:160-186: a float64 canvas, refined 64^3 chunks pasted at their origins; the
+// predictions went through `.cpu().half()` first, trainer/train_refinement.py:160-167): m chunks of a refined batch df [b][64^3] fp32 -> rounded to float16
+// (round to nearest even, as torch's .half()) -> widened to float64 (exact) -> canvas rows.  sel[i] = the chunk's index in the batch, dst[i] = the element
+// offset of its origin in `flat`, sx / sy = the canvas' strides of x and y in elements (z is contiguous).  One workgroup per (chunk, x): a 64 x 64 (y, z)
+// plane, rows of 64 doubles = 512 contiguous bytes.  Replaces df.half() -> .double() -> gather -> index_put (four passes over 67 MB per 32 chunks).
+__global__ __launch_bounds__(256) void k_paste_chunks(const float* __restrict__ df, const int* __restrict__ sel, const long long* __restrict__ dst, long long sx,
+                                                      long long sy, int round_half, double* __restrict__ flat) {
+    const int c = blockIdx.x >> 6, x = blockIdx.x & 63;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(df + ((size_t)sel[c] * 64 + x) * 4096);
+    double* __restrict__ out = flat + dst[c] + (long long)x * sx;
+    for (int q = threadIdx.x; q < 1024; q += 256) {                  // float4 q: (y, z) = (q >> 4, 4 (q & 15))
+        float4 v = src[q];
+        if (round_half) { v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; v.z = (float)(_Float16)v.z; v.w = (float)(_Float16)v.w; }
+        double* o = out + (long long)(q >> 4) * sy + 4 * (q & 15);
+        *reinterpret_cast<double2*>(o) = make_double2((double)v.x, (double)v.y);
+        *reinterpret_cast<double2*>(o + 2) = make_double2((double)v.z, (double)v.w);
+    }
+}
+
+extern "C" int rf_paste_chunks(const float* df, int b, const int* sel, const long long* dst, int m, long long sx, long long sy, int round_half, double* flat,
+                               void* stream) {
+    RF_REQUIRE(df && sel && dst && flat && b > 0 && m >= 0, RF_E_INVALID, "rf_paste_chunks: bad arguments");
+    RF_REQUIRE(sy >= 64 && sx >= 64 * sy && sy % 2 == 0 && sx % 2 == 0, RF_E_INVALID, "rf_paste_chunks: canvas strides sx=%lld sy=%lld (need even, sy >= 64, sx >= 64 sy)", sx, sy);
+    if (m == 0) return RF_OK;
+    hipLaunchKernelGGL(k_paste_chunks, dim3((unsigned)m * 64u), dim3(256), 0, (hipStream_t)stream, df, sel, dst, sx, sy, round_half, flat);
+    RF_CHECK_LAUNCH("rf_paste_chunks");
+    return RF_OK;
+}

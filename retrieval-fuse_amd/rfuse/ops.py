@@ -1254,6 +1254,16 @@ def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, s
     return out
 
 
+def paste_chunks(df, sel, dst, sx, sy, flat, round_half=True):
+    """combine_predictions on the device: chunks ``sel`` (int32, indices into the refined batch df [b, 1, 64, 64, 64]) -> float16 rounding -> float64 ->
+    ``flat`` (float64) at element offsets ``dst`` (int64) with canvas strides sx, sy (reference dataset/patched_scene_dataset.py:160-186)."""
+    _req(df, 'df'), _req(sel, 'sel', torch.int32), _req(dst, 'dst', torch.int64), _req(flat, 'flat', torch.float64)
+    if tuple(df.shape[1:]) != (1, 64, 64, 64) or sel.numel() != dst.numel():
+        raise ValueError('paste_chunks: df must be [b, 1, 64, 64, 64] and sel / dst of one length (got %s, %d, %d)' % (tuple(df.shape), sel.numel(), dst.numel()))
+    _lib.check(_lib.load().rf_paste_chunks(_p(df), df.shape[0], _p(sel), _p(dst), sel.numel(), int(sx), int(sy), 1 if round_half else 0, _p(flat), _stream()),
+               'rf_paste_chunks')
+
+
 # every public tensor op is scoped to its tensors' device (see _device_scoped)
 for _name, _fn in list(vars(sys.modules[__name__]).items()):
     if isinstance(_fn, type(_device_scoped)) and _fn.__module__ == __name__ and not _name.startswith('_'):

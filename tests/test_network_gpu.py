@@ -524,6 +524,13 @@ def test_scene_driver_matches_chunkwise_refinement(gpu):
     both = scene.refine_scene(eng, names2, chunks2, batch=4)
     ref2 = scene.refine_scene(eng, names2, chunks2, batch=4, assemble_on_device=False)
     assert list(both) == ['sceneR__room0', 'sceneQ__room0'] and all(np.array_equal(both[k], ref2[k]) for k in both)
+    # many scenes through ONE pipelined stream (refine_scenes: a scene is handed out while the next one is being refined): each equals its own refine_scene call
+    seq = [(names, chunks), (names2, chunks2), (names[:2], chunks[:2]), (names, chunks)]
+    streamed = list(scene.refine_scenes(eng, iter(seq), batch=3))
+    assert len(streamed) == len(seq)
+    for (nm, ch), got in zip(seq, streamed):
+        want = scene.refine_scene(eng, nm, ch, batch=3)
+        assert list(got) == list(want) and all(np.array_equal(got[k], want[k]) for k in want)
 
 
 @pytest.mark.parametrize('cfg_name,B', [('C3', 8), ('C4', 4)])
