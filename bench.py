@@ -207,9 +207,9 @@ def kernel_bytes(name, a, nulls=()):
     if name in ('rf_conv3d_split_k3_gn_relu_pointwise_tanh', 'rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8'):
         cin, n, edge, cout = a[:4]
         return 4.0 * n * edge ** 3 * (cin + 1)
-    if name == 'rf_conv3d_split_pre_k3_relu_pool_presplit':          # pre-split in, pooled fp32 out + the pooled tensor pre-split (as many bytes) out
+    if name == 'rf_conv3d_split_pre_k3_relu_pool_presplit':          # pre-split in, the pooled tensor pre-split out (no fp32 pooled tensor: a scratch slot per workgroup)
         cin, n, edge, cout = a[:4]
-        return 4.0 * n * edge ** 3 * (cin + 2 * cout / 8.0)
+        return 4.0 * n * edge ** 3 * (cin + cout / 8.0)
     if name == 'rf_conv3d_split_pre_presplit':
         cin, n, edge, cout = a[:4]
         return 4.0 * n * edge ** 3 * (cin + cout)

@@ -472,9 +472,11 @@ int rf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t 
  * rf_conv3d_split_pre_k3_relu_pool_presplit = rf_conv3d_split_pre_k3_relu (pooled output only) whose persistent workgroups also write the pooled tensor
  * pre-split for the NEXT level's first conv (that layer's GroupNorm applied from the sample's own statistics: next_gamma / next_beta [cout], next_groups, eps);
  * rf_conv3d_split_pre_presplit = that first conv, pre-split in and pre-split out (whole 8^3 samples).  No rf_gn_from_stats launch, no conversion in either
- * consumer.  pool_out fp32 is still written (the kernel reads it back through L2 once the sample's statistics are known). */
+ * consumer.  pool_scratch: rf_conv3d_split_pre_pool_presplit_scratch_floats(cout) floats of workspace -- a slot per persistent workgroup for the pooled fp32
+ * values of the sample in flight (read back through L2 once the sample's statistics are known); NOT a pooled tensor: nothing else consumes one. */
+size_t rf_conv3d_split_pre_pool_presplit_scratch_floats(int cout);
 int rf_conv3d_split_pre_pool_presplit_supported(int cin, int n, int edge, int cout, int next_groups);
-int rf_conv3d_split_pre_k3_relu_pool_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, float* pool_out,
+int rf_conv3d_split_pre_k3_relu_pool_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, float* pool_scratch,
                                               double* pool_stats, const float* next_gamma, const float* next_beta, int next_groups, float eps,
                                               void* out_presplit, void* stream);
 int rf_conv3d_split_pre_presplit_supported(int cin, int n, int edge, int cout, int next_groups);

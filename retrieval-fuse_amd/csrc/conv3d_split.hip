@@ -872,10 +872,14 @@ extern "C" int rf_conv3d_split_k3_gn_relu_pointwise_tanh_ch8(const float* src_ch
 // rf_conv3d_split_pre_k3_relu of a level-0 second conv (pooled output only) that ALSO hands the pooled tensor to the next level's first conv pre-split: the
 // persistent form walks whole 16^3 samples, so at a sample's end it has the statistics of the pooled [cout][8^3] tensor, applies that layer's GroupNorm
 // (next_gamma / next_beta [cout], next_groups, eps), splits and writes rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_presplit /
-// rf_conv3d_split_pre_k3_relu.  pool_out (fp32, required: the values are read back through L2) and pool_stats (optional) as rf_conv3d_split_pre_k3_relu.
+// rf_conv3d_split_pre_k3_relu.  pool_scratch: rf_conv3d_split_pre_pool_presplit_scratch_floats(cout) floats of workspace (a slot per persistent workgroup: the
+// pooled fp32 values of the sample in flight, read back through L2 once its statistics are known -- NOT a pooled tensor); pool_stats (optional) as
+// rf_conv3d_split_pre_k3_relu.
 extern "C" int rf_conv3d_split_pre_pool_presplit_supported(int cin, int n, int edge, int cout, int next_groups) {
     return rf_split_zc_takes(cin, n, edge, cout) && cout % 8 == 0 && next_groups > 0 && cout % next_groups == 0;
 }
+
+extern "C" size_t rf_conv3d_split_pre_pool_presplit_scratch_floats(int cout) { return (size_t)512 * (size_t)(cout > 0 ? cout : 0) * 512; }      // 512 workgroups x [cout][8^3]
 
 extern "C" int rf_conv3d_split_pre_k3_relu_pool_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, float* pool_out,
                                                          double* pool_stats, const float* next_gamma, const float* next_beta, int next_groups, float eps,

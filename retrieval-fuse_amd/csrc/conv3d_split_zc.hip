@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, SplitPreO
             }
         }
         if (sample_end) {
-            if (a.pool_stats) {
+            if (a.pool_stats || po.out) {                              // (the hand-over needs the pooled sample's sums whether or not the caller wants them)
                 const double s1 = psm + __shfl_xor(psm, 16, 64), s2 = psq + __shfl_xor(psq, 16, 64);      // the two x halves (lane groups 0 and 1)
                 if (lane < 16) red[wave * 16 + lane] = make_double2(s1, s2);
             }
@@ -268,17 +268,20 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, SplitPreO
             if (co < a.cout) {
                 const int n0 = boxA >> 3, z0 = ((boxA >> 2) & 1) * 4, y0 = ((boxA >> 1) & 1) * 4;
                 const float4 v = *reinterpret_cast<const float4*>(tile + co * ZC_TILE_STRIDE + pz * 32 + w4 * 4);
-                *reinterpret_cast<float4*>(a.pool_out + ((size_t)n0 * a.cout + co) * PVOL + (size_t)(z0 + pz) * 64 + y0 * 8 + w4 * 4) = v;
+                // hand-over mode (po.out): pool_out is a per-workgroup scratch slot -- the values are read back at the sample's end and nobody else wants them,
+                // so 32 KB per workgroup stay in L2 instead of a [n][cout][8^3] tensor streaming to HBM and back (0.27 GB each way per launch)
+                const size_t slot = po.out ? (size_t)blockIdx.x : (size_t)n0;
+                *reinterpret_cast<float4*>(a.pool_out + (slot * a.cout + co) * PVOL + (size_t)(z0 + pz) * 64 + y0 * 8 + w4 * 4) = v;
             }
         }
         if (sample_end && tv < 32) {
             const int which = tv >> 4, co = tv & 15;
             double2* dst = which ? a.stats : a.pool_stats;
-            if ((FULL || !which) && dst && co < a.cout) {
+            if ((FULL || !which) && (dst || (!which && po.out)) && co < a.cout) {
                 double sm = 0.0, sq = 0.0;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) { const double2 v = red[which * 128 + w * 16 + co]; sm += v.x; sq += v.y; }
-                dst[(size_t)(boxA >> 3) * a.cout + co] = make_double2(sm, sq);
+                if (dst) dst[(size_t)(boxA >> 3) * a.cout + co] = make_double2(sm, sq);
                 if (!which && po.out) reinterpret_cast<double2*>(lds + ZC_SCRATCH)[co] = make_double2(sm, sq);
             }
         }
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zc(ConvArgs a, SplitPreO
             }
             lds_barrier();
             const int n0 = boxA >> 3;
-            const float* pv = a.pool_out + (size_t)n0 * a.cout * PVOL + (unsigned)tv;
+            const float* pv = a.pool_out + (size_t)blockIdx.x * a.cout * PVOL + (unsigned)tv;       // this workgroup's scratch slot (see the pooled stores)
             h8* __restrict__ o = po.out + (size_t)n0 * (a.cout >> 3) * 2 * PVOL + (unsigned)tv;
             for (int sg = 0; sg < (a.cout >> 3); ++sg) {
                 float y[8];

@@ -137,6 +137,7 @@ SIGNATURES = {
     'rf_gather_rows': (c_i, [c_fp, c_i64, c_p, c_i64, c_i, c_fp, c_p]),
     'rf_conv3d_split_pre_pool_presplit_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_pre_k3_relu_pool_presplit': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_fp, c_p, c_fp, c_fp, c_i, c_f, c_p, c_p]),
+    'rf_conv3d_split_pre_pool_presplit_scratch_floats': (ctypes.c_size_t, [c_i]),
     'rf_conv3d_split_pre_presplit_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_pre_presplit': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_fp, c_fp, c_i, c_f, c_p, c_p, c_p]),
     'rf_conv3d_up_split_ch8_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),

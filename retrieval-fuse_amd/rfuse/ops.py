@@ -570,19 +570,16 @@ def conv_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups):
 
 
 def conv3d_split_pre_relu_pool_presplit(pre, cin, n, edge, w_split_packed, cout, next_gamma, next_beta, next_groups, eps):
-    """conv3d_split_pre_relu(pool='only') whose pooled output is ALSO emitted pre-split for the next level's first conv: -> (pooled fp32 with its
-    statistics attached, PreSplit of the pooled tensor)"""
+    """conv3d_split_pre_relu(pool='only') whose pooled output is emitted pre-split for the next level's first conv: -> (None, PreSplit of the pooled tensor).
+    No fp32 pooled tensor exists: the kernel keeps the pooled values of the sample in flight in a per-workgroup scratch slot (16 MB in all, L2-resident)."""
     dev = pre.device
     lib = _lib.load()
     half = edge // 2
-    pooled = torch.empty((n, cout, half, half, half), dtype=torch.float32, device=dev)
-    pstats = torch.empty((n, cout, 1, 2), dtype=torch.float64, device=dev) if USE_FUSED_STATS else None
+    scratch = torch.empty(lib.rf_conv3d_split_pre_pool_presplit_scratch_floats(cout), dtype=torch.float32, device=dev)
     out = torch.empty(lib.rf_split_act_bytes(n, cout, half), dtype=torch.uint8, device=dev)
-    _lib.check(lib.rf_conv3d_split_pre_k3_relu_pool_presplit(_p(pre), cin, n, edge, _p(w_split_packed), cout, _p(pooled), _p(pstats), _p(next_gamma.detach()),
+    _lib.check(lib.rf_conv3d_split_pre_k3_relu_pool_presplit(_p(pre), cin, n, edge, _p(w_split_packed), cout, _p(scratch), _p(None), _p(next_gamma.detach()),
                                                              _p(next_beta.detach()), next_groups, eps, _p(out), _stream()), 'rf_conv3d_split_pre_k3_relu_pool_presplit')
-    if pstats is not None:
-        pooled._rf_stats = (pstats, 1, pooled._version)
-    return pooled, PreSplit(out, n, cout, half)
+    return None, PreSplit(out, n, cout, half)
 
 
 def conv_split_pre_presplit_supported(cin, n, edge, cout, next_groups):
