@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0              # HBM3E, same guide
 F16_MFMA_PEAK_TFLOPS = 2500.0      # dense f16/bf16 MFMA peak, same guide ("~2.5 PF dense"; 16x the fp32 MFMA rate)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
@@ -59,8 +59,32 @@ def parse():
     ap.add_argument('--repeats', type=int, default=4, help='further blocks of K steps timed after the contract\'s K (reported as `blocks`: min / median; never `value`)')
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
     ap.add_argument('--kernels-top', type=int, default=8, help='rows of the serial per-kernel table')
-    ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank under torch.distributed.run, still run the all-gather + merge protocol')
-    return ap.parse_args()
+    ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank, still run the all-gather + all-to-all + merge protocol over RCCL')
+    ap.add_argument('--resident-batches', type=int, default=4, help='distinct resident input batches rotated through the timed loop')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_plan(args, argv, environ):
+    """None when this process is a rank (or the plain one-GPU run); otherwise the command line that starts the ranks.
+
+    `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (the shape of the driver's one-GPU command) launches its own N ranks: one
+    process per GPU under torch.distributed.run on 127.0.0.1 with a free port.  The ranks' stdout is this process's stdout, and only rank 0 writes the JSON
+    line to it.  `--gpus 1 --force-collectives` takes the same route with one rank (the RCCL protocol needs a rendezvous)."""
+    if 'WORLD_SIZE' in environ or 'RANK' in environ:
+        return None
+    if args.gpus == 1 and not args.force_collectives:
+        return None
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(free_port()), str(Path(__file__).resolve())] + list(argv)
 
 
 def synthetic_database(cfg, n_patches, device, seed=1234):
@@ -182,13 +206,15 @@ def parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev, chunks=(0, 17
     _, trunc_t = configs.truncations(cfg)
     out = {'value': worst, 'chunks': [b for b in chunks if b < B], 'against': 'oracle/refpath.py (fp32 torch-CPU networks, float64 exact kNN)',
            'tanh_output_max_abs': worst * 2.0 / trunc_t}
-    if trunc_t <= 1.0:
-        out.update(bar=1e-4, bar_applies_to='df (north_star: 1e-4 abs on the reconstructed TSDF)', met=worst <= 1e-4)
-    else:
-        # Matterport3D (trunc 11.25): the fp32 reference itself is 4.1e-4 from the float64 evaluation on df (tests/golden/truth_C4.npz), so 1e-4 on df against an
-        # fp32 oracle is not a property an exact evaluation would have; the bar that applies is 1e-4 on the network's own (tanh) output, df error * 2 / trunc
-        out.update(bar=1e-4, bar_applies_to='tanh output = df error * 2 / trunc (trunc %.4g; tests/test_network_gpu.py:assert_df_parity)' % trunc_t,
-                   met=worst * 2.0 / trunc_t <= 1e-4)
+    # Both figures, always: `met` is north_star's bar -- 1e-4 abs on df against the fp32 oracle.  Where the truncation is above 1 (Matterport3D, 11.25)
+    # the fp32 reference itself is 4.1e-4 from its own float64 evaluation on df (tests/golden/truth_C4.npz), so `met` is expected False there for ANY
+    # evaluation order but ATen's; `met_tanh` is the bar the GPU tests apply on that config (1e-4 on the network's own tanh output, df error * 2 / trunc,
+    # beside "no further from the float64 truth than the reference", tests/test_network_gpu.py:assert_df_parity).
+    out.update(bar=1e-4, bar_applies_to='df (north_star: 1e-4 abs on the reconstructed TSDF)', met=worst <= 1e-4,
+               met_tanh=worst * 2.0 / trunc_t <= 1e-4, trunc=trunc_t)
+    if trunc_t > 1.0:
+        out['note'] = ('trunc %.4g: the fp32 reference is itself 4.1e-4 from its float64 evaluation on df here (tests/golden/truth_C4.npz); the bar the GPU tests '
+                       'hold this config to is met_tanh plus no-further-from-the-truth-than-the-reference' % trunc_t)
     return out
 
 
@@ -475,7 +501,13 @@ def host_io_rate(eng, raws_host, device, steps=10):
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    plan = launch_plan(args, argv, os.environ)
+    if plan is not None:
+        import subprocess
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(plan))
     # The contract is ONE line on stdout.  RCCL and gloo print banners to the C-level stdout of every rank ("RCCL version : ...", "[Gloo] Rank 0 is connected
     # ..."): keep a private handle on the real stdout for the JSON line and point file descriptor 1 at stderr for everything else.
     sys.stdout.flush()
@@ -484,9 +516,9 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if args.gpus != world and not (world == 1 and args.gpus == 1):
-        raise SystemExit('--gpus %d needs exactly that many ranks (WORLD_SIZE is %d): launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+    if args.gpus != world:
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d: start `python bench.py --gpus %d` without WORLD_SIZE / RANK in the environment (it launches its own '
+                         'ranks) or under torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback for the hot path)'
     knobs = sorted(k for k in os.environ if k.startswith('RFUSE_') and k != 'RFUSE_LIB')
     assert not knobs, 'refusing to measure with developer switches set: %s' % knobs
@@ -512,8 +544,17 @@ def main():
     collective_events = [] if (world > 1 or force_dist) else None
     eng = RefinementEngine(cfg, device, database)
     # every rank refines its own B chunks (chunk-parallel replicas); inputs resident in HBM
-    raws = np.stack([synthetic.make_chunk(10_000 + rank * B + b, cfg)['input_raw'] for b in range(B)])
-    raw_dev = torch.from_numpy(raws).to(device)
+    # R distinct batches stay resident and the loops rotate through them, so consecutive steps search for different queries and gather different database
+    # patches (one batch replayed K times would fetch the same 8192 patches, 134 MB, out of the Infinity Cache every step).  Batch 0 of rank 0 is the batch
+    # the parity / recall legs check against the oracle.
+    R = max(1, args.resident_batches)
+    raws_all = [np.stack([synthetic.make_chunk(10_000 + (r * world + rank) * B + b, cfg)['input_raw'] for b in range(B)]) for r in range(R)]
+    raws = raws_all[0]
+    batches = [torch.from_numpy(x).to(device) for x in raws_all]
+    raw_dev = batches[0]
+
+    def rotate(n):
+        return (batches[i % R] for i in range(n))
 
     def barrier():
         if world > 1 or force_dist:
@@ -526,7 +567,7 @@ def main():
     # Device spin-up ahead of the W warm-up steps (untimed, reported as `spinup_steps`): an idle MI355X needs a few hundred milliseconds of work to reach its
     # clocks, and the first passes also pack the weight images and grow both streams' allocator pools.  The timed region is exactly K steps after W warm-up steps.
     SPINUP = 12
-    for df in eng.refine_stream(raw_dev for _ in range(SPINUP)):
+    for df in eng.refine_stream(rotate(SPINUP)):
         pass
     # roofline: WHICH launch is the dominant one is decided by a serial pass (HIP events around every C-ABI launch, one step after the other, nothing
     # overlapped: the launch with the largest mean duration among those with a roofline) -- inside the pipelined step a launch shares the CUs with the other
@@ -536,7 +577,7 @@ def main():
     from rfuse import _lib
     lib = _lib.load()
     kernels, dominant = kernel_table(eng, raw_dev, cfg, top=args.kernels_top)
-    for df in eng.refine_stream(raw_dev for _ in range(args.warmup)):
+    for df in eng.refine_stream(rotate(args.warmup)):
         pass
     torch.cuda.synchronize()
     dom_records = []
@@ -546,7 +587,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for df in eng.refine_stream(raw_dev for _ in range(args.steps)):
+    for df in eng.refine_stream(rotate(args.steps)):
         pass
     torch.cuda.synchronize()
     barrier()
@@ -559,7 +600,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        for df in eng.refine_stream(raw_dev for _ in range(args.steps)):
+        for df in eng.refine_stream(rotate(args.steps)):
             pass
         torch.cuda.synchronize()
         barrier()
@@ -569,8 +610,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.refine(raw_dev)
+    for x in rotate(args.steps):
+        eng.refine(x)
     torch.cuda.synchronize()
     barrier()
     elapsed_plain = time.perf_counter() - t1
@@ -605,12 +646,21 @@ def main():
                 peak, unit, scale = HBM_PEAK_GBS, 'GB/s', 1e9
             else:
                 peak, unit, scale = (F16_MFMA_PEAK_TFLOPS if bound == 'mfma-f16' else FP32_MFMA_PEAK_TFLOPS), 'TFLOP/s', 1e12
-            achieved = work / (kern_ms * 1e-3) / scale
+            issued = work / (kern_ms * 1e-3) / scale                # what the matrix pipe was fed (split operands, tap slots, cout padding)
+            shape = conv_shape(entry, ints)
+            direct = None
+            if shape is not None and bound != 'hbm':
+                c0_, c1_, n_, edge_, cout_ = shape
+                direct = 2.0 * 27 * (c0_ + c1_) * cout_ * edge_ ** 3 * n_      # the layer as the reference evaluates it
+            # `achieved` / `frac`: SURVEY 8(d)'s algorithmic work of the launch (a conv layer: 2 * 27 * cin * cout flop per output voxel, the reference's direct
+            # form; an HBM-bound launch: its algorithmic bytes) / the launch's mean in-step duration / the peak of the pipe the launch runs on.
+            # `issue_frac`: the flop actually ISSUED on that pipe / the same peak (pipe occupancy; round 4 printed this one as `frac`).
+            algo_work = direct if direct is not None else work
+            achieved = algo_work / (kern_ms * 1e-3) / scale
             # HBM traffic of the dominant kernel: OFFLINE PMC (separate rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
             # summary committed under profiles/), scaled per sample to this launch; None when the committed summary is of another kernel
             traffic, pmc_name = None, None
-            shape = conv_shape(entry, ints)
-            for pmc_file in (REPO / 'profiles' / 'r04_dominant_kernel.json', REPO / 'profiles' / 'r03_dominant_kernel.json'):
+            for pmc_file in (REPO / 'profiles' / 'r05_dominant_kernel.json', REPO / 'profiles' / 'r04_dominant_kernel.json'):
                 if not pmc_file.exists() or shape is None:
                     continue
                 pmc = json.loads(pmc_file.read_text())
@@ -618,31 +668,33 @@ def main():
                 if same and pmc.get('shape') == [shape[0], shape[1], shape[3], shape[4]]:
                     traffic, pmc_name = pmc['traffic_bytes_per_sample'] * shape[2], pmc_file.name
                     break
+            pipe = {'hbm': 'HBM3E', 'mfma-f16': 'the dense f16 MFMA peak: the launch multiplies on v_mfma_f32_16x16x32_f16 (fp32 operands as two f16 pieces, 3 MFMAs per product '
+                                                'tile, exact products, separate hi / lo fp32 accumulators), so that pipe is the one that bounds it -- against the fp32 MFMA '
+                                                'peak (157.3 TFLOP/s) the same rate would read above 1',
+                    'mfma': 'the dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)'}.get(bound, bound)
             roof = {'bound': 'hbm' if bound == 'hbm' else 'mfma',
-                    'kernel': '%s %s%s' % (entry, list(ints), ': fp32 operands as two f16 pieces on v_mfma_f32_16x16x32_f16 (3 MFMAs per product tile, exact products, hi/lo fp32 '
-                                           'accumulators)' if bound == 'mfma-f16' else ''),
+                    'kernel': '%s %s' % (entry, list(ints)),
                     'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
-                    'work_per_launch': work, 'work': work_unit,
+                    'work_per_launch': algo_work,
+                    'work': ('SURVEY 8(d) algorithmic flop of the layer: 2 * 27 * cin * cout per output voxel (the reference\'s direct form)' if direct is not None else work_unit)
+                            + '; peak = ' + pipe,
+                    'issue_frac': issued / peak, 'issued_per_launch': work, 'issued': work_unit,
                     'launch_ms': kern_ms, 'launches_timed': len(in_step),
-                    'launch_ms_serial': serial_ms, 'frac_serial': work / (serial_ms * 1e-3) / scale / peak,
+                    'launch_ms_serial': serial_ms, 'frac_serial': algo_work / (serial_ms * 1e-3) / scale / peak, 'issue_frac_serial': work / (serial_ms * 1e-3) / scale / peak,
                     'chosen_by': 'largest mean duration per launch in the serial per-kernel pass (`kernels`); launch_ms = the same entry point bracketed with HIP events on its '
                                  'launch stream inside the timed (pipelined) region',
                     'traffic': traffic, 'traffic_unit': 'bytes/launch, OFFLINE PMC (%s), not measured in this run' % (pmc_name or 'no summary of this kernel committed'),
                     'algorithmic_bytes_per_launch': nbytes, 'hbm_frac': (nbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if nbytes else None,
                     'heavy_launches_ms_serial': {'%s %s' % (r['entry'], r['args']): r['ms_per_launch'] for r in kernels['top']}}
-            if shape is not None and bound != 'hbm':
-                c0_, c1_, n_, edge_, cout_ = shape
-                direct = 2.0 * 27 * (c0_ + c1_) * cout_ * edge_ ** 3 * n_                                      # the layer as the reference evaluates it
-                # `frac` prices the flop ISSUED on the matrix pipe of `peak` (pipe occupancy); `useful_frac` prices the layer's direct-form multiply-adds
-                # (2 * 27 * cin * cout per voxel) against the same peak: what the reference's arithmetic would cost there
-                roof.update(useful_frac=direct / (kern_ms * 1e-3) / 1e12 / peak, direct_form_flops_per_launch=direct,
+            if direct is not None:
+                roof.update(useful_frac=roof['frac'], direct_form_flops_per_launch=direct,      # alias of `frac`, kept for one round
                             fp32_equivalent_tflops=2.0 * (27 * c0_ + (8 if 'up' in entry else 27) * c1_) * cout_ * edge_ ** 3 * n_ / (kern_ms * 1e-3) / 1e12)
-                assert roof['useful_frac'] <= 1.0, roof
-            assert roof['frac'] <= 1.0 and roof['frac_serial'] <= 1.0, roof
+            assert roof['frac'] <= 1.0 and roof['issue_frac'] <= 1.0 and roof['issue_frac_serial'] <= 1.0, roof
         out = {
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'spinup_steps': SPINUP, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (%d distinct resident batches rotated through the timed loop)' % R,
             'arithmetic': 'fp32 tensors and fp32 accumulation throughout; the heavy 3x3x3 convolutions multiply on the F16 matrix cores with every fp32 operand '
                           'carried as two f16 pieces (x = h + l / 2^11, exact f16 x f16 products, separate hi / lo fp32 accumulators): measured error against '
                           'float64 is lower than that of the fp32 MFMA chain (tests/test_kernels_gpu.py, tools/micro/split_probe.hip)' if ops.CONV_ARITH == 'split' else 'fp32 (v_mfma_f32_16x16x4_f32)',
@@ -674,7 +726,7 @@ def main():
                     pass
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for df in eng.refine_stream(raw_dev for _ in range(args.steps)):
+                for df in eng.refine_stream(rotate(args.steps)):
                     pass
                 torch.cuda.synchronize()
                 plain_ms = 1e3 * (time.perf_counter() - t1) / args.steps
