@@ -41,18 +41,24 @@ class QueryCountCheck:
     mis-slice silently.  Every call of the sharded search posts ONE non-blocking gloo all-gather of its count (a CPU int64, no device
     synchronisation) -- the same collective sequence on every rank, whatever each rank has seen before -- and
 
-      * the FIRST time this rank passes a given count it waits for the exchange and raises before any device collective is issued;
-      * otherwise it does not wait: the exchange of call i is examined at call i + 1 (or at ``flush()``), when it has long completed.  In steady
-        state no rank's enqueue thread blocks on the slowest rank (round 3 did one blocking ``all_gather_object`` per step).
+      * whenever this rank's count CHANGES -- a count it has not used before, or one that differs from its previous call's -- it waits for the exchange
+        and raises before any device collective is issued (round 4 waited only for a never-seen count: two ranks that had both used 64 and 128 before
+        could then walk into an all-gather of 64 against 128, ADVICE r4);
+      * a count equal to the previous call's is not waited for: the exchange of call i is examined at ``flush()`` -- ``PatchDatabase.check()``, which
+        the engine calls once the whole step is enqueued and before it hands results out, by which time the peers have long posted theirs -- or at the
+        next call.  In steady state no rank's enqueue thread blocks on the slowest rank ahead of its launches (round 3 did one blocking
+        ``all_gather_object`` per step).
 
-    A mismatch a rank could not see on its own (its count is one it has used before, a peer's is not) is therefore raised by the peer at once and by
-    this rank one call later -- the peer never enters the mismatched device collectives."""
+    A rank whose own count did not change cannot see a peer's change on its own: the peer (whose count changed) refuses at once and never enters the
+    device collectives; this rank has only ENQUEUED them and gets the ValueError from ``check()`` before any host synchronisation on the results
+    (engine.refine / refine_stream / scene.refine_scene(s) all end a step with it), not a hang."""
 
     def __init__(self, host_group):
         import torch.distributed as dist
         self.host_group = host_group
         self.world = dist.get_world_size(host_group)
         self.seen = set()
+        self.last = None               # this rank's count at the previous call
         self.pending = None            # (work, counts tensors, mine tensor) of the previous call
 
     @staticmethod
@@ -78,7 +84,9 @@ class QueryCountCheck:
         counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
         work = dist.all_gather(counts, mine, group=self.host_group, async_op=True)
         self.pending = (work, counts, mine)
-        if nq not in self.seen or not defer:
+        changed = nq not in self.seen or nq != self.last
+        self.last = nq
+        if changed or not defer:
             self.flush()
             self.seen.add(nq)
 

@@ -161,7 +161,16 @@ class RefinementEngine:
             patches, _ = self.retrieve(input_raw, query_scene, patch_mask, q=q)
             feats = self.retrieval_backbone(patches)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        return self._attend_and_decode(x_back, feats, gumbel_noise)
+        df = self._attend_and_decode(x_back, feats, gumbel_noise)
+        self._check_database()
+        return df
+
+    def _check_database(self):
+        """Sharded database: examine the query-count exchange of this step's search now that the step is enqueued (host-side, no device synchronisation; the
+        peers posted their counts at the start of their step) -- a mismatch surfaces here as a ValueError, before the caller synchronises on results whose
+        collectives a peer never joined."""
+        if self.database is not None and not torch.cuda.is_current_stream_capturing():
+            self.database.check()
 
     def refine_stream(self, batches, query_scenes=None, patch_masks=None):
         """Software-pipelined ``refine`` over a sequence of batches (a generator of refined TSDFs, one per batch, in order).
@@ -196,6 +205,7 @@ class RefinementEngine:
                     done.record(front)
                 out = self._finish_pipelined(main, *pending) if pending is not None else None
                 pending = (patches, x_back, done)
+                self._check_database()
             if out is not None:
                 yield out
         if pending is not None:

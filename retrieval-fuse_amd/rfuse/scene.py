@@ -79,6 +79,10 @@ def _scene_layout(chunk_names, dataset_name, chunk_size=64):
     for i, name in enumerate(chunk_names):
         key, origin = superscene_and_position(name, dataset_name)
         members.setdefault(key, []).append((i, tuple(int(v) for v in origin.astype(np.int32))))
+        if (origin < 0).any():
+            # combine_chunks would follow numpy's slice semantics (an empty or wrapped destination); on the device a negative origin is an offset in front of
+            # the canvas buffer.  No dataset of the reference produces one (positions are multiples of 64 from 0): refuse instead of guessing.
+            raise ValueError('chunk %r has a negative origin %s: device recomposition needs origins >= 0' % (name, origin.tolist()))
     return {key: (tuple(int(r) for r in (np.max([o for _, o in items], axis=0) + chunk_size)), items) for key, items in members.items()}
 
 
@@ -170,6 +174,8 @@ class _DeviceAssembly:
             self.groups = []                                          # (sx, sy, ids ascending (numpy), offsets (device int64))
             for (sx, sy), grp in by_stride.items():
                 grp.sort()
+                # rf_paste_chunks writes 64 x 64 runs of 64 elements from each offset and checks nothing: the plan is validated here, on the host
+                assert all(0 <= o and o + 63 * sx + 63 * sy + 64 <= flat.numel() for _, o in grp), 'paste plan reaches outside the canvas buffer'
                 ids = np.array([i for i, _ in grp], dtype=np.int64)
                 # (ids on the device too: a batch's `sel` is a device subtraction -- a host -> device copy per batch would be a synchronous one and stall the
                 # software pipeline behind the whole previous batch)
@@ -259,8 +265,9 @@ def refine_scenes(engine, scenes, batch=32, half=True):
     import torch
     dev = engine.device
     out_dtype = torch.float16 if half else torch.float32
-    route = collections.deque()                                      # (assembly, lo, hi, last batch of its scene) per batch in flight
+    route = collections.deque()                                      # (assembly, lo, hi, last batch of its scene, empty scenes right before this scene) per batch in flight
     qs_of, pm_of = [], []                                            # per batch, indexed by refine_stream
+    empties = [0]                                                    # scenes without chunks seen since the last scene with chunks: each yields {} in its place
 
     def batches():
         for sc in scenes:
@@ -268,25 +275,34 @@ def refine_scenes(engine, scenes, batch=32, half=True):
             query_scene = sc[2] if len(sc) > 2 else None
             patch_mask = sc[3] if len(sc) > 3 else None
             n = len(names)
+            if n == 0:                                               # nothing to refine: no batch carries it, the consumer yields {} at its position
+                empties[0] += 1
+                continue
             x = torch.as_tensor(np.asarray(inputs, dtype=np.float32))
             assert x.shape[0] == n, 'one input chunk per name'
             x_pin = x.pin_memory() if dev.type == 'cuda' and not x.is_pinned() else x
             asm = _DeviceAssembly(engine, names, out_dtype)
             spans = [(lo, min(lo + batch, n)) for lo in range(0, n, batch)]
             for lo, hi in spans:
-                route.append((asm, lo, hi, hi == n))
+                route.append((asm, lo, hi, hi == n, empties[0] if lo == 0 else 0))
+                if lo == 0:
+                    empties[0] = 0
                 qs_of.append(query_scene[lo * 64:hi * 64] if query_scene is not None else None)
                 pm_of.append(patch_mask[lo:hi] if patch_mask is not None else None)
                 yield x_pin[lo:hi].to(dev, non_blocking=True)
 
     finished = collections.deque()
     for df in engine.refine_stream(batches(), qs_of, pm_of):
-        asm, lo, hi, last = route.popleft()
+        asm, lo, hi, last, empty_before = route.popleft()
         while finished:                                              # the previous scene: its last transfers ran under the batch that has just been enqueued
             yield finished.popleft().result()
+        for _ in range(empty_before):
+            yield {}
         asm.paste(lo, hi, df)
         if last:
             finished.append(asm)
     while finished:
         yield finished.popleft().result()
+    for _ in range(empties[0]):                                      # empty scenes after the last scene with chunks
+        yield {}
 

@@ -196,6 +196,41 @@ def test_query_count_check_deferred_mode(tmp_path):
         assert r[k].startswith('a|b|c|refused') and '[5, 6, 6]' in r[k]
 
 
+def _both_seen_worker(rank, world, port, out_dir):
+    for p in (str(REPO), str(REPO / 'retrieval-fuse_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rfuse.database import QueryCountCheck, make_host_group
+    chk = QueryCountCheck(make_host_group(None))
+    log = []
+    try:
+        for nq in (6, 5, 5):                         # every rank has now used both counts; the last call was 5
+            chk.post(nq)
+        log.append('warm' if chk.pending is not None else 'warm-waited')
+        chk.post(6 if rank == 0 else 5)              # rank 0 goes back to 6 (a SEEN count, but not its previous one): must wait and refuse at once
+        log.append('posted')
+        chk.flush()                                  # PatchDatabase.check(): the ranks whose count did not change learn of it here, before any host sync
+        log.append('flushed')
+    except ValueError as e:
+        log.append('refused: ' + str(e))
+    Path(out_dir, f'rank{rank}.txt').write_text('|'.join(log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_count_check_both_counts_seen_but_different(tmp_path):
+    """with 'wait only for a never-seen count' two ranks that had both used 6 and 5 walked into mismatched device collectives.  Now a rank
+    whose count differs from its own previous call waits and refuses before enqueuing; its peers (count unchanged, deferred) are told by check()."""
+    world = 2
+    mp.spawn(_both_seen_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [(tmp_path / f'rank{k}.txt').read_text() for k in range(world)]
+    assert r[0].startswith('warm|refused') and '[6, 5]' in r[0], r
+    assert r[1].startswith('warm|posted|refused') and '[6, 5]' in r[1], r
+
+
 def test_shard_bounds_cover_rows_exactly():
     sys.path.insert(0, str(REPO / 'retrieval-fuse_amd'))
     from rfuse.database import shard_bounds

@@ -525,12 +525,20 @@ def test_scene_driver_matches_chunkwise_refinement(gpu):
     ref2 = scene.refine_scene(eng, names2, chunks2, batch=4, assemble_on_device=False)
     assert list(both) == ['sceneR__room0', 'sceneQ__room0'] and all(np.array_equal(both[k], ref2[k]) for k in both)
     # many scenes through ONE pipelined stream (refine_scenes: a scene is handed out while the next one is being refined): each equals its own refine_scene call
-    seq = [(names, chunks), (names2, chunks2), (names[:2], chunks[:2]), (names, chunks)]
+    # (scenes without chunks -- first, in the middle, twice in a row, last -- yield {} at their position: ADVICE r4, the results must stay zip-able with the scenes)
+    none = ([], np.zeros((0, 8, 8, 8), np.float32))
+    seq = [none, (names, chunks), (names2, chunks2), none, none, (names[:2], chunks[:2]), (names, chunks), none]
     streamed = list(scene.refine_scenes(eng, iter(seq), batch=3))
     assert len(streamed) == len(seq)
     for (nm, ch), got in zip(seq, streamed):
+        if not len(nm):
+            assert got == {}
+            continue
         want = scene.refine_scene(eng, nm, ch, batch=3)
         assert list(got) == list(want) and all(np.array_equal(got[k], want[k]) for k in want)
+    # a negative origin would be an offset in front of the canvas buffer on the device: refused when the scene is laid out
+    with pytest.raises(ValueError, match='negative origin'):
+        scene.refine_scene(eng, ['sceneN__room0__-64_0_0', 'sceneN__room0__0_0_0'], chunks[:2], batch=2)
 
 
 @pytest.mark.parametrize('cfg_name,B', [('C3', 8), ('C4', 4)])
