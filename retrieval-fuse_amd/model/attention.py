@@ -1,5 +1,7 @@
 """Patch attention -- MI355X-native stand-ins for the reference's model/attention.py (same names, constructor
-arguments, ``state_dict`` keys incl. the unused-but-serialised sig_scale / sig_shift).  Inference only.
+arguments, ``state_dict`` keys incl. the unused-but-serialised sig_scale / sig_shift).  The no-grad route below is the
+hot path; with grad enabled and inputs that require it the modules take rfuse/autograd.py (HIP kernels for the Linear layers,
+plain differentiable torch ops for the per-row weights and the blend: the N4 training slice).
 
   AttentionFeatureEncoder  = 4 x rf_linear (fp32 MFMA GEMM, LeakyReLU(0.01) fused)          reference :29-46
   AttentionBlock.forward   = theta/phi encoders + rf_attn_fuse                               reference :84-113

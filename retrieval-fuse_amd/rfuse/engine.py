@@ -53,8 +53,8 @@ class RefinementEngine:
             self.decoder = rf_model.get_decoder(config)
             self.retrieval_backbone = rf_model.get_retrieval_backbone(config)
             self.patched_attention_block = rf_model.get_attention_block(config)
-            self.fenc_input, _ = rf_model.get_retrieval_networks(config['retrieval_model'])
-        for m in self.modules().values():
+            self.fenc_input, self.fenc_target = rf_model.get_retrieval_networks(config['retrieval_model'])
+        for m in list(self.modules().values()) + ([self.fenc_target] if self.fenc_target is not None else []):
             m.to(self.device).eval()
         self.database = database
         self._side_streams = {}          # one helper stream per caller stream (several batches may be in flight)
@@ -67,6 +67,21 @@ class RefinementEngine:
     def load_state_dicts(self, sds):
         for name, sd in sds.items():
             self.modules()[name].load_state_dict(sd)
+
+    def load_checkpoints(self, refinement_ckpt=None, retrieval_ckpt=None):
+        """The reference's checkpoint hand-over (trainer/train_refinement.py:295-306, util/retrieval.py:224-225 via util/misc.py:23-36): Lightning-shaped
+        ``{'state_dict': {'unet_backbone.network.0...': ..., 'decoder...': ..., 'retrieval_backbone...': ..., 'patched_attention_block...': ...}}`` for the
+        refinement networks, ``{'state_dict': {'fenc_input.layers.0...': ..., 'fenc_target...': ...}}`` for the patch encoders (``fenc_target`` embeds
+        database patches: ``PatchDatabase.build(config, engine.fenc_target, ...)``).  Paths or loaded checkpoints; strict: a missing or unexpected key
+        raises.  -> the attribute names loaded."""
+        from . import checkpoint
+        loaded = []
+        if refinement_ckpt is not None:
+            loaded += checkpoint.load_prefixed(self.modules(), refinement_ckpt, checkpoint.REFINEMENT_PREFIXES, self.device)
+        if retrieval_ckpt is not None:
+            loaded += checkpoint.load_prefixed({'fenc_input': self.fenc_input, 'fenc_target': self.fenc_target}, retrieval_ckpt,
+                                               checkpoint.RETRIEVAL_PREFIXES, self.device)
+        return loaded
 
     # ---------------------------------------------------------------------------------------------- stages
     @_on_engine_device

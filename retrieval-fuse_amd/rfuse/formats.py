@@ -8,7 +8,9 @@ composed retrievals written by either code base are readable by the other.
   compose/<scene>.npz 'arr_0' = [K,64,64,64] float32 retrieval volumes                (util/retrieval.py:248)
   patch names         '<scene>--x0_x1_y0_y1_z0_z1', 4-digit zero padded, PADDED extents (dataset/scene.py:169-177)
 
-Host-side numpy only; nothing here is on the hot path.
+The format helpers are host-side numpy.  ``create_dictionary`` / ``retrieval_mapping`` / ``compose_scene`` / ``retrievals_to_disk`` drive the DEVICE path
+(query encoder, exact top-2K, demotion, patch gather: the same launches the engine's online step uses) and write the reference's files from it -- the
+reference's offline ``util/retrieval.py --mode map`` / ``--mode compose`` (:210-248).
 """
 import json
 from pathlib import Path
@@ -85,3 +87,118 @@ def save_compose(retrievals_dir, scene, volumes):
 
 def load_compose(retrievals_dir, scene):
     return np.load(Path(retrievals_dir) / 'compose' / f'{scene}.npz')['arr_0']
+
+
+# ------------------------------------------------------------------------------------------------ the device path -> the reference's files
+def create_dictionary(config, fenc_target, volumes, scene_names, tree_path, device, patch_mask=None):
+    """The reference's ``create_dictionary`` (util/retrieval.py:29-48) on the device: the 64 target windows of every scene chunk ``volumes[s]`` ([S,64,64,64] raw)
+    embedded by ``fenc_target`` + the sentinel row -> ``<tree_path>/database.npy`` and ``index.json`` (position in ``scene_names`` = scene_idx) -> the
+    PatchDatabase over the same rows (resident in HBM, ready to be queried).  The FLANN index file the reference also writes (:49-55) has no counterpart:
+    the search here is exact."""
+    from .database import PatchDatabase, build_database_rows
+    if len(scene_names) != len(volumes):
+        raise ValueError('one scene name per scene chunk (%d names, %d volumes)' % (len(scene_names), len(volumes)))
+    emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
+    save_database(tree_path, meta.cpu().numpy(), emb.cpu().numpy(), scene_names)
+    return PatchDatabase(emb, meta, volumes, device)
+
+
+def _per_chunk(scene_names, patch_size, context):
+    return [n for scene in scene_names for n in chunk_patch_names(scene, patch_size, context)]
+
+
+def retrieval_mapping(database, q, scene_names, K, index=None, ignore_patches_from_source=False, patch_mask=None, patch_size=16, context=8):
+    """``RetrievalInterface.get_retrieval_mapping`` after the feature extraction (util/retrieval.py:184-187 -> :127-135 -> flann_knn_worker :87-100), on the
+    device: ``q`` [n*64, latent] unit query embeddings of the 64 patches of each of the n chunks ``scene_names`` (device tensor, the engine's
+    ``embed_queries`` order = the reference's extent enumeration) -> top-2K -> same-scene demotion when ``ignore_patches_from_source`` and the query's scene
+    is in ``index`` (the database's index.json list; :94-97) -> first K -> {patch name: [K,8] float32 rows [scene_idx, box6, dist]}.
+    ``patch_mask`` [n,64] bool: the dataset's occupancy filter -- dropped patches are no dataset items, so they are absent from the mapping
+    (dataset/patched_scene_dataset.py:28-32)."""
+    import torch
+    n = len(scene_names)
+    if q.shape[0] != n * 64:
+        raise ValueError('%d query rows for %d chunks of 64 patches' % (q.shape[0], n))
+    query_scene = None
+    if ignore_patches_from_source:
+        if index is None:
+            raise ValueError('ignore_patches_from_source needs the database index (the list of index.json)')
+        pos = {name: i for i, name in reversed(list(enumerate(index)))}          # list.index semantics: the first occurrence
+        per_chunk = np.array([pos.get(s, -1) for s in scene_names], dtype=np.int32)
+        query_scene = torch.from_numpy(np.repeat(per_chunk, 64)).to(q.device)
+    keep = None
+    if patch_mask is not None:
+        keep = torch.as_tensor(patch_mask).reshape(-1).to(q.device, torch.bool).contiguous()
+    meta, dist, _ = database.retrieve(q, K, query_scene, keep)
+    database.check()
+    names = _per_chunk(scene_names, patch_size, context)
+    mapping = mapping_to_dict(names, meta.cpu().numpy(), dist.cpu().numpy())
+    if patch_mask is not None:
+        flags = np.asarray(torch.as_tensor(patch_mask).cpu()).reshape(-1)
+        mapping = {nm: row for nm, row, f in zip(names, mapping.values(), flags) if f}
+    return mapping
+
+
+def compose_scene(database, mapping, scene, K, trunc_fill, trunc_ratio=1.0, patch_size=16, context=8, no_overlap=True):
+    """``create_retrieval_from_mapping`` (util/retrieval.py:145-164) for one 64^3 scene chunk on the device: the K retrieval volumes [K,64,64,64] float32
+    (numpy), raw values (times ``trunc_ratio`` = query trunc / database trunc, :159).  Patches absent from ``mapping`` (occupancy filter) and sentinel hits
+    (scene_idx < 0, :157-158) keep the truncation fill (:148)."""
+    import torch
+    from . import ops
+    names = chunk_patch_names(scene, patch_size, context)
+    rows = np.zeros((64, K, 7), dtype=np.int32)
+    rows[:, :, 0] = -1
+    for p, nm in enumerate(names):
+        if nm in mapping and mapping[nm] is not None:
+            rows[p] = np.asarray(mapping[nm])[:K, :7].astype(np.int32)
+    meta = torch.from_numpy(rows).to(database.device)
+    out = ops.gather_patches(database.volumes, meta, 1, K, trunc_fill, trunc_ratio, 0.0, 1.0, layout=0, no_overlap=no_overlap)
+    return out[0].cpu().numpy()
+
+
+def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=32):
+    """The reference's ``retrievals_to_disk`` (util/retrieval.py:210-248) driven by the device path.
+
+    ``splits``: {'train': (scene_names, input_chunks[, patch_mask]), 'val': (...)} -- ``input_chunks`` [n,S,S,S] raw low-resolution chunks (one per scene
+    name: a dataset "scene" is a 64^3 chunk, dataset/scene.py), ``patch_mask`` [n,64] the occupancy filter or None.  ``engine``: a RefinementEngine whose
+    ``fenc_input`` holds the retrieval checkpoint and whose ``database`` is the dictionary (``create_dictionary`` / ``PatchDatabase``); ``index``: the
+    database's scene-name list (index.json), needed for the train split's same-scene demotion.
+
+      mode 'map'      query embeddings (engine.embed_queries) -> ``retrieval_mapping`` -> ``map_train.npy`` with ignore_patches_from_source=True (:233-235),
+                      ``map_val.npy`` with False (:236-238)
+      mode 'compose'  reads the two map files back and writes ``compose/<scene>.npz`` for every scene of both splits (:239-248)
+
+    -> the list of files written."""
+    import torch
+    cfg = engine.config
+    K = cfg['K']
+    g = cfg['query_geometry']
+    ps, ctx = g['patch_size_target'], g['patch_context_target']
+    retrievals_dir = Path(retrievals_dir)
+    written = []
+    if mode == 'map':
+        retrievals_dir.mkdir(parents=True, exist_ok=True)
+        for split, ignore in (('train', True), ('val', False)):
+            if split not in splits:
+                continue
+            names, chunks = splits[split][0], np.asarray(splits[split][1], dtype=np.float32)
+            mask = splits[split][2] if len(splits[split]) > 2 else None
+            mapping = {}
+            for lo in range(0, len(names), batch):
+                hi = min(lo + batch, len(names))
+                q = engine.embed_queries(torch.from_numpy(chunks[lo:hi]).to(engine.device))
+                mapping.update(retrieval_mapping(engine.database, q, names[lo:hi], K, index, ignore, None if mask is None else np.asarray(mask)[lo:hi], ps, ctx))
+            save_mapping(retrievals_dir / ('map_%s.npy' % split), mapping)
+            written.append(retrievals_dir / ('map_%s.npy' % split))
+    elif mode == 'compose':
+        from .configs import truncations
+        _, trunc_t = truncations(cfg)
+        for split in ('train', 'val'):
+            if split not in splits:
+                continue
+            mapping = load_mapping(retrievals_dir / ('map_%s.npy' % split))
+            for scene in splits[split][0]:
+                save_compose(retrievals_dir, scene, compose_scene(engine.database, mapping, scene, K, trunc_t, 1.0, ps, ctx))
+                written.append(retrievals_dir / 'compose' / ('%s.npz' % scene))
+    else:
+        raise ValueError("mode must be 'map' or 'compose' (the reference's 'evaluate' computes IoU / Chamfer metrics: out of scope)")
+    return written

@@ -1239,7 +1239,12 @@ def gather_rows(src, idx):
     return out
 
 
-def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, std, layout):
+def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, std, layout, no_overlap=True):
+    """create_retrieval_from_mapping's copy loop (reference util/retrieval.py:145-164) for patch grids WITHOUT overlap (stride == patch size: every shipped
+    config, dataset/patched_scene_dataset.py:113-115), where the branch at :156 always copies.  The overlapping branch (a later patch overwrites a voxel only
+    if its distance is below the mean stored distance of its box: an order-dependent reduction) is not built and is refused, not assumed."""
+    if not no_overlap:
+        raise NotImplementedError('gather_patches: only the no_overlap branch of create_retrieval_from_mapping (util/retrieval.py:156) is built')
     _req(db_volumes, 'db_volumes'), _req(meta, 'meta', torch.int32)
     dev = db_volumes.device
     if layout == 1:

@@ -26,6 +26,15 @@ def golden_dir():
     return REPO / 'tests' / 'golden'
 
 
+@pytest.fixture(scope='session')
+def gpu():
+    """cuda:0, or skip (test modules with their own ``gpu`` fixture shadow this one)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    return torch.device('cuda:0')
+
+
 @pytest.fixture(autouse=True)
 def poison_gpu_memory(request):
     """Before every GPU test: fill the caching allocator's free memory with NaN bit patterns, so that `torch.empty` workspaces and

@@ -158,3 +158,100 @@ def test_scene_driver_recomposition_matches_reference_golden():
     assert chunks.shape == (4, 8, 8, 8) and names[0] == 'sceneZ__room0__0_0_0' and names[-1] == 'sceneZ__room0__64_0_64'
     back = scene.combine_chunks(names, list(chunks), '3DFront', scale_factor=8, chunk_size=8, trunc_val=-1.0)['sceneZ__room0']
     assert np.array_equal(back[:16, :8, :12], low) and (back[:, :, 12:] == -1.0).all()
+
+
+# ------------------------------------------------------------------------------------------------ N2: the device path writes the reference's files
+@pytest.mark.gpu
+def test_device_written_map_and_compose_files_match_reference_golden(gpu, tmp_path):
+    """`formats.retrieval_mapping` / `compose_scene` (device top-2K + demotion + patch gather) -> map_train.npy / map_val.npy / compose/<scene>.npz, read back with
+    load_mapping / load_compose, against tests/golden/retrieval_map_compose.npz: the reference's own flann_knn_worker (exact stand-in for FLANN) with
+    ignore_patches_from_source True / False and create_retrieval_from_mapping (util/retrieval.py:87-100,145-164,233-248)."""
+    from rfuse.database import PatchDatabase
+    fix = helpers.load_fixture('retrieval_map_compose')
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    K, q_scene = cfg['K'], int(fix['q_scene'])
+    db = synthetic.make_database(int(fix['seed']), cfg, int(fix['n_patches']))
+    index = ['scene%03d' % i for i in range(db['n_scenes'])]
+    scene = index[q_scene]
+    pdb = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu)
+    q = torch.from_numpy(fix['queries']).to(gpu)
+    names = formats.chunk_patch_names(scene)
+    for split, ignore in (('train', True), ('val', False)):
+        formats.save_mapping(tmp_path / ('map_%s.npy' % split), formats.retrieval_mapping(pdb, q, [scene], K, index, ignore))
+        back = formats.load_mapping(tmp_path / ('map_%s.npy' % split))
+        assert list(back) == names and back[names[0]].dtype == np.float32 and back[names[0]].shape == (K, 8)
+        rows = np.stack([back[n] for n in names])
+        np.testing.assert_array_equal(rows[..., :7], fix['map_' + split][..., :7])              # scene index + box: exact
+        np.testing.assert_allclose(rows[..., 7], fix['map_' + split][..., 7], rtol=0, atol=1e-6)   # squared L2 distance: the stand-in's float64 brute force
+    # a scene that is NOT in the database index is not demoted even with ignore_patches_from_source (util/retrieval.py:95)
+    other = formats.retrieval_mapping(pdb, q, ['elsewhere'], K, index, True)
+    np.testing.assert_array_equal(np.stack(list(other.values()))[..., :7], fix['map_val'][..., :7])
+    # compose from the files: train from the device-written map; val from the fixture's map with its injected sentinel hit (the idx < 0 branch)
+    train_map = formats.load_mapping(tmp_path / 'map_train.npy')
+    formats.save_compose(tmp_path, scene, formats.compose_scene(pdb, train_map, scene, K, trunc_t))
+    got = formats.load_compose(tmp_path, scene)
+    assert got.shape == (K, 64, 64, 64) and got.dtype == np.float32 and helpers.sha(got) == str(fix['compose_train_sha'])
+    np.testing.assert_array_equal(got[:, ::4, ::4, ::4], fix['compose_train_sub'])
+    val_s = {n: fix['map_val_sentinel'][i] for i, n in enumerate(names)}
+    assert helpers.sha(formats.compose_scene(pdb, val_s, scene, K, trunc_t)) == str(fix['compose_val_sha'])
+    # occupancy filter: dropped patches are absent from the mapping file and keep the truncation fill in the composed volumes
+    keep = fix['patch_keep']
+    masked = formats.retrieval_mapping(pdb, q, [scene], K, index, False, patch_mask=keep[None])
+    assert list(masked) == [n for n, f in zip(names, keep) if f]
+    masked_s = {n: val_s[n] for n in masked}
+    assert helpers.sha(formats.compose_scene(pdb, masked_s, scene, K, trunc_t)) == str(fix['compose_masked_sha'])
+    with pytest.raises(NotImplementedError, match='no_overlap'):
+        formats.compose_scene(pdb, val_s, scene, K, trunc_t, no_overlap=False)
+
+
+@pytest.mark.gpu
+def test_retrievals_to_disk_from_chunks_matches_oracle(gpu, tmp_path):
+    """The whole offline pipeline from raw chunks on the device -- create_dictionary (fenc_target on the scene chunks -> database.npy / index.json) ->
+    retrievals_to_disk('map') (fenc_input -> top-2K -> demotion -> map files) -> retrievals_to_disk('compose') -- against the oracle's restatement of the
+    same stages on the database rows that were written."""
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C1')
+    trunc_i, trunc_t = rf_configs.truncations(cfg)
+    K = cfg['K']
+    eng = RefinementEngine(cfg, gpu, None)
+    sds = {n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 40 + i) for i, (n, m) in enumerate(eng.modules().items())}
+    eng.load_state_dicts(sds)
+    fenc_target, sd_t = _target_sd(cfg, 6)
+    eng.fenc_target.load_state_dict(sd_t)
+    scenes = [synthetic.make_chunk(7000 + i, cfg) for i in range(6)]
+    index = ['shape%02d' % i for i in range(6)]
+    volumes = np.stack([c['target_raw'] for c in scenes])
+    eng.database = formats.create_dictionary(cfg, eng.fenc_target, volumes, index, tmp_path / 'tree', gpu)
+    meta, emb, index_back = formats.load_database(tmp_path / 'tree')
+    assert index_back == index and emb.shape == (6 * 64 + 1, 64) and meta[-1, 0] == -1
+    # train = the database's own scenes (every query has same-scene rows to demote), val = two new scenes, one with an occupancy filter
+    val_chunks = [synthetic.make_chunk(7100 + i, cfg) for i in range(2)]
+    mask = np.ones((2, 64), dtype=bool)
+    mask[1, ::3] = False
+    splits = {'train': (index, np.stack([c['input_raw'] for c in scenes])),
+              'val': (['new00', 'new01'], np.stack([c['input_raw'] for c in val_chunks]), mask)}
+    out = tmp_path / 'retrievals'
+    written = formats.retrievals_to_disk('map', eng, out, splits, index=index, batch=4)
+    assert [p.name for p in written] == ['map_train.npy', 'map_val.npy']
+    written = formats.retrievals_to_disk('compose', eng, out, splits)
+    assert len(written) == 8 and all(p.exists() for p in written)
+    for split, (names, chunks, *rest) in splits.items():
+        mapping = formats.load_mapping(out / ('map_%s.npy' % split))
+        keep = rest[0] if rest else np.ones((len(names), 64), dtype=bool)
+        assert len(mapping) == int(keep.sum())
+        for c, scene in enumerate(names):
+            with torch.no_grad():
+                q = refpath.embed_queries(refpath.extract_query_windows(chunks[c], cfg, trunc_i), sds['fenc_input'], cfg).numpy()
+            idx, dist = refpath.knn_exact(q, emb, 2 * K)
+            qs = index.index(scene) if (split == 'train' and scene in index) else -1
+            want = refpath.demote_same_scene(refpath.mapping_rows(idx, dist, meta), np.full(64, qs), K)
+            pn = formats.chunk_patch_names(scene)
+            got = np.stack([mapping[n] if keep[c, p] else want[p] for p, n in enumerate(pn)])
+            # neighbour lists: the device's fp32 query embeddings differ from the oracle's by ~1e-7, so a near-tie may swap -- compare by distance
+            np.testing.assert_allclose(got[..., 7], want[..., 7], rtol=0, atol=5e-6)
+            same = (got[..., :7] == want[..., :7]).all(axis=-1)
+            assert same.mean() >= 0.98
+            vols = formats.load_compose(out, scene)
+            ref = refpath.compose_retrieval(got, volumes, K, trunc_t, patch_keep=keep[c])
+            np.testing.assert_array_equal(vols, ref)
