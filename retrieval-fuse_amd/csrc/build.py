@@ -79,16 +79,19 @@ def check_isa(so=OUT, name=None):
     return len(cos)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, extra_flags=(), objdir=None):
+    """``out`` / ``extra_flags`` / ``objdir``: a development variant of the library (e.g. -DRF_PERSIST_ROUNDS=2) built beside the product one, for same-box A/B
+    runs through RFUSE_LIB (tools/ab_bench.sh); the product build takes none of them."""
     hipcc = _hipcc()
-    objdir = HERE / 'build'
-    objdir.mkdir(exist_ok=True)
+    OUT = Path(out) if out is not None else globals()['OUT']
+    objdir = Path(objdir) if objdir is not None else HERE / 'build'
+    objdir.mkdir(exist_ok=True, parents=True)
     headers = [HERE / 'common.h', HERE / 'conv_box.h', HERE / 'conv_split_common.h', HERE / 'attn_row.h', HERE.parents[1] / 'include' / 'rfuse.h']
 
     def compile_one(src):
         obj = objdir / (src.replace('.hip', '.o'))
         if force or _stale(obj, [HERE / src, HERE / 'build.py'] + headers):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', str(HERE / src), '-o', str(obj)]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + EXTRA_FLAGS.get(src, []) + ['-c', str(HERE / src), '-o', str(obj)]
             if verbose:
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True)
@@ -105,7 +108,7 @@ def build(force=False, verbose=False):
             print(' '.join(cmd))
         try:
             subprocess.run(cmd, check=True)
-            check_isa(tmp_out, name=OUT.name)
+            check_isa(tmp_out, name='librfuse_hip.so')
         except BaseException:
             tmp_out.unlink(missing_ok=True)
             OUT.unlink(missing_ok=True)

@@ -48,6 +48,29 @@ static inline bool rf_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int rf_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int rf_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Workgroups of a PERSISTENT launch (k_conv3_split_zc / _zcm, k_conv3_up_split_boxp: 512 threads, <= 80 KB of LDS, <= 128 VGPRs -> two resident per CU): two per
+// CU of the current device (hipDeviceProp_t::multiProcessorCount, 256 on MI355X -> 512; ADVICE r4: this was a literal 512 in three launchers and in the
+// scratch-slot count), times RF_PERSIST_ROUNDS.  One round = every workgroup resident for the whole launch, a static share of the items each -- and then
+// the launch ends when its UNLUCKIEST workgroup does: inside the pipelined step the other streams' kernels (the chunk-level U-Net's ~40 small launches, the
+// top-k scan) hold a CU for 10-100 us at a time, the workgroup that waits for that CU starts late and still has its full share in front of it (round 5:
+// the U-Net backbone beside the back end cost the step 0.35 ms for ~0.1 ms of work, tools/overlap_parts.py).  With FOUR rounds the workgroups of a late CU's
+// later rounds go to whichever CU is free: same-box A/B of the C2 step 1 / 2 / 4 / 8 rounds = 6.47 / 6.43 / 6.39 / 6.42 ms (tools/abn_bench.sh; 8 pays more
+// prologues -- weights to LDS, first halo image -- than it balances).  The launchers and rf_conv3d_split_pre_pool_presplit_scratch_floats (a scratch
+// slot per workgroup, slot = blockIdx.x) all take the count from here.
+#ifndef RF_PERSIST_ROUNDS
+#define RF_PERSIST_ROUNDS 4
+#endif
+static inline int rf_resident_wgs() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 512;
+    return 2 * prop.multiProcessorCount;
+}
+static inline int rf_persistent_wgs() {
+    static const int resident = rf_resident_wgs();                  // (one device model per process: every MI355X of a node has the same CU count)
+    return resident * RF_PERSIST_ROUNDS;
+}
+
 // wave64 sum reduction; result valid in every lane
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -679,7 +679,9 @@ extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int co
     // channel counts that are not multiples of 8 are padded up with zero channels: taken when at least 3/4 of the slots are real (6, 12, 20, 28, 42 ...)
     if (c1 != 0 || c0 < 6 || 4 * c0 < 3 * rf_round_up(c0, 8) || n <= 0 || cout <= 0 || !rf_is_pow2(edge) || edge < 8 || edge > 128) return 0;
     const int cout16 = rf_round_up(cout, 16);
-    return cout16 <= 32 && rf_conv_use_big(n, edge, cout16);
+    // >= 256 boxes (rf_conv_use_big asks for 1024 workgroups: a chip-filling launch): the chunk-level U-Net's 32 -> 32 @16^3 conv at B = 32 is 256 boxes and took
+    // 0.25 ms of a 1024-workgroup fp32-MFMA launch beside the retrieval path; the box kernel does it in a fraction of that on the F16 cores
+    return cout16 <= 32 && (rf_conv_use_big(n, edge, cout16) || (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 256);
 }
 
 template <int NB, int WPS, bool ONE, bool PADC = false, bool PRE = false>
@@ -879,7 +881,7 @@ extern "C" int rf_conv3d_split_pre_pool_presplit_supported(int cin, int n, int e
     return rf_split_zc_takes(cin, n, edge, cout) && cout % 8 == 0 && next_groups > 0 && cout % next_groups == 0;
 }
 
-extern "C" size_t rf_conv3d_split_pre_pool_presplit_scratch_floats(int cout) { return (size_t)512 * (size_t)(cout > 0 ? cout : 0) * 512; }      // 512 workgroups x [cout][8^3]
+extern "C" size_t rf_conv3d_split_pre_pool_presplit_scratch_floats(int cout) { return (size_t)rf_persistent_wgs() * (size_t)(cout > 0 ? cout : 0) * 512; }      // workgroups x [cout][8^3]
 
 extern "C" int rf_conv3d_split_pre_k3_relu_pool_presplit(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout, float* pool_out,
                                                          double* pool_stats, const float* next_gamma, const float* next_beta, int next_groups, float eps,

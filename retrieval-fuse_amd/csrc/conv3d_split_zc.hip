@@ -703,7 +703,7 @@ int rf_split_zc_launch(const ConvArgs& a, const SplitPreOut& po, hipStream_t str
     auto kern = full ? k_conv3_split_zc<true> : k_conv3_split_zc<false>;
     static RfLdsOptIn opt[2];
     if (int rc = opt[full].ensure(reinterpret_cast<const void*>(kern), ZC_LDS_BYTES, "rf_conv3d_split_pre_k3_relu")) return rc;
-    const int wgs = a.n < 512 ? a.n : 512;                            // two workgroups per CU, whole samples each
+    const int wgs = a.n < rf_persistent_wgs() ? a.n : rf_persistent_wgs();      // two workgroups per CU, whole samples each
     const int per = (a.n + wgs - 1) / wgs;
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.n + per - 1) / per)), dim3(512), ZC_LDS_BYTES, stream, a, po, per);
     RF_CHECK_LAUNCH("rf_conv3d_split_pre_k3_relu");
@@ -724,7 +724,7 @@ static int zcm_launch(const ConvArgs& a, const SplitPreOut& po, hipStream_t stre
     static RfLdsOptIn opt;
     if (int rc = opt.ensure(reinterpret_cast<const void*>(kern), ZM_LDS_BYTES, who)) return rc;
     const long long boxes = (long long)a.n * (a.edge / 8) * (a.edge / 8) * (a.edge / 8);
-    const int wgs = 512;                                              // two workgroups per CU
+    const int wgs = rf_persistent_wgs();                              // two workgroups per CU
     const unsigned cob_blocks = (unsigned)(a.cout16 / 16);
     const int per = (int)((boxes * cob_blocks + wgs - 1) / wgs);
     hipLaunchKernelGGL(kern, dim3((unsigned)((boxes + per - 1) / per), cob_blocks), dim3(512), ZM_LDS_BYTES, stream, a, po, per, (int)boxes);

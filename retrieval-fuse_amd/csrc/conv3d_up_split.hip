@@ -1193,7 +1193,9 @@ static bool up_split_boxskip_takes(int c0, int c1, int n, int edge, int cout) {
 
 static bool up_split_box_takes(int c0, int c1, int n, int edge, int cout) {
     if (c0 != 0 || c1 <= 0 || c1 % 8 || c1 > 8 * US_MAX_CGB || cout <= 0 || cout > 32 || !rf_is_pow2(edge) || edge < 16 || edge > 128) return false;
-    return (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 1024;        // enough boxes to fill the chip
+    // >= 256 boxes: the launch need not fill the chip -- the chunk-level U-Net runs on a side stream beside the retrieval path -- but below that the
+    // position-major fp32 kernels' latency wins (B = 32 chunks: the 16^3 stage is 256 boxes, 0.058 ms as k_conv3_up on the fp32 matrix path)
+    return (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 256;
 }
 
 extern "C" int rf_conv3d_up_split_stats_tiles(int c0, int c1, int n, int edge, int cout) {
@@ -1225,7 +1227,7 @@ static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, in
 extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                               const void* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts), 4^3 samples (n >= 1024) or 8^3 boxes of edge >= 16 volumes (without a skip source: c1 <= 64, <= 32 couts, >= 1024 boxes; with one: c1 <= 96, <= 96 couts, >= 512 boxes); c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_up_split_k3_gn_relu: takes whole 8^3 samples (n >= 256, c1 <= 64, 33..64 couts), 4^3 samples (n >= 1024) or 8^3 boxes of edge >= 16 volumes (without a skip source: c1 <= 64, <= 32 couts, >= 256 boxes; with one: c1 <= 96, <= 96 couts, >= 512 boxes); c0 and c1 in multiples of 8 (got c0=%d c1=%d n=%d edge=%d cout=%d)",
                c0, c1, n, edge, cout);
     RF_REQUIRE((c0 == 0 || src0) && src1 && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu: null pointer");
     UpSplitArgs a;
@@ -1246,7 +1248,7 @@ static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, in
 #define RF_BOXP(I_, NBG_, CGO_)                                                                                                      \
             do {                                                                                                                     \
                 if (int rc = opt_p[I_].ensure(reinterpret_cast<const void*>(k_conv3_up_split_boxp<NBG_, CGO_>), UP_LDS_BYTES, "rf_conv3d_up_split_k3_gn_relu_ch8")) return rc; \
-                hipLaunchKernelGGL((k_conv3_up_split_boxp<NBG_, CGO_>), dim3(512), dim3(512), UP_LDS_BYTES, (hipStream_t)stream, a, edge, (int)boxes); \
+                hipLaunchKernelGGL((k_conv3_up_split_boxp<NBG_, CGO_>), dim3((unsigned)rf_persistent_wgs()), dim3(512), UP_LDS_BYTES, (hipStream_t)stream, a, edge, (int)boxes); \
             } while (0)
             if (c1 == 16 && cout == 16) RF_BOXP(0, 2, 2);
             else if (c1 == 16) RF_BOXP(1, 2, 1);
@@ -1345,7 +1347,7 @@ extern "C" int rf_conv3d_up_split_ch8_supported(int c0, int c1, int n, int edge,
 extern "C" int rf_conv3d_up_split_k3_gn_relu_ch8(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                                   const void* w_packed, int cout, float* out_ch8, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_ch8_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_up_split_k3_gn_relu_ch8: takes the box form of rf_conv3d_up_split_k3_gn_relu (no skip source, >= 1024 boxes) with cout in eights (got c0=%d c1=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_up_split_k3_gn_relu_ch8: takes the box form of rf_conv3d_up_split_k3_gn_relu (no skip source, >= 256 boxes) with cout in eights (got c0=%d c1=%d n=%d edge=%d cout=%d)",
                c0, c1, n, edge, cout);
     RF_REQUIRE(src1 && gn_affine && w_packed && out_ch8, RF_E_INVALID, "rf_conv3d_up_split_k3_gn_relu_ch8: null pointer");
     UpSplitArgs a;

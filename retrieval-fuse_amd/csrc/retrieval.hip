@@ -720,7 +720,7 @@ static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2,
 
 // Which scan (measured on MI355X, tools/topk_bench.py; k2 = 8): 2048 queries -- 50 k rows: VALU 0.47 ms / MFMA 0.59 ms, 125 k: 0.92 / 0.79,
 // 1 M: 6.3 / 2.7;  16384 queries (8 ranks' queries against one shard) -- 50 k: 2.8 / 2.0, 125 k: 6.4 / 3.4.
-static bool use_mfma_scan(int nq, int64_t n) { return n >= 100000 || (nq >= 8192 && n >= 40000); }
+static bool use_mfma_scan(int nq, int64_t n) { return n >= 40000; }
 
 // workspace: [per-slice lists: 64 x nq x k2p keys][sample pass: nq x k2p (dist f32, idx i64)]
 static int topk_impl(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
@@ -751,7 +751,7 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         const float* hd = rows_img + (size_t)rf_rows32(n) * RF_DIM;
         // sample pass: exact top-k2p of the shard's first n/64 rows (1 k..16 k, whole 64-row blocks) with the VALU scan; the
         // blocked view of the first rows of the shard IS the blocked view of the sample
-        long long sample = n / 64;
+        long long sample = n / 8;
         if (sample < 1024) sample = 1024;
         if (sample > 16384) sample = 16384;
         sample = (sample + 63) / 64 * 64;

@@ -133,5 +133,5 @@ class RetrievalUNetBackbone(nn.Module):
         self.nf = nf
         self.network = _unet(nf, nf, layer_order, num_levels, f_maps=f_maps, trim=1)
 
-    def forward(self, x):
-        return self.network(x)
+    def forward(self, x, after_encoders=None):
+        return self.network(x, after_encoders=after_encoders) if after_encoders is not None else self.network(x)

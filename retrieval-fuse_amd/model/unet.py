@@ -390,7 +390,8 @@ class UNet3D(nn.Module):
                                     conv_layer_order=layer_order, num_groups=num_groups))
         self.decoders = nn.ModuleList(decoders)
 
-    def forward(self, x):
+    def forward(self, x, after_encoders=None):
+        """``after_encoders``: optional callable run between the encoder and the decoder launches (the engine issues the next batch's front end there)"""
         feats = []
         n_enc, n_dec = len(self.encoders), len(self.decoders)
         pooled = None
@@ -406,6 +407,8 @@ class UNet3D(nn.Module):
                 x, pooled = encoder(x, prepooled=pooled, pool='also' if is_skip else 'only', next_block=nxt if isinstance(nxt, DoubleConv) else None)
             feats.insert(0, x)
         feats = feats[1:]                                            # model/unet.py:500-504
+        if after_encoders is not None:
+            after_encoders()
         for decoder, skip in zip(self.decoders, feats):              # zip truncates, model/unet.py:507
             x = decoder(skip, x)
         return x

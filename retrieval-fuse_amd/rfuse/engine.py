@@ -59,6 +59,7 @@ class RefinementEngine:
         self.database = database
         self._side_streams = {}          # one helper stream per caller stream (several batches may be in flight)
         self.serial = False              # True: keep the U-Net backbone on the caller's stream (per-kernel timing wants no overlap)
+        self.front_at = 'start'          # refine_stream: where the next batch's front end is issued ('start' of this batch's back end | 'decoders')
 
     def modules(self):
         return {'unet_backbone': self.unet_backbone, 'decoder': self.decoder, 'retrieval_backbone': self.retrieval_backbone,
@@ -199,27 +200,42 @@ class RefinementEngine:
         # collected if the consumer breaks out)
         pending = None
         main = None
+        state = {}
+
+        def issue_front(raw, qs, pm, after=None):
+            """front end of one batch on the helper stream; ``after``: an event of the caller's stream it must not start before"""
+            front = self._side_streams.get(('front', main.cuda_stream))
+            if front is None:
+                front = self._side_streams[('front', main.cuda_stream)] = torch.cuda.Stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)                                   # whatever produced `raw` on the caller's stream (and, with `after`, the split point of the back end)
+            front.wait_event(ready)
+            with torch.cuda.stream(front):
+                raw.record_stream(front)
+                x_back, side = self._fork_backbone(self.normalise_input(raw))      # ... the backbone beside the retrieval on its own stream, as in refine()
+                patches, _ = self.retrieve(raw, qs, pm)
+                front.wait_stream(side)
+                done = torch.cuda.Event()
+                done.record(front)
+            return patches, x_back, done
+
         for i, raw in enumerate(batches):
             qs = query_scenes[i] if query_scenes is not None else None
             pm = patch_masks[i] if patch_masks is not None else None
             with torch.cuda.device(self.device), torch.no_grad():
                 if main is None:
                     main = torch.cuda.current_stream(self.device)
-                front = self._side_streams.get(('front', main.cuda_stream))
-                if front is None:
-                    front = self._side_streams[('front', main.cuda_stream)] = torch.cuda.Stream(self.device)
-                ready = torch.cuda.Event()
-                ready.record(main)                                   # whatever produced `raw` on the caller's stream
-                front.wait_event(ready)
-                with torch.cuda.stream(front):
-                    raw.record_stream(front)
-                    x_back, side = self._fork_backbone(self.normalise_input(raw))      # ... the backbone beside the retrieval on its own stream, as in refine()
-                    patches, _ = self.retrieve(raw, qs, pm)
-                    front.wait_stream(side)
-                    done = torch.cuda.Event()
-                    done.record(front)
-                out = self._finish_pipelined(main, *pending) if pending is not None else None
-                pending = (patches, x_back, done)
+                if pending is None or self.front_at == 'start':
+                    nxt = issue_front(raw, qs, pm)
+                    out = self._finish_pipelined(main, *pending) if pending is not None else None
+                else:
+                    # the next batch's front end is issued from INSIDE this batch's back end, behind its encoder launches: it then runs beside the decoder
+                    # stages (MFMA-bound) instead of beside the first encoder layers (VALU / HBM-bound like the front end's own scan and gather)
+                    def mid():
+                        state['nxt'] = issue_front(raw, qs, pm)
+                    out = self._finish_pipelined(main, *pending, after_encoders=mid)
+                    nxt = state.pop('nxt')
+                pending = nxt
                 self._check_database()
             if out is not None:
                 yield out
@@ -228,11 +244,11 @@ class RefinementEngine:
                 out = self._finish_pipelined(main, *pending)
             yield out
 
-    def _finish_pipelined(self, main, patches, x_back, done):
+    def _finish_pipelined(self, main, patches, x_back, done, after_encoders=None):
         main.wait_event(done)
         patches.record_stream(main)
         x_back.record_stream(main)
-        feats = self.retrieval_backbone(patches)
+        feats = self.retrieval_backbone(patches, after_encoders=after_encoders)
         return self._attend_and_decode(x_back, feats, None)
 
     @_on_engine_device

@@ -1,0 +1,44 @@
+"""Dev tool (GPU box): which part of the front end costs the pipelined C2 step its 0.75 ms over the back end alone?  Back end on the main stream with, beside
+it on the helper stream, (a) nothing, (b) the retrieval front (query encoder, top-k, demotion, gather) only, (c) the U-Net backbone only, (d) both."""
+import sys, time
+from pathlib import Path
+REPO = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(REPO), str(REPO / 'retrieval-fuse_amd')]
+import numpy as np, torch
+import bench
+from rfuse import configs, synthetic, ops
+from rfuse.database import PatchDatabase
+from rfuse.engine import RefinementEngine
+cfg = configs.get_config('C2'); B = 32
+device = torch.device('cuda:0')
+torch.manual_seed(0)
+emb, meta, vols = bench.synthetic_database(cfg, cfg['db_patches'], device)
+eng = RefinementEngine(cfg, device, PatchDatabase(emb, meta, vols, device, 0, 1))
+batches = [torch.from_numpy(np.stack([synthetic.make_chunk(10_000 + r * B + b, cfg)['input_raw'] for b in range(B)])).to(device) for r in range(4)]
+N = 40
+main = torch.cuda.current_stream(); front = torch.cuda.Stream(device); side = torch.cuda.Stream(device)
+with torch.no_grad():
+    x_in = eng.normalise_input(batches[0]); patches, _ = eng.retrieve(batches[0]); x_back = eng.unet_backbone(x_in)
+    torch.cuda.synchronize()
+    def run(do_retr, do_unet, parts=None):
+        def go():
+            for i in range(N):
+                ev = torch.cuda.Event(); ev.record(main); front.wait_event(ev)
+                with torch.cuda.stream(front):
+                    if do_unet:
+                        side.wait_stream(front)
+                        with torch.cuda.stream(side): eng.unet_backbone(x_in)
+                    if do_retr:
+                        if parts is None: eng.retrieve(batches[i % 4])
+                        else: parts(batches[i % 4])
+                    if do_unet: front.wait_stream(side)
+                    done = torch.cuda.Event(); done.record(front)
+                eng._attend_and_decode(x_back, eng.retrieval_backbone(patches), None)
+                main.wait_event(done)
+        go(); torch.cuda.synchronize(); t0 = time.perf_counter(); go(); torch.cuda.synchronize(); return (time.perf_counter() - t0) / N * 1e3
+    def only_embed(x): eng.embed_queries(x)
+    q = eng.embed_queries(batches[0])
+    def only_search(x): eng.database.retrieve(q, eng.K, None, None)
+    for rep in range(3):
+        print('back alone %.3f | + retrieve %.3f | + unet %.3f | + both %.3f | + embed only %.3f | + search only %.3f' % (
+            run(False, False), run(True, False), run(False, True), run(True, True), run(True, False, only_embed), run(True, False, only_search)), flush=True)
