@@ -60,6 +60,7 @@ def parse(argv=None):
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
     ap.add_argument('--kernels-top', type=int, default=8, help='rows of the serial per-kernel table')
     ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank, still run the all-gather + all-to-all + merge protocol over RCCL')
+    ap.add_argument('--half-store', action='store_true', help='keep the replicated voxel store as float16 (the reference\'s own scene precision; same gathered bits, half the bytes)')
     ap.add_argument('--resident-batches', type=int, default=4, help='distinct resident input batches rotated through the timed loop')
     return ap.parse_args(argv)
 
@@ -337,9 +338,9 @@ def kernel_work(name, a, cfg):
     if name == 'rf_attn_blend':
         b, k, c, s, t = a[:5]
         return 'hbm', 4.0 * b * c * s ** 3 * (2 + k), 'bytes'
-    if name == 'rf_gather_patches':
+    if name in ('rf_gather_patches', 'rf_gather_patches_f16'):
         n_scenes, chunks, K = a[:3]
-        return 'hbm', 8.0 * chunks * K * 64 * 4096, 'bytes'
+        return 'hbm', (6.0 if name.endswith('f16') else 8.0) * chunks * K * 64 * 4096, 'bytes'
     if name == 'rf_query_windows':
         b, s, ps, ctx = a[:4]
         return 'hbm', 8.0 * b * (s // ps) ** 3 * (ps + 2 * ctx) ** 3, 'bytes'
@@ -539,7 +540,10 @@ def main():
 
     torch.manual_seed(0)
     emb, meta, vols = synthetic_database(cfg, n_patches, device)
-    database = PatchDatabase(emb, meta, vols, device, rank, world)
+    database = PatchDatabase(emb, meta, vols, device, rank, world, half_store=args.half_store)
+    if args.half_store:
+        del vols
+        vols = database.volumes
     database.force_collectives = force_dist
     collective_events = [] if (world > 1 or force_dist) else None
     eng = RefinementEngine(cfg, device, database)
@@ -755,7 +759,7 @@ def main():
         host_db_ok = n_patches <= 200_000                        # the oracle needs the voxel store on the host (16 GB at 1 M patches)
         if world == 1 and host_db_ok and not (args.no_cpu_baseline and args.no_extras):
             state = state or {n: {k: v.detach().cpu() for k, v in m.state_dict().items()} for n, m in eng.modules().items()}
-            db_host = {'emb': emb.cpu().numpy(), 'meta': meta.numpy(), 'volumes': vols.cpu().numpy()}
+            db_host = {'emb': emb.cpu().numpy(), 'meta': meta.numpy(), 'volumes': vols.float().cpu().numpy()}
             if not args.no_extras:
                 out['parity_max_abs'] = parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev)
             out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(cfg, state, db_host, raws, n_chunks=args.cpu_chunks)

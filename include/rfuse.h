@@ -460,6 +460,13 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
                       float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
                       float* out, void* stream);
 
+/* The same gather from a float16 voxel store [n_scenes][64^3] -- the precision the reference itself holds scenes in (dataset/scene.py:61 np.float16 on
+ * disk, :71 in memory; `get_scene_target` widens, util/retrieval.py:158) -- widened on the fly: the same bits as rf_gather_patches on the widened store
+ * for half the bytes read (PatchDatabase(half_store=True): 1 M patches = 8.2 GB per GPU instead of 16.4 GB). */
+int rf_gather_patches_f16(const void* db_volumes_f16, int64_t n_scenes, const int32_t* meta, int chunks, int K,
+                          float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
+                          float* out, void* stream);
+
 /* out[m][width] = src[idx[m]][width] (width % 4 == 0): row gather used to fetch cached, query-independent retrieval
  * backbone features of database patches (an optional serving mode; the reference recomputes them,
  * trainer/train_refinement.py:112).  idx[m] < 0 ("no neighbour") or >= n_src selects row n_src-1, where the database keeps

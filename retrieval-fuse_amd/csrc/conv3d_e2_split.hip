@@ -21,7 +21,6 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int E2_MT = 64;                                    // samples per workgroup
 constexpr int E2_NC = 256;                                   // columns per workgroup (32 couts)
 constexpr int E2_STEP_H8 = (E2_NC / 16) * 2 * 64;            // h8 elements of one k-step of one n-chunk: 2048 = 32 KB
 constexpr int E2_LDS_BYTES = 2 * E2_STEP_H8 * 16;            // 65,536
@@ -86,15 +85,19 @@ struct E2Args {
     int cin, cout, n;
 };
 
-template <int V>      // voxels per volume: 8 (edge 2) or 1 (edge 1)
+// MT: samples per workgroup.  64: 4 waves as 2 (32 samples) x 2 (128 columns).  32: 4 waves x 64 columns, all 32 samples -- twice the workgroups for launches
+// that would otherwise put ONE workgroup (one wave per SIMD) on a CU: the k-step chain (B block global -> registers -> LDS -> barrier -> MFMAs) is a
+// latency chain, and a lone wave per SIMD has nothing to run while it waits (64 -> 64 on 8192 samples: 256 workgroups, 61 us for 6 us of MFMAs).
+template <int V, int MT>      // V: voxels per volume: 8 (edge 2) or 1 (edge 1)
 __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
+    constexpr int WN = MT == 64 ? 2 : 4, NJ = 16 / WN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     h8* bufs = reinterpret_cast<h8*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = MT == 64 ? wave >> 1 : 0, wn = MT == 64 ? wave & 1 : wave;
     const int li = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * E2_MT, chunk = blockIdx.y;
+    const int n0 = blockIdx.x * MT, chunk = blockIdx.y;
     const int cin = a.cin, cout = a.cout, ksteps = V == 8 ? cin >> 2 : (cin + 31) >> 5;
     const h8* __restrict__ wsrc = a.wp + (size_t)chunk * ksteps * E2_STEP_H8 + tid;
 
@@ -108,11 +111,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
         xrow[i] = a.src + (V == 8 ? ((size_t)sm * cin + kg) * 8 : (size_t)sm * cin + kg * 8);
         arow[i] = a.affine + (V == 8 ? (size_t)sm * cin + kg : (size_t)sm * cin + kg * 8);
     }
-    f32x4 hi[2][8], lo[2][8];
+    f32x4 hi[2][NJ], lo[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < NJ; ++j) { hi[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     float4 xa[2][2], af[2];                                       // edge 2: the raw row and its affine, converted after the MFMAs they were loaded under
     h8 nah[2], nal[2];                                             // edge 1: converted at once (8 affines per row would not fit beside the accumulators)
@@ -173,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
     for (int s = 0; s < ksteps; ++s) {
         const bool more = s + 1 < ksteps;
         if (more) load_step(s + 1);                                 // in flight under this step's MFMAs
-        const h8* bb = bufs + (s & 1) * E2_STEP_H8 + (wn * 8) * 128 + lane;
+        const h8* bb = bufs + (s & 1) * E2_STEP_H8 + (wn * NJ) * 128 + lane;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const h8 bh = bb[j * 128], bl = bb[j * 128 + 64];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_e2_split(E2Args a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int col = chunk * E2_NC + (wn * 8 + j) * 16 + li;
+        for (int j = 0; j < NJ; ++j) {
+            const int col = chunk * E2_NC + (wn * NJ + j) * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int sm = n0 + (2 * wm + i) * 16 + kg * 4 + r;
@@ -229,18 +232,23 @@ extern "C" int rf_conv3d_e2_split_k3_gn_relu(const float* src, int cin, int n, i
     RF_REQUIRE(rf_conv3d_e2_split_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
                "rf_conv3d_e2_split_k3_gn_relu: takes whole 2^3 volumes (cin a multiple of 4) or 1^3 volumes, cin >= 8, at least 16 samples (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
     RF_REQUIRE(src && gn_affine && w_packed && out, RF_E_INVALID, "rf_conv3d_e2_split_k3_gn_relu: null pointer");
-    static RfLdsOptIn opt8, opt1;
     E2Args a;
     a.src = src; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed); a.out = out;
     a.stats = reinterpret_cast<double2*>(stats); a.cin = cin; a.cout = cout; a.n = n;
-    const dim3 grid((unsigned)((n + E2_MT - 1) / E2_MT), (unsigned)e2_chunks(cout, edge));
-    if (edge == 2) {
-        if (int rc = opt8.ensure(reinterpret_cast<const void*>(k_conv3_e2_split<8>), E2_LDS_BYTES, "rf_conv3d_e2_split_k3_gn_relu")) return rc;
-        hipLaunchKernelGGL(k_conv3_e2_split<8>, grid, dim3(256), E2_LDS_BYTES, (hipStream_t)stream, a);
-    } else {
-        if (int rc = opt1.ensure(reinterpret_cast<const void*>(k_conv3_e2_split<1>), E2_LDS_BYTES, "rf_conv3d_e2_split_k3_gn_relu")) return rc;
-        hipLaunchKernelGGL(k_conv3_e2_split<1>, grid, dim3(256), E2_LDS_BYTES, (hipStream_t)stream, a);
-    }
+    // 64-sample workgroups when they still give every CU two workgroups, else 32-sample ones
+    const unsigned chunks = (unsigned)e2_chunks(cout, edge);
+    const bool wide = (long long)((n + 63) / 64) * chunks >= rf_persistent_wgs() / RF_PERSIST_ROUNDS;
+    const dim3 grid((unsigned)((n + (wide ? 63 : 31)) / (wide ? 64 : 32)), chunks);
+    static RfLdsOptIn opt[4];
+    auto launch = [&](auto kern, int slot) -> int {
+        if (int rc = opt[slot].ensure(reinterpret_cast<const void*>(kern), E2_LDS_BYTES, "rf_conv3d_e2_split_k3_gn_relu")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), E2_LDS_BYTES, (hipStream_t)stream, a);
+        return RF_OK;
+    };
+    int rc;
+    if (edge == 2) rc = wide ? launch(k_conv3_e2_split<8, 64>, 0) : launch(k_conv3_e2_split<8, 32>, 1);
+    else rc = wide ? launch(k_conv3_e2_split<1, 64>, 2) : launch(k_conv3_e2_split<1, 32>, 3);
+    if (rc != RF_OK) return rc;
     RF_CHECK_LAUNCH("rf_conv3d_e2_split_k3_gn_relu");
     return RF_OK;
 }

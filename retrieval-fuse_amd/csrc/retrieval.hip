@@ -907,15 +907,17 @@ extern "C" int rf_demote_same_scene(const float* dist, const int64_t* idx, int n
 }
 
 // ------------------------------------------------------------------------------------------------ patch gather
-// one workgroup per (chunk, k, slot): copies a 16^3 box of a DB scene
-__global__ __launch_bounds__(256) void k_gather_patches(const float* __restrict__ vols, long long n_scenes, const int* __restrict__ meta, int K,
+// one workgroup per (chunk, k, slot): copies a 16^3 box of a DB scene.  T = float: the fp32 voxel store; T = _Float16: the store in the reference's own
+// precision (scenes are float16 on disk and in memory, dataset/scene.py:61,71 -- widening is exact, so the two stores gather the same bits)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_patches(const T* __restrict__ vols, long long n_scenes, const int* __restrict__ meta, int K,
                                                         float trunc_fill, float ratio, float mean, float stddev, int layout,
                                                         float* __restrict__ out) {
     const int slot = blockIdx.x & 63, k = (blockIdx.x >> 6) % K, chunk = (blockIdx.x >> 6) / K;
     const int* m = meta + (((size_t)chunk * 64 + slot) * K + k) * 7;
     const int scene = m[0], x0 = m[1], y0 = m[3], z0 = m[5];
     const bool have = scene >= 0 && scene < n_scenes;
-    const float* src = vols + (size_t)(have ? scene : 0) * 64 * 64 * 64;
+    const T* src = vols + (size_t)(have ? scene : 0) * 64 * 64 * 64;
     float* dst;
     size_t dsx, dsy;                                            // destination strides of the two slow dims
     if (layout == 1) {
@@ -929,21 +931,34 @@ __global__ __launch_bounds__(256) void k_gather_patches(const float* __restrict_
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const int dz = i & 15, dy = (i >> 4) & 15, dx = i >> 8;
         float v = trunc_fill;
-        if (have) v = src[((size_t)(x0 + dx) * 64 + (y0 + dy)) * 64 + (z0 + dz)];
+        if (have) v = (float)src[((size_t)(x0 + dx) * 64 + (y0 + dy)) * 64 + (z0 + dz)];
         v = __fmul_rn(v, ratio);
         dst[dx * dsx + dy * dsy + dz] = __fdiv_rn(__fsub_rn(v, mean), stddev);
     }
 }
 
+template <typename T>
+static int gather_patches(const T* db_volumes, int64_t n_scenes, const int32_t* meta, int chunks, int K, float trunc_fill, float trunc_ratio, float mean,
+                          float stddev, int layout, float* out, void* stream, const char* who) {
+    RF_REQUIRE(db_volumes && meta && out && chunks > 0 && K > 0 && n_scenes > 0, RF_E_INVALID, "%s: bad arguments", who);
+    RF_REQUIRE(layout == 0 || layout == 1, RF_E_INVALID, "%s: layout %d", who, layout);
+    hipLaunchKernelGGL(k_gather_patches<T>, dim3((unsigned)chunks * K * 64), dim3(256), 0, (hipStream_t)stream, db_volumes, (long long)n_scenes, meta,
+                       K, trunc_fill, trunc_ratio, mean, stddev, layout, out);
+    RF_CHECK_LAUNCH(who);
+    return RF_OK;
+}
+
 extern "C" int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* meta, int chunks, int K,
                                  float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
                                  float* out, void* stream) {
-    RF_REQUIRE(db_volumes && meta && out && chunks > 0 && K > 0 && n_scenes > 0, RF_E_INVALID, "rf_gather_patches: bad arguments");
-    RF_REQUIRE(layout == 0 || layout == 1, RF_E_INVALID, "rf_gather_patches: layout %d", layout);
-    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)chunks * K * 64), dim3(256), 0, (hipStream_t)stream, db_volumes, (long long)n_scenes, meta,
-                       K, trunc_fill, trunc_ratio, mean, stddev, layout, out);
-    RF_CHECK_LAUNCH("rf_gather_patches");
-    return RF_OK;
+    return gather_patches<float>(db_volumes, n_scenes, meta, chunks, K, trunc_fill, trunc_ratio, mean, stddev, layout, out, stream, "rf_gather_patches");
+}
+
+extern "C" int rf_gather_patches_f16(const void* db_volumes_f16, int64_t n_scenes, const int32_t* meta, int chunks, int K,
+                                     float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
+                                     float* out, void* stream) {
+    return gather_patches<_Float16>(reinterpret_cast<const _Float16*>(db_volumes_f16), n_scenes, meta, chunks, K, trunc_fill, trunc_ratio, mean, stddev, layout, out,
+                                    stream, "rf_gather_patches_f16");
 }
 
 // ------------------------------------------------------------------------------------------------- row gather

@@ -223,13 +223,17 @@ class PatchDatabase:
         emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
         return cls(emb, meta, volumes, device, rank, world, group)
 
-    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend, host_group=None):
+    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend, host_group=None, half_store=False):
         """emb [N+1,64] float32 (unit rows), meta [N+1,7] int32, volumes [S,64,64,64] float32 -- host or device tensors /
         numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes.
 
         With world > 1 (or an initialised process group) the constructor is COLLECTIVE: unless ``host_group`` (a gloo group over the ranks of
         ``group``) is passed, it creates the gloo twin of ``group`` for the query-count check, and ``dist.new_group`` must be entered by every
-        rank of the default group -- construct the database on all ranks at the same point of the program."""
+        rank of the default group -- construct the database on all ranks at the same point of the program.
+
+        ``half_store=True`` keeps the replicated voxel store as float16, the precision the reference holds scenes in (dataset/scene.py:61,71): half the
+        HBM (1 M patches: 8.2 GB instead of 16.4 GB per GPU) and half the bytes the patch gather reads, the same gathered bits -- the constructor checks
+        that every voxel survives the round trip (true for anything that came out of the reference's float16 scenes) and refuses a store that would not."""
         emb = torch.as_tensor(emb)
         self.count_check = None
         if world > 1:
@@ -245,7 +249,18 @@ class PatchDatabase:
         shard = emb[self.lo:self.hi].to(self.device, torch.float32).contiguous()
         self.emb_packed = backend.pack(shard)
         self.meta = torch.as_tensor(meta).to(self.device, torch.int32).contiguous()
-        self.volumes = torch.as_tensor(volumes).to(self.device, torch.float32).contiguous()
+        vols = torch.as_tensor(volumes)
+        if half_store and vols.dtype != torch.float16:
+            vols = vols.to(self.device)
+            narrowed = torch.empty(vols.shape, dtype=torch.float16, device=self.device)
+            for lo in range(0, vols.shape[0], 1024):                   # in pieces: the check's temporaries would otherwise triple a 16 GB store
+                piece = vols[lo:lo + 1024].to(torch.float32)
+                narrowed[lo:lo + 1024] = piece.to(torch.float16)
+                if not torch.equal(narrowed[lo:lo + 1024].to(torch.float32), piece):
+                    raise ValueError('half_store=True: the voxel store holds values float16 cannot represent (the reference\'s scenes are float16, '
+                                     'dataset/scene.py:61,71); keep the float32 store for this database')
+            vols = narrowed
+        self.volumes = vols.to(self.device, torch.float16 if half_store else torch.float32).contiguous()
         self.n_scenes = self.volumes.shape[0]
         self.feature_cache = None        # see build_feature_cache
 

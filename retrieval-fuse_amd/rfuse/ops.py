@@ -1245,14 +1245,16 @@ def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, s
     if its distance is below the mean stored distance of its box: an order-dependent reduction) is not built and is refused, not assumed."""
     if not no_overlap:
         raise NotImplementedError('gather_patches: only the no_overlap branch of create_retrieval_from_mapping (util/retrieval.py:156) is built')
-    _req(db_volumes, 'db_volumes'), _req(meta, 'meta', torch.int32)
+    half = db_volumes.dtype == torch.float16                    # the voxel store in the reference's own precision (PatchDatabase(half_store=True))
+    _req(db_volumes, 'db_volumes', torch.float16 if half else torch.float32), _req(meta, 'meta', torch.int32)
     dev = db_volumes.device
     if layout == 1:
         out = torch.empty((chunks * K * 64, 1, 16, 16, 16), dtype=torch.float32, device=dev)
     else:
         out = torch.empty((chunks, K, 64, 64, 64), dtype=torch.float32, device=dev)
-    _lib.check(_lib.load().rf_gather_patches(_p(db_volumes), db_volumes.shape[0], _p(meta), chunks, K, trunc_fill, trunc_ratio, mean, std,
-                                             layout, _p(out), _stream()), 'rf_gather_patches')
+    lib = _lib.load()
+    fn, name = (lib.rf_gather_patches_f16, 'rf_gather_patches_f16') if half else (lib.rf_gather_patches, 'rf_gather_patches')
+    _lib.check(fn(_p(db_volumes), db_volumes.shape[0], _p(meta), chunks, K, trunc_fill, trunc_ratio, mean, std, layout, _p(out), _stream()), name)
     return out
 
 

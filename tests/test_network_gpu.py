@@ -345,6 +345,39 @@ def test_engine_patch_mask_matches_reference_compose(gpu):
     np.testing.assert_array_equal(composed[:, ::4, ::4, ::4], fix['compose_masked_sub'])
 
 
+def test_half_voxel_store_gathers_the_same_bits(gpu):
+    """PatchDatabase(half_store=True): the voxel store in the reference's own precision (float16 scenes, dataset/scene.py:61,71) -- half the bytes, the same
+    gathered patches and the same refined chunks bit for bit; a store float16 cannot hold exactly is refused."""
+    from rfuse import ops
+    from rfuse.database import PatchDatabase
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C3')
+    _, trunc_t = rf_configs.truncations(cfg)
+    d, K = cfg['dataset_train'], cfg['K']
+    db = synthetic.make_database(9, cfg, 64 * 12)
+    full = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu)
+    half = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu, half_store=True)
+    assert half.volumes.dtype == torch.float16 and half.volumes.numel() * 2 == full.volumes.numel() * full.volumes.element_size() // 2
+    q = torch.nn.functional.normalize(torch.randn(128, 64, generator=torch.Generator().manual_seed(4)), dim=1).to(gpu)
+    meta, _, _ = full.retrieve(q, K)
+    meta[3, 1, 0] = -1                                                # a "no neighbour" entry: truncation fill from either store
+    for layout in (0, 1):
+        a = ops.gather_patches(full.volumes, meta, 2, K, trunc_t, 1.0, d['target_mean'], d['target_std'], layout=layout)
+        b = ops.gather_patches(half.volumes, meta, 2, K, trunc_t, 1.0, d['target_mean'], d['target_std'], layout=layout)
+        assert torch.equal(a, b)
+    raws = torch.from_numpy(np.stack([synthetic.make_chunk(440 + b, cfg)['input_raw'] for b in range(2)])).to(gpu)
+    outs = []
+    for pdb in (full, half):
+        eng = RefinementEngine(cfg, gpu, pdb)
+        eng.load_state_dicts({n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 210 + i) for i, (n, m) in enumerate(eng.modules().items())})
+        outs.append(eng.refine(raws).clone())
+    assert torch.equal(outs[0], outs[1])
+    lossy = db['volumes'].copy()
+    lossy[0, 0, 0, 0] = np.float32(0.1)                               # 0.1 is not a float16
+    with pytest.raises(ValueError, match='float16 cannot represent'):
+        PatchDatabase(db['emb'], db['meta'], lossy, gpu, half_store=True)
+
+
 def test_engine_patch_mask_end_to_end(gpu):
     """refine(patch_mask=...) == the oracle composing with the same dropped patches, then the networks"""
     from rfuse.database import PatchDatabase
