@@ -720,10 +720,14 @@ static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2,
 
 // Which scan (measured on MI355X, tools/topk_bench.py; k2 = 8): 2048 queries -- 50 k rows: VALU 0.47 ms / MFMA 0.59 ms, 125 k: 0.92 / 0.79,
 // 1 M: 6.3 / 2.7;  16384 queries (8 ranks' queries against one shard) -- 50 k: 2.8 / 2.0, 125 k: 6.4 / 3.4.
-static bool use_mfma_scan(int nq, int64_t n) { return n >= 40000; }
+// (round 5, after the sample pass went from n/64 to n/8 rows and became recursive: 2048 queries -- 12.5 k rows: VALU 0.19 ms / f16 filter 0.26, 50 k: 0.46 / 0.31,
+// 1 M: 6.2 / 1.10; 1024 queries x 50 k: 0.30 / 0.24; 16384 queries x 125 k (one of 8 shards, all ranks' queries): 6.0 / 2.0.)  The filtered scan pays from ~4e7
+// (query, row) pairs on, whichever way they split.
+static bool use_mfma_scan(int nq, int64_t n) { return n >= 4096 && (double)nq * (double)n >= 4.0e7; }
 
 // workspace: [per-slice lists: 64 x nq x k2p keys][sample pass: nq x k2p (dist f32, idx i64)]
-static int topk_impl(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
+// n_layout: the row count the packed image was built for (the offsets of its views depend on it); n <= n_layout: the rows scanned (the first n of the shard)
+static int topk_impl(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t n_layout, int64_t row_base, int k2, int algo,
                      float* out_dist, int64_t* out_idx, u64* out_keys, void* ws, size_t ws_bytes, void* stream) {
     RF_REQUIRE(q && db_packed && (out_keys || (out_dist && out_idx)) && ws && nq > 0 && n > 0, RF_E_INVALID, "rf_l2_topk: bad arguments");
     RF_REQUIRE(dim == RF_DIM, RF_E_UNSUPPORTED, "rf_l2_topk: embedding dim %d (only 64, the latent_dim of every shipped config)", dim);
@@ -747,22 +751,25 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         if (sl < 1) sl = 1;
         const long long bps = (nblk + sl - 1) / sl;
         slices = (int)((nblk + bps - 1) / bps);
-        const float* rows_img = db_packed + rf_blocked_floats(n);
-        const float* hd = rows_img + (size_t)rf_rows32(n) * RF_DIM;
-        // sample pass: exact top-k2p of the shard's first n/64 rows (1 k..16 k, whole 64-row blocks) with the VALU scan; the
-        // blocked view of the first rows of the shard IS the blocked view of the sample
+        const float* rows_img = db_packed + rf_blocked_floats(n_layout);
+        const float* hd = rows_img + (size_t)rf_rows32(n_layout) * RF_DIM;
+        // sample pass: exact top-k2p of the first n/8 rows (whole 64-row blocks; the blocked / row views of the first rows of the shard ARE the views of the
+        // sample).  Its k2-th distance T0 bounds the final one, so the filtered scan re-checks ~k2 * n / sample = 64 pairs per query instead of every pair
+        // that beats a list's own, slowly tightening, worst (with the n/64 sample of round 4: ~400 per query at 50 k rows, serial per wave: 0.52 ms; n/8:
+        // 0.31).  A sample big enough for the filtered scan (use_mfma_scan) is itself searched by this function -- 1 M rows: VALU scan of 15.6 k rows -> filtered scan of 125 k rows ->
+        // filtered scan of all of them -- and the nested call's result lands where this level reads its thresholds from (stream order keeps the levels apart).
         long long sample = n / 8;
         if (sample < 1024) sample = 1024;
-        if (sample > 16384) sample = 16384;
         sample = (sample + 63) / 64 * 64;
         if (sample > n) sample = n;
         float* t_dist = reinterpret_cast<float*>(parts + (size_t)64 * nq * k2p);
         int64_t* t_idx = reinterpret_cast<int64_t*>(t_dist + (size_t)nq * k2p) ;
-        int rc = topk_impl(q, nq, dim, db_packed, sample, row_base, k2p, 1, t_dist, t_idx, nullptr, ws, ws_bytes, stream);
+        const int sample_algo = use_mfma_scan(nq, sample) ? (f16_filter ? 3 : 2) : 1;
+        int rc = topk_impl(q, nq, dim, db_packed, sample, n_layout, row_base, k2p, sample_algo, t_dist, t_idx, nullptr, ws, ws_bytes, stream);
         if (rc != RF_OK) return rc;
         const float* t0 = t_dist + (k2 - 1);                         // the k2-th best of query qi: t0[qi * k2p]
-        const _Float16* rows16 = reinterpret_cast<const _Float16*>(hd + rf_rows32(n));
-        const float* hd16 = reinterpret_cast<const float*>(rows16 + (size_t)rf_rows32(n) * RF_DIM);
+        const _Float16* rows16 = reinterpret_cast<const _Float16*>(hd + rf_rows32(n_layout));
+        const float* hd16 = reinterpret_cast<const float*>(rows16 + (size_t)rf_rows32(n_layout) * RF_DIM);
         if (f16_filter) {
             if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
             else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
@@ -788,12 +795,12 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
 
 extern "C" int rf_l2_topk(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
                           float* out_dist, int64_t* out_idx, void* ws, size_t ws_bytes, void* stream) {
-    return topk_impl(q, nq, dim, db_packed, n, row_base, k2, algo, out_dist, out_idx, nullptr, ws, ws_bytes, stream);
+    return topk_impl(q, nq, dim, db_packed, n, n, row_base, k2, algo, out_dist, out_idx, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int rf_l2_topk_keys(const float* q, int nq, int dim, const float* db_packed, int64_t n, int64_t row_base, int k2, int algo,
                                uint64_t* out_keys, void* ws, size_t ws_bytes, void* stream) {
-    return topk_impl(q, nq, dim, db_packed, n, row_base, k2, algo, nullptr, nullptr, (u64*)out_keys, ws, ws_bytes, stream);
+    return topk_impl(q, nq, dim, db_packed, n, n, row_base, k2, algo, nullptr, nullptr, (u64*)out_keys, ws, ws_bytes, stream);
 }
 
 extern "C" int rf_topk_merge_keys(const uint64_t* in_keys, int parts, int nq, int k2, float* out_dist, int64_t* out_idx, void* stream) {
