@@ -632,17 +632,34 @@ __global__ __launch_bounds__(512, 4) void k_conv3_cin1_presplit(Cin1PreArgs a) {
         nxt[tid] = gn_affine(mean, 1.0 / sqrt(var + a.eps), a.gamma[tid], a.beta[tid]);
     }
     __syncthreads();
-    float4 t[8];
+    // normalise + split on cout PAIRS: the 2^-4 activation scale is folded into the triple (exact: a power of two commutes with the fma's rounding), the
+    // GroupNorm apply runs as v_pk_add_f32 / v_pk_fma_f32 on the pairs the accumulators already are, and both conversions are v_cvt_pk_f16_f32 --
+    // 3.5 VALU instructions per value instead of 7 (this kernel is VALU-bound: DESIGN 10)
+    f32x2 negc[4], sc[4], sh[4];
 #pragma unroll
-    for (int co = 0; co < 8; ++co) t[co] = nxt[co];
+    for (int cp = 0; cp < 4; ++cp) {
+        const float4 t0 = nxt[2 * cp], t1 = nxt[2 * cp + 1];
+        negc[cp] = (f32x2){-t0.x, -t1.x};
+        sc[cp] = (f32x2){t0.y * CS_ACT_SCALE, t1.y * CS_ACT_SCALE};
+        sh[cp] = (f32x2){t0.z * CS_ACT_SCALE, t1.z * CS_ACT_SCALE};
+    }
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     unsigned char* outp = a.out + (size_t)nn * 2 * VOL * 16;
 #pragma unroll
     for (int z = 0; z < 8; ++z) {
-        float yv[8];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) yv[co] = fmaf(act[z][co] - t[co].x, t[co].y, t[co].z);
         h8 h, l;
-        cs_split8(yv, h, l);
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+            const f32x2 relu = (f32x2){act[z][2 * cp], act[z][2 * cp + 1]};
+            f32x2 v = __builtin_elementwise_fma(relu + negc[cp], sc[cp], sh[cp]);
+            v[0] = __builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f);
+            v[1] = __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f);
+            const h2 hh = __builtin_convertvector(v, h2);
+            const f32x2 back = __builtin_convertvector(hh, f32x2);
+            const h2 ll = __builtin_convertvector((v - back) * CS_LO, h2);      // v - h is exact in fp32
+            h[2 * cp] = hh[0]; h[2 * cp + 1] = hh[1];
+            l[2 * cp] = ll[0]; l[2 * cp + 1] = ll[1];
+        }
         const size_t vox = ((size_t)(z0 + z) * E + y) * E + x;
         *reinterpret_cast<h8*>(outp + vox * 16) = h;
         *reinterpret_cast<h8*>(outp + ((size_t)VOL + vox) * 16) = l;

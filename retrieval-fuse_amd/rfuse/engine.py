@@ -202,22 +202,25 @@ class RefinementEngine:
         main = None
         state = {}
 
-        def issue_front(raw, qs, pm, after=None):
-            """front end of one batch on the helper stream; ``after``: an event of the caller's stream it must not start before"""
+        def issue_front(raw, qs, pm, with_backbone=True):
+            """front end of one batch on the helper stream: normalise -> (the chunk-level U-Net on its own stream) ; query encoder -> top-k -> demotion -> gather"""
             front = self._side_streams.get(('front', main.cuda_stream))
             if front is None:
                 front = self._side_streams[('front', main.cuda_stream)] = torch.cuda.Stream(self.device)
             ready = torch.cuda.Event()
-            ready.record(main)                                   # whatever produced `raw` on the caller's stream (and, with `after`, the split point of the back end)
+            ready.record(main)                                   # whatever produced `raw` on the caller's stream
             front.wait_event(ready)
             with torch.cuda.stream(front):
                 raw.record_stream(front)
-                x_back, side = self._fork_backbone(self.normalise_input(raw))      # ... the backbone beside the retrieval on its own stream, as in refine()
+                x_in = self.normalise_input(raw)
+                if with_backbone:
+                    x_back, side = self._fork_backbone(x_in)     # ... the backbone beside the retrieval on its own stream, as in refine()
                 patches, _ = self.retrieve(raw, qs, pm)
-                front.wait_stream(side)
+                if with_backbone:
+                    front.wait_stream(side)
                 done = torch.cuda.Event()
                 done.record(front)
-            return patches, x_back, done
+            return (patches, x_back, done) if with_backbone else (patches, x_in, done)
 
         for i, raw in enumerate(batches):
             qs = query_scenes[i] if query_scenes is not None else None
@@ -225,9 +228,10 @@ class RefinementEngine:
             with torch.cuda.device(self.device), torch.no_grad():
                 if main is None:
                     main = torch.cuda.current_stream(self.device)
-                if pending is None or self.front_at == 'start':
-                    nxt = issue_front(raw, qs, pm)
-                    out = self._finish_pipelined(main, *pending) if pending is not None else None
+                late_unet = self.front_at == 'unet_decoders'
+                if pending is None or self.front_at in ('start', 'unet_decoders'):
+                    nxt = issue_front(raw, qs, pm, with_backbone=not late_unet)
+                    out = self._finish_pipelined(main, *pending, late_unet=late_unet) if pending is not None else None
                 else:
                     # the next batch's front end is issued from INSIDE this batch's back end, behind its encoder launches: it then runs beside the decoder
                     # stages (MFMA-bound) instead of beside the first encoder layers (VALU / HBM-bound like the front end's own scan and gather)
@@ -241,13 +245,24 @@ class RefinementEngine:
                 yield out
         if pending is not None:
             with torch.cuda.device(self.device), torch.no_grad():
-                out = self._finish_pipelined(main, *pending)
+                out = self._finish_pipelined(main, *pending, late_unet=self.front_at == 'unet_decoders')
             yield out
 
-    def _finish_pipelined(self, main, patches, x_back, done, after_encoders=None):
+    def _finish_pipelined(self, main, patches, x_back, done, after_encoders=None, late_unet=False):
         main.wait_event(done)
         patches.record_stream(main)
         x_back.record_stream(main)
+        if late_unet:
+            # `x_back` is the normalised INPUT: the chunk-level U-Net of this batch is forked from inside its own back end, behind the encoder launches, and
+            # joined in front of the attention -- its ~40 small launches then run beside the decoder stages (non-persistent launches of thousands of
+            # workgroups, which absorb a borrowed CU) instead of beside the persistent first layers
+            x_in, box = x_back, {}
+
+            def fork():
+                box['x_back'], box['side'] = self._fork_backbone(x_in)
+            feats = self.retrieval_backbone(patches, after_encoders=fork)
+            main.wait_stream(box['side'])
+            return self._attend_and_decode(box['x_back'], feats, None)
         feats = self.retrieval_backbone(patches, after_encoders=after_encoders)
         return self._attend_and_decode(x_back, feats, None)
 

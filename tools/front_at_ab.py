@@ -22,9 +22,9 @@ def timed():
     pipe(10); torch.cuda.synchronize(); t0 = time.perf_counter(); pipe(); torch.cuda.synchronize(); return (time.perf_counter() - t0) / 40 * 1e3
 for rep in range(4):
     res = []
-    for mode in ('start', 'decoders'):
+    for mode in ('start', 'unet_decoders'):
         eng.front_at = mode; res.append(timed())
-    print('%s B=%d  front at start %.3f ms   behind the encoders %.3f ms' % (name, B, res[0], res[1]), flush=True)
+    print('%s B=%d  front at start %.3f ms   U-Net behind its own encoders %.3f ms' % (name, B, res[0], res[1]), flush=True)
 eng.front_at = 'start'; a = [x.clone() for x in eng.refine_stream(batches)]
-eng.front_at = 'decoders'; b = [x.clone() for x in eng.refine_stream(batches)]
+eng.front_at = 'unet_decoders'; b = [x.clone() for x in eng.refine_stream(batches)]
 print('bit-equal:', all(torch.equal(x, y) for x, y in zip(a, b)))
