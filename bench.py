@@ -181,6 +181,11 @@ def recall_at_k(eng, database, emb_full, raw_dev, K, n_sub=128):
     out['exact_order'] = (got == ref).all(dim=1).float().mean().item()
     out['queries'] = int(sub.numel())
     out['reference'] = 'float64 brute force over all %d rows' % emb_full.shape[0]
+    # how many DISTINCT database rows the batch's lists name: with random-init encoder weights the 64 windows of a synthetic chunk embed almost alike, so a
+    # step's B * 64 * 2K list entries name only a few dozen rows (trained encoders spread them).  Nothing in the engine exploits that -- every one of the
+    # B * K * 64 retrieved patches goes through the retrieval backbone -- but the patch gather of this workload is cache-resident whatever the batch.
+    out['distinct_rows_in_the_batch_lists'] = int(torch.unique(idx_g).numel())
+    out['list_entries'] = int(idx_g.numel())
     return out
 
 
