@@ -53,6 +53,22 @@ with torch.no_grad():
         go(); torch.cuda.synchronize(); t0 = time.perf_counter(); go(); torch.cuda.synchronize(); return (time.perf_counter() - t0) / N * 1e3
     print('unet stages beside the back end: 8^3 U-Net only %.3f | 16^3 stage only %.3f | 32^3 stage only %.3f' % (
         stage_cost(lambda: net[0](x_in)), stage_cost(lambda: net[1](y0)), stage_cost(lambda: net[2](y1))), flush=True)
+    x_in4 = torch.cat([x_in] * 4)
+    eng.unet_backbone(x_in4); torch.cuda.synchronize()
+    def grouped():
+        def go():
+            for i in range(N):
+                ev = torch.cuda.Event(); ev.record(main); front.wait_event(ev)
+                with torch.cuda.stream(front):
+                    if i % 4 == 0:
+                        side.wait_stream(front)
+                        with torch.cuda.stream(side): eng.unet_backbone(x_in4)
+                        front.wait_stream(side)
+                    done = torch.cuda.Event(); done.record(front)
+                eng._attend_and_decode(x_back, eng.retrieval_backbone(patches), None)
+                main.wait_event(done)
+        go(); torch.cuda.synchronize(); t0 = time.perf_counter(); go(); torch.cuda.synchronize(); return (time.perf_counter() - t0) / N * 1e3
+    print('back end + the U-Net of FOUR batches (n = 128) every fourth step: %.3f ms per step (per batch every step: %.3f)' % (grouped(), run(False, True)), flush=True)
     for rep in range(2):
         print('back alone %.3f | + retrieve %.3f | + unet %.3f | + both %.3f | + embed only %.3f | + search only %.3f' % (
             run(False, False), run(True, False), run(False, True), run(True, True), run(True, False, only_embed), run(True, False, only_search)), flush=True)
