@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument('--kernels-top', type=int, default=8, help='rows of the serial per-kernel table')
     ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank, still run the all-gather + all-to-all + merge protocol over RCCL')
     ap.add_argument('--half-store', action='store_true', help='keep the replicated voxel store as float16 (the reference\'s own scene precision; same gathered bits, half the bytes)')
+    ap.add_argument('--ranks-share-gpu', action='store_true', help='dev: every rank on cuda:0 with the collectives over gloo (RCCL refuses two ranks on one device): runs the whole multi-rank bench on a one-GPU box; the line says so and is no scaling measurement')
     ap.add_argument('--resident-batches', type=int, default=4, help='distinct resident input batches rotated through the timed loop')
     return ap.parse_args(argv)
 
@@ -528,11 +529,16 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs the GPU (no CPU fallback for the hot path)'
     knobs = sorted(k for k in os.environ if k.startswith('RFUSE_') and k != 'RFUSE_LIB')
     assert not knobs, 'refusing to measure with developer switches set: %s' % knobs
+    if args.ranks_share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     force_dist = world == 1 and args.force_collectives and 'RANK' in os.environ        # dev: run the whole RCCL protocol with one rank
     if world > 1 or force_dist:
-        dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
+        if args.ranks_share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)      # RCCL on ROCm
         assert dist.get_world_size() == args.gpus or force_dist, '--gpus %d but the process group has %d ranks' % (args.gpus, dist.get_world_size())
 
     from rfuse import configs, ops, synthetic
@@ -720,11 +726,13 @@ def main():
             'kernels': kernels,
             'recall_at_k': recall,
         }
-        out['rccl_ranks'] = dist.get_world_size() if (world > 1 or force_dist) else 0
+        out['rccl_ranks'] = dist.get_world_size() if (world > 1 or force_dist) and not args.ranks_share_gpu else 0
+        if args.ranks_share_gpu:
+            out['ranks_share_gpu'] = 'dev run: %d ranks on ONE GPU, collectives over gloo (staged through the host) -- a functional run of the multi-rank path, not a scaling measurement' % world
         if collective_events:
             q_ms, k_ms = per_rank_collectives[0]
             out['collectives'] = {'per_rank_ms': [{'rank': r, 'all_gather_queries_ms': v[0], 'all_to_all_keys_ms': v[1]} for r, v in enumerate(per_rank_collectives)],
-                                  'rccl_ranks': dist.get_world_size(), 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_to_all_keys_ms': k_ms,
+                                  ('gloo_ranks_on_one_gpu' if args.ranks_share_gpu else 'rccl_ranks'): dist.get_world_size(), 'per_step': 2, 'all_gather_queries_ms': q_ms, 'all_to_all_keys_ms': k_ms,
                                   'keys_bytes_received_per_rank': world * B * 64 * 2 * K * 8, 'step_ms': 1e3 * elapsed / args.steps,
                                   'note': 'HIP events on the issuing stream around each collective (includes waiting for the slowest rank); the U-Net backbone '
                                           'forked onto the side stream before the search keeps running while they are in flight'}

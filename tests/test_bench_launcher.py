@@ -65,3 +65,23 @@ def test_self_launched_ranks_print_one_json_line():
     assert out['n_gpus'] == 1 and out['rccl_ranks'] == 1 and out['steps'] == 4 and out['value'] > 0
     assert [c['rank'] for c in out['collectives']['per_rank_ms']] == [0]
     assert out['collectives']['all_to_all_keys_ms'] > 0 and out['collectives']['all_gather_queries_ms'] > 0
+
+
+@pytest.mark.gpu
+def test_two_self_launched_ranks_on_one_gpu():
+    """The multi-rank bench path end to end on a one-GPU box: `python bench.py --gpus 2 --ranks-share-gpu` (both ranks on cuda:0, collectives over gloo -- RCCL
+    refuses two ranks on one device) launches its ranks, shards the database two ways, runs the timed loops, the per-rank collective timings and the
+    recall leg (a collective search), and prints exactly one JSON line with n_gpus = 2 and recall 1.0.  A functional run, not a scaling measurement."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT') and not k.startswith('RFUSE_')}
+    r = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', '2', '--ranks-share-gpu', '--steps', '3', '--warmup', '1', '--repeats', '0', '--batch', '4',
+                        '--db', '4099', '--no-cpu-baseline', '--resident-batches', '2'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0 and 'ranks_share_gpu' in out
+    assert [c['rank'] for c in out['collectives']['per_rank_ms']] == [0, 1]
+    assert out['recall_at_k']['recall@1'] == 1.0 and out['recall_at_k']['exact_order'] == 1.0

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, n_patches, B):
+def _worker(rank, world, port, out_dir, n_patches, B, backend='nccl'):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     for p in (str(REPO), str(REPO / 'retrieval-fuse_amd'), str(REPO / 'tests')):
@@ -30,9 +30,14 @@ def _worker(rank, world, port, out_dir, n_patches, B):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = torch.device('cuda', rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    # 'nccl' (RCCL): one GPU per rank.  'gloo': every rank on cuda:0 -- the collectives stage the device tensors through the host, the shard scans, the key
+    # merge and the demotion are the HIP kernels: the sharded protocol with W > 1 on ONE GPU (RCCL refuses two ranks on one device)
+    dev = torch.device('cuda', rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     import helpers
     from rfuse import configs, synthetic
     from rfuse.database import PatchDatabase
@@ -61,9 +66,9 @@ def _worker(rank, world, port, out_dir, n_patches, B):
     dist.destroy_process_group()
 
 
-def _run(world, tmp_path, n_patches=64 * 30 + 7, B=2):
+def _run(world, tmp_path, n_patches=64 * 30 + 7, B=2, backend='nccl'):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_patches, B), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_patches, B, backend), nprocs=world, join=True)
     for rank in range(world):
         assert (tmp_path / f'rank{rank}.txt').read_text() == 'ok'
 
@@ -72,6 +77,16 @@ def test_rccl_protocol_with_one_rank(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip('no GPU visible')
     _run(1, tmp_path)
+
+
+@pytest.mark.parametrize('world,n_patches', [(2, 64 * 30 + 7), (4, 64 * 50 + 3), (3, 5)])
+def test_sharded_search_several_ranks_on_one_gpu(tmp_path, world, n_patches):
+    """W ranks sharing cuda:0 over gloo: every rank's HIP shard scan (packed keys), the all-to-all of the keys, rf_topk_merge_keys and the demotion against the
+    single-scan engine, end to end through refine() -- the multi-rank protocol on the device kernels without needing W GPUs (5 rows on 3 ranks: an empty
+    shard and lists shorter than 2K)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    _run(world, tmp_path, n_patches=n_patches, backend='gloo')
 
 
 def test_rccl_sharded_search_two_ranks(tmp_path):
