@@ -723,7 +723,9 @@ static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2,
 // (round 5, after the sample pass went from n/64 to n/8 rows and became recursive: 2048 queries -- 12.5 k rows: VALU 0.19 ms / f16 filter 0.26, 50 k: 0.46 / 0.31,
 // 1 M: 6.2 / 1.10; 1024 queries x 50 k: 0.30 / 0.24; 16384 queries x 125 k (one of 8 shards, all ranks' queries): 6.0 / 2.0.)  The filtered scan pays from ~4e7
 // (query, row) pairs on, whichever way they split.
-static bool use_mfma_scan(int nq, int64_t n) { return n >= 4096 && (double)nq * (double)n >= 4.0e7; }
+// Short shards under many queries stay on the VALU scan (one rank of 8 on the 50 k-row database: 16384 queries x 6250 rows 0.46 / 0.60 ms; x 12.5 k: 0.82 / 0.72:
+// the filtered scan pays per query for its lists and re-checks): tools/topk_shard_shapes.py.
+static bool use_mfma_scan(int nq, int64_t n) { return n >= 10000 && (double)nq * (double)n >= 4.0e7; }
 
 // workspace: [per-slice lists: 64 x nq x k2p keys][sample pass: nq x k2p (dist f32, idx i64)]
 // n_layout: the row count the packed image was built for (the offsets of its views depend on it); n <= n_layout: the rows scanned (the first n of the shard)
