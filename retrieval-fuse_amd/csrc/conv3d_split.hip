@@ -414,7 +414,10 @@ __global__ __launch_bounds__(512, NB == 1 ? 4 : 2) void k_conv3_split_s4(ConvArg
     const int ns = n0 + wave < a.n ? n0 + wave : a.n - 1;         // ragged last group: re-reads the last sample, the epilogue masks its stores
     const float4* __restrict__ aff = a.affine + (size_t)ns * cin;
     const float* __restrict__ s0 = a.src0 + (size_t)ns * cin * 64 + lane;             // this thread's voxel (z, y, x) = (lane >> 4, (lane >> 2) & 3, lane & 3)
-    unsigned char* const myslot = lds + (wave * 216 + ((lane >> 4) + 1) * 36 + (((lane >> 2) & 3) + 1) * 6 + (lane & 3) + 1) * 16;
+    // halo cube [6][6][6] in 16-byte slots, Y-MAJOR: slot(z, y, x) = y * 36 + z * 6 + x.  An A operand is a ds_read_b128 of an m-block = one z plane (4 y x 4 x);
+    // with the rows of the plane 36 = 4 (mod 16) slots apart its 16 voxels sit on 16 different slot positions (z-major, rows 6 apart: rows 0 and 3 collide --
+    // tools/lds_bank_model.py's count: 2.07 -> 1.71 LDS cycles per 16-lane group over the 7 k-steps; what is left is where two taps meet in one group)
+    unsigned char* const myslot = lds + (wave * 216 + ((lane >> 4) + 1) * 6 + (((lane >> 2) & 3) + 1) * 36 + (lane & 3) + 1) * 16;
 
     auto stage_load = [&](float (&x)[8], int ca) {
 #pragma unroll
@@ -439,12 +442,12 @@ __global__ __launch_bounds__(512, NB == 1 ? 4 : 2) void k_conv3_split_s4(ConvArg
 
     // operand addressing: row i of m-block m = voxel (z = m, y = i >> 2, x = i & 3) of sample `wave`; lane group g supplies tap 4 s + g
     const int g = lane >> 4, ri = lane & 15;
-    const unsigned char* const abase = lds + (wave * 216 + 36 + ((ri >> 2) + 1) * 6 + (ri & 3) + 1) * 16;
+    const unsigned char* const abase = lds + (wave * 216 + 6 + ((ri >> 2) + 1) * 36 + (ri & 3) + 1) * 16;
     int atap[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         const int tp = 4 * s + g < 27 ? 4 * s + g : 26;             // tap 27: zero weights
-        atap[s] = ((tp / 9 - 1) * 36 + ((tp / 3) % 3 - 1) * 6 + (tp % 3 - 1)) * 16;
+        atap[s] = ((tp / 9 - 1) * 6 + ((tp / 3) % 3 - 1) * 36 + (tp % 3 - 1)) * 16;
     }
     f32x4 hi[4][NB], lo[4][NB];
 #pragma unroll
@@ -474,8 +477,8 @@ __global__ __launch_bounds__(512, NB == 1 ? 4 : 2) void k_conv3_split_s4(ConvArg
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if ((m == 0 && s < 2) || (m == 3 && s >= 5)) continue;      // every tap of the k-step reads the plane below / above the volume: zeros
-                const h8 ah = *reinterpret_cast<const h8*>(abase + m * 576 + atap[s]);
-                const h8 al = *reinterpret_cast<const h8*>(abase + m * 576 + atap[s] + S4_PLANE);
+                const h8 ah = *reinterpret_cast<const h8*>(abase + m * 96 + atap[s]);
+                const h8 al = *reinterpret_cast<const h8*>(abase + m * 96 + atap[s] + S4_PLANE);
                 cs_mfma_block<NB>(hi[m], lo[m], ah, al, bh, bl);
             }
 #pragma unroll
