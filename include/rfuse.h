@@ -256,6 +256,19 @@ int rf_conv3d_split_pre_supported(int cin, int n, int edge, int cout);
 int rf_conv3d_split_pre_stats_tiles(int cin, int n, int edge, int cout);
 int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, int n, int edge, const void* w_packed, int cout,
                                 float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
+/* The decoder pair of the retrieval backbone's last stage (reference model/refinement.py:64-73, model/unet.py:149-159) with the hand-over in PARITY-MAJOR slot
+ * order: per (sample, 8-channel group, h | l) the 512 voxel slots of an 8^3 sample at ((z & 1) 4 + (y & 1) 2 + (x & 1)) 64 + (z >> 1) 16 + (y >> 1) 4 + (x >> 1)
+ * instead of z 64 + y 8 + x.  rf_conv3d_up_split_presplit_pm is the persistent producer (csrc/conv3d_up_split.hip: k_conv3_up_split_pp; one workgroup per CU
+ * walks samples, a wave owns one output parity and leaves its slots from registers in 256-byte runs); same values and statistics as
+ * rf_conv3d_up_split_presplit up to the summation order.  rf_conv3d_split_pre_pm_k3_relu = rf_conv3d_split_pre_k3_relu on such a tensor (persistent multi-chunk
+ * form: n >= 2048 samples, cin >= 16 in eights, <= 32 couts). */
+int rf_conv3d_up_split_presplit_pm_supported(int c0, int c1, int n, int edge, int cout, int next_groups);
+int rf_conv3d_up_split_presplit_pm(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine, const void* w_packed,
+                                   int cout, const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit_pm,
+                                   double* stats, void* stream);
+int rf_conv3d_split_pre_pm_supported(int cin, int n, int edge, int cout);
+int rf_conv3d_split_pre_pm_k3_relu(const void* src_presplit_pm, int cin, int n, int edge, const void* w_packed, int cout,
+                                   float* out, double* stats, float* pool_out, double* pool_stats, void* stream);
 
 /* ------------------------------------------------------------------------------- backward (training slice, N4) */
 

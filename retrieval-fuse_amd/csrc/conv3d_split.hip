@@ -829,6 +829,31 @@ extern "C" int rf_conv3d_split_pre_k3_relu(const void* src_presplit, int cin, in
     return cin == 8 ? launch_split<1, 6, true, false, true>(a, (hipStream_t)stream) : launch_split<1, 4, false, false, true>(a, (hipStream_t)stream);
 }
 
+// rf_conv3d_split_pre_k3_relu on a pre-split input of whole 8^3 samples whose voxel slots are in PARITY-MAJOR order (rf_conv3d_up_split_presplit_pm): the
+// persistent multi-chunk form only (>= 2048 samples, cin >= 16 in eights, <= 32 couts)
+extern "C" int rf_conv3d_split_pre_pm_supported(int cin, int n, int edge, int cout) {
+    return edge == 8 && rf_conv3d_split_pre_supported(cin, n, edge, cout) && !rf_split_zc_takes(cin, n, edge, cout) && rf_round_up(cout, 16) <= 32 && rf_split_zcm_takes(cin, n, edge, cout);
+}
+
+extern "C" int rf_conv3d_split_pre_pm_k3_relu(const void* src_presplit_pm, int cin, int n, int edge, const void* w_packed, int cout,
+                                              float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_split_pre_pm_supported(cin, n, edge, cout), RF_E_UNSUPPORTED,
+               "rf_conv3d_split_pre_pm_k3_relu: takes whole 8^3 samples (n >= 2048), cin >= 16 in eights, up to 32 couts (got cin=%d n=%d edge=%d cout=%d)", cin, n, edge, cout);
+    RF_REQUIRE(src_presplit_pm && w_packed && (out || pool_out), RF_E_INVALID, "rf_conv3d_split_pre_pm_k3_relu: null pointer");
+    RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_split_pre_pm_k3_relu: statistics of an output that is not written");
+    RF_REQUIRE(pool_out || !pool_stats, RF_E_INVALID, "rf_conv3d_split_pre_pm_k3_relu: pooled statistics without a pooled output");
+    ConvArgs a;
+    a.src0 = reinterpret_cast<const float*>(src_presplit_pm); a.src1 = nullptr; a.affine = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.out = out;
+    a.c0 = cin; a.c1 = 0; a.n = n; a.edge = edge; a.cout = cout; a.cin4 = cin; a.cout16 = rf_round_up(cout, 16);
+    a.stats = reinterpret_cast<double2*>(stats);
+    a.stats_tiles = (stats || pool_stats) ? 1 : 0;
+    a.pool_out = pool_out; a.pool_stats = reinterpret_cast<double2*>(pool_stats);
+    a.pool_mode = pool_out ? (out ? 1 : 2) : 0;
+    a.floor = 0.f;
+    a.src_pm = 1;
+    return rf_split_zcm_launch(a, SplitPreOut{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, nullptr, 0.f, 0.f}, true, (hipStream_t)stream, "rf_conv3d_split_pre_pm_k3_relu");
+}
+
 // rf_conv3d_split_k3_gn_relu on whole 8^3 samples with up to 16 couts, its output handed to the NEXT SingleConv pre-split: the workgroup holds
 // the sample, so it applies the next layer's GroupNorm (next_gamma / next_beta [cout], next_groups, eps) from the sample's own statistics, splits and
 // writes rf_split_act_bytes(n, cout, 8) bytes for rf_conv3d_split_pre_k3_relu; the fp32 output is not written.  stats (optional): [n][cout] (sum, sum of squares).

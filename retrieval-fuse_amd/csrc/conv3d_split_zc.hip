@@ -394,8 +394,9 @@ __global__ __launch_bounds__(512, 4) void k_conv3_split_zcm(ConvArgs a, SplitPre
             const int z = z0 - 1 + (hpos[r] >> 16), y = y0 - 1 + ((hpos[r] >> 8) & 255), x = x0 - 1 + (hpos[r] & 255);
             st.in[r] = (unsigned)z < (unsigned)edge && (unsigned)y < (unsigned)edge && (unsigned)x < (unsigned)edge && (r == 0 || tid < CS_VOX - 512);
             // uniform 64-bit base per (sample, chunk) + 32-bit lane offsets: address registers the compiler does not have to carry (or spill) as pairs
-            const unsigned off = st.in[r] ? (unsigned)((z * edge + y) * edge + x) : 0u;
+            unsigned off = st.in[r] ? (unsigned)((z * edge + y) * edge + x) : 0u;
             if constexpr (PRE) {
+                if (a.src_pm) off = st.in[r] ? (unsigned)((((z & 1) * 4 + (y & 1) * 2 + (x & 1)) << 6) + ((z >> 1) << 4) + ((y >> 1) << 2) + (x >> 1)) : 0u;      // edge 8 only
                 const unsigned char* p = reinterpret_cast<const unsigned char*>(a.src0) + ((size_t)n0 * nC + ca) * 2 * vol * 16;
                 st.ph[r] = *reinterpret_cast<const h8*>(p + off * 16u);
                 st.pl[r] = *reinterpret_cast<const h8*>(p + ((unsigned)vol + off) * 16u);

@@ -137,6 +137,9 @@ struct UpSplitArgs {
     float neps;
     // box kernel only: `out` is written channel-interleaved, [n][cout / 8][voxel][8 channels] fp32 (rf_conv3d_up_split_k3_gn_relu_ch8)
     int out_ch8;
+    // persistent whole-sample kernel only: the voxel slots of `pre_out` in PARITY-MAJOR order -- slot index ((z & 1) 4 + (y & 1) 2 + (x & 1)) 64 + (z >> 1) 16 + (y >> 1) 4
+    // + (x >> 1) instead of z 64 + y 8 + x -- so that a wave, which owns one output parity, stores 256-byte runs (RF_PRESPLIT_PARITY_MAJOR)
+    int pre_pm;
 };
 
 // 8 normalised channel values of one voxel -> the two f16 pieces (scaled by 2^-4; saturating, never inf)
@@ -456,6 +459,569 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
         for (int msk = 1; msk < 8; msk <<= 1) { sm += __shfl_xor(sm, msk, 64); sq += __shfl_xor(sq, msk, 64); }
         if (part == 0 && co < cout) a.stats[(size_t)n * cout + co] = make_double2(sm, sq);
     }
+    };   // run
+    if (pz == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+// ------------------------------------------------------------------------------------------- persistent form, MFMA roles swapped
+// k_conv3_up_split_pp: the same layer (whole 8^3 samples, 33..64 couts, pre-split output only) as a PERSISTENT kernel -- one workgroup per CU walks
+// samples n, n + grid, ... -- built so that nothing but the epilogue of a sample stands between its last MFMA and the next sample's first:
+//  * MFMA ROLES SWAPPED: the weights are the A operand (M = 16 couts), the voxels the B operand (N = 16 voxels of the wave's parity class in one z
+//    plane).  An accumulator lane then holds 4 consecutive M rows of ONE voxel; with the rows of cout-block pair (2p, 2p + 1) permuted
+//    (row 4 g' + r of block 2p + j  <->  cout 32 p + 8 g' + 4 j + r: a per-lane gather out of the SAME weight image, no second pack) lane (g, v) holds the 8 couts
+//    32 p + 8 g .. + 7 of voxel v: exactly one 16-byte slot of the pre-split output.  ReLU, statistics, the next layer's GroupNorm, the h / l split and
+//    the stores all leave from registers -- no LDS tile (the 132 KB tile of k_conv3_up_split aliases every image, which is what forbade staging sample
+//    i + 1 under sample i).
+//  * PHASE ORDER B -> A: the low-res images are dead once phase B is over, so the NEXT sample's low-res voxels are staged into them during phase A
+//    (chunks 1 and 2), and its first skip chunk goes into the idle halo buffer during the last chunk (c0 / 8 even): the per-sample prologue (zero fill,
+//    staging, barrier: ~10 k of ~98 k cycles) is paid once per workgroup.
+//  * WEIGHTS IN ONE ROLLING REGISTER SET: a k-step walks the cout-block pairs in the OUTER loop (voxel operands are read twice per k-step from LDS:
+//    85 B/clk per CU, free on this part -- tools/micro/mfma_lds_power.hip), so pair 0's fragments are dead after half a k-step and the next k-step's
+//    are loaded over them: 32 registers of weights instead of 64 -- the room the persistent loop needs at 256 VGPRs (round 3's attempt spilled 66).
+// Statistics of a channel are summed in float64 per lane (4 values), across the 16 lanes of a row, then over the 8 waves in wave order.
+namespace {
+constexpr int PP_CHST = US_LDS_BYTES;                            // [8 waves][64 couts] double2
+constexpr int PP_TRIP = PP_CHST + 8 * 64 * 16;                   // [64 couts] float4
+constexpr int PP_CHS = PP_TRIP + 64 * 16;                        // [64 couts] double2: a channel's sums over the sample
+constexpr int PP_GB = PP_CHS + 64 * 16;                          // [64 couts] float2: the next layer's gamma, beta
+constexpr int PP_AFF = PP_GB + 64 * 8;                        // [2 sample parities][center | scale | shift][128 input channels] floats: the input GroupNorm's triples, SoA
+constexpr int PP_LDS_ALLOC = PP_AFF + 2 * 3 * 128 * 4;           // 146,432
+}   // namespace
+
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ double pp_row16_sum(double v) {
+#define PP_DPP_STEP(CTRL_)                                                                          \
+    {                                                                                                \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL_, 0xf, 0xf, false);   \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL_, 0xf, 0xf, false);   \
+        v += __hiloint2double(hi_, lo_);                                                             \
+    }
+    PP_DPP_STEP(0xB1)
+    PP_DPP_STEP(0x4E)
+    PP_DPP_STEP(0x141)
+    PP_DPP_STEP(0x140)
+#undef PP_DPP_STEP
+    return v;
+}
+// one value of the lane's row partner under a DPP control (float64 as two dwords)
+template <int CTRL>
+__device__ __forceinline__ double pp_dpp_f64(double v) {
+    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi_, lo_);
+}
+// 16 values per lane, summed over the 16 lanes of a DPP row so that lane n of the row ends up with the row's total of value n: a butterfly that halves the
+// value count per level (partner lanes n ^ 15, n ^ 7, n ^ 2, n ^ 1: every partner agrees with the lane on the bits already used) -- 15 exchanges instead of 64
+__device__ __forceinline__ double pp_row16_transpose_sum(double (&d)[16], int n) {
+#define PP_LEVEL(W_, CTRL_, BIT_)                                                                   \
+    {                                                                                               \
+        const bool up_ = (n & BIT_) != 0;                                                           \
+        _Pragma("unroll") for (int i = 0; i < W_; ++i) {                                            \
+            const double keep_ = up_ ? d[i + W_] : d[i], send_ = up_ ? d[i] : d[i + W_];            \
+            d[i] = keep_ + pp_dpp_f64<CTRL_>(send_);                                                \
+        }                                                                                           \
+    }
+    PP_LEVEL(8, 0x140, 8)
+    PP_LEVEL(4, 0x141, 4)
+    PP_LEVEL(2, 0x4E, 2)
+    PP_LEVEL(1, 0xB1, 1)
+#undef PP_LEVEL
+    return d[0];
+}
+
+// development ablations (tools/pp_ablation.py; wrong results): bit 0 = no staging (requests, conversions), 1 = no epilogue, 2 = no weight loads, 3 = no MFMAs
+#ifndef RF_PP_ABL
+#define RF_PP_ABL 0
+#endif
+#ifdef RF_PP_STAMPS
+// development build (tools/pp_stamps.py): s_memtime at the phase borders of every workgroup's 4th sample, waves 0 and 4, kept in SGPRs until the kernel's end
+__device__ unsigned long long g_pp_stamps[1024 * 2 * 16];
+extern "C" int rft_pp_read_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp_stamps), sizeof(g_pp_stamps)); }
+#define PP_STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st[i] = it == 3 ? t_ : st[i]; } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef RF_PP_STAMPS
+    unsigned long long st[16] = {};
+    int it = 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3;
+    const int G = (int)gridDim.x;
+
+    // ---- the workgroup's first sample: low-res groups (wave = group) and skip chunk 0 (thread = voxel), requested before the zero fill
+    {
+        const int n = blockIdx.x;
+        const float4* __restrict__ aff = a.affine + (size_t)n * cin;
+        const float* __restrict__ sb0 = a.src0 + (size_t)n * c0 * 512;
+        float xl[8], x0[8];
+        const int cg = wave < nB ? wave : nB - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xl[j] = a.src1[((size_t)n * c1 + cg * 8 + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x0[j] = sb0[j * 512 + tid];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int i = tid; i < US_LDS_BYTES / 16; i += 512) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < a.cout) reinterpret_cast<float2*>(lds + PP_GB)[tid] = make_float2(a.ngamma[tid], a.nbeta[tid]);
+        if (tid < cin) {
+            const float4 t4 = aff[tid];
+            float* tb = reinterpret_cast<float*>(lds + PP_AFF);
+            tb[tid] = t4.x; tb[128 + tid] = t4.y; tb[256 + tid] = t4.z;
+        }
+        __syncthreads();
+        if (wave < nB) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 af = aff[c0 + cg * 8 + j];
+                y[j] = fmaf(xl[j] - af.x, af.y, af.z);
+            }
+            h8 h, l;
+            us_split8(y, h, l);
+            const int slot = ((lane >> 4) + 1) * US_BZ + (((lane >> 2) & 3) + 1) * US_BY + (lane & 3) + 1;
+            unsigned char* p = lds + US_B_OFF + cg * 2 * US_B_PLANE + slot * 16;
+            *reinterpret_cast<h8*>(p) = h;
+            *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
+        }
+        {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 af = aff[j];
+                y[j] = fmaf(x0[j] - af.x, af.y, af.z);
+            }
+            h8 h, l;
+            us_split8(y, h, l);
+            const int vs = ((tid >> 6) + 1) * US_SZ + (((tid >> 3) & 7) + 1) * US_SY + (tid & 7) + 1;
+            unsigned char* p = lds + vs * 16;
+            *reinterpret_cast<h8*>(p) = h;
+            *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
+        }
+    }
+
+    auto run = [&](auto PZ_) {
+    constexpr int PZ = decltype(PZ_)::value;
+    // ---- per-lane operand addressing (voxel operand: lane group g = tap of the k-step, lane & 15 = voxel (Y, X) of the parity lattice's z plane)
+    const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
+    const int abase = ((PZ + 1) * US_SZ + (2 * rj + py + 1) * US_SY + (2 * ri + px + 1)) * 16;
+    // the lane group's tap offset of k-step s (tap 4 s + g; the dummy 28th tap reads tap 26's voxel), in 16-byte slots, three 10-bit fields per register
+    int tpk[3] = {0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int t = 4 * s + g < 27 ? 4 * s + g : 26;
+        tpk[s / 3] |= (((t / 9 - 1) * US_SZ + ((t / 3) % 3 - 1) * US_SY + (t % 3 - 1)) & 1023) << (10 * (s % 3));
+    }
+    auto atap = [&](int s) {
+        int t = tpk[s / 3];
+        asm volatile("" : "+v"(t));                                  // unpacked where it is used, not seven registers' worth outside the sample loop
+        return __builtin_amdgcn_sbfe(t, 10 * (s % 3), 10) * 16;
+    };
+    const int bbase = (PZ * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;
+    // weight operand: row m = lane & 15 of cout-block 2p + j is cout 32 p + 8 (m >> 2) + 4 j + (m & 3), which the image (fragment order [n-block][h | l][lane],
+    // lane = 16 g + (cout & 15)) keeps in n-block 2 p + (m >> 3) at lane 16 g + 8 ((m >> 2) & 1) + 4 j + (m & 3)
+    const int m16 = lane & 15;
+    const unsigned wlb = (unsigned)(((m16 >> 3) * 128 + 8 * ((m16 >> 2) & 1) + (m16 & 3) + 16 * g) * 16);
+    constexpr int STEP = 4 * 2 * 64;                                 // 16-byte fragments per k-step of the image (NB = 4)
+    // Every global access of the sample loop is a BUFFER access (descriptor in SGPRs + one 32-bit lane offset + scalar offset + immediate): with flat / global
+    // addressing hipcc forms 64-bit lane addresses -- one VGPR pair per (k-step, fragment row) of the weight image, hoisted out of the sample loop and spilled;
+    // a spill reload is a scratch load in the in-order vmcnt queue, i.e. a wait for the staging loads in front of it, between MFMAs
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<h8*>(a.wp), 0, (int)((((size_t)nA * 7 + 16 * (size_t)nB + 1) * STEP) * 16), 0x00020000);
+    const int wA = 0;                                                // byte offsets into the image
+    const int wB = (nA * 7 + wave * nB * 2) * STEP * 16;
+    constexpr int STEPB = STEP * 16;
+    h8 R0[4], R1[4];                                                 // fragments [j * 2 + (h | l)] of pair 0 / pair 1
+    auto ldw = [&](h8 (&R)[4], int base, auto P_) {
+        constexpr int P = decltype(P_)::value;
+        if constexpr ((RF_PP_ABL & 4) != 0) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(R[f]));
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                R[j * 2 + hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, wlb, base + 4096 * P + (64 * hl + 4 * j) * 16, 0));
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    ldw(R0, wB, P0{});
+    ldw(R1, wB, P1{});
+
+    f32x4 hi[4][4], lo[4][4];                                        // [voxel block][cout block]
+    h8 vh[2], vl[2];
+    auto mfma6 = [&](int vb, auto P_, const h8 (&R)[4], const h8& xh, const h8& xl) {
+        constexpr int P = decltype(P_)::value;
+        if constexpr ((RF_PP_ABL & 8) != 0) {
+            hi[vb][2 * P][0] += (float)R[0][0] * (float)xh[0] + (float)R[1][0] * (float)xl[0];
+            hi[vb][2 * P + 1][0] += (float)R[2][0] * (float)xh[0] + (float)R[3][0] * (float)xl[0];
+            return;
+        }
+        hi[vb][2 * P] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[0], xh, hi[vb][2 * P], 0, 0, 0);
+        hi[vb][2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[2], xh, hi[vb][2 * P + 1], 0, 0, 0);
+        lo[vb][2 * P] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[1], xh, lo[vb][2 * P], 0, 0, 0);
+        lo[vb][2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[3], xh, lo[vb][2 * P + 1], 0, 0, 0);
+        lo[vb][2 * P] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[0], xl, lo[vb][2 * P], 0, 0, 0);
+        lo[vb][2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[2], xl, lo[vb][2 * P + 1], 0, 0, 0);
+    };
+    // one k-step.  On entry (vh[0], vl[0]) hold voxel block 0 of `vp`.  Pair 0 over the four voxel blocks, the NEXT k-step's pair-0 fragments over R0, pair 1, the
+    // next k-step's pair-1 fragments over R1; `xload` (staging requests) behind them.  has_pre: `pre` = voxel block 0 of the next k-step (same chunk).
+    auto kstep = [&](auto skip_c, auto has_pre, auto&& xload, const unsigned char* vp, const unsigned char* pre, int mstride, int lplane, int wnext) {
+        constexpr int skip = decltype(skip_c)::value;
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb) {
+            const unsigned char* q = vb < 3 ? vp + (vb + 1) * mstride : vp;
+            vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q);
+            vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q + lplane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (vb != skip) mfma6(vb, P0{}, R0, vh[vb & 1], vl[vb & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ldw(R0, wnext, P0{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb) {
+            if (vb < 3) {
+                vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(vp + (vb + 1) * mstride);
+                vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(vp + (vb + 1) * mstride + lplane);
+            } else if constexpr (decltype(has_pre)::value) {
+                vh[0] = *reinterpret_cast<const h8*>(pre);
+                vl[0] = *reinterpret_cast<const h8*>(pre + lplane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (vb != skip) mfma6(vb, P1{}, R1, vh[vb & 1], vl[vb & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ldw(R1, wnext, P1{});
+        xload();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // x <- (x - center) * scale + shift with the 8 triples of a channel group out of the LDS table (uniform addresses), in two stages of 8 / 16 registers: the
+    // conversion sits at the kernel's register peak (accumulators + the next k-step's weights + the staged voxels)
+    auto normalise8 = [&](float (&x)[8], int table, int ch) {
+        const float* tb = reinterpret_cast<const float*>(lds + PP_AFF) + table * 384 + ch;
+        {
+            const float4 c0_ = *reinterpret_cast<const float4*>(tb), c1_ = *reinterpret_cast<const float4*>(tb + 4);
+            x[0] -= c0_.x; x[1] -= c0_.y; x[2] -= c0_.z; x[3] -= c0_.w; x[4] -= c1_.x; x[5] -= c1_.y; x[6] -= c1_.z; x[7] -= c1_.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float4 s0_ = *reinterpret_cast<const float4*>(tb + 128), s1_ = *reinterpret_cast<const float4*>(tb + 132);
+            const float4 h0_ = *reinterpret_cast<const float4*>(tb + 256), h1_ = *reinterpret_cast<const float4*>(tb + 260);
+            x[0] = fmaf(x[0], s0_.x, h0_.x); x[1] = fmaf(x[1], s0_.y, h0_.y); x[2] = fmaf(x[2], s0_.z, h0_.z); x[3] = fmaf(x[3], s0_.w, h0_.w);
+            x[4] = fmaf(x[4], s1_.x, h1_.x); x[5] = fmaf(x[5], s1_.y, h1_.y); x[6] = fmaf(x[6], s1_.z, h1_.z); x[7] = fmaf(x[7], s1_.w, h1_.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // phase B's k-step: the weights there are the wave's OWN (its parity's pre-summed taps: every fragment comes from L2, where phase A's are shared by the
+    // eight waves and mostly hit in L1), and half a k-step does not cover that latency.  Phase B stages nothing, so it has the registers for a second weight set
+    // (N0 / N1, dead in phase A): the next k-step's eight fragments are requested at the start of the step, the voxel operands are read once per step.
+    h8 N0[4], N1[4];
+    auto kstep_b = [&](auto skip_c, const unsigned char* vp, const unsigned char* pre, int mstride, int lplane, int wnext, const h8 (&C0)[4], const h8 (&C1)[4], h8 (&X0)[4], h8 (&X1)[4]) {
+        constexpr int skip = decltype(skip_c)::value;
+        ldw(X0, wnext, P0{});
+        ldw(X1, wnext, P1{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb) {
+            const unsigned char* q = vb < 3 ? vp + (vb + 1) * mstride : pre;
+            vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q);
+            vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q + lplane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (vb != skip && (RF_PP_ABL & 8)) {
+                hi[vb][0][0] += (float)C0[0][0] * (float)vh[vb & 1][0] + (float)C0[1][0] * (float)vl[vb & 1][0] + (float)C0[2][0] + (float)C0[3][0];
+                hi[vb][2][0] += (float)C1[0][0] * (float)vh[vb & 1][0] + (float)C1[1][0] * (float)vl[vb & 1][0] + (float)C1[2][0] + (float)C1[3][0];
+            } else if (vb != skip) {
+                const h8& xh = vh[vb & 1];
+                const h8& xl = vl[vb & 1];
+                hi[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[0], xh, hi[vb][0], 0, 0, 0);
+                hi[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[2], xh, hi[vb][1], 0, 0, 0);
+                hi[vb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[0], xh, hi[vb][2], 0, 0, 0);
+                hi[vb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[2], xh, hi[vb][3], 0, 0, 0);
+                lo[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[1], xh, lo[vb][0], 0, 0, 0);
+                lo[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[3], xh, lo[vb][1], 0, 0, 0);
+                lo[vb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[1], xh, lo[vb][2], 0, 0, 0);
+                lo[vb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[3], xh, lo[vb][3], 0, 0, 0);
+                lo[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[0], xl, lo[vb][0], 0, 0, 0);
+                lo[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[2], xl, lo[vb][1], 0, 0, 0);
+                lo[vb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[0], xl, lo[vb][2], 0, 0, 0);
+                lo[vb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[2], xl, lo[vb][3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto no_x = [] {};
+    using no_skip = std::integral_constant<int, -1>;
+    using skip_lo = std::integral_constant<int, US_ZSKIP && PZ == 0 ? 0 : -1>;
+    using skip_hi = std::integral_constant<int, US_ZSKIP && PZ == 1 ? 3 : -1>;
+
+    __syncthreads();                                                 // the first sample's images are in place
+    int sp = 0;                                                      // which triple table is this sample's (the other one is filled for the next sample in chunk 0)
+    for (int n = blockIdx.x; n < a.n; n += G, sp ^= 1) {
+        const int nn = n + G < a.n ? n + G : n;                      // the sample staged under this one (the last one re-stages itself: harmless)
+        PP_STAMP(0);
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) { hi[vb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[vb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+        // ---- phase B: upsampled channels in low resolution (this parity's pre-summed taps), 2 k-steps per 8-channel group
+        {
+            const unsigned char* bb = lds + US_B_OFF + bbase;
+            vh[0] = *reinterpret_cast<const h8*>(bb);
+            vl[0] = *reinterpret_cast<const h8*>(bb + US_B_PLANE);
+            int wn = wB + STEPB;
+            for (int cb = 0; cb < nB; ++cb) {
+                const unsigned char* ap = bb + cb * 2 * US_B_PLANE;
+                const bool last = cb + 1 == nB;
+                kstep_b(skip_lo{}, ap, ap + US_BZ * 16, US_BZ * 16, US_B_PLANE, wn, R0, R1, N0, N1);                                   // tz = 0
+                wn += STEPB;
+                kstep_b(skip_hi{}, ap + US_BZ * 16, last ? ap : ap + 2 * US_B_PLANE, US_BZ * 16, US_B_PLANE, last ? wA : wn, N0, N1, R0, R1);     // tz = 1
+                wn += STEPB;
+            }
+        }
+        PP_STAMP(1);
+
+        // ---- phase A: skip channels, 7 k-steps per chunk on the double-buffered halo box (chunk ca in buffer ca & 1; c0 / 8 is even).  Waves 0..3 (PZ = 0, the
+        // SIMD arbiter's favourites: they finish a chunk ~4 k cycles before their partners) stage: the next chunk (two voxels per thread, requested behind k-steps
+        // 0 / 3, converted behind k-steps 2 / 6) -- after the last chunk the NEXT sample's chunk 0 -- and, in chunks 1 and 2, the next sample's low-res groups
+        // (slot k: group (tid >> 6) + 4 k, voxel lane; requested behind k-step 1, converted behind k-step 4).
+        auto chunk_a = [&](int ca, auto BK_) {
+            constexpr int BK = decltype(BK_)::value;                 // -1: no low-res staging in this chunk
+            float x[8];                                              // ONE staging register set, three windows per chunk: requested behind k-steps 0 / 2 / 4, converted behind 2 / 4 / 6
+            const bool more = ca + 1 < nA;
+            const int cx = more ? ca + 1 : 0, nx = more ? n : nn;
+            const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0) + ((size_t)nx * c0 + cx * 8) * 512, 0, 8 * 512 * 4, 0x00020000);
+            const int toff = (tid & 255) * 4;
+            // the input GroupNorm's triples come out of LDS (uniform address): a global load here is a VECTOR load -- the epilogue's stores make hipcc treat the
+            // table as clobbered, so no s_load -- with L2 latency in front of every conversion and 8 more entries in the in-order vmcnt queue
+            float4 afn;                                              // chunk 0: this thread's entry of the NEXT sample's table
+            const int cgb = BK < 0 ? 0 : (wave + 4 * BK < nB ? wave + 4 * BK : nB - 1);
+            auto xload_a = [&] {
+                if constexpr (PZ == 0 && !(RF_PP_ABL & 1)) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, toff, j * 2048, 0));
+                    if constexpr (BK == -2) {
+                        const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.affine) + (size_t)nn * cin, 0, cin * 16, 0x00020000);
+                        afn = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rF, (tid < cin ? tid : cin - 1) * 16, 0, 0));
+                    }
+                }
+            };
+            auto xload_b = [&] {
+                if constexpr (PZ == 0 && !(RF_PP_ABL & 1)) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, toff, j * 2048 + 1024, 0));
+                }
+            };
+            auto xload_low = [&] {
+                if constexpr (PZ == 0 && BK >= 0 && !(RF_PP_ABL & 1)) {
+                    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1) + ((size_t)nn * c1 + cgb * 8) * 64, 0, 8 * 64 * 4, 0x00020000);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rL, lane * 4, j * 256, 0));
+                }
+            };
+            auto convert_store = [&](int half) {
+                if constexpr (PZ == 0 && !(RF_PP_ABL & 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    normalise8(x, more ? sp : sp ^ 1, cx * 8);
+                    h8 h, l;
+                    us_split8(x, h, l);
+                    int vs = tid;
+                    asm volatile("" : "+v"(vs));
+                    vs = ((vs >> 6) + 1 + 4 * half) * US_SZ + (((vs >> 3) & 7) + 1) * US_SY + (vs & 7) + 1;       // tid < 256: z = 0..3 (+ 4)
+                    unsigned char* p = lds + ((ca + 1) & 1) * US_A_BUF + vs * 16;
+                    *reinterpret_cast<h8*>(p) = h;
+                    *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
+                    if constexpr (BK == -2) {
+                        if (half == 0) {
+                            float* tb = reinterpret_cast<float*>(lds + PP_AFF) + (sp ^ 1) * 384 + (tid < cin ? tid : cin - 1);
+                            tb[0] = afn.x; tb[128] = afn.y; tb[256] = afn.z;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto convert_low = [&] {
+                if constexpr (PZ == 0 && BK >= 0 && !(RF_PP_ABL & 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    normalise8(x, sp ^ 1, c0 + cgb * 8);
+                    h8 h, l;
+                    us_split8(x, h, l);
+                    int ls = tid;
+                    asm volatile("" : "+v"(ls));
+                    ls = (((ls >> 4) & 3) + 1) * US_BZ + (((ls >> 2) & 3) + 1) * US_BY + (ls & 3) + 1;
+                    unsigned char* p = lds + US_B_OFF + cgb * 2 * US_B_PLANE + ls * 16;
+                    *reinterpret_cast<h8*>(p) = h;
+                    *reinterpret_cast<h8*>(p + US_B_PLANE) = l;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // this chunk's halo buffer + the lane's voxel, opaque: hipcc otherwise keeps (buffer, tap) address variants across the whole sample loop
+            int abuf = abase + (ca & 1) * US_A_BUF;
+            asm volatile("" : "+v"(abuf));
+            const unsigned char* buf = lds + abuf;
+            vh[0] = *reinterpret_cast<const h8*>(buf + atap(0));
+            vl[0] = *reinterpret_cast<const h8*>(buf + atap(0) + US_A_PLANE);
+            constexpr int MS = 2 * US_SZ * 16;
+            const int wn = wA + (ca * 7 + 1) * STEPB;
+            auto v0 = [&](int s_) {                                  // voxel block 0 of k-step s_, read AFTER a conversion (its registers are not held across it)
+                if constexpr (PZ == 0) {
+                    vh[0] = *reinterpret_cast<const h8*>(buf + atap(s_));
+                    vl[0] = *reinterpret_cast<const h8*>(buf + atap(s_) + US_A_PLANE);
+                }
+            };
+            using pre_c = std::integral_constant<bool, PZ != 0>;     // the staging waves (PZ = 0) do not prefetch across a conversion
+            kstep(skip_lo{}, std::true_type{}, xload_a, buf + atap(0), buf + atap(1), MS, US_A_PLANE, wn);
+            kstep(skip_lo{}, std::true_type{}, no_x, buf + atap(1), buf + atap(2), MS, US_A_PLANE, wn + STEPB);
+            if constexpr (BK >= 0) {
+                kstep(no_skip{}, pre_c{}, no_x, buf + atap(2), buf + atap(3), MS, US_A_PLANE, wn + 2 * STEPB);
+                convert_store(0);
+                v0(3);
+                kstep(no_skip{}, std::true_type{}, xload_low, buf + atap(3), buf + atap(4), MS, US_A_PLANE, wn + 3 * STEPB);     // (the request goes out behind the conversion)
+                kstep(no_skip{}, std::true_type{}, no_x, buf + atap(4), buf + atap(5), MS, US_A_PLANE, wn + 4 * STEPB);
+                kstep(skip_hi{}, pre_c{}, no_x, buf + atap(5), buf + atap(6), MS, US_A_PLANE, wn + 5 * STEPB);
+                convert_low();
+                xload_b();
+                v0(6);
+                kstep(skip_hi{}, std::false_type{}, no_x, buf + atap(6), buf + atap(6), MS, US_A_PLANE, more ? wn + 6 * STEPB : wB);
+            } else {
+                kstep(no_skip{}, pre_c{}, no_x, buf + atap(2), buf + atap(3), MS, US_A_PLANE, wn + 2 * STEPB);
+                convert_store(0);
+                v0(3);
+                kstep(no_skip{}, std::true_type{}, xload_b, buf + atap(3), buf + atap(4), MS, US_A_PLANE, wn + 3 * STEPB);
+                kstep(no_skip{}, std::true_type{}, no_x, buf + atap(4), buf + atap(5), MS, US_A_PLANE, wn + 4 * STEPB);
+                kstep(skip_hi{}, std::true_type{}, no_x, buf + atap(5), buf + atap(6), MS, US_A_PLANE, wn + 5 * STEPB);
+                kstep(skip_hi{}, std::false_type{}, no_x, buf + atap(6), buf + atap(6), MS, US_A_PLANE, more ? wn + 6 * STEPB : wB);
+            }
+            convert_store(1);
+            __syncthreads();
+        };
+        chunk_a(0, std::integral_constant<int, -2>{});             // (-2: no low-res staging, but the next sample's triple table)
+        PP_STAMP(2);
+        chunk_a(1, std::integral_constant<int, 0>{});
+        PP_STAMP(3);
+        chunk_a(2, std::integral_constant<int, 1>{});
+        PP_STAMP(4);
+        for (int ca = 3; ca < nA; ++ca) chunk_a(ca, std::integral_constant<int, -1>{});
+        PP_STAMP(5);
+
+        // ---- epilogue, from registers: v = relu(hi + lo / 2^11); lane (g, v) holds couts 32 p + 8 g + 4 j + r of voxel (2 vb + PZ, 2 rj + py, 2 ri + px)
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        const int el = te & 63, eg = el >> 4;
+        if constexpr ((RF_PP_ABL & 2) != 0) {
+            float sink = 0.f;
+#pragma unroll
+            for (int vb = 0; vb < 4; ++vb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sink += hi[vb][cb][r] + lo[vb][cb][r];
+            if (sink == 123.456f) a.pre_out[te][0] = (_Float16)sink;
+            continue;
+        }
+#pragma unroll
+        for (int vb = 0; vb < 4; ++vb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hi[vb][cb][r] = fmaxf(fmaf(lo[vb][cb][r], 1.0f / US_LO, hi[vb][cb][r]), 0.f);
+        double2* chst = reinterpret_cast<double2*>(lds + PP_CHST);
+        double2* chs = reinterpret_cast<double2*>(lds + PP_CHS);
+        float4* trip = reinterpret_cast<float4*>(lds + PP_TRIP);
+        {
+            // per cout: the lane's four voxels in float64, then over the 16 voxel lanes of the row: lane n keeps the total of its value n = 4 cb + r
+            double sm[16], sq[16];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double s_ = 0.0, q_ = 0.0;
+#pragma unroll
+                    for (int vb = 0; vb < 4; ++vb) {
+                        const double v = (double)hi[vb][cb][r];
+                        s_ += v; q_ += v * v;
+                    }
+                    sm[cb * 4 + r] = s_; sq[cb * 4 + r] = q_;
+                }
+            const int nl = el & 15;
+            const double ts = pp_row16_transpose_sum(sm, nl), tq = pp_row16_transpose_sum(sq, nl);
+            chst[wave * 64 + 32 * (nl >> 3) + 8 * eg + 4 * ((nl >> 2) & 1) + (nl & 3)] = make_double2(ts, tq);
+        }
+        PP_STAMP(6);
+        __syncthreads();
+        PP_STAMP(7);
+        const int cout = a.cout;
+        {   // thread (channel te >> 3, wave te & 7): the channel's sums over the eight waves (fixed order), lane 0 of the eight publishes them
+            double2 v = chst[(te & 7) * 64 + (te >> 3)];
+            v.x += pp_dpp_f64<0xB1>(v.x); v.y += pp_dpp_f64<0xB1>(v.y);
+            v.x += pp_dpp_f64<0x4E>(v.x); v.y += pp_dpp_f64<0x4E>(v.y);
+            v.x += pp_dpp_f64<0x141>(v.x); v.y += pp_dpp_f64<0x141>(v.y);
+            if ((te & 7) == 0) {
+                chs[te >> 3] = v;
+                if (a.stats && (te >> 3) < cout) a.stats[(size_t)n * cout + (te >> 3)] = v;
+            }
+        }
+        __syncthreads();
+        if (te < cout) {                                             // as rf_gn_from_stats: group sums in channel order, float64
+            int cpg = cout / a.ngroups;
+            float neps = a.neps;
+            asm volatile("" : "+s"(cpg), "+s"(neps));              // (their float64 forms are not to live in VGPR pairs across the sample loop)
+            const int cbeg = (te / cpg) * cpg;
+            double sm = 0.0, sq = 0.0;
+            for (int c = cbeg; c < cbeg + cpg; ++c) { sm += chs[c].x; sq += chs[c].y; }
+            const double count = (double)cpg * 512.0, mean = sm / count;
+            double var = sq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float2 gb = reinterpret_cast<const float2*>(lds + PP_GB)[te];
+            trip[te] = gn_affine(mean, 1.0 / sqrt(var + (double)neps), gb.x, gb.y);
+        }
+        PP_STAMP(8);
+        __syncthreads();
+        PP_STAMP(9);
+        {
+            // slot of the lane's voxel (2 vb + PZ, 2 rj + py, 2 ri + px): linear z 64 + y 8 + x, or parity-major (wave 64 + vb 16 + lane & 15: 256-byte runs)
+            const int nl = el & 15;
+            const int vox = a.pre_pm ? wave * 64 + nl : PZ * 64 + (2 * (nl >> 2) + py) * 8 + 2 * (nl & 3) + px;
+            const int vbs = a.pre_pm ? 16 : 128;
+            h8* __restrict__ po = a.pre_out + (size_t)n * (cout >> 3) * 2 * 512 + vox;
+            const int nsg = cout >> 3;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int sg = 4 * p + eg;
+                float4 t4[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t4[i] = trip[(sg < nsg ? sg : 0) * 8 + i];
+#pragma unroll
+                for (int vb = 0; vb < 4; ++vb) {
+                    float y[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = fmaf(hi[vb][2 * p + (i >> 2)][i & 3] - t4[i].x, t4[i].y, t4[i].z);
+                    h8 h, l;
+                    us_split8(y, h, l);
+                    if (sg < nsg) {
+                        po[(size_t)sg * 2 * 512 + vb * vbs] = h;
+                        po[(size_t)sg * 2 * 512 + 512 + vb * vbs] = l;
+                    }
+                }
+            }
+        }
+        PP_STAMP(10);
+#ifdef RF_PP_STAMPS
+        ++it;
+#endif
+    }
+#ifdef RF_PP_STAMPS
+    if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 1024) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g_pp_stamps[(blockIdx.x * 2 + (wave >> 2)) * 16 + i] = st[i];
+    }
+#endif
     };   // run
     if (pz == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
@@ -1224,6 +1790,30 @@ static int launch_up_split(const UpSplitArgs& a, hipStream_t stream) {
 
 static int up_split_dispatch(UpSplitArgs& a, int c0, int c1, int n, int edge, int cout, void* stream);
 
+// The persistent form (k_conv3_up_split_pp) takes the pre-split launches with four cout blocks, an even number (>= 4) of skip chunks and enough samples for
+// every CU to walk several: one workgroup per CU (134 KB of LDS, 256 VGPRs), RF_UP_PP_ROUNDS rounds of them (see rf_persistent_wgs on why more than one).
+#ifndef RF_UP_PP
+#define RF_UP_PP 1
+#endif
+#ifndef RF_UP_PP_ROUNDS
+#define RF_UP_PP_ROUNDS 1
+#endif
+#ifndef RF_UP_PP_LINEAR
+#define RF_UP_PP_LINEAR 1                                          // development: 0 = the linear-order entry point stays on k_conv3_up_split
+#endif
+static bool up_split_pp_takes(int c0, int c1, int n, int cout) {
+    return RF_UP_PP && cout > 48 && cout <= 64 && cout % 8 == 0 && c0 >= 32 && c0 % 16 == 0 && c1 >= 8 && c1 % 8 == 0 && c1 <= 8 * US_MAX_CGB && n >= 1024;
+}
+
+static int launch_up_split_pp(const UpSplitArgs& a, hipStream_t stream) {
+    static RfLdsOptIn opt_in;
+    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_conv3_up_split_pp), PP_LDS_ALLOC, "rf_conv3d_up_split_presplit")) return rc;
+    const int wgs = (rf_resident_wgs() / 2) * RF_UP_PP_ROUNDS;
+    hipLaunchKernelGGL(k_conv3_up_split_pp, dim3((unsigned)(a.n < wgs ? a.n : wgs)), dim3(512), PP_LDS_ALLOC, stream, a);
+    RF_CHECK_LAUNCH("rf_conv3d_up_split_presplit");
+    return RF_OK;
+}
+
 extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine,
                                               const void* w_packed, int cout, float* out, double* stats, void* stream) {
     RF_REQUIRE(rf_conv3d_up_split_supported(c0, c1, n, edge, cout), RF_E_UNSUPPORTED,
@@ -1233,7 +1823,7 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu(const float* src0, int c0, const fl
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = out; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
-    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f; a.out_ch8 = 0;
+    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f; a.out_ch8 = 0; a.pre_pm = 0;
     return up_split_dispatch(a, c0, c1, n, edge, cout, stream);
 }
 
@@ -1331,8 +1921,30 @@ extern "C" int rf_conv3d_up_split_presplit(const float* src0, int c0, const floa
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = nullptr; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
-    a.pre_out = reinterpret_cast<h8*>(out_presplit); a.ngamma = next_gamma; a.nbeta = next_beta; a.ngroups = next_groups; a.neps = eps; a.out_ch8 = 0;
+    a.pre_out = reinterpret_cast<h8*>(out_presplit); a.ngamma = next_gamma; a.nbeta = next_beta; a.ngroups = next_groups; a.neps = eps; a.out_ch8 = 0; a.pre_pm = 0;
+    if (RF_UP_PP_LINEAR && up_split_pp_takes(c0, c1, n, cout)) return launch_up_split_pp(a, (hipStream_t)stream);
     return rf_round_up(cout, 16) == 48 ? launch_up_split<3>(a, (hipStream_t)stream) : launch_up_split<4>(a, (hipStream_t)stream);
+}
+
+// The same with the voxel slots of the output in PARITY-MAJOR order (UpSplitArgs::pre_pm; consumer: rf_conv3d_split_pre_pm_k3_relu): the persistent kernel
+// k_conv3_up_split_pp, whose waves own one output parity each and leave their slots from registers -- in the linear order those are 16-byte pieces 32 bytes
+// apart, in this order 256-byte runs.
+extern "C" int rf_conv3d_up_split_presplit_pm_supported(int c0, int c1, int n, int edge, int cout, int next_groups) {
+    return rf_conv3d_up_split_presplit_supported(c0, c1, n, edge, cout, next_groups) && up_split_pp_takes(c0, c1, n, cout);
+}
+
+extern "C" int rf_conv3d_up_split_presplit_pm(const float* src0, int c0, const float* src1, int c1, int n, int edge, const float* gn_affine, const void* w_packed,
+                                              int cout, const float* next_gamma, const float* next_beta, int next_groups, float eps, void* out_presplit_pm,
+                                              double* stats, void* stream) {
+    RF_REQUIRE(rf_conv3d_up_split_presplit_pm_supported(c0, c1, n, edge, cout, next_groups), RF_E_UNSUPPORTED,
+               "rf_conv3d_up_split_presplit_pm: takes whole 8^3 samples (n >= 1024), 49..64 couts in eights and in whole groups, c0 >= 32 in sixteens, c1 <= 64 in eights (got c0=%d c1=%d n=%d edge=%d cout=%d groups=%d)",
+               c0, c1, n, edge, cout, next_groups);
+    RF_REQUIRE(src0 && src1 && gn_affine && w_packed && out_presplit_pm && next_gamma && next_beta, RF_E_INVALID, "rf_conv3d_up_split_presplit_pm: null pointer");
+    UpSplitArgs a;
+    a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
+    a.out = nullptr; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
+    a.pre_out = reinterpret_cast<h8*>(out_presplit_pm); a.ngamma = next_gamma; a.nbeta = next_beta; a.ngroups = next_groups; a.neps = eps; a.out_ch8 = 0; a.pre_pm = 1;
+    return launch_up_split_pp(a, (hipStream_t)stream);
 }
 
 // rf_conv3d_up_split_k3_gn_relu with the output CHANNEL-INTERLEAVED, [n][cout / 8][edge^3][8 channels] fp32 ("ch8"), for a consumer that stages the 8 channels
@@ -1353,6 +1965,6 @@ extern "C" int rf_conv3d_up_split_k3_gn_relu_ch8(const float* src0, int c0, cons
     UpSplitArgs a;
     a.src0 = src0; a.src1 = src1; a.affine = reinterpret_cast<const float4*>(gn_affine); a.wp = reinterpret_cast<const h8*>(w_packed);
     a.out = out_ch8; a.stats = reinterpret_cast<double2*>(stats); a.c0 = c0; a.c1 = c1; a.n = n; a.cout = cout;
-    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f; a.out_ch8 = 1;
+    a.pre_out = nullptr; a.ngamma = a.nbeta = nullptr; a.ngroups = 0; a.neps = 0.f; a.out_ch8 = 1; a.pre_pm = 0;
     return up_split_dispatch(a, c0, c1, n, edge, cout, stream);
 }

@@ -21,6 +21,9 @@ struct ConvArgs {
     double2* pool_stats;
     int pool_mode;
     float floor;       // output clamp from below: 0 = ReLU (the forward layers), -inf = none (rf_conv3d_k3_gn with relu = 0: the dgrad conv)
+    // pre-split input of whole 8^3 samples in PARITY-MAJOR slot order (what rf_conv3d_up_split_presplit_pm writes: the slot of voxel (z, y, x) is
+    // ((z & 1) 4 + (y & 1) 2 + (x & 1)) 64 + (z >> 1) 16 + (y >> 1) 4 + (x >> 1)); k_conv3_split_zcm<PRE> only
+    int src_pm = 0;
 };
 
 // Voxel order inside the 8^3 box of the 8-wave x MB 4 tile: m = wave*64 + mb*16 + i -> (z, y, x) such that one lane's

@@ -201,8 +201,10 @@ def _decoder_pair_presplit(c1, c2, x, upsampled):
     g1, g2 = c1.groupnorm, c2.groupnorm
     aff = ops.gn_affine(x, upsampled, g1.weight, g1.bias, g1.num_groups, g1.eps)
     c0 = x.shape[1] if x is not None else 0
-    pre = ops.conv3d_up_split_presplit(x, upsampled, aff, c1.conv.packed_up_split(c0), c1.conv.out_channels, g2.weight, g2.bias, _groups_of(g2), g2.eps)
-    return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, upsampled.shape[0], 2 * upsampled.shape[2], c2.conv.packed_split(), c2.conv.out_channels)
+    # parity-major hand-over where the persistent producer and the persistent consumer both take the shapes (the bench's 8192 patches: k_conv3_up_split_pp)
+    pm = ops.conv_up_split_presplit_pm_supported(x, upsampled, c1.conv.out_channels, _groups_of(g2), c2.conv.out_channels)
+    pre = ops.conv3d_up_split_presplit(x, upsampled, aff, c1.conv.packed_up_split(c0), c1.conv.out_channels, g2.weight, g2.bias, _groups_of(g2), g2.eps, parity_major=pm)
+    return ops.conv3d_split_pre_relu(pre, c1.conv.out_channels, upsampled.shape[0], 2 * upsampled.shape[2], c2.conv.packed_split(), c2.conv.out_channels, parity_major=pm)
 
 
 class DoubleConv(nn.Module):

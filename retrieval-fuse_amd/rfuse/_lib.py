@@ -80,6 +80,10 @@ SIGNATURES = {
     'rf_conv3d_split_pre_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_pre_stats_tiles': (c_i, [c_i, c_i, c_i, c_i]),
     'rf_conv3d_split_pre_k3_relu': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_fp, c_p, c_fp, c_p, c_p]),
+    'rf_conv3d_up_split_presplit_pm_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_up_split_presplit_pm': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_p, c_i, c_fp, c_fp, c_i, c_f, c_p, c_p, c_p]),
+    'rf_conv3d_split_pre_pm_supported': (c_i, [c_i, c_i, c_i, c_i]),
+    'rf_conv3d_split_pre_pm_k3_relu': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_conv3_up_split_packed_bytes': (c_sz, [c_i, c_i, c_i]),
     'rf_conv3_up_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_p, c_p]),
     'rf_conv3d_up_split_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),

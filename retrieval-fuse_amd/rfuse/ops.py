@@ -529,9 +529,21 @@ def conv_up_split_presplit_supported(x, upsampled, cout, next_groups):
     return bool(_lib.load().rf_conv3d_up_split_presplit_supported(c0, upsampled.shape[1], upsampled.shape[0], 2 * upsampled.shape[2], cout, next_groups))
 
 
-def conv3d_up_split_presplit(x, upsampled, gn_affine_t, w_packed, cout, next_gamma, next_beta, next_groups, eps):
+def conv_up_split_presplit_pm_supported(x, upsampled, cout, next_groups, next_cout):
+    """the decoder pair can hand over in PARITY-MAJOR slot order: the persistent producer (rf_conv3d_up_split_presplit_pm) AND the persistent consumer
+    (rf_conv3d_split_pre_pm_k3_relu) take the shapes"""
+    if not USE_PRESPLIT or not USE_PRESPLIT_PM or CONV_ARITH != 'split' or upsampled is None or x is None:
+        return False
+    lib = _lib.load()
+    n, edge = upsampled.shape[0], 2 * upsampled.shape[2]
+    return bool(lib.rf_conv3d_up_split_presplit_pm_supported(x.shape[1], upsampled.shape[1], n, edge, cout, next_groups)) and \
+        bool(lib.rf_conv3d_split_pre_pm_supported(cout, n, edge, next_cout))
+
+
+def conv3d_up_split_presplit(x, upsampled, gn_affine_t, w_packed, cout, next_gamma, next_beta, next_groups, eps, parity_major=False):
     """relu(conv(GN([x, up(upsampled)]))) of whole 8^3 samples, emitted as the pre-split input of the NEXT layer (its GroupNorm applied from the
-    sample's own statistics): uint8 buffer for conv3d_split_pre_relu"""
+    sample's own statistics): uint8 buffer for conv3d_split_pre_relu (parity_major: its voxel slots in the order of rf_conv3d_up_split_presplit_pm, for
+    conv3d_split_pre_relu(..., parity_major=True))"""
     _req(upsampled, 'upsampled')
     n, edge = upsampled.shape[0], 2 * upsampled.shape[2]
     c0 = x.shape[1] if x is not None else 0
@@ -542,14 +554,16 @@ def conv3d_up_split_presplit(x, upsampled, gn_affine_t, w_packed, cout, next_gam
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(lib.rf_conv3d_up_split_presplit(_p(x), c0, _p(upsampled), c1, n, edge, _p(gn_affine_t), _p(w_packed), cout, _p(next_gamma.detach()),
-                                               _p(next_beta.detach()), next_groups, eps, _p(out), _p(None), _stream()), 'rf_conv3d_up_split_presplit')
+    entry = 'rf_conv3d_up_split_presplit_pm' if parity_major else 'rf_conv3d_up_split_presplit'
+    _lib.check(getattr(lib, entry)(_p(x), c0, _p(upsampled), c1, n, edge, _p(gn_affine_t), _p(w_packed), cout, _p(next_gamma.detach()),
+                                   _p(next_beta.detach()), next_groups, eps, _p(out), _p(None), _stream()), entry)
     if timed:
         ev1.record()
         conv_events.append((ev0, ev1, conv_up_split_issued_flops(c0, c1, n, edge, cout), ('rf_conv3d_up_split_presplit', 'f16 split', (c0, c1, n, edge, cout))))
     return out
 
 
+USE_PRESPLIT_PM = True          # False: the decoder pair hands over in the linear slot order (cross-checks)
 USE_PREPOOL = True              # False: the level-0 max-pool hands an fp32 tensor to the next level (the round-3 route; kept for cross-checks)
 
 
@@ -595,13 +609,14 @@ def conv3d_split_pre_presplit(pre, w_split_packed, cout, next_gamma, next_beta, 
     return PreSplit(out, pre.n, cout, pre.edge)
 
 
-def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None):
-    """conv3d_split_gn_relu on a pre-split input (already normalised for this layer and split by its producer)."""
+def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None, parity_major=False):
+    """conv3d_split_gn_relu on a pre-split input (already normalised for this layer and split by its producer; parity_major: in the slot order of
+    conv3d_up_split_presplit(..., parity_major=True))."""
     dev = pre.device
     lib = _lib.load()
     out = torch.empty((n, cout, edge, edge, edge), dtype=torch.float32, device=dev) if pool != 'only' else None
     pooled = torch.empty((n, cout, edge // 2, edge // 2, edge // 2), dtype=torch.float32, device=dev) if pool is not None else None
-    tiles = lib.rf_conv3d_split_pre_stats_tiles(cin, n, edge, cout)      # one per 8^3 box, or one per sample (persistent form)
+    tiles = 1 if parity_major else lib.rf_conv3d_split_pre_stats_tiles(cin, n, edge, cout)      # one per 8^3 box, or one per sample (persistent form)
     stats = pstats = None
     if USE_FUSED_STATS:
         stats = torch.empty((n, cout, tiles, 2), dtype=torch.float64, device=dev) if out is not None else None
@@ -610,8 +625,8 @@ def conv3d_split_pre_relu(pre, cin, n, edge, w_split_packed, cout, pool=None):
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(lib.rf_conv3d_split_pre_k3_relu(_p(pre), cin, n, edge, _p(w_split_packed), cout, _p(out), _p(stats), _p(pooled), _p(pstats), _stream()),
-               'rf_conv3d_split_pre_k3_relu')
+    entry = 'rf_conv3d_split_pre_pm_k3_relu' if parity_major else 'rf_conv3d_split_pre_k3_relu'
+    _lib.check(getattr(lib, entry)(_p(pre), cin, n, edge, _p(w_split_packed), cout, _p(out), _p(stats), _p(pooled), _p(pstats), _stream()), entry)
     if timed:
         ev1.record()
         conv_events.append((ev0, ev1, conv_split_issued_flops(cin, n, edge, cout), ('rf_conv3d_split_pre_k3_relu', 'f16 split', (cin, 0, n, edge, cout))))
