@@ -465,45 +465,35 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split(UpSplitArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- persistent form, MFMA roles swapped
-// k_conv3_up_split_pp: the same layer (whole 8^3 samples, 33..64 couts, pre-split output only) as a PERSISTENT kernel -- one workgroup per CU walks
+// k_conv3_up_split_pp: the same layer (whole 8^3 samples, 49..64 couts, pre-split output only) as a PERSISTENT kernel -- one workgroup per CU walks
 // samples n, n + grid, ... -- built so that nothing but the epilogue of a sample stands between its last MFMA and the next sample's first:
-//  * MFMA ROLES SWAPPED: the weights are the A operand (M = 16 couts), the voxels the B operand (N = 16 voxels of the wave's parity class in one z
-//    plane).  An accumulator lane then holds 4 consecutive M rows of ONE voxel; with the rows of cout-block pair (2p, 2p + 1) permuted
-//    (row 4 g' + r of block 2p + j  <->  cout 32 p + 8 g' + 4 j + r: a per-lane gather out of the SAME weight image, no second pack) lane (g, v) holds the 8 couts
-//    32 p + 8 g .. + 7 of voxel v: exactly one 16-byte slot of the pre-split output.  ReLU, statistics, the next layer's GroupNorm, the h / l split and
-//    the stores all leave from registers -- no LDS tile (the 132 KB tile of k_conv3_up_split aliases every image, which is what forbade staging sample
-//    i + 1 under sample i).
-//  * PHASE ORDER B -> A: the low-res images are dead once phase B is over, so the NEXT sample's low-res voxels are staged into them during phase A
-//    (chunks 1 and 2), and its first skip chunk goes into the idle halo buffer during the last chunk (c0 / 8 even): the per-sample prologue (zero fill,
-//    staging, barrier: ~10 k of ~98 k cycles) is paid once per workgroup.
-//  * WEIGHTS IN ONE ROLLING REGISTER SET: a k-step walks the cout-block pairs in the OUTER loop (voxel operands are read twice per k-step from LDS:
-//    85 B/clk per CU, free on this part -- tools/micro/mfma_lds_power.hip), so pair 0's fragments are dead after half a k-step and the next k-step's
-//    are loaded over them: 32 registers of weights instead of 64 -- the room the persistent loop needs at 256 VGPRs (round 3's attempt spilled 66).
-// Statistics of a channel are summed in float64 per lane (4 values), across the 16 lanes of a row, then over the 8 waves in wave order.
+//  * MFMA ROLES SWAPPED: the weights are the A operand (M = 16 couts), the voxels the B operand (N = 16 voxels).  An accumulator lane then holds 4 consecutive M
+//    rows of ONE voxel; with the rows of a cout-block pair permuted (row 4 g' + r of block 2 p + j  <->  cout 32 p + 8 g' + 4 j + r: a per-lane gather out of the
+//    SAME weight image, no second pack) lane (g, v) holds the 8 couts 32 p + 8 g .. + 7 of voxel v: exactly one 16-byte slot of the pre-split output.  ReLU,
+//    statistics, the next layer's GroupNorm, the h / l split and the stores all leave from registers -- no LDS tile (the 132 KB tile of k_conv3_up_split aliases
+//    every image, which is what forbade staging sample i + 1 under sample i).
+//  * TILE 8 VOXEL BLOCKS x 2 COUT BLOCKS per wave: wave = (cout half ch, (py, px)); its voxel blocks are the 8 z planes of the (py, px) column, i.e. BOTH z
+//    parities.  tools/pp_ablation.py on the first form (4 x 4 tile, tools/variants/): the k-loops wait for the weight stream through the L1 -- 8 KB per wave and
+//    k-step, 43 of the L1's 64 B/clk at full MFMA rate.  Here a wave needs its cout half only: 4 KB per k-step in phase A (phase B: 8 KB, two parities -- every
+//    (parity, cout block) fragment has exactly one owner, the minimum), a k-step's fragments are 16 registers, and a SECOND set (one whole k-step ahead, as
+//    k_conv3_up_split has it) costs no more than that kernel's single set.  The z-border k-steps are skipped by every wave (plane 0 / plane 7): one code path.
+//  * PHASE ORDER B -> A: the low-res images are dead once phase B is over, so the NEXT sample's low-res voxels are staged into them during phase A (chunk 1), and
+//    its first skip chunk goes into the idle halo buffer during the last chunk (c0 / 8 even): the per-sample prologue (zero fill, staging, barrier: ~10 k of ~98 k
+//    cycles) is paid once per workgroup.  Every thread stages one voxel per chunk.
+//  * Every global access of the sample loop is a BUFFER access (descriptor in SGPRs + one 32-bit lane offset + scalar offset): with flat / global addressing
+//    hipcc forms 64-bit lane addresses per (k-step, fragment) outside the sample loop and spills them; a spill reload is a scratch load in the in-order vmcnt
+//    queue, i.e. a wait for every staging load in front of it, between MFMAs.  The input GroupNorm's triples come out of an LDS table (a global load of them
+//    is a VECTOR load once the loop has stores: hipcc no longer proves the table unclobbered).
+// Statistics of a channel: float64 per lane (8 planes), a butterfly over the 16 voxel lanes of a row, then the four (py, px) waves in order.
 namespace {
-constexpr int PP_CHST = US_LDS_BYTES;                            // [8 waves][64 couts] double2
-constexpr int PP_TRIP = PP_CHST + 8 * 64 * 16;                   // [64 couts] float4
+constexpr int PP_CHST = US_LDS_BYTES;                            // [2 cout halves][4 (py, px)][32 couts] double2
+constexpr int PP_TRIP = PP_CHST + 8 * 32 * 16;                   // [64 couts] float4
 constexpr int PP_CHS = PP_TRIP + 64 * 16;                        // [64 couts] double2: a channel's sums over the sample
 constexpr int PP_GB = PP_CHS + 64 * 16;                          // [64 couts] float2: the next layer's gamma, beta
-constexpr int PP_AFF = PP_GB + 64 * 8;                        // [2 sample parities][center | scale | shift][128 input channels] floats: the input GroupNorm's triples, SoA
-constexpr int PP_LDS_ALLOC = PP_AFF + 2 * 3 * 128 * 4;           // 146,432
+constexpr int PP_AFF = PP_GB + 64 * 8;                           // [2 sample parities][center | scale | shift][128 input channels] floats: the input GroupNorm's triples, SoA
+constexpr int PP_LDS_ALLOC = PP_AFF + 2 * 3 * 128 * 4;           // 142,336
 }   // namespace
 
-// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-__device__ __forceinline__ double pp_row16_sum(double v) {
-#define PP_DPP_STEP(CTRL_)                                                                          \
-    {                                                                                                \
-        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL_, 0xf, 0xf, false);   \
-        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL_, 0xf, 0xf, false);   \
-        v += __hiloint2double(hi_, lo_);                                                             \
-    }
-    PP_DPP_STEP(0xB1)
-    PP_DPP_STEP(0x4E)
-    PP_DPP_STEP(0x141)
-    PP_DPP_STEP(0x140)
-#undef PP_DPP_STEP
-    return v;
-}
 // one value of the lane's row partner under a DPP control (float64 as two dwords)
 template <int CTRL>
 __device__ __forceinline__ double pp_dpp_f64(double v) {
@@ -511,9 +501,9 @@ __device__ __forceinline__ double pp_dpp_f64(double v) {
     const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi_, lo_);
 }
-// 16 values per lane, summed over the 16 lanes of a DPP row so that lane n of the row ends up with the row's total of value n: a butterfly that halves the
-// value count per level (partner lanes n ^ 15, n ^ 7, n ^ 2, n ^ 1: every partner agrees with the lane on the bits already used) -- 15 exchanges instead of 64
-__device__ __forceinline__ double pp_row16_transpose_sum(double (&d)[16], int n) {
+// 8 values per lane, summed over the 16 lanes of a DPP row: a butterfly that halves the value count per level (partner lanes n ^ 15, n ^ 7, n ^ 2: every partner
+// agrees with the lane on the bits already used), then one plain exchange with lane n ^ 1 -- lanes n and n ^ 1 end up with the row's total of value n >> 1
+__device__ __forceinline__ double pp_row16_transpose_sum8(double (&d)[8], int n) {
 #define PP_LEVEL(W_, CTRL_, BIT_)                                                                   \
     {                                                                                               \
         const bool up_ = (n & BIT_) != 0;                                                           \
@@ -522,12 +512,11 @@ __device__ __forceinline__ double pp_row16_transpose_sum(double (&d)[16], int n)
             d[i] = keep_ + pp_dpp_f64<CTRL_>(send_);                                                \
         }                                                                                           \
     }
-    PP_LEVEL(8, 0x140, 8)
-    PP_LEVEL(4, 0x141, 4)
-    PP_LEVEL(2, 0x4E, 2)
-    PP_LEVEL(1, 0xB1, 1)
+    PP_LEVEL(4, 0x140, 8)
+    PP_LEVEL(2, 0x141, 4)
+    PP_LEVEL(1, 0x4E, 2)
 #undef PP_LEVEL
-    return d[0];
+    return d[0] + pp_dpp_f64<0xB1>(d[0]);
 }
 
 // development ablations (tools/pp_ablation.py; wrong results): bit 0 = no staging (requests, conversions), 1 = no epilogue, 2 = no weight loads, 3 = no MFMAs
@@ -550,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+    const int ch = wave & 1, q = wave >> 1, py = q >> 1, px = q & 1;         // cout half, (y, x) parity of the wave's voxel column
     const int c0 = a.c0, c1 = a.c1, cin = c0 + c1, nA = c0 >> 3, nB = c1 >> 3;
     const int G = (int)gridDim.x;
 
@@ -604,11 +593,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
         }
     }
 
-    auto run = [&](auto PZ_) {
-    constexpr int PZ = decltype(PZ_)::value;
-    // ---- per-lane operand addressing (voxel operand: lane group g = tap of the k-step, lane & 15 = voxel (Y, X) of the parity lattice's z plane)
+    // ---- per-lane operand addressing.  Voxel operand: lane group g = tap of the k-step, lane & 15 = (Y, X) of the (py, px) lattice, voxel block vb = z plane
     const int g = lane >> 4, rj = (lane >> 2) & 3, ri = lane & 3;
-    const int abase = ((PZ + 1) * US_SZ + (2 * rj + py + 1) * US_SY + (2 * ri + px + 1)) * 16;
+    const int abase = (US_SZ + (2 * rj + py + 1) * US_SY + (2 * ri + px + 1)) * 16;            // + vb US_SZ 16 + tap offset
     // the lane group's tap offset of k-step s (tap 4 s + g; the dummy 28th tap reads tap 26's voxel), in 16-byte slots, three 10-bit fields per register
     int tpk[3] = {0, 0, 0};
 #pragma unroll
@@ -621,22 +608,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
         asm volatile("" : "+v"(t));                                  // unpacked where it is used, not seven registers' worth outside the sample loop
         return __builtin_amdgcn_sbfe(t, 10 * (s % 3), 10) * 16;
     };
-    const int bbase = (PZ * US_BZ + (rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;
-    // weight operand: row m = lane & 15 of cout-block 2p + j is cout 32 p + 8 (m >> 2) + 4 j + (m & 3), which the image (fragment order [n-block][h | l][lane],
-    // lane = 16 g + (cout & 15)) keeps in n-block 2 p + (m >> 3) at lane 16 g + 8 ((m >> 2) & 1) + 4 j + (m & 3)
+    // low-res operand of output plane z = vb (parity pz = vb & 1), k-step tz, lane group (ty, tx): halo voxel ((vb + 1 >> 1) + tz, rj + py + ty, ri + px + tx)
+    const int bbase = ((rj + py + (g >> 1)) * US_BY + (ri + px + (g & 1))) * 16;
+    // weight operand: row m = lane & 15 of cout-block 2 ch + j is cout 32 ch + 8 (m >> 2) + 4 j + (m & 3), which the image (fragment order [n-block][h | l][lane],
+    // lane = 16 g + (cout & 15)) keeps in n-block 2 ch + (m >> 3) at lane 16 g + 8 ((m >> 2) & 1) + 4 j + (m & 3)
     const int m16 = lane & 15;
-    const unsigned wlb = (unsigned)(((m16 >> 3) * 128 + 8 * ((m16 >> 2) & 1) + (m16 & 3) + 16 * g) * 16);
-    constexpr int STEP = 4 * 2 * 64;                                 // 16-byte fragments per k-step of the image (NB = 4)
-    // Every global access of the sample loop is a BUFFER access (descriptor in SGPRs + one 32-bit lane offset + scalar offset + immediate): with flat / global
-    // addressing hipcc forms 64-bit lane addresses -- one VGPR pair per (k-step, fragment row) of the weight image, hoisted out of the sample loop and spilled;
-    // a spill reload is a scratch load in the in-order vmcnt queue, i.e. a wait for the staging loads in front of it, between MFMAs
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<h8*>(a.wp), 0, (int)((((size_t)nA * 7 + 16 * (size_t)nB + 1) * STEP) * 16), 0x00020000);
-    const int wA = 0;                                                // byte offsets into the image
-    const int wB = (nA * 7 + wave * nB * 2) * STEP * 16;
-    constexpr int STEPB = STEP * 16;
-    h8 R0[4], R1[4];                                                 // fragments [j * 2 + (h | l)] of pair 0 / pair 1
-    auto ldw = [&](h8 (&R)[4], int base, auto P_) {
-        constexpr int P = decltype(P_)::value;
+    const int wlb = (((m16 >> 3) * 128 + 8 * ((m16 >> 2) & 1) + (m16 & 3) + 16 * g) * 16);
+    constexpr int STEPB = 4 * 2 * 64 * 16;                           // bytes per k-step of the image (NB = 4)
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<h8*>(a.wp), 0, (int)(((size_t)nA * 7 + 16 * (size_t)nB + 1) * STEPB), 0x00020000);
+    const int wA = 4096 * ch;                                        // byte offsets of the wave's streams: phase A, phase B for pz = 0 / 1
+    const int wB0 = (nA * 7 + (2 * py + px) * nB * 2) * STEPB + 4096 * ch;
+    const int wB1 = (nA * 7 + (4 + 2 * py + px) * nB * 2) * STEPB + 4096 * ch;
+    auto ldw = [&](h8 (&R)[4], int base) {                           // a cout half's fragments of one k-step: [j * 2 + (h | l)]
         if constexpr ((RF_PP_ABL & 4) != 0) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(R[f]));
@@ -645,66 +628,72 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
-                R[j * 2 + hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, wlb, base + 4096 * P + (64 * hl + 4 * j) * 16, 0));
+            for (int hl = 0; hl < 2; ++hl) R[j * 2 + hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, wlb, base + (64 * hl + 4 * j) * 16, 0));
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    ldw(R0, wB, P0{});
-    ldw(R1, wB, P1{});
+    h8 T0[4], T1[4], T2[4], T3[4];                                   // phase A: T0 / T1 alternate; phase B: (T0, T2) / (T1, T3) = (pz 0, pz 1) alternate
+    ldw(T0, wB0);
+    ldw(T2, wB1);
 
-    f32x4 hi[4][4], lo[4][4];                                        // [voxel block][cout block]
+    f32x4 hi[8][2], lo[8][2];                                        // [z plane][cout block of the half]
     h8 vh[2], vl[2];
-    auto mfma6 = [&](int vb, auto P_, const h8 (&R)[4], const h8& xh, const h8& xl) {
-        constexpr int P = decltype(P_)::value;
+    auto mfma6 = [&](int vb, const h8 (&W)[4], const h8& xh, const h8& xl) {
         if constexpr ((RF_PP_ABL & 8) != 0) {
-            hi[vb][2 * P][0] += (float)R[0][0] * (float)xh[0] + (float)R[1][0] * (float)xl[0];
-            hi[vb][2 * P + 1][0] += (float)R[2][0] * (float)xh[0] + (float)R[3][0] * (float)xl[0];
+            hi[vb][0][0] += (float)W[0][0] * (float)xh[0] + (float)W[1][0] * (float)xl[0];
+            hi[vb][1][0] += (float)W[2][0] * (float)xh[0] + (float)W[3][0] * (float)xl[0];
             return;
         }
-        hi[vb][2 * P] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[0], xh, hi[vb][2 * P], 0, 0, 0);
-        hi[vb][2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[2], xh, hi[vb][2 * P + 1], 0, 0, 0);
-        lo[vb][2 * P] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[1], xh, lo[vb][2 * P], 0, 0, 0);
-        lo[vb][2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[3], xh, lo[vb][2 * P + 1], 0, 0, 0);
-        lo[vb][2 * P] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[0], xl, lo[vb][2 * P], 0, 0, 0);
-        lo[vb][2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(R[2], xl, lo[vb][2 * P + 1], 0, 0, 0);
+        hi[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0], xh, hi[vb][0], 0, 0, 0);
+        hi[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[2], xh, hi[vb][1], 0, 0, 0);
+        lo[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1], xh, lo[vb][0], 0, 0, 0);
+        lo[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[3], xh, lo[vb][1], 0, 0, 0);
+        lo[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0], xl, lo[vb][0], 0, 0, 0);
+        lo[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[2], xl, lo[vb][1], 0, 0, 0);
     };
-    // one k-step.  On entry (vh[0], vl[0]) hold voxel block 0 of `vp`.  Pair 0 over the four voxel blocks, the NEXT k-step's pair-0 fragments over R0, pair 1, the
-    // next k-step's pair-1 fragments over R1; `xload` (staging requests) behind them.  has_pre: `pre` = voxel block 0 of the next k-step (same chunk).
-    auto kstep = [&](auto skip_c, auto has_pre, auto&& xload, const unsigned char* vp, const unsigned char* pre, int mstride, int lplane, int wnext) {
+    // phase-A k-step on the 8 planes at `vp` (plane stride US_SZ slots): the NEXT k-step's fragments first (a whole k-step ahead), `xload` (staging requests) behind
+    // them -- vmcnt retires in order --, plane p + 1 read under the MFMAs of plane p.  On entry (vh[0], vl[0]) hold plane 0; has_pre: `pre` = plane 0 of the next k-step.
+    auto kstep_a = [&](auto skip_c, auto has_pre, auto&& xload, const unsigned char* vp, const unsigned char* pre, h8 (&C)[4], h8 (&N)[4], int wnext) {
         constexpr int skip = decltype(skip_c)::value;
-#pragma unroll
-        for (int vb = 0; vb < 4; ++vb) {
-            const unsigned char* q = vb < 3 ? vp + (vb + 1) * mstride : vp;
-            vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q);
-            vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q + lplane);
-            __builtin_amdgcn_sched_barrier(0);
-            if (vb != skip) mfma6(vb, P0{}, R0, vh[vb & 1], vl[vb & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ldw(R0, wnext, P0{});
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int vb = 0; vb < 4; ++vb) {
-            if (vb < 3) {
-                vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(vp + (vb + 1) * mstride);
-                vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(vp + (vb + 1) * mstride + lplane);
-            } else if constexpr (decltype(has_pre)::value) {
-                vh[0] = *reinterpret_cast<const h8*>(pre);
-                vl[0] = *reinterpret_cast<const h8*>(pre + lplane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (vb != skip) mfma6(vb, P1{}, R1, vh[vb & 1], vl[vb & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ldw(R1, wnext, P1{});
+        ldw(N, wnext);
         xload();
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int vb = 0; vb < 8; ++vb) {
+            if (vb < 7) {
+                vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(vp + (vb + 1) * (US_SZ * 16));
+                vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(vp + (vb + 1) * (US_SZ * 16) + US_A_PLANE);
+            } else if constexpr (decltype(has_pre)::value) {
+                vh[0] = *reinterpret_cast<const h8*>(pre);
+                vl[0] = *reinterpret_cast<const h8*>(pre + US_A_PLANE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (vb != skip) mfma6(vb, C, vh[vb & 1], vl[vb & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // phase-B k-step tz of one 8-channel group at `bp` (low-res halo plane stride US_BZ slots): output plane vb reads halo plane ((vb + 1) >> 1) + tz, so planes
+    // P = 1..4 serve vb = {2 P - 1, 2 P} (tz = 0; vb = 0 reads padding: skipped) or {2 P - 3, 2 P - 2} (tz = 1; vb = 7 skipped); weights by the plane's z parity
+    // (C0 / C1).  On entry (vh[0], vl[0]) hold plane 1; `pre` = plane 1 of the next k-step.
+    auto kstep_b = [&](auto TZ_, const unsigned char* bp, const unsigned char* pre, h8 (&C0)[4], h8 (&C1)[4], h8 (&N0)[4], h8 (&N1)[4], int wn0, int wn1) {
+        constexpr int TZ = decltype(TZ_)::value;
+        ldw(N0, wn0);
+        ldw(N1, wn1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                // halo plane P = k + 1 in ring slot k & 1
+            const unsigned char* qn = k < 3 ? bp + (k + 2) * (US_BZ * 16) : pre;
+            vh[(k + 1) & 1] = *reinterpret_cast<const h8*>(qn);
+            vl[(k + 1) & 1] = *reinterpret_cast<const h8*>(qn + US_B_PLANE);
+            __builtin_amdgcn_sched_barrier(0);
+            const int vodd = 2 * (k + 1) - 1 - 2 * TZ, veven = vodd + 1;      // the pz = 1 plane and the pz = 0 plane this halo plane serves
+            if (vodd >= 0 && vodd <= 7 && !(TZ == 1 && vodd == 7)) mfma6(vodd, C1, vh[k & 1], vl[k & 1]);
+            if (veven >= 0 && veven <= 7 && !(TZ == 0 && veven == 0)) mfma6(veven, C0, vh[k & 1], vl[k & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // x <- (x - center) * scale + shift with the 8 triples of a channel group out of the LDS table (uniform addresses), in two stages of 8 / 16 registers: the
-    // conversion sits at the kernel's register peak (accumulators + the next k-step's weights + the staged voxels)
-    auto normalise8 = [&](float (&x)[8], int table, int ch) {
-        const float* tb = reinterpret_cast<const float*>(lds + PP_AFF) + table * 384 + ch;
+    // conversion sits at the kernel's register peak (accumulators + two k-steps' weights + the staged voxels)
+    auto normalise8 = [&](float (&x)[8], int table, int chn) {
+        const float* tb = reinterpret_cast<const float*>(lds + PP_AFF) + table * 384 + chn;
         {
             const float4 c0_ = *reinterpret_cast<const float4*>(tb), c1_ = *reinterpret_cast<const float4*>(tb + 4);
             x[0] -= c0_.x; x[1] -= c0_.y; x[2] -= c0_.z; x[3] -= c0_.w; x[4] -= c1_.x; x[5] -= c1_.y; x[6] -= c1_.z; x[7] -= c1_.w;
@@ -718,47 +707,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // phase B's k-step: the weights there are the wave's OWN (its parity's pre-summed taps: every fragment comes from L2, where phase A's are shared by the
-    // eight waves and mostly hit in L1), and half a k-step does not cover that latency.  Phase B stages nothing, so it has the registers for a second weight set
-    // (N0 / N1, dead in phase A): the next k-step's eight fragments are requested at the start of the step, the voxel operands are read once per step.
-    h8 N0[4], N1[4];
-    auto kstep_b = [&](auto skip_c, const unsigned char* vp, const unsigned char* pre, int mstride, int lplane, int wnext, const h8 (&C0)[4], const h8 (&C1)[4], h8 (&X0)[4], h8 (&X1)[4]) {
-        constexpr int skip = decltype(skip_c)::value;
-        ldw(X0, wnext, P0{});
-        ldw(X1, wnext, P1{});
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int vb = 0; vb < 4; ++vb) {
-            const unsigned char* q = vb < 3 ? vp + (vb + 1) * mstride : pre;
-            vh[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q);
-            vl[(vb + 1) & 1] = *reinterpret_cast<const h8*>(q + lplane);
-            __builtin_amdgcn_sched_barrier(0);
-            if (vb != skip && (RF_PP_ABL & 8)) {
-                hi[vb][0][0] += (float)C0[0][0] * (float)vh[vb & 1][0] + (float)C0[1][0] * (float)vl[vb & 1][0] + (float)C0[2][0] + (float)C0[3][0];
-                hi[vb][2][0] += (float)C1[0][0] * (float)vh[vb & 1][0] + (float)C1[1][0] * (float)vl[vb & 1][0] + (float)C1[2][0] + (float)C1[3][0];
-            } else if (vb != skip) {
-                const h8& xh = vh[vb & 1];
-                const h8& xl = vl[vb & 1];
-                hi[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[0], xh, hi[vb][0], 0, 0, 0);
-                hi[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[2], xh, hi[vb][1], 0, 0, 0);
-                hi[vb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[0], xh, hi[vb][2], 0, 0, 0);
-                hi[vb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[2], xh, hi[vb][3], 0, 0, 0);
-                lo[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[1], xh, lo[vb][0], 0, 0, 0);
-                lo[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[3], xh, lo[vb][1], 0, 0, 0);
-                lo[vb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[1], xh, lo[vb][2], 0, 0, 0);
-                lo[vb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[3], xh, lo[vb][3], 0, 0, 0);
-                lo[vb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[0], xl, lo[vb][0], 0, 0, 0);
-                lo[vb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C0[2], xl, lo[vb][1], 0, 0, 0);
-                lo[vb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[0], xl, lo[vb][2], 0, 0, 0);
-                lo[vb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(C1[2], xl, lo[vb][3], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
     auto no_x = [] {};
     using no_skip = std::integral_constant<int, -1>;
-    using skip_lo = std::integral_constant<int, US_ZSKIP && PZ == 0 ? 0 : -1>;
-    using skip_hi = std::integral_constant<int, US_ZSKIP && PZ == 1 ? 3 : -1>;
+    using skip_lo = std::integral_constant<int, US_ZSKIP ? 0 : -1>;      // k-steps whose taps all have dz = -1: plane 0 reads padding
+    using skip_hi = std::integral_constant<int, US_ZSKIP ? 7 : -1>;      // ... dz = +1: plane 7
 
     __syncthreads();                                                 // the first sample's images are in place
     int sp = 0;                                                      // which triple table is this sample's (the other one is filled for the next sample in chunk 0)
@@ -766,88 +718,84 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
         const int nn = n + G < a.n ? n + G : n;                      // the sample staged under this one (the last one re-stages itself: harmless)
         PP_STAMP(0);
 #pragma unroll
-        for (int vb = 0; vb < 4; ++vb)
+        for (int vb = 0; vb < 8; ++vb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) { hi[vb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[vb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < 2; ++j) { hi[vb][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[vb][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-        // ---- phase B: upsampled channels in low resolution (this parity's pre-summed taps), 2 k-steps per 8-channel group
+        // ---- phase B: upsampled channels in low resolution (the two z parities' pre-summed taps), 2 k-steps per 8-channel group
         {
-            const unsigned char* bb = lds + US_B_OFF + bbase;
+            int bb_ = bbase;
+            asm volatile("" : "+v"(bb_));
+            const unsigned char* bb = lds + US_B_OFF + bb_ + US_BZ * 16;       // halo plane 1
             vh[0] = *reinterpret_cast<const h8*>(bb);
             vl[0] = *reinterpret_cast<const h8*>(bb + US_B_PLANE);
-            int wn = wB + STEPB;
+            int w0 = wB0 + STEPB, w1 = wB1 + STEPB;
             for (int cb = 0; cb < nB; ++cb) {
-                const unsigned char* ap = bb + cb * 2 * US_B_PLANE;
+                const unsigned char* bp = bb + cb * 2 * US_B_PLANE - US_BZ * 16;       // halo plane 0 of the group
                 const bool last = cb + 1 == nB;
-                kstep_b(skip_lo{}, ap, ap + US_BZ * 16, US_BZ * 16, US_B_PLANE, wn, R0, R1, N0, N1);                                   // tz = 0
-                wn += STEPB;
-                kstep_b(skip_hi{}, ap + US_BZ * 16, last ? ap : ap + 2 * US_B_PLANE, US_BZ * 16, US_B_PLANE, last ? wA : wn, N0, N1, R0, R1);     // tz = 1
-                wn += STEPB;
+                kstep_b(std::integral_constant<int, 0>{}, bp, bp + US_BZ * 16, T0, T2, T1, T3, w0, w1);
+                w0 += STEPB; w1 += STEPB;
+                // (after the last k-step: phase A's first fragments go to T0; T2 takes any fragment of the image)
+                kstep_b(std::integral_constant<int, 1>{}, bp, last ? bp + US_BZ * 16 : bp + 2 * US_B_PLANE + US_BZ * 16, T1, T3, T0, T2, last ? wA : w0, last ? wA : w1);
+                w0 += STEPB; w1 += STEPB;
             }
         }
         PP_STAMP(1);
 
-        // ---- phase A: skip channels, 7 k-steps per chunk on the double-buffered halo box (chunk ca in buffer ca & 1; c0 / 8 is even).  Waves 0..3 (PZ = 0, the
-        // SIMD arbiter's favourites: they finish a chunk ~4 k cycles before their partners) stage: the next chunk (two voxels per thread, requested behind k-steps
-        // 0 / 3, converted behind k-steps 2 / 6) -- after the last chunk the NEXT sample's chunk 0 -- and, in chunks 1 and 2, the next sample's low-res groups
-        // (slot k: group (tid >> 6) + 4 k, voxel lane; requested behind k-step 1, converted behind k-step 4).
-        auto chunk_a = [&](int ca, auto BK_) {
-            constexpr int BK = decltype(BK_)::value;                 // -1: no low-res staging in this chunk
-            float x[8];                                              // ONE staging register set, three windows per chunk: requested behind k-steps 0 / 2 / 4, converted behind 2 / 4 / 6
+        // ---- phase A: skip channels, 7 k-steps per chunk on the double-buffered halo box (chunk ca in buffer ca & 1; c0 / 8 is even).  Every thread stages one voxel
+        // per chunk -- the next chunk's (after the last chunk: the NEXT sample's chunk 0), requested behind k-step 0, converted behind k-step 2 -- and in chunk 1 one
+        // low-res voxel of the next sample (group = wave, requested behind k-step 3, converted behind k-step 5); chunk 0 also copies the next sample's triple table.
+        auto chunk_a = [&](int ca, auto BK_, h8 (&CA)[4], h8 (&NA)[4]) {
+            constexpr int BK = decltype(BK_)::value;                 // 1: low-res staging in this chunk; -2: the next sample's triple table; -1: neither
+            float x[8];
             const bool more = ca + 1 < nA;
             const int cx = more ? ca + 1 : 0, nx = more ? n : nn;
             const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0) + ((size_t)nx * c0 + cx * 8) * 512, 0, 8 * 512 * 4, 0x00020000);
-            const int toff = (tid & 255) * 4;
-            // the input GroupNorm's triples come out of LDS (uniform address): a global load here is a VECTOR load -- the epilogue's stores make hipcc treat the
-            // table as clobbered, so no s_load -- with L2 latency in front of every conversion and 8 more entries in the in-order vmcnt queue
+            const int cgb = wave < nB ? wave : nB - 1;
             float4 afn;                                              // chunk 0: this thread's entry of the NEXT sample's table
-            const int cgb = BK < 0 ? 0 : (wave + 4 * BK < nB ? wave + 4 * BK : nB - 1);
             auto xload_a = [&] {
-                if constexpr (PZ == 0 && !(RF_PP_ABL & 1)) {
+                if constexpr (!(RF_PP_ABL & 1)) {
+                    int t4_ = tid;
+                    asm volatile("" : "+v"(t4_));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, toff, j * 2048, 0));
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, t4_ * 4, j * 2048, 0));
                     if constexpr (BK == -2) {
                         const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.affine) + (size_t)nn * cin, 0, cin * 16, 0x00020000);
-                        afn = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rF, (tid < cin ? tid : cin - 1) * 16, 0, 0));
+                        afn = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rF, (t4_ < cin ? t4_ : cin - 1) * 16, 0, 0));
                     }
                 }
             };
-            auto xload_b = [&] {
-                if constexpr (PZ == 0 && !(RF_PP_ABL & 1)) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, toff, j * 2048 + 1024, 0));
-                }
-            };
             auto xload_low = [&] {
-                if constexpr (PZ == 0 && BK >= 0 && !(RF_PP_ABL & 1)) {
+                if constexpr (BK == 1 && !(RF_PP_ABL & 1)) {
                     const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1) + ((size_t)nn * c1 + cgb * 8) * 64, 0, 8 * 64 * 4, 0x00020000);
+                    int l4_ = tid;
+                    asm volatile("" : "+v"(l4_));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rL, lane * 4, j * 256, 0));
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rL, (l4_ & 63) * 4, j * 256, 0));
                 }
             };
-            auto convert_store = [&](int half) {
-                if constexpr (PZ == 0 && !(RF_PP_ABL & 1)) {
+            auto convert_store = [&] {
+                if constexpr (!(RF_PP_ABL & 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     normalise8(x, more ? sp : sp ^ 1, cx * 8);
                     h8 h, l;
                     us_split8(x, h, l);
                     int vs = tid;
                     asm volatile("" : "+v"(vs));
-                    vs = ((vs >> 6) + 1 + 4 * half) * US_SZ + (((vs >> 3) & 7) + 1) * US_SY + (vs & 7) + 1;       // tid < 256: z = 0..3 (+ 4)
+                    const int tix = vs;
+                    vs = ((vs >> 6) + 1) * US_SZ + (((vs >> 3) & 7) + 1) * US_SY + (vs & 7) + 1;
                     unsigned char* p = lds + ((ca + 1) & 1) * US_A_BUF + vs * 16;
                     *reinterpret_cast<h8*>(p) = h;
                     *reinterpret_cast<h8*>(p + US_A_PLANE) = l;
                     if constexpr (BK == -2) {
-                        if (half == 0) {
-                            float* tb = reinterpret_cast<float*>(lds + PP_AFF) + (sp ^ 1) * 384 + (tid < cin ? tid : cin - 1);
-                            tb[0] = afn.x; tb[128] = afn.y; tb[256] = afn.z;
-                        }
+                        float* tb = reinterpret_cast<float*>(lds + PP_AFF) + (sp ^ 1) * 384 + (tix < cin ? tix : cin - 1);
+                        tb[0] = afn.x; tb[128] = afn.y; tb[256] = afn.z;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             auto convert_low = [&] {
-                if constexpr (PZ == 0 && BK >= 0 && !(RF_PP_ABL & 1)) {
+                if constexpr (BK == 1 && !(RF_PP_ABL & 1)) {
                     __builtin_amdgcn_sched_barrier(0);
                     normalise8(x, sp ^ 1, c0 + cgb * 8);
                     h8 h, l;
@@ -867,104 +815,85 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
             const unsigned char* buf = lds + abuf;
             vh[0] = *reinterpret_cast<const h8*>(buf + atap(0));
             vl[0] = *reinterpret_cast<const h8*>(buf + atap(0) + US_A_PLANE);
-            constexpr int MS = 2 * US_SZ * 16;
             const int wn = wA + (ca * 7 + 1) * STEPB;
-            auto v0 = [&](int s_) {                                  // voxel block 0 of k-step s_, read AFTER a conversion (its registers are not held across it)
-                if constexpr (PZ == 0) {
-                    vh[0] = *reinterpret_cast<const h8*>(buf + atap(s_));
-                    vl[0] = *reinterpret_cast<const h8*>(buf + atap(s_) + US_A_PLANE);
-                }
-            };
-            using pre_c = std::integral_constant<bool, PZ != 0>;     // the staging waves (PZ = 0) do not prefetch across a conversion
-            kstep(skip_lo{}, std::true_type{}, xload_a, buf + atap(0), buf + atap(1), MS, US_A_PLANE, wn);
-            kstep(skip_lo{}, std::true_type{}, no_x, buf + atap(1), buf + atap(2), MS, US_A_PLANE, wn + STEPB);
-            if constexpr (BK >= 0) {
-                kstep(no_skip{}, pre_c{}, no_x, buf + atap(2), buf + atap(3), MS, US_A_PLANE, wn + 2 * STEPB);
-                convert_store(0);
-                v0(3);
-                kstep(no_skip{}, std::true_type{}, xload_low, buf + atap(3), buf + atap(4), MS, US_A_PLANE, wn + 3 * STEPB);     // (the request goes out behind the conversion)
-                kstep(no_skip{}, std::true_type{}, no_x, buf + atap(4), buf + atap(5), MS, US_A_PLANE, wn + 4 * STEPB);
-                kstep(skip_hi{}, pre_c{}, no_x, buf + atap(5), buf + atap(6), MS, US_A_PLANE, wn + 5 * STEPB);
-                convert_low();
-                xload_b();
-                v0(6);
-                kstep(skip_hi{}, std::false_type{}, no_x, buf + atap(6), buf + atap(6), MS, US_A_PLANE, more ? wn + 6 * STEPB : wB);
-            } else {
-                kstep(no_skip{}, pre_c{}, no_x, buf + atap(2), buf + atap(3), MS, US_A_PLANE, wn + 2 * STEPB);
-                convert_store(0);
-                v0(3);
-                kstep(no_skip{}, std::true_type{}, xload_b, buf + atap(3), buf + atap(4), MS, US_A_PLANE, wn + 3 * STEPB);
-                kstep(no_skip{}, std::true_type{}, no_x, buf + atap(4), buf + atap(5), MS, US_A_PLANE, wn + 4 * STEPB);
-                kstep(skip_hi{}, std::true_type{}, no_x, buf + atap(5), buf + atap(6), MS, US_A_PLANE, wn + 5 * STEPB);
-                kstep(skip_hi{}, std::false_type{}, no_x, buf + atap(6), buf + atap(6), MS, US_A_PLANE, more ? wn + 6 * STEPB : wB);
-            }
-            convert_store(1);
+            kstep_a(skip_lo{}, std::true_type{}, xload_a, buf + atap(0), buf + atap(1), CA, NA, wn);
+            kstep_a(skip_lo{}, std::true_type{}, no_x, buf + atap(1), buf + atap(2), NA, CA, wn + STEPB);
+            kstep_a(no_skip{}, std::true_type{}, no_x, buf + atap(2), buf + atap(3), CA, NA, wn + 2 * STEPB);
+            convert_store();
+            kstep_a(no_skip{}, std::true_type{}, xload_low, buf + atap(3), buf + atap(4), NA, CA, wn + 3 * STEPB);
+            kstep_a(no_skip{}, std::true_type{}, no_x, buf + atap(4), buf + atap(5), CA, NA, wn + 4 * STEPB);
+            kstep_a(skip_hi{}, std::true_type{}, no_x, buf + atap(5), buf + atap(6), NA, CA, wn + 5 * STEPB);
+            convert_low();
+            // (no branch around MFMAs: hipcc copies the accumulators at every join.)  The sample's last k-step fetches the NEXT sample's first phase-B k-step, its
+            // pz = 0 half, into NA (= T0: c0 / 8 is even); the pz = 1 half goes to T2 behind the last chunk
+            kstep_a(skip_hi{}, std::false_type{}, no_x, buf + atap(6), buf + atap(6), CA, NA, more ? wn + 6 * STEPB : wB0);
             __syncthreads();
         };
-        chunk_a(0, std::integral_constant<int, -2>{});             // (-2: no low-res staging, but the next sample's triple table)
+        chunk_a(0, std::integral_constant<int, -2>{}, T0, T1);
         PP_STAMP(2);
-        chunk_a(1, std::integral_constant<int, 0>{});
+        chunk_a(1, std::integral_constant<int, 1>{}, T1, T0);
         PP_STAMP(3);
-        chunk_a(2, std::integral_constant<int, 1>{});
-        PP_STAMP(4);
-        for (int ca = 3; ca < nA; ++ca) chunk_a(ca, std::integral_constant<int, -1>{});
+        for (int ca = 2; ca < nA; ca += 2) {
+            chunk_a(ca, std::integral_constant<int, -1>{}, T0, T1);
+            chunk_a(ca + 1, std::integral_constant<int, -1>{}, T1, T0);
+        }
+        ldw(T2, wB1);
         PP_STAMP(5);
 
-        // ---- epilogue, from registers: v = relu(hi + lo / 2^11); lane (g, v) holds couts 32 p + 8 g + 4 j + r of voxel (2 vb + PZ, 2 rj + py, 2 ri + px)
+        // ---- epilogue, from registers: v = relu(hi + lo / 2^11); lane (g, v) holds couts 32 ch + 8 g + 4 j + r of voxel (vb, 2 rj + py, 2 ri + px)
         int te = tid;
         asm volatile("" : "+v"(te));
-        const int el = te & 63, eg = el >> 4;
+        const int el = te & 63, eg = el >> 4, nl = el & 15;
         if constexpr ((RF_PP_ABL & 2) != 0) {
             float sink = 0.f;
 #pragma unroll
-            for (int vb = 0; vb < 4; ++vb)
+            for (int vb = 0; vb < 8; ++vb)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sink += hi[vb][cb][r] + lo[vb][cb][r];
+                    for (int r = 0; r < 4; ++r) sink += hi[vb][j][r] + lo[vb][j][r];
             if (sink == 123.456f) a.pre_out[te][0] = (_Float16)sink;
             continue;
         }
 #pragma unroll
-        for (int vb = 0; vb < 4; ++vb)
+        for (int vb = 0; vb < 8; ++vb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hi[vb][cb][r] = fmaxf(fmaf(lo[vb][cb][r], 1.0f / US_LO, hi[vb][cb][r]), 0.f);
+                for (int r = 0; r < 4; ++r) hi[vb][j][r] = fmaxf(fmaf(lo[vb][j][r], 1.0f / US_LO, hi[vb][j][r]), 0.f);
         double2* chst = reinterpret_cast<double2*>(lds + PP_CHST);
         double2* chs = reinterpret_cast<double2*>(lds + PP_CHS);
         float4* trip = reinterpret_cast<float4*>(lds + PP_TRIP);
         {
-            // per cout: the lane's four voxels in float64, then over the 16 voxel lanes of the row: lane n keeps the total of its value n = 4 cb + r
-            double sm[16], sq[16];
+            // per cout: the lane's eight planes in float64, then over the 16 voxel lanes of the row: lanes n, n ^ 1 keep the total of value n >> 1 = 4 j + r
+            double sm[8], sq[8];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double s_ = 0.0, q_ = 0.0;
 #pragma unroll
-                    for (int vb = 0; vb < 4; ++vb) {
-                        const double v = (double)hi[vb][cb][r];
+                    for (int vb = 0; vb < 8; ++vb) {
+                        const double v = (double)hi[vb][j][r];
                         s_ += v; q_ += v * v;
                     }
-                    sm[cb * 4 + r] = s_; sq[cb * 4 + r] = q_;
+                    sm[j * 4 + r] = s_; sq[j * 4 + r] = q_;
                 }
-            const int nl = el & 15;
-            const double ts = pp_row16_transpose_sum(sm, nl), tq = pp_row16_transpose_sum(sq, nl);
-            chst[wave * 64 + 32 * (nl >> 3) + 8 * eg + 4 * ((nl >> 2) & 1) + (nl & 3)] = make_double2(ts, tq);
+            const double ts = pp_row16_transpose_sum8(sm, nl), tq = pp_row16_transpose_sum8(sq, nl);
+            if ((nl & 1) == 0) chst[(ch * 4 + q) * 32 + 8 * eg + (nl >> 1)] = make_double2(ts, tq);
         }
         PP_STAMP(6);
         __syncthreads();
         PP_STAMP(7);
         const int cout = a.cout;
-        {   // thread (channel te >> 3, wave te & 7): the channel's sums over the eight waves (fixed order), lane 0 of the eight publishes them
-            double2 v = chst[(te & 7) * 64 + (te >> 3)];
+        if (te < 256) {   // thread (channel te >> 2, column te & 3): the channel's sums over the four (py, px) waves (fixed order), lane 0 of the four publishes them
+            const int c = te >> 2;
+            double2 v = chst[((c >> 5) * 4 + (te & 3)) * 32 + (c & 31)];
             v.x += pp_dpp_f64<0xB1>(v.x); v.y += pp_dpp_f64<0xB1>(v.y);
             v.x += pp_dpp_f64<0x4E>(v.x); v.y += pp_dpp_f64<0x4E>(v.y);
-            v.x += pp_dpp_f64<0x141>(v.x); v.y += pp_dpp_f64<0x141>(v.y);
-            if ((te & 7) == 0) {
-                chs[te >> 3] = v;
-                if (a.stats && (te >> 3) < cout) a.stats[(size_t)n * cout + (te >> 3)] = v;
+            if ((te & 3) == 0) {
+                chs[c] = v;
+                if (a.stats && c < cout) a.stats[(size_t)n * cout + c] = v;
             }
         }
         __syncthreads();
@@ -985,29 +914,25 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
         __syncthreads();
         PP_STAMP(9);
         {
-            // slot of the lane's voxel (2 vb + PZ, 2 rj + py, 2 ri + px): linear z 64 + y 8 + x, or parity-major (wave 64 + vb 16 + lane & 15: 256-byte runs)
-            const int nl = el & 15;
-            const int vox = a.pre_pm ? wave * 64 + nl : PZ * 64 + (2 * (nl >> 2) + py) * 8 + 2 * (nl & 3) + px;
-            const int vbs = a.pre_pm ? 16 : 128;
-            h8* __restrict__ po = a.pre_out + (size_t)n * (cout >> 3) * 2 * 512 + vox;
-            const int nsg = cout >> 3;
+            // slot of the lane's voxel (vb, 2 rj + py, 2 ri + px): linear vb 64 + y 8 + x, or parity-major ((vb & 1) 4 + 2 py + px) 64 + (vb >> 1) 16 + (lane & 15):
+            // 256-byte runs per 8-channel group
+            const int sg = 4 * ch + eg, nsg = cout >> 3;
+            const int vox = a.pre_pm ? (2 * py + px) * 64 + nl : (2 * (nl >> 2) + py) * 8 + 2 * (nl & 3) + px;
+            h8* __restrict__ po = a.pre_out + ((size_t)n * nsg + (sg < nsg ? sg : 0)) * 2 * 512 + vox;
+            float4 t4[8];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int sg = 4 * p + eg;
-                float4 t4[8];
+            for (int i = 0; i < 8; ++i) t4[i] = trip[(sg < nsg ? sg : 0) * 8 + i];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t4[i] = trip[(sg < nsg ? sg : 0) * 8 + i];
+            for (int vb = 0; vb < 8; ++vb) {
+                float y[8];
 #pragma unroll
-                for (int vb = 0; vb < 4; ++vb) {
-                    float y[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) y[i] = fmaf(hi[vb][2 * p + (i >> 2)][i & 3] - t4[i].x, t4[i].y, t4[i].z);
-                    h8 h, l;
-                    us_split8(y, h, l);
-                    if (sg < nsg) {
-                        po[(size_t)sg * 2 * 512 + vb * vbs] = h;
-                        po[(size_t)sg * 2 * 512 + 512 + vb * vbs] = l;
-                    }
+                for (int i = 0; i < 8; ++i) y[i] = fmaf(hi[vb][i >> 2][i & 3] - t4[i].x, t4[i].y, t4[i].z);
+                h8 h, l;
+                us_split8(y, h, l);
+                const int so = a.pre_pm ? (vb & 1) * 256 + (vb >> 1) * 16 : vb * 64;
+                if (sg < nsg) {
+                    po[so] = h;
+                    po[512 + so] = l;
                 }
             }
         }
@@ -1022,9 +947,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
         for (int i = 0; i < 16; ++i) g_pp_stamps[(blockIdx.x * 2 + (wave >> 2)) * 16 + i] = st[i];
     }
 #endif
-    };   // run
-    if (pz == 0) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------- 4^3 volumes
