@@ -153,6 +153,17 @@ __device__ __forceinline__ void us_split8(const float (&y)[8], h8& h, h8& l) {
     }
 }
 
+// ... of values that already carry the 2^-4 (folded into the GroupNorm triple: (x - c) (s / 16) + b / 16 rounds like ((x - c) s + b) / 16)
+__device__ __forceinline__ void us_split8_scaled(const float (&y)[8], h8& h, h8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = __builtin_amdgcn_fmed3f(y[j], -65504.f, 65504.f);
+        const _Float16 hh = (_Float16)v;
+        h[j] = hh;
+        l[j] = (_Float16)fmaf(-US_LO, (float)hh, v * US_LO);
+    }
+}
+
 template <int NB>
 __device__ __forceinline__ void us_mfma_block(f32x4 (&hi)[NB], f32x4 (&lo)[NB], const h8& ah, const h8& al, const h8 (&bh)[NB], const h8 (&bl)[NB]) {
     // three passes over the n-blocks: consecutive MFMAs never share an accumulator
@@ -712,6 +723,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
     using skip_lo = std::integral_constant<int, US_ZSKIP ? 0 : -1>;      // k-steps whose taps all have dz = -1: plane 0 reads padding
     using skip_hi = std::integral_constant<int, US_ZSKIP ? 7 : -1>;      // ... dz = +1: plane 7
 
+    // 1 / (values per GroupNorm group of the output), float64, kept as two scalars (a VGPR pair across the sample loop is a spill candidate)
+    int icnt_lo, icnt_hi;
+    {
+        const double ic = 1.0 / ((double)(a.cout / a.ngroups) * 512.0);
+        icnt_lo = __builtin_amdgcn_readfirstlane(__double2loint(ic));
+        icnt_hi = __builtin_amdgcn_readfirstlane(__double2hiint(ic));
+    }
     __syncthreads();                                                 // the first sample's images are in place
     int sp = 0;                                                      // which triple table is this sample's (the other one is filled for the next sample in chunk 0)
     for (int n = blockIdx.x; n < a.n; n += G, sp ^= 1) {
@@ -904,11 +922,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
             const int cbeg = (te / cpg) * cpg;
             double sm = 0.0, sq = 0.0;
             for (int c = cbeg; c < cbeg + cpg; ++c) { sm += chs[c].x; sq += chs[c].y; }
-            const double count = (double)cpg * 512.0, mean = sm / count;
-            double var = sq / count - mean * mean;
+            const double icnt = __hiloint2double(icnt_hi, icnt_lo), mean = sm * icnt;
+            double var = sq * icnt - mean * mean;
             if (var < 0.0) var = 0.0;
+            // 1 / sqrt in float64 by the hardware estimate + two Newton steps (the IEEE sqrt and division are ~100 dependent instructions between two barriers)
+            const double xv = var + (double)neps;
+            double rs = __builtin_amdgcn_rsq(xv);
+            rs = rs * (1.5 - 0.5 * xv * rs * rs);
+            rs = rs * (1.5 - 0.5 * xv * rs * rs);
             const float2 gb = reinterpret_cast<const float2*>(lds + PP_GB)[te];
-            trip[te] = gn_affine(mean, 1.0 / sqrt(var + (double)neps), gb.x, gb.y);
+            float4 t4 = gn_affine(mean, rs, gb.x, gb.y);
+            t4.y *= US_ACT_SCALE; t4.z *= US_ACT_SCALE;              // the split's 2^-4, exact
+            trip[te] = t4;
         }
         PP_STAMP(8);
         __syncthreads();
@@ -928,7 +953,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3_up_split_pp(UpSplitArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) y[i] = fmaf(hi[vb][i >> 2][i & 3] - t4[i].x, t4[i].y, t4[i].z);
                 h8 h, l;
-                us_split8(y, h, l);
+                us_split8_scaled(y, h, l);
                 const int so = a.pre_pm ? (vb & 1) * 256 + (vb >> 1) * 16 : vb * 64;
                 if (sg < nsg) {
                     po[so] = h;
