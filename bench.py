@@ -60,7 +60,8 @@ def parse(argv=None):
     ap.add_argument('--cpu-chunks', type=int, default=0, help='chunks for the CPU baseline sample (0 = sized to ~15 s)')
     ap.add_argument('--kernels-top', type=int, default=8, help='rows of the serial per-kernel table')
     ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank, still run the all-gather + all-to-all + merge protocol over RCCL')
-    ap.add_argument('--half-store', action='store_true', help='keep the replicated voxel store as float16 (the reference\'s own scene precision; same gathered bits, half the bytes)')
+    ap.add_argument('--half-store', action='store_true', help='insist on the float16 voxel store (the default already keeps it as float16 -- the reference\'s own scene precision -- whenever every voxel survives the round trip: same gathered bits, half the bytes)')
+    ap.add_argument('--fp32-store', action='store_true', help='keep the replicated voxel store as float32')
     ap.add_argument('--ranks-share-gpu', action='store_true', help='dev: every rank on cuda:0 with the collectives over gloo (RCCL refuses two ranks on one device): runs the whole multi-rank bench on a one-GPU box; the line says so and is no scaling measurement')
     ap.add_argument('--resident-batches', type=int, default=4, help='distinct resident input batches rotated through the timed loop')
     return ap.parse_args(argv)
@@ -551,8 +552,8 @@ def main():
 
     torch.manual_seed(0)
     emb, meta, vols = synthetic_database(cfg, n_patches, device)
-    database = PatchDatabase(emb, meta, vols, device, rank, world, half_store=args.half_store)
-    if args.half_store:
+    database = PatchDatabase(emb, meta, vols, device, rank, world, half_store=True if args.half_store else (False if args.fp32_store else None))
+    if database.half_store:
         del vols
         vols = database.volumes
     database.force_collectives = force_dist

@@ -25,21 +25,29 @@ def rename_state_dict(state_dict, key):
     return renamed
 
 
-def read_checkpoint(ckpt, map_location='cpu'):
-    """a path (torch.load) or an already loaded checkpoint -> its ``state_dict`` mapping.  A bare state dict (no 'state_dict' entry) is taken as it is."""
+def read_checkpoint(ckpt, map_location='cpu', trust_pickle=False):
+    """a path (torch.load) or an already loaded checkpoint -> its ``state_dict`` mapping.  A bare state dict (no 'state_dict' entry) is taken as it is.
+    Files are read with ``weights_only=True`` (tensors and plain containers only).  A Lightning checkpoint that pickles other objects beside its state dict
+    (hyper-parameter namespaces, callbacks) needs ``trust_pickle=True``, which unpickles ARBITRARY code from the file: only for checkpoints you produced."""
     import torch
     if isinstance(ckpt, (str, Path)):
-        ckpt = torch.load(str(ckpt), map_location=map_location, weights_only=False)
+        try:
+            ckpt = torch.load(str(ckpt), map_location=map_location, weights_only=True)
+        except Exception as e:                                     # (pickle.UnpicklingError from the weights-only unpickler)
+            if not trust_pickle:
+                raise RuntimeError('%s holds more than tensors and plain containers (%s); pass trust_pickle=True to unpickle it -- that executes code from the '
+                                   'file, so only for checkpoints whose origin you trust' % (ckpt, str(e).splitlines()[0][:200])) from e
+            ckpt = torch.load(str(ckpt), map_location=map_location, weights_only=False)
     if not hasattr(ckpt, 'keys'):
         raise TypeError('a checkpoint is a path or a mapping, got %s' % type(ckpt).__name__)
     return ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
 
 
-def load_prefixed(modules, ckpt, prefixes, map_location='cpu'):
+def load_prefixed(modules, ckpt, prefixes, map_location='cpu', trust_pickle=False):
     """``modules``: {attribute name: nn.Module}.  Loads every module whose attribute name is in ``prefixes`` from ``ckpt`` by the reference's rule.
     A prefix without a single key in the checkpoint raises KeyError naming it (the reference would die inside load_state_dict with every key missing);
     missing / unexpected keys under a prefix raise RuntimeError from the strict ``load_state_dict``.  -> the attribute names loaded."""
-    sd = read_checkpoint(ckpt, map_location)
+    sd = read_checkpoint(ckpt, map_location, trust_pickle)
     loaded = []
     for name in prefixes:
         if name not in modules or modules[name] is None:

@@ -218,12 +218,21 @@ def build_database_rows(config, fenc_target, volumes, device, patch_mask=None, c
 
 class PatchDatabase:
     @classmethod
-    def build(cls, config, fenc_target, volumes, device, rank=0, world=1, group=None, patch_mask=None):
+    def build(cls, config, fenc_target, volumes, device, rank=0, world=1, group=None, patch_mask=None, half_store=None):
         """Database straight from scene chunks: embeddings computed on the device (see build_database_rows)."""
         emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
-        return cls(emb, meta, volumes, device, rank, world, group)
+        return cls(emb, meta, volumes, device, rank, world, group, half_store=half_store)
 
-    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend, host_group=None, half_store=False):
+    @staticmethod
+    def _fits_float16(vols, rows_per_piece=1024):
+        """every voxel of the store survives float16 (true for anything read from the reference's float16 scenes) -- checked where the store lives"""
+        for lo in range(0, vols.shape[0], rows_per_piece):
+            piece = vols[lo:lo + rows_per_piece].to(torch.float32)
+            if not torch.equal(torch.nan_to_num(piece.to(torch.float16).to(torch.float32), nan=0.0), torch.nan_to_num(piece, nan=0.0)):
+                return False
+        return True
+
+    def __init__(self, emb, meta, volumes, device, rank=0, world=1, group=None, backend=HipSearchBackend, host_group=None, half_store=None):
         """emb [N+1,64] float32 (unit rows), meta [N+1,7] int32, volumes [S,64,64,64] float32 -- host or device tensors /
         numpy arrays of the FULL database; this rank keeps its embedding shard and replicas of meta/volumes.
 
@@ -231,9 +240,10 @@ class PatchDatabase:
         ``group``) is passed, it creates the gloo twin of ``group`` for the query-count check, and ``dist.new_group`` must be entered by every
         rank of the default group -- construct the database on all ranks at the same point of the program.
 
-        ``half_store=True`` keeps the replicated voxel store as float16, the precision the reference holds scenes in (dataset/scene.py:61,71): half the
-        HBM (1 M patches: 8.2 GB instead of 16.4 GB per GPU) and half the bytes the patch gather reads, the same gathered bits -- the constructor checks
-        that every voxel survives the round trip (true for anything that came out of the reference's float16 scenes) and refuses a store that would not."""
+        ``half_store``: keep the replicated voxel store as float16, the precision the reference holds scenes in (dataset/scene.py:61,71): half the HBM
+        (1 M patches: 8.2 GB instead of 16.4 GB per GPU) and half the bytes the patch gather reads, the same gathered bits.  None (default): float16 whenever
+        every voxel survives the round trip (true for anything that came out of the reference's float16 scenes), float32 otherwise; True: float16 or a
+        ValueError; False: float32."""
         emb = torch.as_tensor(emb)
         self.count_check = None
         if world > 1:
@@ -250,16 +260,21 @@ class PatchDatabase:
         self.emb_packed = backend.pack(shard)
         self.meta = torch.as_tensor(meta).to(self.device, torch.int32).contiguous()
         vols = torch.as_tensor(volumes)
+        if half_store is None:
+            half_store = vols.dtype == torch.float16 or self._fits_float16(vols)
         if half_store and vols.dtype != torch.float16:
-            vols = vols.to(self.device)
+            # piece by piece FROM WHERE THE STORE IS (copying the whole fp32 store to the device first costs 16.4 + 8.2 GB at 1 M patches -- more than a GPU
+            # that would hold the narrowed store may have left)
             narrowed = torch.empty(vols.shape, dtype=torch.float16, device=self.device)
-            for lo in range(0, vols.shape[0], 1024):                   # in pieces: the check's temporaries would otherwise triple a 16 GB store
-                piece = vols[lo:lo + 1024].to(torch.float32)
-                narrowed[lo:lo + 1024] = piece.to(torch.float16)
-                if not torch.equal(narrowed[lo:lo + 1024].to(torch.float32), piece):
+            for lo in range(0, vols.shape[0], 1024):
+                piece = vols[lo:lo + 1024].to(self.device, torch.float32)
+                half = piece.to(torch.float16)
+                if not torch.equal(torch.nan_to_num(half.to(torch.float32), nan=0.0), torch.nan_to_num(piece, nan=0.0)) or not torch.equal(half.isnan(), piece.isnan()):
                     raise ValueError('half_store=True: the voxel store holds values float16 cannot represent (the reference\'s scenes are float16, '
                                      'dataset/scene.py:61,71); keep the float32 store for this database')
+                narrowed[lo:lo + 1024] = half
             vols = narrowed
+        self.half_store = bool(half_store)
         self.volumes = vols.to(self.device, torch.float16 if half_store else torch.float32).contiguous()
         self.n_scenes = self.volumes.shape[0]
         self.feature_cache = None        # see build_feature_cache

@@ -59,7 +59,7 @@ class RefinementEngine:
         self.database = database
         self._side_streams = {}          # one helper stream per caller stream (several batches may be in flight)
         self.serial = False              # True: keep the U-Net backbone on the caller's stream (per-kernel timing wants no overlap)
-        self.front_at = 'start'          # refine_stream: where the next batch's front end is issued ('start' of this batch's back end | 'decoders')
+        self.front_at = 'start'          # refine_stream: where the next batch's front end is issued -- at the 'start' of this batch's back end, behind its encoder launches ('decoders'), or 'unet_decoders': front end at the start, but this batch's chunk-level U-Net forked behind the encoders
 
     def modules(self):
         return {'unet_backbone': self.unet_backbone, 'decoder': self.decoder, 'retrieval_backbone': self.retrieval_backbone,
@@ -69,19 +69,20 @@ class RefinementEngine:
         for name, sd in sds.items():
             self.modules()[name].load_state_dict(sd)
 
-    def load_checkpoints(self, refinement_ckpt=None, retrieval_ckpt=None):
+    def load_checkpoints(self, refinement_ckpt=None, retrieval_ckpt=None, trust_pickle=False):
         """The reference's checkpoint hand-over (trainer/train_refinement.py:295-306, util/retrieval.py:224-225 via util/misc.py:23-36): Lightning-shaped
         ``{'state_dict': {'unet_backbone.network.0...': ..., 'decoder...': ..., 'retrieval_backbone...': ..., 'patched_attention_block...': ...}}`` for the
         refinement networks, ``{'state_dict': {'fenc_input.layers.0...': ..., 'fenc_target...': ...}}`` for the patch encoders (``fenc_target`` embeds
         database patches: ``PatchDatabase.build(config, engine.fenc_target, ...)``).  Paths or loaded checkpoints; strict: a missing or unexpected key
-        raises.  -> the attribute names loaded."""
+        raises.  Files are read with torch.load(weights_only=True); ``trust_pickle=True`` falls back to full unpickling for checkpoints that carry other Python
+        objects -- that EXECUTES code stored in the file, so only for checkpoints of known origin.  -> the attribute names loaded."""
         from . import checkpoint
         loaded = []
         if refinement_ckpt is not None:
-            loaded += checkpoint.load_prefixed(self.modules(), refinement_ckpt, checkpoint.REFINEMENT_PREFIXES, self.device)
+            loaded += checkpoint.load_prefixed(self.modules(), refinement_ckpt, checkpoint.REFINEMENT_PREFIXES, self.device, trust_pickle)
         if retrieval_ckpt is not None:
             loaded += checkpoint.load_prefixed({'fenc_input': self.fenc_input, 'fenc_target': self.fenc_target}, retrieval_ckpt,
-                                               checkpoint.RETRIEVAL_PREFIXES, self.device)
+                                               checkpoint.RETRIEVAL_PREFIXES, self.device, trust_pickle)
         return loaded
 
     # ---------------------------------------------------------------------------------------------- stages
@@ -222,14 +223,17 @@ class RefinementEngine:
                 done.record(front)
             return (patches, x_back, done) if with_backbone else (patches, x_in, done)
 
+        front_at = self.front_at                                     # snapshot: the pending tuple's meaning depends on it
+        if front_at not in ('start', 'decoders', 'unet_decoders'):
+            raise ValueError("RefinementEngine.front_at must be 'start', 'decoders' or 'unet_decoders', got %r" % (front_at,))
         for i, raw in enumerate(batches):
             qs = query_scenes[i] if query_scenes is not None else None
             pm = patch_masks[i] if patch_masks is not None else None
             with torch.cuda.device(self.device), torch.no_grad():
                 if main is None:
                     main = torch.cuda.current_stream(self.device)
-                late_unet = self.front_at == 'unet_decoders'
-                if pending is None or self.front_at in ('start', 'unet_decoders'):
+                late_unet = front_at == 'unet_decoders'
+                if pending is None or front_at in ('start', 'unet_decoders'):
                     nxt = issue_front(raw, qs, pm, with_backbone=not late_unet)
                     out = self._finish_pipelined(main, *pending, late_unet=late_unet) if pending is not None else None
                 else:
@@ -245,7 +249,7 @@ class RefinementEngine:
                 yield out
         if pending is not None:
             with torch.cuda.device(self.device), torch.no_grad():
-                out = self._finish_pipelined(main, *pending, late_unet=self.front_at == 'unet_decoders')
+                out = self._finish_pipelined(main, *pending, late_unet=front_at == 'unet_decoders')
             yield out
 
     def _finish_pipelined(self, main, patches, x_back, done, after_encoders=None, late_unet=False):

@@ -90,7 +90,7 @@ def load_compose(retrievals_dir, scene):
 
 
 # ------------------------------------------------------------------------------------------------ the device path -> the reference's files
-def create_dictionary(config, fenc_target, volumes, scene_names, tree_path, device, patch_mask=None):
+def create_dictionary(config, fenc_target, volumes, scene_names, tree_path, device, patch_mask=None, half_store=None):
     """The reference's ``create_dictionary`` (util/retrieval.py:29-48) on the device: the 64 target windows of every scene chunk ``volumes[s]`` ([S,64,64,64] raw)
     embedded by ``fenc_target`` + the sentinel row -> ``<tree_path>/database.npy`` and ``index.json`` (position in ``scene_names`` = scene_idx) -> the
     PatchDatabase over the same rows (resident in HBM, ready to be queried).  The FLANN index file the reference also writes (:49-55) has no counterpart:
@@ -100,7 +100,7 @@ def create_dictionary(config, fenc_target, volumes, scene_names, tree_path, devi
         raise ValueError('one scene name per scene chunk (%d names, %d volumes)' % (len(scene_names), len(volumes)))
     emb, meta = build_database_rows(config, fenc_target, volumes, device, patch_mask)
     save_database(tree_path, meta.cpu().numpy(), emb.cpu().numpy(), scene_names)
-    return PatchDatabase(emb, meta, volumes, device)
+    return PatchDatabase(emb, meta, volumes, device, half_store=half_store)
 
 
 def _per_chunk(scene_names, patch_size, context):
@@ -131,11 +131,14 @@ def retrieval_mapping(database, q, scene_names, K, index=None, ignore_patches_fr
     meta, dist, _ = database.retrieve(q, K, query_scene, keep)
     database.check()
     names = _per_chunk(scene_names, patch_size, context)
-    mapping = mapping_to_dict(names, meta.cpu().numpy(), dist.cpu().numpy())
-    if patch_mask is not None:
-        flags = np.asarray(torch.as_tensor(patch_mask).cpu()).reshape(-1)
-        mapping = {nm: row for nm, row, f in zip(names, mapping.values(), flags) if f}
-    return mapping
+    if len(set(names)) != len(names):
+        raise ValueError('retrieval_mapping: a scene chunk is named twice (patch names are the keys of the mapping; ADVICE r5)')
+    meta_h, dist_h = meta.cpu().numpy(), dist.cpu().numpy()
+    if patch_mask is None:
+        return mapping_to_dict(names, meta_h, dist_h)
+    flags = np.asarray(torch.as_tensor(patch_mask).cpu()).reshape(-1).astype(bool)
+    kept = [i for i in range(len(names)) if flags[i]]               # by index: the mask and the rows are aligned with `names`, not with a dict's order
+    return mapping_to_dict([names[i] for i in kept], meta_h[kept], dist_h[kept])
 
 
 def compose_scene(database, mapping, scene, K, trunc_fill, trunc_ratio=1.0, patch_size=16, context=8, no_overlap=True):
@@ -152,10 +155,19 @@ def compose_scene(database, mapping, scene, K, trunc_fill, trunc_ratio=1.0, patc
             rows[p] = np.asarray(mapping[nm])[:K, :7].astype(np.int32)
     meta = torch.from_numpy(rows).to(database.device)
     out = ops.gather_patches(database.volumes, meta, 1, K, trunc_fill, trunc_ratio, 0.0, 1.0, layout=0, no_overlap=no_overlap)
-    return out[0].cpu().numpy()
+    vols = out[0].cpu().numpy()
+    if trunc_ratio != 1.0:
+        # patches the mapping does not hold were never visited by the reference's loop (:151): they keep the initial fill (:148), unscaled -- unlike sentinel
+        # hits, which are scaled like any patch (:160-162)
+        o = range(0, 64 - patch_size + 1, patch_size)
+        for p, (xx, yy, zz) in enumerate((x, y, z) for x in o for y in o for z in o):
+            if names[p] not in mapping or mapping[names[p]] is None:
+                vols[:, xx:xx + patch_size, yy:yy + patch_size, zz:zz + patch_size] = np.float32(trunc_fill)
+    return vols
 
 
-def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=32):
+def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=32, use_target_for_feats=False, fenc_target=None, target_chunks=None,
+                       truncations_by_split=None):
     """The reference's ``retrievals_to_disk`` (util/retrieval.py:210-248) driven by the device path.
 
     ``splits``: {'train': (scene_names, input_chunks[, patch_mask]), 'val': (...)} -- ``input_chunks`` [n,S,S,S] raw low-resolution chunks (one per scene
@@ -163,9 +175,13 @@ def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=3
     ``fenc_input`` holds the retrieval checkpoint and whose ``database`` is the dictionary (``create_dictionary`` / ``PatchDatabase``); ``index``: the
     database's scene-name list (index.json), needed for the train split's same-scene demotion.
 
-      mode 'map'      query embeddings (engine.embed_queries) -> ``retrieval_mapping`` -> ``map_train.npy`` with ignore_patches_from_source=True (:233-235),
-                      ``map_val.npy`` with False (:236-238)
-      mode 'compose'  reads the two map files back and writes ``compose/<scene>.npz`` for every scene of both splits (:239-248)
+      mode 'map'      query embeddings -> ``retrieval_mapping`` -> ``map_train.npy`` with ignore_patches_from_source=True (:233-235), ``map_val.npy`` with
+                      False (:236-238).  Queries: ``engine.embed_queries`` of the input chunks, or -- ``use_target_for_feats`` (:230-231: ``fenc_target`` /
+                      ``extract_target_features``) -- the TARGET windows of ``target_chunks[split]`` ([n,64,64,64] raw) embedded by ``fenc_target``, i.e. the
+                      rows ``create_dictionary`` would give those chunks
+      mode 'compose'  reads the two map files back and writes ``compose/<scene>.npz`` for every scene of both splits (:239-248).  Fill value and scale follow the
+                      reference (:148,159): a split's volumes are filled with THAT split's target truncation and database patches are scaled by split
+                      truncation / train truncation -- ``truncations_by_split`` {'train': t, 'val': t} when the two datasets differ (default: the config's)
 
     -> the list of files written."""
     import torch
@@ -185,19 +201,28 @@ def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=3
             mapping = {}
             for lo in range(0, len(names), batch):
                 hi = min(lo + batch, len(names))
-                q = engine.embed_queries(torch.from_numpy(chunks[lo:hi]).to(engine.device))
+                if use_target_for_feats:
+                    if fenc_target is None or target_chunks is None or split not in target_chunks:
+                        raise ValueError('use_target_for_feats needs fenc_target and target_chunks[%r] (the 64^3 target chunks of the split)' % split)
+                    from .database import build_database_rows
+                    q = build_database_rows(cfg, fenc_target, np.asarray(target_chunks[split], dtype=np.float32)[lo:hi], engine.device)[0][:-1]      # (no sentinel row)
+                else:
+                    q = engine.embed_queries(torch.from_numpy(chunks[lo:hi]).to(engine.device))
                 mapping.update(retrieval_mapping(engine.database, q, names[lo:hi], K, index, ignore, None if mask is None else np.asarray(mask)[lo:hi], ps, ctx))
             save_mapping(retrievals_dir / ('map_%s.npy' % split), mapping)
             written.append(retrievals_dir / ('map_%s.npy' % split))
     elif mode == 'compose':
         from .configs import truncations
         _, trunc_t = truncations(cfg)
+        tby = dict(truncations_by_split or {})
+        trunc_train = float(tby.get('train', trunc_t))              # the database's volumes are the train split's targets (dataset_train.get_scene_target, :158)
         for split in ('train', 'val'):
             if split not in splits:
                 continue
+            trunc_split = float(tby.get(split, trunc_t))
             mapping = load_mapping(retrievals_dir / ('map_%s.npy' % split))
             for scene in splits[split][0]:
-                save_compose(retrievals_dir, scene, compose_scene(engine.database, mapping, scene, K, trunc_t, 1.0, ps, ctx))
+                save_compose(retrievals_dir, scene, compose_scene(engine.database, mapping, scene, K, trunc_split, trunc_split / trunc_train, ps, ctx))
                 written.append(retrievals_dir / 'compose' / ('%s.npz' % scene))
     else:
         raise ValueError("mode must be 'map' or 'compose' (the reference's 'evaluate' computes IoU / Chamfer metrics: out of scope)")

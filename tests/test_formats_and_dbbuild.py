@@ -255,3 +255,54 @@ def test_retrievals_to_disk_from_chunks_matches_oracle(gpu, tmp_path):
             vols = formats.load_compose(out, scene)
             ref = refpath.compose_retrieval(got, volumes, K, trunc_t, patch_keep=keep[c])
             np.testing.assert_array_equal(vols, ref)
+
+
+@pytest.mark.gpu
+def test_retrievals_to_disk_target_features_and_split_truncations(gpu, tmp_path):
+    """retrievals_to_disk with use_target_for_feats (reference util/retrieval.py:230-231: queries = fenc_target on the TARGET windows) and a val split whose
+    truncation differs from the train split's (:148,159: fill with the split's truncation, scale database patches by split / train)."""
+    from rfuse.engine import RefinementEngine
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    K = cfg['K']
+    eng = RefinementEngine(cfg, gpu, None)
+    sds = {n: helpers.seeded_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, 60 + i) for i, (n, m) in enumerate(eng.modules().items())}
+    eng.load_state_dicts(sds)
+    fenc_target, sd_t = _target_sd(cfg, 9)
+    eng.fenc_target.load_state_dict(sd_t)
+    scenes = [synthetic.make_chunk(7300 + i, cfg) for i in range(4)]
+    index = ['shape%02d' % i for i in range(4)]
+    volumes = np.stack([c['target_raw'] for c in scenes])
+    eng.database = formats.create_dictionary(cfg, eng.fenc_target, volumes, index, tmp_path / 'tree', gpu)
+    meta, emb, _ = formats.load_database(tmp_path / 'tree')
+    val = [synthetic.make_chunk(7400 + i, cfg) for i in range(2)]
+    mask = np.ones((2, 64), dtype=bool)
+    mask[0, 1::4] = False
+    splits = {'train': (index, np.stack([c['input_raw'] for c in scenes])), 'val': (['new00', 'new01'], np.stack([c['input_raw'] for c in val]), mask)}
+    targets = {'train': volumes, 'val': np.stack([c['target_raw'] for c in val])}
+    out = tmp_path / 'retrievals'
+    with pytest.raises(ValueError):
+        formats.retrievals_to_disk('map', eng, out, splits, index=index, use_target_for_feats=True)
+    formats.retrievals_to_disk('map', eng, out, splits, index=index, batch=3, use_target_for_feats=True, fenc_target=eng.fenc_target, target_chunks=targets)
+    # a train chunk queried with its own target features: its own rows are the nearest (distance ~0) and are demoted behind the other scenes'
+    m_train = formats.load_mapping(out / 'map_train.npy')
+    for c, scene in enumerate(index):
+        for nm in formats.chunk_patch_names(scene):
+            assert (m_train[nm][:, 0] != c).all()
+    # a val chunk that IS a database scene finds itself at distance ~0 (no demotion on val)
+    splits2 = {'val': (['again'], splits['train'][1][:1])}
+    formats.retrievals_to_disk('map', eng, tmp_path / 'r2', splits2, index=index, use_target_for_feats=True, fenc_target=eng.fenc_target, target_chunks={'val': volumes[:1]})
+    m2 = formats.load_mapping(tmp_path / 'r2' / 'map_val.npy')
+    for nm in formats.chunk_patch_names('again'):
+        assert m2[nm][0, 0] == 0 and m2[nm][0, 7] <= 1e-5
+    # compose with a val truncation of half the train truncation: fill = the split's truncation, database patches and sentinel hits scaled by 1/2
+    formats.retrievals_to_disk('compose', eng, out, splits, truncations_by_split={'train': trunc_t, 'val': trunc_t / 2})
+    m_val = formats.load_mapping(out / 'map_val.npy')
+    assert len(m_val) == int(mask.sum())
+    for c, scene in enumerate(splits['val'][0]):
+        pn = formats.chunk_patch_names(scene)
+        got = np.stack([m_val[n] if mask[c, p] else np.zeros((K, 8), dtype=np.float32) for p, n in enumerate(pn)])
+        want = refpath.compose_retrieval(got, volumes, K, trunc_t / 2, trunc_ratio=0.5, patch_keep=mask[c])
+        np.testing.assert_array_equal(formats.load_compose(out, scene), want)
+    np.testing.assert_array_equal(formats.load_compose(out, index[0]),
+                                  refpath.compose_retrieval(np.stack([m_train[n] for n in formats.chunk_patch_names(index[0])]), volumes, K, trunc_t, patch_keep=np.ones(64, dtype=bool)))

@@ -1335,6 +1335,36 @@ def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
     assert (got - plain).abs().max().item() <= 2e-6 * max(1.0, scale)
 
 
+def test_parity_major_handover_of_the_decoder_pair_equals_the_linear_one(ops):
+    """The persistent decoder-form producer (rf_conv3d_up_split_presplit_pm, k_conv3_up_split_pp) writes the voxel slots of its pre-split output in parity-major
+    order -- slot ((z & 1) 4 + (y & 1) 2 + (x & 1)) 64 + (z >> 1) 16 + (y >> 1) 4 + (x >> 1) -- and rf_conv3d_split_pre_pm_k3_relu reads that order: the bytes are the
+    linear entry point's bytes permuted, the consumer's output is bit-equal, and statistics requested from the producer are the plain kernel's (reference
+    model/refinement.py:64-73, model/unet.py:149-159: dec1 of the retrieval backbone)"""
+    n, c0, c1, cmid, cout, groups = 2100, 32, 64, 56, 16, 8
+    gen = torch.Generator().manual_seed(77)
+    skip, low = rnd(gen, n, c0, 8, 8, 8).relu_().to(DEV), rnd(gen, n, c1, 4, 4, 4).relu_().to(DEV)
+    w1, w2 = (rnd(gen, cmid, c0 + c1, 3, 3, 3) * 0.05).to(DEV), (rnd(gen, cout, cmid, 3, 3, 3) * 0.05).to(DEV)
+    g1w, g1b = (1 + 0.2 * rnd(gen, c0 + c1)).to(DEV), (0.2 * rnd(gen, c0 + c1)).to(DEV)
+    g2w, g2b = (1 + 0.2 * rnd(gen, cmid)).to(DEV), (0.2 * rnd(gen, cmid)).to(DEV)
+    aff = ops.gn_affine(skip, low, g1w, g1b, groups, 1e-5)
+    wp1, wp2 = ops.pack_conv3_up_split_weight(w1, c0), ops.pack_conv3_split_weight(w2)
+    assert ops.conv_up_split_presplit_pm_supported(skip, low, cmid, groups, cout)
+    lin = ops.conv3d_up_split_presplit(skip, low, aff, wp1, cmid, g2w, g2b, groups, 1e-5)
+    pm = ops.conv3d_up_split_presplit(skip, low, aff, wp1, cmid, g2w, g2b, groups, 1e-5, parity_major=True)
+    z, y, x = torch.meshgrid(torch.arange(8), torch.arange(8), torch.arange(8), indexing='ij')
+    perm = (((z & 1) * 4 + (y & 1) * 2 + (x & 1)) * 64 + (z >> 1) * 16 + (y >> 1) * 4 + (x >> 1)).reshape(-1).to(DEV)
+    lin5, pm5 = lin.view(n, cmid // 8, 2, 512, 16), pm.view(n, cmid // 8, 2, 512, 16)
+    assert torch.equal(pm5[:, :, :, perm], lin5), 'parity-major bytes are not the linear bytes permuted'
+    out_lin = ops.conv3d_split_pre_relu(lin, cmid, n, 8, wp2, cout)
+    out_pm = ops.conv3d_split_pre_relu(pm, cmid, n, 8, wp2, cout, parity_major=True)
+    assert torch.equal(out_lin, out_pm)
+    # against float64 on a few samples
+    x64 = torch.cat((skip[:6].cpu(), F.interpolate(low[:6].cpu(), scale_factor=2, mode='nearest')), 1).double()
+    for gw, gb, w in ((g1w, g1b, w1), (g2w, g2b, w2)):
+        x64 = F.relu(F.conv3d(F.group_norm(x64, groups, gw.double().cpu(), gb.double().cpu(), 1e-5), w.double().cpu(), padding=1))
+    close(out_pm[:6], x64.float(), 1e-5, 'decoder pair through the parity-major hand-over')
+
+
 @pytest.mark.parametrize('n', [1030, 2070])
 def test_presplit_route_of_an_encoder_pair_on_whole_samples(ops, n):
     """DoubleConv of an encoder level on whole 8^3 samples (the retrieval backbone's 16 -> 16 -> 32 @8^3, fused pool): the split box kernel hands the second
