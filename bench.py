@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument('--force-collectives', action='store_true', help='dev: with one rank, still run the all-gather + all-to-all + merge protocol over RCCL')
     ap.add_argument('--half-store', action='store_true', help='insist on the float16 voxel store (the default already keeps it as float16 -- the reference\'s own scene precision -- whenever every voxel survives the round trip: same gathered bits, half the bytes)')
     ap.add_argument('--fp32-store', action='store_true', help='keep the replicated voxel store as float32')
+    ap.add_argument('--isotropic-db', action='store_true', help='database embeddings as isotropic unit Gaussians (rounds 1-5) instead of laid where the query encoder puts synthetic chunks')
     ap.add_argument('--ranks-share-gpu', action='store_true', help='dev: every rank on cuda:0 with the collectives over gloo (RCCL refuses two ranks on one device): runs the whole multi-rank bench on a one-GPU box; the line says so and is no scaling measurement')
     ap.add_argument('--resident-batches', type=int, default=4, help='distinct resident input batches rotated through the timed loop')
     return ap.parse_args(argv)
@@ -90,13 +91,24 @@ def launch_plan(args, argv, environ):
             '--master-port', str(free_port()), str(Path(__file__).resolve())] + list(argv)
 
 
-def synthetic_database(cfg, n_patches, device, seed=1234):
-    """Seeded synthetic DB built on the device: unit Gaussian embeddings (DB-side encoder = 'next' row N1), reference row
-    semantics for meta (util/retrieval.py:32,39-45 + sentinel), U(0,trunc) fp16-rounded scene chunks as the voxel store."""
+def synthetic_database(cfg, n_patches, device, seed=1234, anchors=None):
+    """Seeded synthetic DB built on the device: unit embeddings, reference row semantics for meta (util/retrieval.py:32,39-45 + sentinel), U(0,trunc) fp16-rounded
+    scene chunks as the voxel store.  Embeddings: with ``anchors`` [A, 64] (unit query embeddings of synthetic chunks under the engine's weights) row i is a random
+    anchor plus Gaussian noise of the anchors' own nearest-neighbour spacing, re-normalised -- the database then lies where the queries lie, as a trained encoder pair's
+    would, and a batch's neighbour lists name thousands of different rows.  Without anchors: isotropic unit Gaussians -- under a random-init query encoder, whose
+    embeddings all sit within 0.1 of one direction, every query then prefers the same ~100 rows (the patch gather read 1.5 MB instead of 134 MB)."""
     from rfuse import configs, synthetic
     _, trunc_t = configs.truncations(cfg)
     g = torch.Generator(device=device).manual_seed(seed)
     emb = torch.randn(n_patches + 1, 64, generator=g, device=device, dtype=torch.float32)
+    if anchors is not None:
+        a = anchors.to(device, torch.float32)
+        sub = a[torch.randperm(a.shape[0], generator=g, device=device)[:1024]]
+        d2 = (2.0 - 2.0 * sub @ a.T).clamp_min(0)
+        d2[d2 < 1e-9] = 9.0                                          # (itself and exact duplicates)
+        sigma = d2.min(dim=1).values.median().sqrt().item() / 8.0       # per-dimension noise: |noise| ~ the anchors' nearest-neighbour distance
+        pick = torch.randint(0, a.shape[0], (n_patches + 1,), generator=g, device=device)
+        emb = a[pick] + sigma * emb
     emb = emb / emb.norm(dim=1, keepdim=True).clamp_min(1e-12)
     meta = torch.from_numpy(synthetic.make_database(seed, cfg, n_patches, with_volumes=False, with_embeddings=False)['meta'])
     n_scenes = (n_patches + 63) // 64
@@ -105,6 +117,26 @@ def synthetic_database(cfg, n_patches, device, seed=1234):
         hi = min(lo + 1024, n_scenes)
         vols[lo:hi] = (torch.rand(hi - lo, 64, 64, 64, generator=g, device=device) * trunc_t).half().float()
     return emb, meta, vols
+
+
+def algorithmic_flops(name, a):
+    """SURVEY 8(d)-style algorithmic flop of a launch that is not a padded 3^3 box conv (those: conv_shape): 2 * cin * k^3 * cout per output voxel for the patch encoders'
+    valid convs, 2 * n_in * n_out per row and Linear layer for the attention encoder, the 3^3 direct form for the 2^3 / 1^3 GEMM level -- no operand-splitting factor,
+    no tile padding.  None: no such figure for this entry (the caller keeps the issued work and says so)."""
+    name = ENTRY_ALIAS.get(name, name)
+    if name in ('rf_conv3d_valid_leaky_split', 'rf_conv3d_valid_leaky_mfma', 'rf_conv3d_valid_leaky_lds', 'rf_conv3d_valid_leaky_valu', 'rf_conv3d_valid_leaky_valu_ex', 'rf_conv3d_valid_leaky'):
+        n, cin, s, cout, k, stride = a[:6]
+        return 2.0 * cin * k ** 3 * cout * ((s - k) // stride + 1) ** 3 * n
+    if name == 'rf_conv3d_valid_leaky_split_ex':
+        _, n, cin, s, cout, k, stride = a[:7]
+        return 2.0 * cin * k ** 3 * cout * ((s - k) // stride + 1) ** 3 * n
+    if name in ('rf_attn_mlp_split_volume', 'rf_attn_mlp_volume'):
+        b, kv, c, s, t = a[:5]
+        return b * kv * (s // 2) ** 3 * 2.0 * (c * 8 * 128 + 2 * 128 * 128 + 128 * 32)
+    if name == 'rf_conv3d_e2_split_k3_gn_relu':
+        cin, n, edge, cout = a[:4]
+        return 2.0 * 27 * cin * cout * edge ** 3 * n
+    return None
 
 
 def oracle_chunk(refpath, cfg, state, db_host, raw, noise, knn):
@@ -226,9 +258,14 @@ def parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev, chunks=(0, 17
     return out
 
 
+# entry points that are another one's launch with a different hand-over layout: same argument list, same work
+ENTRY_ALIAS = {'rf_conv3d_up_split_presplit_pm': 'rf_conv3d_up_split_presplit', 'rf_conv3d_split_pre_pm_k3_relu': 'rf_conv3d_split_pre_k3_relu'}
+
+
 def kernel_bytes(name, a, nulls=()):
     """algorithmic HBM bytes of one launch -- every input element read once, every output element written once -- or None.
     ``nulls``: positions of the launch's null pointer arguments (an output that is not written is not counted)"""
+    name = ENTRY_ALIAS.get(name, name)
     if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_k3_gn_relu_direct', 'rf_conv3d_up_k3_gn_relu',
                 'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit', 'rf_conv3d_up_split_k3_gn_relu_ch8'):
         c0, c1, n, edge, cout = a[:5]
@@ -264,6 +301,7 @@ def kernel_bytes(name, a, nulls=()):
 
 def conv_shape(name, a):
     """(c0, c1, n, edge, cout) of a 3x3x3 GroupNorm-conv launch, or None"""
+    name = ENTRY_ALIAS.get(name, name)
     if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_up_k3_gn_relu', 'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit',
                 'rf_conv3d_up_split_k3_gn_relu_ch8'):
         return tuple(a[:5])
@@ -276,6 +314,7 @@ def conv_shape(name, a):
 
 def kernel_work(name, a, cfg):
     """(bound, work per launch, unit) of one C-ABI launch from its integer arguments, or None when the launch is bookkeeping"""
+    name = ENTRY_ALIAS.get(name, name)
     if name in ('rf_conv3d_k3_gn_relu', 'rf_conv3d_k3_gn_relu_stats', 'rf_conv3d_k3_gn_relu_pool', 'rf_conv3d_k3_gn_relu_direct'):
         c0, c1, n, edge, cout = a[:5]
         if c0 + c1 == 1:                                         # first layer: reads 4 B, writes 4*cout B per voxel
@@ -551,14 +590,21 @@ def main():
     B, K = args.batch, cfg['K']
 
     torch.manual_seed(0)
-    emb, meta, vols = synthetic_database(cfg, n_patches, device)
+    eng = RefinementEngine(cfg, device, None)
+    # the database's embeddings are laid where the query encoder puts synthetic chunks (rank- and world-independent anchor chunks: every rank builds the same rows)
+    anchors = None
+    if not args.isotropic_db:
+        with torch.no_grad():
+            anchors = torch.cat([eng.embed_queries(torch.from_numpy(np.stack([synthetic.make_chunk(10_000 + a0 + b, cfg)['input_raw'] for b in range(32)])).to(device))
+                                 for a0 in range(0, 128, 32)])
+    emb, meta, vols = synthetic_database(cfg, n_patches, device, anchors=anchors)
     database = PatchDatabase(emb, meta, vols, device, rank, world, half_store=True if args.half_store else (False if args.fp32_store else None))
     if database.half_store:
         del vols
         vols = database.volumes
     database.force_collectives = force_dist
     collective_events = [] if (world > 1 or force_dist) else None
-    eng = RefinementEngine(cfg, device, database)
+    eng.database = database
     # every rank refines its own B chunks (chunk-parallel replicas); inputs resident in HBM
     # R distinct batches stay resident and the loops rotate through them, so consecutive steps search for different queries and gather different database
     # patches (one batch replayed K times would fetch the same 8192 patches, 134 MB, out of the Infinity Cache every step).  Batch 0 of rank 0 is the batch
@@ -671,16 +717,18 @@ def main():
             # `achieved` / `frac`: SURVEY 8(d)'s algorithmic work of the launch (a conv layer: 2 * 27 * cin * cout flop per output voxel, the reference's direct
             # form; an HBM-bound launch: its algorithmic bytes) / the launch's mean in-step duration / the peak of the pipe the launch runs on.
             # `issue_frac`: the flop actually ISSUED on that pipe / the same peak (pipe occupancy; round 4 printed this one as `frac`).
+            if direct is None and bound != 'hbm':
+                direct = algorithmic_flops(entry, ints)              # valid convs, attention MLP, 2^3 GEMM form: the reference's direct form, not the issued f16 flop
             algo_work = direct if direct is not None else work
             achieved = algo_work / (kern_ms * 1e-3) / scale
             # HBM traffic of the dominant kernel: OFFLINE PMC (separate rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
             # summary committed under profiles/), scaled per sample to this launch; None when the committed summary is of another kernel
             traffic, pmc_name = None, None
-            for pmc_file in (REPO / 'profiles' / 'r05_dominant_kernel.json', REPO / 'profiles' / 'r04_dominant_kernel.json'):
+            for pmc_file in (REPO / 'profiles' / 'r06_dominant_kernel.json', REPO / 'profiles' / 'r05_dominant_kernel.json', REPO / 'profiles' / 'r04_dominant_kernel.json'):
                 if not pmc_file.exists() or shape is None:
                     continue
                 pmc = json.loads(pmc_file.read_text())
-                same = pmc.get('entry') == entry or {pmc.get('entry'), entry} <= {'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit'}      # (both launch k_conv3_up_split<NB>)
+                same = pmc.get('entry') == entry or {pmc.get('entry'), entry} <= {'rf_conv3d_up_split_k3_gn_relu', 'rf_conv3d_up_split_presplit', 'rf_conv3d_up_split_presplit_pm'}
                 if same and pmc.get('shape') == [shape[0], shape[1], shape[3], shape[4]]:
                     traffic, pmc_name = pmc['traffic_bytes_per_sample'] * shape[2], pmc_file.name
                     break
@@ -692,7 +740,9 @@ def main():
                     'kernel': '%s %s' % (entry, list(ints)),
                     'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
                     'work_per_launch': algo_work,
-                    'work': ('SURVEY 8(d) algorithmic flop of the layer: 2 * 27 * cin * cout per output voxel (the reference\'s direct form)' if direct is not None else work_unit)
+                    'work': (('SURVEY 8(d) algorithmic flop of the layer: 2 * 27 * cin * cout per output voxel (the reference\'s direct form)' if shape is not None else
+                              'algorithmic flop of the launch in the reference\'s direct form (2 * cin * k^3 * cout per output voxel / 2 * n_in * n_out per row and layer; no operand-splitting factor, no tile padding)')
+                             if direct is not None else work_unit)
                             + '; peak = ' + pipe,
                     'issue_frac': issued / peak, 'issued_per_launch': work, 'issued': work_unit,
                     'launch_ms': kern_ms, 'launches_timed': len(in_step),
@@ -710,7 +760,8 @@ def main():
             'metric': '64^3 TSDF chunks/sec (retrieve+attend+refine)', 'value': value, 'unit': 'chunks/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'spinup_steps': SPINUP, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic (%d distinct resident batches rotated through the timed loop)' % R,
+            'data': 'synthetic (%d distinct resident batches rotated through the timed loop; database embeddings %s)' % (
+                R, 'isotropic unit Gaussians' if anchors is None else 'laid where the query encoder puts synthetic chunks: anchors + noise of their nearest-neighbour spacing'),
             'arithmetic': 'fp32 tensors and fp32 accumulation throughout; the heavy 3x3x3 convolutions multiply on the F16 matrix cores with every fp32 operand '
                           'carried as two f16 pieces (x = h + l / 2^11, exact f16 x f16 products, separate hi / lo fp32 accumulators): measured error against '
                           'float64 is lower than that of the fp32 MFMA chain (tests/test_kernels_gpu.py, tools/micro/split_probe.hip)' if ops.CONV_ARITH == 'split' else 'fp32 (v_mfma_f32_16x16x4_f32)',

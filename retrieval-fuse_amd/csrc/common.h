@@ -61,15 +61,20 @@ static inline int rf_round_up(int v, int m) { return (v + m - 1) / m * m; }
 #define RF_PERSIST_ROUNDS 4
 #endif
 static inline int rf_resident_wgs() {
+    // per device of the process (a count cached at first call would be the first device's for every later one), cached: hipGetDeviceProperties is slow
+    static std::atomic<int> cached[64];
     int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 512;
+    if (dev < 64) {
+        const int c = cached[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 512;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 512;
+    if (dev < 64) cached[dev].store(2 * prop.multiProcessorCount, std::memory_order_relaxed);
     return 2 * prop.multiProcessorCount;
 }
-static inline int rf_persistent_wgs() {
-    static const int resident = rf_resident_wgs();                  // (one device model per process: every MI355X of a node has the same CU count)
-    return resident * RF_PERSIST_ROUNDS;
-}
+static inline int rf_persistent_wgs() { return rf_resident_wgs() * RF_PERSIST_ROUNDS; }
 
 // wave64 sum reduction; result valid in every lane
 __device__ __forceinline__ double wave_sum(double v) {

@@ -585,7 +585,9 @@ def conv_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups):
 
 def conv3d_split_pre_relu_pool_presplit(pre, cin, n, edge, w_split_packed, cout, next_gamma, next_beta, next_groups, eps):
     """conv3d_split_pre_relu(pool='only') whose pooled output is emitted pre-split for the next level's first conv: -> (None, PreSplit of the pooled tensor).
-    No fp32 pooled tensor exists: the kernel keeps the pooled values of the sample in flight in a per-workgroup scratch slot (16 MB in all, L2-resident)."""
+    No fp32 pooled tensor exists: the kernel keeps the pooled values of the sample in flight in a per-workgroup scratch slot (one slot of cout x 512 floats per
+    persistent workgroup: 2048 workgroups on MI355X -> 64 MB allocated at cout = 16; a launch touches min(n, workgroups) slots, each re-used sample after sample, so
+    the live part stays cache-resident)."""
     dev = pre.device
     lib = _lib.load()
     half = edge // 2

@@ -85,3 +85,24 @@ def test_two_self_launched_ranks_on_one_gpu():
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0 and 'ranks_share_gpu' in out
     assert [c['rank'] for c in out['collectives']['per_rank_ms']] == [0, 1]
     assert out['recall_at_k']['recall@1'] == 1.0 and out['recall_at_k']['exact_order'] == 1.0
+
+
+@pytest.mark.gpu
+def test_the_north_star_multi_gpu_configuration_through_the_self_launcher():
+    """BASELINE.json configs[2] -- 3DFront 008->064, 1 M patches sharded over the ranks -- is `python bench.py --gpus 8 --config C3 --db 1000000` (README, INTEGRATION).
+    The same command shape on the one-GPU test box: two ranks sharing cuda:0 (collectives over gloo), C3, 200 k patches (100 k rows per shard: the f16-MFMA-filtered
+    scan, as a 1 M database's 125 k-row shards take it), default batch; the line must name the workload and report recall 1.0 with the exact order."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT') and not k.startswith('RFUSE_')}
+    r = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', '2', '--ranks-share-gpu', '--config', 'C3', '--db', '200000', '--steps', '2', '--warmup', '1',
+                        '--repeats', '0', '--no-cpu-baseline', '--resident-batches', '2'], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert 'C3' in out['config']['workload'] and out['config']['db_patches'] == 200000
+    assert [c['rank'] for c in out['collectives']['per_rank_ms']] == [0, 1]
+    assert out['recall_at_k']['recall@1'] == 1.0 and out['recall_at_k']['exact_order'] == 1.0

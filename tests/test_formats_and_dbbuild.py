@@ -284,11 +284,13 @@ def test_retrievals_to_disk_target_features_and_split_truncations(gpu, tmp_path)
     with pytest.raises(ValueError):
         formats.retrievals_to_disk('map', eng, out, splits, index=index, use_target_for_feats=True)
     formats.retrievals_to_disk('map', eng, out, splits, index=index, batch=3, use_target_for_feats=True, fenc_target=eng.fenc_target, target_chunks=targets)
-    # a train chunk queried with its own target features: its own rows are the nearest (distance ~0) and are demoted behind the other scenes'
+    # a train chunk queried with its own target features: its own row is THE nearest (distance ~0) and is demoted behind the other scenes' rows of the top-2K
     m_train = formats.load_mapping(out / 'map_train.npy')
     for c, scene in enumerate(index):
         for nm in formats.chunk_patch_names(scene):
-            assert (m_train[nm][:, 0] != c).all()
+            own = m_train[nm][:, 0] == c
+            assert not own[0] or own.all(), 'a same-scene row ahead of another scene\'s'
+            assert (np.diff(own.astype(np.int8)) >= 0).all(), 'same-scene rows are not at the end of the list'
     # a val chunk that IS a database scene finds itself at distance ~0 (no demotion on val)
     splits2 = {'val': (['again'], splits['train'][1][:1])}
     formats.retrievals_to_disk('map', eng, tmp_path / 'r2', splits2, index=index, use_target_for_feats=True, fenc_target=eng.fenc_target, target_chunks={'val': volumes[:1]})

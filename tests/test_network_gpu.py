@@ -355,8 +355,10 @@ def test_half_voxel_store_gathers_the_same_bits(gpu):
     _, trunc_t = rf_configs.truncations(cfg)
     d, K = cfg['dataset_train'], cfg['K']
     db = synthetic.make_database(9, cfg, 64 * 12)
-    full = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu)
+    full = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu, half_store=False)
     half = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu, half_store=True)
+    auto = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu)                      # default: float16 when every voxel survives the round trip (it does here)
+    assert full.volumes.dtype == torch.float32 and not full.half_store and auto.half_store and torch.equal(auto.volumes, half.volumes)
     assert half.volumes.dtype == torch.float16 and half.volumes.numel() * 2 == full.volumes.numel() * full.volumes.element_size() // 2
     q = torch.nn.functional.normalize(torch.randn(128, 64, generator=torch.Generator().manual_seed(4)), dim=1).to(gpu)
     meta, _, _ = full.retrieve(q, K)
@@ -376,6 +378,11 @@ def test_half_voxel_store_gathers_the_same_bits(gpu):
     lossy[0, 0, 0, 0] = np.float32(0.1)                               # 0.1 is not a float16
     with pytest.raises(ValueError, match='float16 cannot represent'):
         PatchDatabase(db['emb'], db['meta'], lossy, gpu, half_store=True)
+    kept = PatchDatabase(db['emb'], db['meta'], lossy, gpu)                               # ... and the default keeps such a store as float32
+    assert kept.volumes.dtype == torch.float32 and not kept.half_store
+    nan = db['volumes'].copy()
+    nan[1, 2, 3, 4] = np.nan                                                              # a NaN voxel is float16-representable: not a reason to refuse
+    assert PatchDatabase(db['emb'], db['meta'], nan, gpu, half_store=True).volumes.dtype == torch.float16
 
 
 def test_engine_patch_mask_end_to_end(gpu):
