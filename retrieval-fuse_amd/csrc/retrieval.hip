@@ -99,8 +99,10 @@ extern "C" int rf_gather_windows_split(const void* grid, int n, int c, int g, in
 //                                                the 64 contiguous bytes lane (row, g) loads are the dims {4m + g} = the g-th
 //                                                summation chain of the exact distance (see rf_exact_dist below)
 //   hd       [n32]                               (1 - 2^-15) * |row|^2 / 2, +inf for the padding rows (they never pass the filter)
-//   rows16   [n32][64] f16                       the rows rounded to f16, natural dim order: A operands of the f16-filtered scan
-//   hd16     [n32]                               (1 - 2^-9) * |row|^2 / 2; -inf for a row with a component beyond the f16 range (always re-checked)
+//   rows16   [n32][64] f16                       the rows rounded to f16, natural dim order: A operands of the f16-filtered scan (the h pieces)
+//   hd16     [n32]                               (1 - 2^-15) * |row|^2 / 2; -inf for a row with a component beyond the f16 range (always re-checked)
+//   rows16l  [n32][64] f16                       the l pieces: (x - h) * 2^11 rounded to f16 -- x = h + l / 2^11 up to 2^-22 |x| (round 6: the filter multiplies
+//                                                split operands, so that it is as tight as the fp32-MFMA filter at a fifth of its matrix-pipe cycles)
 #define RF_DIM 64
 #define RF_EPS_FILTER 3.0517578125e-05f            // 2^-15, see the error bound at k_l2_topk_mfma
 
@@ -108,7 +110,7 @@ static inline size_t rf_blocked_floats(int64_t n) { return (size_t)((n + 63) / 6
 static inline int64_t rf_rows32(int64_t n) { return (n + 31) / 32 * 32; }
 
 __global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, long long n, float* __restrict__ blocked, float* __restrict__ rows,
-                                                 float* __restrict__ hd, _Float16* __restrict__ rows16, float* __restrict__ hd16) {
+                                                 float* __restrict__ hd, _Float16* __restrict__ rows16, float* __restrict__ hd16, _Float16* __restrict__ rows16l) {
     const long long nblk = (n + 63) / 64, n32 = (n + 31) / 32 * 32;
     const size_t total = (size_t)nblk * RF_DIM * 64;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -124,7 +126,10 @@ __global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, 
             bool fits = row < n;
             if (fits)
                 for (int d = 0; d < RF_DIM; ++d) fits = fits && fabsf(emb[(size_t)row * RF_DIM + d]) < 6.0e4f;
-            rows16[i] = (_Float16)(fits ? emb[(size_t)row * RF_DIM + p] : 0.f);
+            const float xv = fits ? emb[(size_t)row * RF_DIM + p] : 0.f;
+            const _Float16 xh = (_Float16)xv;
+            rows16[i] = xh;
+            rows16l[i] = (_Float16)((xv - (float)xh) * 2048.f);      // (x - h is exact in fp32)
         }
     }
     for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < n32; row += (long long)gridDim.x * blockDim.x) {
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, 
             double nd = 0.0, big = 0.0;
             for (int d = 0; d < RF_DIM; ++d) { const double v = emb[(size_t)row * RF_DIM + d]; nd += v * v; big = fmax(big, fabs(v)); }
             h = (float)((1.0 - (double)RF_EPS_FILTER) * 0.5 * nd);
-            h16 = big < 6.0e4 ? (float)((1.0 - 1.953125e-03) * 0.5 * nd) : -INFINITY;
+            h16 = big < 6.0e4 ? (float)((1.0 - (double)RF_EPS_FILTER) * 0.5 * nd) : -INFINITY;
         }
         hd[row] = h;
         hd16[row] = h16;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void k_db_pack(const float* __restrict__ emb, 
 
 extern "C" size_t rf_db_packed_floats(int64_t n, int dim) {
     (void)dim;
-    return rf_blocked_floats(n) + (size_t)rf_rows32(n) * RF_DIM + (size_t)rf_rows32(n) + (size_t)rf_rows32(n) * (RF_DIM / 2) + (size_t)rf_rows32(n);
+    return rf_blocked_floats(n) + (size_t)rf_rows32(n) * RF_DIM + (size_t)rf_rows32(n) + (size_t)rf_rows32(n) * (RF_DIM / 2) + (size_t)rf_rows32(n) + (size_t)rf_rows32(n) * (RF_DIM / 2);
 }
 
 extern "C" int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float* packed, void* stream) {
@@ -152,8 +157,9 @@ extern "C" int rf_db_pack_embeddings(const float* emb, int64_t n, int dim, float
     float* hd = rows + (size_t)rf_rows32(n) * RF_DIM;
     _Float16* rows16 = reinterpret_cast<_Float16*>(hd + rf_rows32(n));
     float* hd16 = reinterpret_cast<float*>(rows16 + (size_t)rf_rows32(n) * RF_DIM);
+    _Float16* rows16l = reinterpret_cast<_Float16*>(hd16 + rf_rows32(n));
     const size_t want = (rf_blocked_floats(n) + 255) / 256;
-    hipLaunchKernelGGL(k_db_pack, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, emb, (long long)n, packed, rows, hd, rows16, hd16);
+    hipLaunchKernelGGL(k_db_pack, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, emb, (long long)n, packed, rows, hd, rows16, hd16, rows16l);
     RF_CHECK_LAUNCH("rf_db_pack_embeddings");
     return RF_OK;
 }
@@ -466,20 +472,22 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma(const float* __restrict
     }
 }
 
-// The same scan with the FILTER on the F16 matrix cores: q.x of f16-rounded rows and queries, 2 x v_mfma_f32_16x16x32_f16 per 16 x 16 tile
-// instead of 16 x v_mfma_f32_16x16x4_f32 (a sixteenth of the matrix-pipe cycles, half the bytes per row).  The filter only has to BOUND the
-// exact distance: |q~.x~ - q.x| <= (2 * 2^-11 + 2^-22) sum|q_d x_d| <= 2^-10 |q||x| <= 2^-11 (|q|^2 + |x|^2), plus 64 * 2^-24 of fp32
-// accumulation and the f16 subnormal floor (3e-8 per component); a pair whose exact distance is below T has
-//   s' = q~.x~ - (1-eps)|x|^2/2  >=  (|q|^2+|x|^2)(1/2 - 4.93e-4) - T/2 - (1-eps)|x|^2/2  >=  (1-eps)|q|^2/2 - T/2 = a_q
-// as soon as eps >= 9.9e-4; eps = 2^-9.  Rows or queries with a component beyond the f16 range get hd = -inf / a_q = -inf (always
-// re-checked).  Pairs that pass are re-evaluated with THE exact distance from the fp32 rows (fetched for that tile only), so the lists
-// are bit-identical to the other scans'.
-#define RF_EPS_FILTER16 1.953125e-03f              // 2^-9
+// The same scan with the FILTER on the F16 matrix cores, on SPLIT operands (round 6): x = h + l / 2^11 with h = f16(x), l = f16((x - h) 2^11), rows and queries
+// alike, and  q.x ~ qh.xh + (qh.xl + ql.xh) / 2^11  -- 6 x v_mfma_f32_16x16x32_f16 per 16 x 16 tile instead of 16 x v_mfma_f32_16x16x4_f32 (a fifth of the
+// matrix-pipe cycles), exact products, separate fp32 accumulators for the two orders of magnitude.  What is dropped: ql.xl / 2^22 and the f16 rounding of the
+// l pieces, together <= 3 * 2^-22 sum|q_d x_d| <= 3.6e-7 (|q|^2 + |x|^2) -- an eighth of the fp32 chains' own accumulation error -- so the bound of
+// k_l2_topk_mfma carries over with eps/2 >= 7.0e-6 + 3.4e-6: eps = 2^-15 as there.
+// Rounds 3-5 multiplied the h pieces alone (2 MFMAs per tile, eps = 2^-9): a slack of 4e-3 in the squared distance.  On isotropic embeddings (squared distances 2
+// +- 0.25) that is nothing; on CLUSTERED ones -- a database that lies where the queries lie, squared distances to the nearest rows 5e-3..2e-2, which is what
+// a trained encoder pair produces and what bench.py builds since round 6 -- every row of the query's neighbourhood passed such a filter and was re-checked one by
+// one: 2048 queries against 1 M rows 1.1 ms -> 15.4 ms.  Rows or queries with a component beyond the f16 range get hd = -inf / a_q = -inf (always re-checked).
+// Pairs that pass are re-evaluated with THE exact distance from the fp32 rows (fetched for that tile only), so the lists are bit-identical to the other scans'.
+#define RF_EPS_FILTER16 RF_EPS_FILTER              // 2^-15
 typedef _Float16 rf_h8 __attribute__((ext_vector_type(8)));
 template <int K2>
 __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restrict__ q, int nq, const float* __restrict__ rows_img,
-                                                         const _Float16* __restrict__ rows16, const float* __restrict__ hd, long long n, unsigned row_base, int rows_per_slice,
-                                                         const float* __restrict__ t0, int t0_stride, u64* __restrict__ parts) {
+                                                         const _Float16* __restrict__ rows16, const _Float16* __restrict__ rows16l, const float* __restrict__ hd, long long n,
+                                                         unsigned row_base, int rows_per_slice, const float* __restrict__ t0, int t0_stride, u64* __restrict__ parts) {
     __shared__ u64 s_lists[4][64 * K2];
     __shared__ float s_aq[4][64], s_hq[4][64], s_t0[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -528,25 +536,33 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) b[nb][j] = qi < nq ? q[(size_t)qi * RF_DIM + 4 * j + lg] : 0.f;
     }
-    rf_h8 bq[4][2];                                                  // the filter's B operands: k = 32 t + 8 lg + j of query q0 + nb*16 + li, as f16
+    rf_h8 bq[4][2], bql[4][2];                                       // the filter's B operands: k = 32 t + 8 lg + j of query q0 + nb*16 + li, as f16 pieces h, l
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         const int qi = q0 + nb * 16 + li;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bq[nb][t][j] = (_Float16)(qi < nq && hqs[nb * 16 + li] != -INFINITY ? q[(size_t)qi * RF_DIM + 32 * t + 8 * lg + j] : 0.f);   // out-of-range query: zeros, a_q = -inf
+            for (int j = 0; j < 8; ++j) {
+                const float qv = qi < nq && hqs[nb * 16 + li] != -INFINITY ? q[(size_t)qi * RF_DIM + 32 * t + 8 * lg + j] : 0.f;   // out-of-range query: zeros, a_q = -inf
+                const _Float16 qh = (_Float16)qv;
+                bq[nb][t][j] = qh;
+                bql[nb][t][j] = (_Float16)((qv - (float)qh) * 2048.f);
+            }
     }
     float aq[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
 
-    auto load_tile = [&](long long row0, rf_h8 (&a16)[2][2], f32x4 (&h)[2]) {
+    auto load_tile = [&](long long row0, rf_h8 (&a16)[2][2], rf_h8 (&a16l)[2][2], f32x4 (&h)[2]) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const rf_h8* rp = reinterpret_cast<const rf_h8*>(rows16 + (size_t)(row0 + mb * 16 + li) * RF_DIM + 8 * lg);
             a16[mb][0] = rp[0];
             a16[mb][1] = rp[4];                                       // + 32 halves
+            const rf_h8* rl = reinterpret_cast<const rf_h8*>(rows16l + (size_t)(row0 + mb * 16 + li) * RF_DIM + 8 * lg);
+            a16l[mb][0] = rl[0];
+            a16l[mb][1] = rl[4];
             const float4 t = *reinterpret_cast<const float4*>(hd + row0 + mb * 16 + 4 * lg);
             h[mb] = (f32x4){-t.x, -t.y, -t.z, -t.w};
         }
@@ -561,34 +577,37 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
         }
     };
 
-    auto scan_tile = [&](long long row0, const rf_h8 (&a16)[2][2], const f32x4 (&h)[2]) {
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = h[mb];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mb][t], bq[nb][t], acc[mb][nb], 0, 0, 0);
-        // does ANY pair of the tile pass?  per accumulator register one v_cmp whose lane mask is OR-ed on the scalar unit
+    auto scan_tile = [&](long long row0, const rf_h8 (&a16)[2][2], const rf_h8 (&a16l)[2][2], const f32x4 (&h)[2]) {
+        // the tile in four quarters (m-block x pair of n-blocks): 2 x 2 accumulators live at a time -- the kernel holds the 64 queries three times over
+        // (fp32 for the exact re-check, h and l pieces for the filter) and two tiles of rows
+        unsigned m = 0u;                                              // bit (mb*4 + nb)*4 + i: D row 4*lg + i of m-block mb, query column li of n-block nb
         unsigned long long anyhit = 0ull;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int np = 0; np < 2; ++np) {
+                f32x4 acc[2], acl[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) anyhit |= __ballot(acc[mb][nb][i] >= aq[nb]);
+                for (int e = 0; e < 2; ++e) { acc[e] = h[mb]; acl[e] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mb][t], bq[2 * np + e][t], acc[e], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acl[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mb][t], bql[2 * np + e][t], acl[e], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acl[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16l[mb][t], bq[2 * np + e][t], acl[e], 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool pass = fmaf(acl[e][i], 1.0f / 2048.f, acc[e][i]) >= aq[2 * np + e];
+                        anyhit |= __ballot(pass);
+                        m |= (pass ? 1u : 0u) << ((mb * 4 + 2 * np + e) * 4 + i);
+                    }
+            }
         if (anyhit == 0ull) return;
-        unsigned m = 0u;                                              // bit (mb*4 + nb)*4 + i: D row 4*lg + i of m-block mb, query column li of n-block nb
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m |= (acc[mb][nb][i] >= aq[nb] ? 1u : 0u) << ((mb * 4 + nb) * 4 + i);
         // ---- some pair passed the filter: fetch the tile's fp32 rows, exact re-check from registers
         float a[2][16];
         load_exact(row0, a);
@@ -643,17 +662,17 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
         for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
     };
 
-    rf_h8 a0[2][2], a1[2][2];
+    rf_h8 a0[2][2], a1[2][2], l0[2][2], l1[2][2];
     f32x4 h0[2], h1[2];
     long long row0 = r_lo;
-    if (row0 < r_hi) load_tile(row0, a0, h0);
+    if (row0 < r_hi) load_tile(row0, a0, l0, h0);
     while (row0 < r_hi) {
-        if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, h1);
-        scan_tile(row0, a0, h0);
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, l1, h1);
+        scan_tile(row0, a0, l0, h0);
         row0 += 32;
         if (row0 >= r_hi) break;
-        if (row0 + 32 < r_hi) load_tile(row0 + 32, a0, h0);
-        scan_tile(row0, a1, h1);
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a0, l0, h0);
+        scan_tile(row0, a1, l1, h1);
         row0 += 32;
     }
     __builtin_amdgcn_wave_barrier();
@@ -772,9 +791,10 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         const float* t0 = t_dist + (k2 - 1);                         // the k2-th best of query qi: t0[qi * k2p]
         const _Float16* rows16 = reinterpret_cast<const _Float16*>(hd + rf_rows32(n_layout));
         const float* hd16 = reinterpret_cast<const float*>(rows16 + (size_t)rf_rows32(n_layout) * RF_DIM);
+        const _Float16* rows16l = reinterpret_cast<const _Float16*>(hd16 + rf_rows32(n_layout));
         if (f16_filter) {
-            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
-            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         } else if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         else hipLaunchKernelGGL(k_l2_topk_mfma<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         RF_CHECK_LAUNCH("rf_l2_topk(mfma scan)");

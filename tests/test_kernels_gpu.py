@@ -774,7 +774,7 @@ def test_l2_topk(ops, n, nq, k2, algo):
 
 @pytest.mark.parametrize('mfma_algo', [2, 3])
 @pytest.mark.parametrize('n,nq,k2,kind', [(20_000, 200, 8, 'unit'), (70_001, 64, 16, 'unit'), (30_000, 100, 8, 'dups'), (9_000, 130, 8, 'big'),
-                                          (300_000, 512, 8, 'unit'), (12_000, 90, 8, 'huge')])
+                                          (300_000, 512, 8, 'unit'), (12_000, 90, 8, 'huge'), (120_000, 300, 8, 'clustered'), (40_000, 130, 16, 'clustered')])
 def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind, mfma_algo):
     """The matrix-core dot product only FILTERS; every survivor is re-evaluated with the one exact distance of the path, so the
     MFMA scan must return the same bits (distances and row ids) as the VALU scan that evaluates every pair exactly -- on unit
@@ -784,7 +784,15 @@ def test_mfma_filtered_scan_equals_exact_scan_bit_for_bit(ops, n, nq, k2, kind, 
     rng = np.random.default_rng(n + nq)
     emb = rng.standard_normal((n, 64)).astype(np.float32)
     q = rng.standard_normal((nq, 64)).astype(np.float32)
-    if kind == 'huge':
+    if kind == 'clustered':
+        # a database that lies where the queries lie (what a trained encoder pair gives, and bench.py's construction): queries within ~0.3 of one direction,
+        # rows = a random query + noise of the queries' nearest-neighbour spacing -- squared distances to the nearest rows ~1e-2, where a filter on f16-rounded
+        # operands alone (rounds 3-5: slack 4e-3) passed every row of the neighbourhood
+        q = (rng.standard_normal((1, 64)) + 0.04 * rng.standard_normal((nq, 64))).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        emb = (q[rng.integers(0, nq, size=n)] + 0.011 * rng.standard_normal((n, 64))).astype(np.float32)
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    elif kind == 'huge':
         emb *= (10.0 ** rng.uniform(0, 5.5, size=(n, 1))).astype(np.float32)
         q *= (10.0 ** rng.uniform(2, 5.5, size=(nq, 1))).astype(np.float32)
     elif kind != 'big':
