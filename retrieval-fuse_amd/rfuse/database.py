@@ -154,14 +154,28 @@ class HipSearchBackend:
         return ops.db_pack_embeddings(emb_shard) if emb_shard.shape[0] else None
 
     @staticmethod
-    def topk(q, packed, n, row_base, k2):
-        return ops.l2_topk(q, packed, n, row_base, k2)
+    def topk(q, packed, n, row_base, k2, algo=0):
+        return ops.l2_topk(q, packed, n, row_base, k2, algo)
 
     @staticmethod
-    def topk_keys(q, packed, n, row_base, k2):
+    def topk_keys(q, packed, n, row_base, k2, algo=0):
         if n == 0:                                                              # empty shard (fewer rows than ranks): no candidates
             return torch.full((q.shape[0], k2), -1, dtype=torch.int64, device=q.device)
-        return ops.l2_topk_keys(q, packed, n, row_base, k2)
+        return ops.l2_topk_keys(q, packed, n, row_base, k2, algo)
+
+    @staticmethod
+    def choose_scan(emb_shard, packed, row_base):
+        """Which exact scan serves this shard (0 = by size, ops.TOPK_AUTO).  The matrix-core scans FILTER with a dot product whose slack in the squared distance is
+        ~6e-5 for unit rows and re-check every survivor one by one; a shard with CLUMPS -- many rows within that slack of each other: thousands of copies of an
+        empty-space patch, a collapsed encoder -- makes every row of a clump a survivor of every query near it (measured: 1024 queries against 50 k rows of one
+        1e-6-wide clump 35 ms, against 0.3 ms of the VALU scan, whose cost does not depend on the data).  Probed once, at construction: 512 rows of the shard as
+        queries, exact top-16; where the 16th neighbour of more than 2 % of them lies within 2e-4 the shard is searched by the VALU scan."""
+        n = emb_shard.shape[0]
+        if n < 4096:
+            return 0                                                             # (the VALU scan by size anyway)
+        probe = emb_shard[torch.linspace(0, n - 1, 512, device=emb_shard.device).long()].contiguous()
+        d, _ = ops.l2_topk(probe, packed, n, row_base, 16, ops.TOPK_VALU_SCAN)
+        return ops.TOPK_VALU_SCAN if (d[:, 15] < 2e-4).float().mean().item() > 0.02 else 0
 
     @staticmethod
     def merge_keys(key_parts):
@@ -258,6 +272,8 @@ class PatchDatabase:
         self.device = torch.device(device)
         shard = emb[self.lo:self.hi].to(self.device, torch.float32).contiguous()
         self.emb_packed = backend.pack(shard)
+        self.scan_algo = backend.choose_scan(shard, self.emb_packed, self.lo) if hasattr(backend, 'choose_scan') and self.emb_packed is not None else 0
+        self._scan_kw = {'algo': self.scan_algo} if self.scan_algo else {}
         self.meta = torch.as_tensor(meta).to(self.device, torch.int32).contiguous()
         vols = torch.as_tensor(volumes)
         if half_store is None:
@@ -308,11 +324,11 @@ class PatchDatabase:
 
     def local_topk(self, q, k2):
         """Exact squared-L2 top-k2 of q against this rank's shard, global row ids -> (dist, idx)."""
-        return self.backend.topk(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2)
+        return self.backend.topk(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2, **self._scan_kw)
 
     def local_topk_keys(self, q, k2):
         """... as packed 64-bit keys [Q, k2] int64 (what the ranks exchange)."""
-        return self.backend.topk_keys(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2)
+        return self.backend.topk_keys(q.contiguous(), self.emb_packed, self.hi - self.lo, self.lo, k2, **self._scan_kw)
 
     def search(self, q, k2):
         """Top-k2 over the whole database for this rank's queries.  One process: a single scan.  W processes:

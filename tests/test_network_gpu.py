@@ -605,3 +605,26 @@ def test_refine_stream_is_bit_equal_to_refine(gpu, cfg_name, B):
     assert len(got) == 5
     for i, (g, w) in enumerate(zip(got, want)):
         assert torch.equal(g, w), 'batch %d differs' % i
+
+
+def test_clumped_database_is_searched_by_the_data_independent_scan(gpu):
+    """A shard with clumps of near-identical rows (thousands of copies of an empty-space patch; a collapsed encoder) would make every row of a clump a survivor of the
+    matrix-core filter for every query near it: PatchDatabase probes the shard once and takes the VALU scan for it -- the same lists, a cost that does not depend on
+    the data."""
+    from rfuse import ops
+    from rfuse.database import PatchDatabase
+    g = torch.Generator().manual_seed(5)
+    n = 64 * 300
+    emb = torch.nn.functional.normalize(torch.randn(n + 1, 64, generator=g), dim=1)
+    meta = torch.zeros(n + 1, 7, dtype=torch.int32)
+    vols = torch.zeros(300, 64, 64, 64, dtype=torch.float16)
+    plain = PatchDatabase(emb, meta, vols, gpu)
+    assert plain.scan_algo == 0
+    clumped = emb.clone()
+    clumped[torch.randperm(n, generator=g)[: n // 3]] = torch.nn.functional.normalize(emb[7] + 1e-4 * torch.randn(n // 3, 64, generator=g), dim=1)
+    db = PatchDatabase(clumped, meta, vols, gpu)
+    assert db.scan_algo == ops.TOPK_VALU_SCAN
+    q = torch.cat([clumped[7:8], torch.nn.functional.normalize(torch.randn(127, 64, generator=g), dim=1)]).to(gpu)
+    d, i = db.search(q, 8)
+    d3, i3 = ops.l2_topk(q, db.emb_packed, n + 1, 0, 8, ops.TOPK_MFMA16_SCAN)
+    assert torch.equal(i, i3) and torch.equal(d, d3)

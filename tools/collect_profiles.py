@@ -4,9 +4,9 @@ import shutil
 import sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src, dst = REPO / 'gpurun_out' / 'final', REPO / 'profiles'
-for name in ('bench_C2_default', 'bench_C2_force_collectives', 'bench_C2_half_store', 'bench_C1_B16', 'bench_C3_1M', 'bench_C4_B16', 'bench_C5_B16', 'train_C3_B4'):
+for name in ('bench_C2_default', 'bench_C2_force_collectives', 'bench_C2_isotropic_db', 'bench_C2_fp32_store', 'bench_C1_B16', 'bench_C3_1M', 'bench_C4_B16', 'bench_C5_B16', 'train_C3_B4'):
     f = src / (name + '.json')
     if f.exists() and f.stat().st_size:
         shutil.copy(f, dst / ('%s_%s.json' % (tag, name)))

@@ -1,5 +1,5 @@
 # Round-end profiles (GPU box, through gpurun): bench lines of every config, rocprofv3 kernel statistics of the C2 / C3 / C5 bench commands, PMC passes of C2.
-# Everything lands under gpurun_out/final/; tools/collect_profiles.py copies the summaries into profiles/r05_*.
+# Everything lands under gpurun_out/final/; tools/collect_profiles.py copies the summaries into profiles/r06_*.
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
@@ -7,7 +7,8 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench_C2_default.json 2> $O/bench_C2_default.err
 python bench.py --gpus 1 --force-collectives --no-extras --no-cpu-baseline > $O/bench_C2_force_collectives.json 2> $O/bench_C2_force_collectives.err
-python bench.py --half-store --no-extras --no-cpu-baseline --kernels-top 40 > $O/bench_C2_half_store.json 2> $O/bench_C2_half_store.err
+python bench.py --isotropic-db --no-cpu-baseline --kernels-top 40 > $O/bench_C2_isotropic_db.json 2> $O/bench_C2_isotropic_db.err
+python bench.py --fp32-store --no-extras --no-cpu-baseline > $O/bench_C2_fp32_store.json 2> $O/bench_C2_fp32_store.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_C2 -o C2 -- python $R/bench.py --no-extras --no-cpu-baseline --steps 20 > $O/prof_C2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_C5 -o C5 -- python $R/bench.py --config C5 --batch 16 --no-extras --no-cpu-baseline --steps 10 > $O/prof_C5.log 2>&1

@@ -20,7 +20,7 @@ REPO = Path(__file__).resolve().parents[1]
 pmc_dir = Path(sys.argv[1]) if len(sys.argv) > 1 else REPO / 'gpurun_out' / 'pmc'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r02'
 cfg_name = sys.argv[3] if len(sys.argv) > 3 else 'C2'
-DOMINANT = 'k_conv3_up_split<4>'          # rf_conv3d_up_split_k3_gn_relu 32+64->56 @8^3 (C1-C4); one 8^3 sample per workgroup
+DOMINANT = 'k_conv3_up_split_pp'          # rf_conv3d_up_split_presplit_pm 32+64->56 @8^3 (C1-C4); persistent: one workgroup per CU walks the 8192 samples of the B = 32 step
 
 
 def short(name):
@@ -87,8 +87,8 @@ print('wrote', out_csv)
 dom = [r for r in rows if r[1] == DOMINANT]
 if dom and cfg_name == 'C2':
     _, kern, wgs, launches, cycles, mfma, wa, wi, lc, fm, wm = max(dom, key=lambda r: r[2])
-    n_patches = wgs                                   # one 8^3 box = one patch per workgroup, one cout block
-    j = {'kernel': kern, 'entry': 'rf_conv3d_up_split_k3_gn_relu', 'shape': [32, 64, 8, 56], 'batch': n_patches // 256, 'n_patches': n_patches,
+    n_patches = 8192 if kern == 'k_conv3_up_split_pp' else wgs      # (k_conv3_up_split<4>: one patch per workgroup; the persistent form: the bench's B = 32 -> 8192 patches)
+    j = {'kernel': kern, 'entry': 'rf_conv3d_up_split_presplit_pm' if kern == 'k_conv3_up_split_pp' else 'rf_conv3d_up_split_k3_gn_relu', 'shape': [32, 64, 8, 56], 'batch': n_patches // 256, 'n_patches': n_patches,
          'fetch_MB_per_launch': fm, 'write_MB_per_launch': wm,
          'traffic_bytes_per_sample': (fm + wm) * 1e6 / n_patches, 'mfma_busy_pct': mfma, 'cycles_per_launch': cycles,
          'source': 'profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)' % out_csv.name}
