@@ -744,7 +744,8 @@ static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2,
 // (query, row) pairs on, whichever way they split.
 // Short shards under many queries stay on the VALU scan (one rank of 8 on the 50 k-row database: 16384 queries x 6250 rows 0.46 / 0.60 ms; x 12.5 k: 0.82 / 0.72:
 // the filtered scan pays per query for its lists and re-checks): tools/topk_shard_shapes.py.
-static bool use_mfma_scan(int nq, int64_t n) { return n >= 10000 && (double)nq * (double)n >= 4.0e7; }
+// (round 6, split-operand filter, tools/topk_shard_shapes.py: 2048 x 50 k 0.37 / VALU 0.45 ms; 4096 x 25 k 0.41 / 0.43; 8192 x 12.5 k 0.55 / 0.44; 16384 x 125 k 2.9 / 6.1)
+static bool use_mfma_scan(int nq, int64_t n) { return n >= 20000 && (double)nq * (double)n >= 4.0e7; }
 
 // workspace: [per-slice lists: 64 x nq x k2p keys][sample pass: nq x k2p (dist f32, idx i64)]
 // n_layout: the row count the packed image was built for (the offsets of its views depend on it); n <= n_layout: the rows scanned (the first n of the shard)
