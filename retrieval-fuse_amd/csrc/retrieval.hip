@@ -484,10 +484,19 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma(const float* __restrict
 // Pairs that pass are re-evaluated with THE exact distance from the fp32 rows (fetched for that tile only), so the lists are bit-identical to the other scans'.
 #define RF_EPS_FILTER16 RF_EPS_FILTER              // 2^-15
 typedef _Float16 rf_h8 __attribute__((ext_vector_type(8)));
+// [query][chain g][16] = q[query][4 j + g]: the four summation chains of THE exact distance, contiguous per chain (k_l2_topk_mfma16's re-check reads them)
+__global__ __launch_bounds__(256) void k_query_chains(const float* __restrict__ q, int nq, float* __restrict__ qc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nq * RF_DIM) return;
+    const int p = (int)(i % RF_DIM), g = p >> 4, j = p & 15;
+    qc[i] = q[(i / RF_DIM) * RF_DIM + 4 * j + g];
+}
+
 template <int K2>
 __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restrict__ q, int nq, const float* __restrict__ rows_img,
                                                          const _Float16* __restrict__ rows16, const _Float16* __restrict__ rows16l, const float* __restrict__ hd, long long n,
-                                                         unsigned row_base, int rows_per_slice, const float* __restrict__ t0, int t0_stride, u64* __restrict__ parts) {
+                                                         unsigned row_base, int rows_per_slice, const float* __restrict__ t0, int t0_stride, u64* __restrict__ parts,
+                                                         const float* __restrict__ qc) {
     __shared__ u64 s_lists[4][64 * K2];
     __shared__ float s_aq[4][64], s_hq[4][64], s_t0[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -529,13 +538,8 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // ---------------------------------------------------------------- the filtered scan
-    float b[4][16];                                                  // B operands: b[nb][j] = dim 4j + g of query q0 + nb*16 + n
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int qi = q0 + nb * 16 + li;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) b[nb][j] = qi < nq ? q[(size_t)qi * RF_DIM + 4 * j + lg] : 0.f;
-    }
+    // (the fp32 queries are NOT held in registers: the exact re-check reads a query's summation chains from `qc` -- [query][chain g][16] = dims {4 j + g}, written by
+    // k_query_chains -- and the 64 registers hold a third tile of rows instead: the scan waits for memory 76 % of its time with one tile requested ahead)
     rf_h8 bq[4][2], bql[4][2];                                       // the filter's B operands: k = 32 t + 8 lg + j of query q0 + nb*16 + li, as f16 pieces h, l
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -616,41 +620,49 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const unsigned m4 = (m >> ((mb * 4 + nb) * 4)) & 15u;
-                unsigned long long bal = __ballot(m4 != 0u);
-                while (bal) {
-                    const int src = __ffsll((long long)bal) - 1;     // lane (n_, g_) of the D tile
-                    bal &= bal - 1;
-                    unsigned mi = __builtin_amdgcn_readlane(m4, src);
-                    const int n_ = src & 15, g_ = src >> 4;
+                const unsigned long long bal = __ballot(m4 != 0u);
+                unsigned qcols = (unsigned)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xffffull);      // query columns n_ with a passing pair in this m-block
+                while (qcols) {
+                    const int n_ = __ffs((int)qcols) - 1;
+                    qcols &= qcols - 1;
                     const int ql = nb * 16 + n_;
-                    while (mi) {
-                        const int i = __ffs((int)mi) - 1;
-                        mi &= mi - 1;
-                        const int r = 4 * g_ + i;                     // row of the m-block
-                        const long long row = row0 + mb * 16 + r;
-                        if (row >= n) continue;
-                        // chain g of THE exact distance on lane (r, g): the query chunk comes from lane (n_, g)
-                        float P = 0.f;
+                    int qi = q0 + ql;
+                    qi = qi < nq ? qi : nq - 1;
+                    // chain g of THE exact distance of query n_ against the m-block's 16 rows, ONCE: lane (r, g) runs chain g of row r
+                    const float4* qp = reinterpret_cast<const float4*>(qc + (size_t)qi * RF_DIM + 16 * lg);
+                    float P = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const float qv = __shfl(b[nb][j], n_ + (lane & 48), 64);
-                            const float t = qv - a[mb][j];
-                            P = fmaf(t, t, P);
-                        }
-                        const unsigned Pb = __float_as_uint(P);        // readlane moves 32-bit patterns
-                        const float c0 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r)), c1 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 16));
-                        const float c2 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 32)), c3 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 48));
-                        const float dist = (c0 + c2) + (c1 + c3);
-                        const u64 key = make_key(dist, row_base + (unsigned)row);
-                        u64 e = lane < K2 ? lists[ql * K2 + lane] : RF_KEY_NONE;
-                        const unsigned wlo = __builtin_amdgcn_readlane((unsigned)(e & 0xffffffffu), K2 - 1);
-                        const unsigned whi = __builtin_amdgcn_readlane((unsigned)(e >> 32), K2 - 1);
-                        if (key < (((u64)whi << 32) | wlo) && dist <= t0s[ql]) {          // (<=: the sample's own k2-th row must get in)
-                            list_insert<K2>(e, lane, key);
-                            if (lane < K2) lists[ql * K2 + lane] = e;
-                            if (lane == K2 - 1) {                    // T = min(sample bound, the list's k2-th distance once it is full)
-                                const float tl = e == RF_KEY_NONE ? INFINITY : __uint_as_float((unsigned)(e >> 32));
-                                aqs[ql] = hqs[ql] - 0.5f * fminf(tl, t0s[ql]);
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 qv = qp[k];
+                        float t = qv.x - a[mb][4 * k]; P = fmaf(t, t, P);
+                        t = qv.y - a[mb][4 * k + 1]; P = fmaf(t, t, P);
+                        t = qv.z - a[mb][4 * k + 2]; P = fmaf(t, t, P);
+                        t = qv.w - a[mb][4 * k + 3]; P = fmaf(t, t, P);
+                    }
+                    const unsigned Pb = __float_as_uint(P);            // readlane moves 32-bit patterns
+#pragma unroll
+                    for (int g_ = 0; g_ < 4; ++g_) {
+                        unsigned mi = __builtin_amdgcn_readlane(m4, n_ + 16 * g_);
+                        while (mi) {
+                            const int i = __ffs((int)mi) - 1;
+                            mi &= mi - 1;
+                            const int r = 4 * g_ + i;                 // row of the m-block
+                            const long long row = row0 + mb * 16 + r;
+                            if (row >= n) continue;
+                            const float c0 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r)), c1 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 16));
+                            const float c2 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 32)), c3 = __uint_as_float(__builtin_amdgcn_readlane(Pb, r + 48));
+                            const float dist = (c0 + c2) + (c1 + c3);
+                            const u64 key = make_key(dist, row_base + (unsigned)row);
+                            u64 e = lane < K2 ? lists[ql * K2 + lane] : RF_KEY_NONE;
+                            const unsigned wlo = __builtin_amdgcn_readlane((unsigned)(e & 0xffffffffu), K2 - 1);
+                            const unsigned whi = __builtin_amdgcn_readlane((unsigned)(e >> 32), K2 - 1);
+                            if (key < (((u64)whi << 32) | wlo) && dist <= t0s[ql]) {          // (<=: the sample's own k2-th row must get in)
+                                list_insert<K2>(e, lane, key);
+                                if (lane < K2) lists[ql * K2 + lane] = e;
+                                if (lane == K2 - 1) {                    // T = min(sample bound, the list's k2-th distance once it is full)
+                                    const float tl = e == RF_KEY_NONE ? INFINITY : __uint_as_float((unsigned)(e >> 32));
+                                    aqs[ql] = hqs[ql] - 0.5f * fminf(tl, t0s[ql]);
+                                }
                             }
                         }
                     }
@@ -662,17 +674,23 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
         for (int nb = 0; nb < 4; ++nb) aq[nb] = aqs[nb * 16 + li];
     };
 
-    rf_h8 a0[2][2], a1[2][2], l0[2][2], l1[2][2];
-    f32x4 h0[2], h1[2];
+    // three tiles of rows in registers: two requested ahead
+    rf_h8 a0[2][2], a1[2][2], a2[2][2], l0[2][2], l1[2][2], l2[2][2];
+    f32x4 h0[2], h1[2], h2[2];
     long long row0 = r_lo;
     if (row0 < r_hi) load_tile(row0, a0, l0, h0);
+    if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, l1, h1);
     while (row0 < r_hi) {
-        if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, l1, h1);
+        if (row0 + 64 < r_hi) load_tile(row0 + 64, a2, l2, h2);
         scan_tile(row0, a0, l0, h0);
         row0 += 32;
         if (row0 >= r_hi) break;
-        if (row0 + 32 < r_hi) load_tile(row0 + 32, a0, l0, h0);
+        if (row0 + 64 < r_hi) load_tile(row0 + 64, a0, l0, h0);
         scan_tile(row0, a1, l1, h1);
+        row0 += 32;
+        if (row0 >= r_hi) break;
+        if (row0 + 64 < r_hi) load_tile(row0 + 64, a1, l1, h1);
+        scan_tile(row0, a2, l2, h2);
         row0 += 32;
     }
     __builtin_amdgcn_wave_barrier();
@@ -722,7 +740,8 @@ extern "C" size_t rf_l2_topk_ws_bytes(int nq, int64_t n, int k2) {
     (void)n;
     const int k2p = k2 <= 8 ? 8 : 16;
     return (size_t)64 * (size_t)nq * k2p * sizeof(u64)            // one K2-wide list per (slice <= 64, query)
-           + (size_t)nq * k2p * (sizeof(float) + sizeof(int64_t));   // + the sample pass's result (MFMA-filtered scan)
+           + (size_t)nq * k2p * (sizeof(float) + sizeof(int64_t))    // + the sample pass's result (MFMA-filtered scan)
+           + (size_t)nq * 64 * sizeof(float);                        // + the queries in chain order (k_query_chains)
 }
 
 static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2, float* out_dist, int64_t* out_idx, u64* out_keys, hipStream_t s,
@@ -794,8 +813,10 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         const float* hd16 = reinterpret_cast<const float*>(rows16 + (size_t)rf_rows32(n_layout) * RF_DIM);
         const _Float16* rows16l = reinterpret_cast<const _Float16*>(hd16 + rf_rows32(n_layout));
         if (f16_filter) {
-            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
-            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+            float* qc = reinterpret_cast<float*>(t_idx + (size_t)nq * k2p);
+            hipLaunchKernelGGL(k_query_chains, dim3((unsigned)(((size_t)nq * RF_DIM + 255) / 256)), dim3(256), 0, s, q, nq, qc);
+            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts, qc);
+            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts, qc);
         } else if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         else hipLaunchKernelGGL(k_l2_topk_mfma<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
         RF_CHECK_LAUNCH("rf_l2_topk(mfma scan)");
