@@ -799,7 +799,10 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         // that beats a list's own, slowly tightening, worst (with the n/64 sample of round 4: ~400 per query at 50 k rows, serial per wave: 0.52 ms; n/8:
         // 0.31).  A sample big enough for the filtered scan (use_mfma_scan) is itself searched by this function -- 1 M rows: VALU scan of 15.6 k rows -> filtered scan of 125 k rows ->
         // filtered scan of all of them -- and the nested call's result lands where this level reads its thresholds from (stream order keeps the levels apart).
-        long long sample = n / 8;
+#ifndef RF_TOPK_SAMPLE_DIV
+#define RF_TOPK_SAMPLE_DIV 8
+#endif
+        long long sample = n / RF_TOPK_SAMPLE_DIV;
         if (sample < 1024) sample = 1024;
         sample = (sample + 63) / 64 * 64;
         if (sample > n) sample = n;
