@@ -1310,7 +1310,7 @@ def test_prepooled_handover_between_the_first_two_levels(ops):
     close(outs[True][1][:64], F.max_pool3d(x64, 2).float(), 1e-5, 'its fused pool')
 
 
-@pytest.mark.parametrize('shape', [(32, 64, 56, 16, 1030), (32, 48, 48, 16, 1025), (32, 64, 56, 16, 2100)])     # 2100 samples: the consumer on the persistent z-column form
+@pytest.mark.parametrize('shape', [(32, 64, 56, 16, 1030), (32, 48, 48, 16, 1025), (32, 64, 56, 16, 2100), (32, 48, 56, 32, 2070)])     # >= 2048 samples: the persistent producer + the persistent z-column consumer (parity-major hand-over); 1030: the persistent producer, linear order; c1 = 48: six low-res groups
 def test_presplit_route_of_a_decoder_conv_pair(ops, shape):
     """StepDownDoubleConv of the retrieval backbone's last decoder (96 -> 56 -> 16 @8^3, reference model/unet.py:149-159): the first conv hands the second
     its input pre-split (rf_conv3d_up_split_presplit -> rf_conv3d_split_pre_k3_relu, the multi-chunk consumer) -- against float64 torch and against the
@@ -1366,6 +1366,19 @@ def test_parity_major_handover_of_the_decoder_pair_equals_the_linear_one(ops):
     out_lin = ops.conv3d_split_pre_relu(lin, cmid, n, 8, wp2, cout)
     out_pm = ops.conv3d_split_pre_relu(pm, cmid, n, 8, wp2, cout, parity_major=True)
     assert torch.equal(out_lin, out_pm)
+    # the producer's optional statistics output (per (sample, cout): sum and sum of squares of the ReLU'd conv output) against the plain kernel's
+    from rfuse import _lib
+    lib = _lib.load()
+    st_pm = torch.empty((n, cmid, 2), dtype=torch.float64, device=DEV)
+    scratch = torch.empty_like(pm)
+    p = lambda t_: t_.data_ptr() if t_ is not None else None
+    _lib.check(lib.rf_conv3d_up_split_presplit_pm(p(skip), c0, p(low), c1, n, 8, p(aff), p(wp1), cmid, p(g2w), p(g2b), groups, 1e-5, p(scratch), p(st_pm),
+                                                  torch.cuda.current_stream().cuda_stream), 'rf_conv3d_up_split_presplit_pm')
+    assert torch.equal(scratch, pm)
+    plain = ops.conv3d_up_split_gn_relu(skip, low, aff, wp1, cmid)
+    ref_sum, ref_sq = plain.double().sum(dim=(2, 3, 4)), (plain.double() ** 2).sum(dim=(2, 3, 4))
+    assert (st_pm[..., 0] - ref_sum).abs().max().item() <= 1e-6 * ref_sum.abs().max().item()
+    assert (st_pm[..., 1] - ref_sq).abs().max().item() <= 1e-6 * ref_sq.abs().max().item()
     # against float64 on a few samples
     x64 = torch.cat((skip[:6].cpu(), F.interpolate(low[:6].cpu(), scale_factor=2, mode='nearest')), 1).double()
     for gw, gb, w in ((g1w, g1b, w1), (g2w, g2b, w2)):
