@@ -702,37 +702,234 @@ __global__ __launch_bounds__(256, 2) void k_l2_topk_mfma16(const float* __restri
     }
 }
 
-// bitonic sort of up to CAP keys per query in LDS; the first k2 are the answer (as (dist, idx) pairs and / or packed keys)
-template <int CAP>
-__global__ __launch_bounds__(256) void k_merge_keys(const u64* __restrict__ parts, int nparts, int nq, int width, int k2,
-                                                    float* __restrict__ out_dist, long long* __restrict__ out_idx, u64* __restrict__ out_keys) {
-    __shared__ u64 keys[CAP];
-    const int qi = blockIdx.x, tid = threadIdx.x;
-    const int total = nparts * width;
-    for (int i = tid; i < CAP; i += 256) {
-        u64 v = RF_KEY_NONE;
-        if (i < total) { const int part = i / width, j = i % width; v = parts[((size_t)part * nq + qi) * width + j]; }
-        keys[i] = v;
-    }
-    __syncthreads();
-    for (int size = 2; size <= CAP; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < CAP / 2; i += 256) {
-                const int lo = 2 * i - (i & (stride - 1));          // index with bit `stride` cleared
-                const int hi = lo + stride;
-                const bool asc = (lo & size) == 0;
-                const u64 a = keys[lo], b = keys[hi];
-                if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+// The SEED of the filtered scan (round 6; it replaced an exact VALU / nested filtered scan of the shard's first n/8 rows: 0.14 ms of the 0.41 ms search at
+// 2048 x 50 k, a third of it at 1 M rows).  The filtered scan needs, per query, an upper bound T0 of the final k2-th distance.  ANY k2 distinct rows give one
+// (the largest of their exact distances), and the bound is as tight as the rows are good -- so the rows are chosen by the split-operand filter alone, and only the
+// chosen ones are evaluated exactly:
+//   * the same tile walk as k_l2_topk_mfma16 over the seed rows (a wave = 64 queries x a slice of rows; s = q.x - hd from 6 MFMAs per 16 x 16 tile), but a value
+//     is only compared with the running best of its ACCUMULATOR SLOT: lane (li, lg), slot (n-block, i) sees rows 16 u + 4 lg + i (u = 0, 1, ..) of the slice
+//     for query 16 nb + li -- 16 disjoint row classes per (slice, query), a best s and its u each (4 VALU per pair, no ballot, no list, no exact step);
+//   * the two best slots of every (lane, n-block) are published as keys (descending s, local row): 8 candidates per (slice, query), from 8 different classes.
+//     k_merge_wave takes the k2 best of the slices x 8, evaluates THE exact distance of those k2 rows, and writes T0 = the largest.
+// How tight: the true k2 nearest seed rows are all found unless two of them share a class of one slice (same row index mod 16 within the slice) or three a lane:
+// with S slices the k2-th best candidate has expected rank ~ k2 + k2^2 / (32 S) among the seed rows -- 8.03 for k2 = 8, S = 64 (the exact 8th, nearly) -- so the
+// seed can cover HALF OR ALL of the shard at 0.4 matrix-pipe cycles per pair, and the filtered scan behind it re-checks ~k2 n / seed pairs per query instead of 64.
+// Rows the filter cannot rank (hd16 = -inf: s = +inf) win their class and are then measured exactly like any other: the bound stays valid, only looser.
+__device__ __forceinline__ unsigned rf_desc_bits(float s) {          // monotone: larger s -> smaller unsigned
+    const unsigned u = __float_as_uint(-s);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__global__ __launch_bounds__(256, 2) void k_l2_topk_seed16(const float* __restrict__ q, int nq, const _Float16* __restrict__ rows16, const _Float16* __restrict__ rows16l,
+                                                         const float* __restrict__ hd, long long n, int rows_per_slice, u64* __restrict__ parts) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.x;
+    const int q0 = (blockIdx.y * 4 + wave) * 64;
+    if (q0 >= nq) return;
+    const long long n32 = (n + 31) / 32 * 32;
+    const long long r_lo = (long long)slice * rows_per_slice;        // multiple of 32
+    long long r_hi = r_lo + rows_per_slice;
+    if (r_hi > n32) r_hi = n32;
+    const int li = lane & 15, lg = lane >> 4;
+
+    rf_h8 bq[4][2], bql[4][2];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int qi = q0 + nb * 16 + li;
+        float qv[2][8];
+        float big = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                qv[t][j] = qi < nq ? q[(size_t)qi * RF_DIM + 32 * t + 8 * lg + j] : 0.f;
+                big = fmaxf(big, fabsf(qv[t][j]));
             }
-            __syncthreads();
+        big = fmaxf(big, __shfl_xor(big, 16, 64));                    // the query's four lanes hold its 64 dims between them
+        big = fmaxf(big, __shfl_xor(big, 32, 64));
+        const bool fits = big < 6.0e4f;                               // beyond the f16 range: zeros (the seed rows of such a query are arbitrary, the bound stays valid)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = fits ? qv[t][j] : 0.f;
+                const _Float16 qh = (_Float16)v;
+                bq[nb][t][j] = qh;
+                bql[nb][t][j] = (_Float16)((v - (float)qh) * 2048.f);
+            }
+    }
+    float best[4][4];                                                // slot (n-block, i): rows 16 u + 4 lg + i of the slice, u = 2 tile + m-block
+    int bu[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { best[nb][i] = -INFINITY; bu[nb][i] = -1; }
+
+    auto load_tile = [&](long long row0, rf_h8 (&a16)[2][2], rf_h8 (&a16l)[2][2], f32x4 (&h)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const rf_h8* rp = reinterpret_cast<const rf_h8*>(rows16 + (size_t)(row0 + mb * 16 + li) * RF_DIM + 8 * lg);
+            a16[mb][0] = rp[0];
+            a16[mb][1] = rp[4];
+            const rf_h8* rl = reinterpret_cast<const rf_h8*>(rows16l + (size_t)(row0 + mb * 16 + li) * RF_DIM + 8 * lg);
+            a16l[mb][0] = rl[0];
+            a16l[mb][1] = rl[4];
+            const float4 t = *reinterpret_cast<const float4*>(hd + row0 + mb * 16 + 4 * lg);
+            h[mb] = (f32x4){-t.x, -t.y, -t.z, -t.w};
+        }
+    };
+    auto scan_tile = [&](int tile, const rf_h8 (&a16)[2][2], const rf_h8 (&a16l)[2][2], const f32x4 (&h)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                f32x4 acc[2], acl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { acc[e] = h[mb]; acl[e] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mb][t], bq[2 * np + e][t], acc[e], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acl[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[mb][t], bql[2 * np + e][t], acl[e], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acl[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16l[mb][t], bq[2 * np + e][t], acl[e], 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float sv = fmaf(acl[e][i], 1.0f / 2048.f, acc[e][i]);
+                        const bool better = sv > best[2 * np + e][i];
+                        best[2 * np + e][i] = better ? sv : best[2 * np + e][i];
+                        bu[2 * np + e][i] = better ? 2 * tile + mb : bu[2 * np + e][i];
+                    }
+            }
+    };
+    rf_h8 a0[2][2], a1[2][2], l0[2][2], l1[2][2];
+    f32x4 h0[2], h1[2];
+    long long row0 = r_lo;
+    int tile = 0;
+    if (row0 < r_hi) load_tile(row0, a0, l0, h0);
+    while (row0 < r_hi) {
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a1, l1, h1);
+        scan_tile(tile, a0, l0, h0);
+        row0 += 32; ++tile;
+        if (row0 >= r_hi) break;
+        if (row0 + 32 < r_hi) load_tile(row0 + 32, a0, l0, h0);
+        scan_tile(tile, a1, l1, h1);
+        row0 += 32; ++tile;
+    }
+    // publish the two best slots of every (lane, n-block): parts[slice][q][8], class = 2 lg + rank
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int qi = q0 + nb * 16 + li;
+        float s1 = -INFINITY, s2 = -INFINITY;
+        int r1 = -1, r2 = -1;                                        // rows relative to r_lo
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sv = best[nb][i];
+            const int row = bu[nb][i] * 16 + 4 * lg + i;
+            const bool have = bu[nb][i] >= 0;
+            const bool first = have && sv > s1, second = have && !first && sv > s2;
+            s2 = first ? s1 : (second ? sv : s2);
+            r2 = first ? r1 : (second ? row : r2);
+            s1 = first ? sv : s1;
+            r1 = first ? row : r1;
+        }
+        if (qi >= nq) continue;
+        u64* out = parts + ((size_t)slice * nq + qi) * 8 + 2 * lg;
+        out[0] = r1 >= 0 && r_lo + r1 < n ? (((u64)rf_desc_bits(s1) << 32) | (unsigned)(r_lo + r1)) : RF_KEY_NONE;
+        out[1] = r2 >= 0 && r_lo + r2 < n ? (((u64)rf_desc_bits(s2) << 32) | (unsigned)(r_lo + r2)) : RF_KEY_NONE;
+    }
+}
+
+// Merge of candidate lists: the k2 smallest keys per query (as (dist, idx) pairs and / or packed keys).  Rounds 1-5 sorted up to 4096 keys per query in LDS
+// (bitonic, 55 barrier stages for 1024 keys: 58 us for 2048 queries x 61 lists).
+// One WAVE per query holds the candidates in registers (R per lane) and takes the smallest key k2 times (a lane-local minimum,
+// a wave minimum, one copy of the taken key struck out) -- no LDS, no barrier; 512 candidates x 2048 queries: 58 -> ~6 us.
+// seed_q != nullptr: the candidates are k_l2_topk_seed16's (descending s, LOCAL row) keys; the k2 best rows are measured with THE exact distance (lane k takes
+// row k: chains c over dims 4 m + c from the chain-ordered images `seed_rows` / `seed_q`) and seed_t0[query] = the largest of them (+inf with fewer than k2 rows).
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_merge_wave(const u64* __restrict__ parts, int nparts, int nq, int width, int k2, float* __restrict__ out_dist,
+                                                    long long* __restrict__ out_idx, u64* __restrict__ out_keys, const float* __restrict__ seed_q,
+                                                    const float* __restrict__ seed_rows, float* __restrict__ seed_t0) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int total = nparts * width;
+    u64 key[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c = r * 64 + lane;
+        key[r] = RF_KEY_NONE;
+        if (c < total) { const int part = c / width, j = c - part * width; key[r] = parts[((size_t)part * nq + qi) * width + j]; }
+    }
+    u64 mine = RF_KEY_NONE;
+    for (int k = 0; k < k2; ++k) {
+        u64 lm = key[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) lm = key[r] < lm ? key[r] : lm;
+        const u64 wm = wave_min_u64(lm);
+        if (lane == k) mine = wm;
+        if (wm == RF_KEY_NONE) break;                                // wave-uniform: nothing left
+        bool has = false;                                            // strike out ONE copy (merged lists may repeat a key; the sort this replaces kept both)
+#pragma unroll
+        for (int r = 0; r < R; ++r) has = has || key[r] == wm;
+        const unsigned long long holders = __ballot(has);
+        if (lane == __ffsll((long long)holders) - 1) {
+            bool done = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool hit = !done && key[r] == wm;
+                key[r] = hit ? RF_KEY_NONE : key[r];
+                done = done || hit;
+            }
         }
     }
-    if (tid < k2) {
-        const u64 key = keys[tid];
-        const bool none = key == RF_KEY_NONE;
-        if (out_keys) out_keys[(size_t)qi * k2 + tid] = key;
-        if (out_dist) out_dist[(size_t)qi * k2 + tid] = none ? INFINITY : __uint_as_float((unsigned)(key >> 32));
-        if (out_idx) out_idx[(size_t)qi * k2 + tid] = none ? -1ll : (long long)(unsigned)(key & 0xffffffffu);
+    if (seed_t0) {
+        float dist = -INFINITY;
+        if (lane < k2) {
+            dist = INFINITY;
+            if (mine != RF_KEY_NONE) {
+                const float4* xp = reinterpret_cast<const float4*>(seed_rows + (size_t)(unsigned)(mine & 0xffffffffu) * RF_DIM);
+                const float4* qp = reinterpret_cast<const float4*>(seed_q + (size_t)qi * RF_DIM);
+                float c[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float P = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const float4 qv = qp[4 * g + kk], xv = xp[4 * g + kk];
+                        float t = qv.x - xv.x; P = fmaf(t, t, P);
+                        t = qv.y - xv.y; P = fmaf(t, t, P);
+                        t = qv.z - xv.z; P = fmaf(t, t, P);
+                        t = qv.w - xv.w; P = fmaf(t, t, P);
+                    }
+                    c[g] = P;
+                }
+                dist = (c[0] + c[2]) + (c[1] + c[3]);
+            }
+        }
+        dist = wave_max(dist);
+        if (lane == 0) seed_t0[qi] = dist;
+        return;
+    }
+    if (lane < k2) {
+        const bool none = mine == RF_KEY_NONE;
+        if (out_keys) out_keys[(size_t)qi * k2 + lane] = mine;
+        if (out_dist) out_dist[(size_t)qi * k2 + lane] = none ? INFINITY : __uint_as_float((unsigned)(mine >> 32));
+        if (out_idx) out_idx[(size_t)qi * k2 + lane] = none ? -1ll : (long long)(unsigned)(mine & 0xffffffffu);
     }
 }
 
@@ -744,14 +941,24 @@ extern "C" size_t rf_l2_topk_ws_bytes(int nq, int64_t n, int k2) {
            + (size_t)nq * 64 * sizeof(float);                        // + the queries in chain order (k_query_chains)
 }
 
+template <int R>
+static void launch_merge_wave(const u64* parts, int nparts, int nq, int width, int k2, float* out_dist, long long* out_idx, u64* out_keys, const float* seed_q,
+                              const float* seed_rows, float* seed_t0, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_wave<R>, dim3((nq + 3) / 4), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, out_idx, out_keys, seed_q, seed_rows, seed_t0);
+}
+
 static int launch_merge(const u64* parts, int nparts, int nq, int width, int k2, float* out_dist, int64_t* out_idx, u64* out_keys, hipStream_t s,
-                        const char* who) {
+                        const char* who, const float* seed_q = nullptr, const float* seed_rows = nullptr, float* seed_t0 = nullptr) {
     const int total = nparts * width;
     RF_REQUIRE(total <= 4096, RF_E_UNSUPPORTED, "%s: %d candidates per query exceed the merge capacity 4096", who, total);
+    RF_REQUIRE(k2 >= 1 && k2 <= 64, RF_E_UNSUPPORTED, "%s: k2 = %d outside 1..64", who, k2);
     long long* oi = (long long*)out_idx;
-    if (total <= 256) hipLaunchKernelGGL(k_merge_keys<256>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, oi, out_keys);
-    else if (total <= 1024) hipLaunchKernelGGL(k_merge_keys<1024>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, oi, out_keys);
-    else hipLaunchKernelGGL(k_merge_keys<4096>, dim3(nq), dim3(256), 0, s, parts, nparts, nq, width, k2, out_dist, oi, out_keys);
+    if (total <= 128) launch_merge_wave<2>(parts, nparts, nq, width, k2, out_dist, oi, out_keys, seed_q, seed_rows, seed_t0, s);
+    else if (total <= 256) launch_merge_wave<4>(parts, nparts, nq, width, k2, out_dist, oi, out_keys, seed_q, seed_rows, seed_t0, s);
+    else if (total <= 512) launch_merge_wave<8>(parts, nparts, nq, width, k2, out_dist, oi, out_keys, seed_q, seed_rows, seed_t0, s);
+    else if (total <= 1024) launch_merge_wave<16>(parts, nparts, nq, width, k2, out_dist, oi, out_keys, seed_q, seed_rows, seed_t0, s);
+    else if (total <= 2048) launch_merge_wave<32>(parts, nparts, nq, width, k2, out_dist, oi, out_keys, seed_q, seed_rows, seed_t0, s);
+    else launch_merge_wave<64>(parts, nparts, nq, width, k2, out_dist, oi, out_keys, seed_q, seed_rows, seed_t0, s);
     RF_CHECK_LAUNCH(who);
     return RF_OK;
 }
@@ -794,34 +1001,59 @@ static int topk_impl(const float* q, int nq, int dim, const float* db_packed, in
         slices = (int)((nblk + bps - 1) / bps);
         const float* rows_img = db_packed + rf_blocked_floats(n_layout);
         const float* hd = rows_img + (size_t)rf_rows32(n_layout) * RF_DIM;
-        // sample pass: exact top-k2p of the first n/8 rows (whole 64-row blocks; the blocked / row views of the first rows of the shard ARE the views of the
-        // sample).  Its k2-th distance T0 bounds the final one, so the filtered scan re-checks ~k2 * n / sample = 64 pairs per query instead of every pair
-        // that beats a list's own, slowly tightening, worst (with the n/64 sample of round 4: ~400 per query at 50 k rows, serial per wave: 0.52 ms; n/8:
-        // 0.31).  A sample big enough for the filtered scan (use_mfma_scan) is itself searched by this function -- 1 M rows: VALU scan of 15.6 k rows -> filtered scan of 125 k rows ->
-        // filtered scan of all of them -- and the nested call's result lands where this level reads its thresholds from (stream order keeps the levels apart).
+        // The threshold pass.  fp32-filtered scan (algo 2, kept for comparison): exact top-k2p of the first n/8 rows by this function itself (VALU scan, or
+        // nested filtered scans for big samples); its k2-th distance bounds the final one.  f16-filtered scan: k_l2_topk_seed16 + k_merge_wave (see there) over the
+        // first n / RF_TOPK_SEED_DIV rows.
 #ifndef RF_TOPK_SAMPLE_DIV
 #define RF_TOPK_SAMPLE_DIV 8
 #endif
-        long long sample = n / RF_TOPK_SAMPLE_DIV;
-        if (sample < 1024) sample = 1024;
-        sample = (sample + 63) / 64 * 64;
-        if (sample > n) sample = n;
+#ifndef RF_TOPK_SEED_DIV
+#define RF_TOPK_SEED_DIV 2
+#endif
         float* t_dist = reinterpret_cast<float*>(parts + (size_t)64 * nq * k2p);
         int64_t* t_idx = reinterpret_cast<int64_t*>(t_dist + (size_t)nq * k2p) ;
-        const int sample_algo = use_mfma_scan(nq, sample) ? (f16_filter ? 3 : 2) : 1;
-        int rc = topk_impl(q, nq, dim, db_packed, sample, n_layout, row_base, k2p, sample_algo, t_dist, t_idx, nullptr, ws, ws_bytes, stream);
-        if (rc != RF_OK) return rc;
-        const float* t0 = t_dist + (k2 - 1);                         // the k2-th best of query qi: t0[qi * k2p]
+        float* qc = reinterpret_cast<float*>(t_idx + (size_t)nq * k2p);
         const _Float16* rows16 = reinterpret_cast<const _Float16*>(hd + rf_rows32(n_layout));
         const float* hd16 = reinterpret_cast<const float*>(rows16 + (size_t)rf_rows32(n_layout) * RF_DIM);
         const _Float16* rows16l = reinterpret_cast<const _Float16*>(hd16 + rf_rows32(n_layout));
+        const float* t0;
+        int t0_stride;
         if (f16_filter) {
-            float* qc = reinterpret_cast<float*>(t_idx + (size_t)nq * k2p);
             hipLaunchKernelGGL(k_query_chains, dim3((unsigned)(((size_t)nq * RF_DIM + 255) / 256)), dim3(256), 0, s, q, nq, qc);
-            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts, qc);
-            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts, qc);
-        } else if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
-        else hipLaunchKernelGGL(k_l2_topk_mfma<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, k2p, parts);
+            long long seed = n / (n <= 131072 ? RF_TOPK_SEED_DIV : 4 * RF_TOPK_SEED_DIV);     // measured (tools/topk_bench.py): 50 k rows n/2 0.19 ms, n/8 0.22; 1 M rows n/8 1.28, n/2 1.53
+            if (seed < 2048) seed = 2048;
+            seed = (seed + 63) / 64 * 64;
+            if (seed > n) seed = n;
+            // 8 candidates per (slice, query) in the lists' workspace (64 k2p keys per query): at most 64 slices, at least 8 tiles each, ~2048 waves if possible
+            const long long tiles = (seed + 31) / 32;
+            long long ssl = (2048 + qgroups - 1) / qgroups;
+            if (ssl > 64) ssl = 64;
+            if (ssl > tiles / 8) ssl = tiles / 8;
+            if (ssl < 1) ssl = 1;
+            const long long tps = (tiles + ssl - 1) / ssl;
+            const int sslices = (int)((tiles + tps - 1) / tps);
+            hipLaunchKernelGGL(k_l2_topk_seed16, dim3(sslices, qtiles), dim3(256), 0, s, q, nq, rows16, rows16l, hd16, (long long)seed, (int)(tps * 32), parts);
+            RF_CHECK_LAUNCH("rf_l2_topk(seed)");
+            int rc = launch_merge(parts, sslices, nq, 8, k2, nullptr, nullptr, nullptr, s, "rf_l2_topk(seed merge)", qc, rows_img, t_dist);
+            if (rc != RF_OK) return rc;
+            t0 = t_dist;
+            t0_stride = 1;
+        } else {
+            long long sample = n / RF_TOPK_SAMPLE_DIV;
+            if (sample < 1024) sample = 1024;
+            sample = (sample + 63) / 64 * 64;
+            if (sample > n) sample = n;
+            const int sample_algo = use_mfma_scan(nq, sample) ? 2 : 1;
+            int rc = topk_impl(q, nq, dim, db_packed, sample, n_layout, row_base, k2p, sample_algo, t_dist, t_idx, nullptr, ws, ws_bytes, stream);
+            if (rc != RF_OK) return rc;
+            t0 = t_dist + (k2 - 1);                                   // the k2-th best of query qi: t0[qi * k2p]
+            t0_stride = k2p;
+        }
+        if (f16_filter) {
+            if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma16<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, t0_stride, parts, qc);
+            else hipLaunchKernelGGL(k_l2_topk_mfma16<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, rows16, rows16l, hd16, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, t0_stride, parts, qc);
+        } else if (k2p == 8) hipLaunchKernelGGL(k_l2_topk_mfma<8>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, t0_stride, parts);
+        else hipLaunchKernelGGL(k_l2_topk_mfma<16>, dim3(slices, qtiles), dim3(256), 0, s, q, nq, rows_img, hd, (long long)n, (unsigned)row_base, (int)(bps * 64), t0, t0_stride, parts);
         RF_CHECK_LAUNCH("rf_l2_topk(mfma scan)");
     } else {
         const int qtiles = (nq + RF_TQ - 1) / RF_TQ;

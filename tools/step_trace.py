@@ -7,7 +7,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-dom = [i for i, r in enumerate(rows) if 'k_conv3_up_split<' in r['Kernel_Name'] or 'k_conv3_up_wino' in r['Kernel_Name']]
+dom = [i for i, r in enumerate(rows) if 'k_conv3_up_split_pp' in r['Kernel_Name'] or 'k_conv3_up_split<' in r['Kernel_Name']]
 first, last = (dom[-steps] if len(dom) >= steps else dom[0]), dom[-1]
 win = rows[first:last]
 t0, t1 = int(win[0]['Start_Timestamp']), int(win[-1]['Start_Timestamp'])
@@ -30,7 +30,7 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         print('%8.1f us/step  %7.1f us x %4.1f  wg %-12s %s' % (us / nst, us / c, c / nst, g, name))
 # one step of the back-end queue in launch order (the second to last dominant launch to the last)
 rs = byq[main_q]
-di = [i for i, r in enumerate(rs) if 'k_conv3_up_split<' in r['Kernel_Name'] or 'k_conv3_up_wino' in r['Kernel_Name']]
+di = [i for i, r in enumerate(rs) if 'k_conv3_up_split_pp' in r['Kernel_Name'] or 'k_conv3_up_split<' in r['Kernel_Name']]
 if len(di) >= 2:
     print('--- back-end queue, one step in launch order (start offset us, duration us, gap before us)')
     seg = rs[di[-2]:di[-1]]
