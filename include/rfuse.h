@@ -137,6 +137,14 @@ int rf_conv3d_valid_leaky_split_ex(const void* x, int in_split, int n, int cin, 
                                    int stride, float slope, void* out, int out_split, void* stream);
 int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int cin, int k, int s, int stride, void* w_packed, void* stream);
 size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, int stride);
+/* ... and as a PERSISTENT kernel for the layers the encoders evaluate once on the whole padded chunk instead of per window (PCPatch48's 12 -> 24 k3 @140^3,
+ * model/retrieval.py:222): weights and tables LDS-resident, 512-voxel tiles double buffered, split form in and out (x and out as rf_conv3d_valid_leaky_split_ex
+ * with in_split = out_split = 1), the epilogue from registers.  Bit-identical to rf_conv3d_valid_leaky_split_ex; its own weight image. */
+int rf_conv3d_valid_split_pg_supported(int n, int cin, int s, int cout, int k, int stride);
+int rf_conv3d_valid_leaky_split_pg(const void* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k, int stride,
+                                   float slope, void* out, void* stream);
+int rf_convv_split_pg_pack_weight(const float* w_oidhw, int cout, int cin, int k, int s, int stride, void* w_packed, void* stream);
+size_t rf_convv_split_pg_packed_bytes(int cout, int cin, int k, int s, int stride);
 
 /* The same layer on the packed-fp32 VALU for the FIRST layers of the patch encoders (stride 1; 1 -> 8/12 with k = 3/5, 1 -> 16,
  * 8 -> 16 and 12 -> 24 with k = 3): couts of 12 / 24 waste a quarter of the 16-wide MFMA tiles, the vector unit has the same fp32

@@ -8,7 +8,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 OUT = HERE.parent / 'rfuse' / 'librfuse_hip.so'
-SOURCES = ['capi.hip', 'conv3d.hip', 'conv3d_mfma.hip', 'conv3d_up.hip', 'conv3d_up_split.hip', 'conv3d_split.hip', 'conv3d_split_zc.hip', 'conv3d_e2_split.hip', 'conv3d_small.hip', 'conv3d_backward.hip', 'conv3d_wgrad_split.hip', 'conv_valid_mfma.hip', 'conv_valid_split.hip', 'linear.hip', 'attention.hip', 'attention_fused.hip', 'retrieval.hip', 'mesh.hip']
+SOURCES = ['capi.hip', 'conv3d.hip', 'conv3d_mfma.hip', 'conv3d_up.hip', 'conv3d_up_split.hip', 'conv3d_split.hip', 'conv3d_split_zc.hip', 'conv3d_e2_split.hip', 'conv3d_small.hip', 'conv3d_backward.hip', 'conv3d_wgrad_split.hip', 'conv_valid_mfma.hip', 'conv_valid_split.hip', 'conv_valid_split_pg.hip', 'linear.hip', 'attention.hip', 'attention_fused.hip', 'retrieval.hip', 'mesh.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # the attention / gather-normalise kernels restate torch expressions op by op: no a*b+c fusion across operations (explicit fmaf() stays an FMA).
 # hipcc's default -ffp-contract=fast fuses in the backend, where neither __fmul_rn nor `#pragma clang fp contract(off)` reach.

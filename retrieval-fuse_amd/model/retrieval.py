@@ -99,6 +99,9 @@ class _ConvPatchEncoder(nn.Module):
     def _conv(self, layer, x, out_split=False):
         """one conv + bias + LeakyReLU; `x` fp32 or ops.SplitActs; out_split: leave the output in split form (the caller knows the next layer reads it)"""
         shape = (x.shape[0], x.shape[1], x.shape[2])
+        if isinstance(x, ops.SplitActs) and out_split and ops.conv_valid_split_pg_supported(shape, layer.out_channels, layer.kernel_size, layer.stride) \
+                and ops.split_range_ok(layer.weight):
+            return ops.conv3d_valid_leaky_split_pg(x, layer.packed_valid_split_pg(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2)
         if isinstance(x, ops.SplitActs) or self._split_takes(layer, shape):
             return ops.conv3d_valid_leaky_split(x, layer.packed_valid_split(x.shape[2]), layer.bias, layer.out_channels, layer.kernel_size, layer.stride, 0.2,
                                                 out_split=out_split)

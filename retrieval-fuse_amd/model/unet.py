@@ -55,6 +55,7 @@ class Conv3dParams(nn.Module):
         self._packed_lds = ops.PackedWeight('convvl')
         self._packed_valu = ops.PackedWeight('convvv')
         self._packed_vsplit = ops.PackedWeight('convvs')
+        self._packed_vpg = ops.PackedWeight('convvpg')
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -77,6 +78,10 @@ class Conv3dParams(nn.Module):
     def packed_valid_split(self, s):
         """f16 fragment image of the split-operand valid-conv form for input edge s (csrc/conv_valid_split.hip)"""
         return self._packed_vsplit.get(self.weight, s, self.stride)
+
+    def packed_valid_split_pg(self, s):
+        """weight image of the persistent grid form of the split-operand valid conv for input edge s (csrc/conv_valid_split_pg.hip)"""
+        return self._packed_vpg.get(self.weight, s, self.stride)
 
     def packed_up(self, c0):
         """operand image of the decoder form (first c0 input channels = skip source, rest = upsampled source)"""

@@ -52,6 +52,10 @@ SIGNATURES = {
     'rf_conv3d_valid_leaky_split_ex': (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_fp, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     'rf_convv_split_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'rf_convv_split_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_valid_split_pg_supported': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    'rf_conv3d_valid_leaky_split_pg': (c_i, [c_p, c_i, c_i, c_i, c_p, c_fp, c_i, c_i, c_i, c_f, c_p, c_p]),
+    'rf_convv_split_pg_pack_weight': (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'rf_convv_split_pg_packed_bytes': (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_pool_supported': (c_i, [c_i, c_i, c_i, c_i, c_i]),
     'rf_conv3d_k3_gn_relu_pool': (c_i, [c_fp, c_i, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_p, c_fp, c_p, c_p]),
     'rf_conv3_up_packed_floats': (c_sz, [c_i, c_i, c_i]),

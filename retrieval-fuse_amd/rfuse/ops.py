@@ -96,7 +96,7 @@ class PackedWeight:
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device) + extra
         if key != self._key:
             self._packed = {'conv3': pack_conv3_weight, 'linear': pack_linear_weight, 'convv': pack_convv_weight,
-                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight, 'conv3e2': pack_conv3_e2_split_weight, 'convvs': pack_convv_split_weight}[self.kind](w, *extra)
+                            'convvl': pack_convv_lds_weight, 'convvv': pack_convv_valu_weight, 'conv3up': pack_conv3_up_weight, 'conv3ups': pack_conv3_up_split_weight, 'conv3s': pack_conv3_split_weight, 'conv3e2': pack_conv3_e2_split_weight, 'convvs': pack_convv_split_weight, 'convvpg': pack_convv_split_pg_weight}[self.kind](w, *extra)
             self._key = key
             self._ready.packed_on(w.device)
         else:
@@ -878,6 +878,42 @@ def conv3d_valid_leaky_split(x, w_packed, bias, cout, k, stride, slope, out_spli
     _lib.check(_lib.load().rf_conv3d_valid_leaky_split_ex(_p(xt), int(in_split), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k,
                                                           stride, slope, _p(out), int(out_split), _stream()), 'rf_conv3d_valid_leaky_split')
     return SplitActs(out) if out_split else out
+
+
+USE_CONVV_PG = True             # False: grid-sized split-form layers stay on the tile-per-workgroup kernel
+
+
+def conv_valid_split_pg_supported(shape, cout, k, stride):
+    """True when the persistent grid form (rf_conv3d_valid_leaky_split_pg) takes a split-form input of shape (n, cin, s)"""
+    return USE_CONVV_PG and CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_valid_split_pg_supported(max(shape[0], 1), shape[1], shape[2], cout, k, stride))
+
+
+def pack_convv_split_pg_weight(w, s, stride):
+    """weight image (tables + f16 fragments) of the persistent grid form for input edge s"""
+    _req(w.detach(), 'conv weight')
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    lib = _lib.load()
+    nbytes = lib.rf_convv_split_pg_packed_bytes(cout, cin, k, s, stride)
+    if nbytes == 0:
+        raise ValueError('pack_convv_split_pg_weight: layer %s @%d^3 stride %d is not taken by the persistent grid form' % (tuple(w.shape), s, stride))
+    out = torch.empty(nbytes // 2, dtype=torch.float16, device=w.device)
+    _lib.check(lib.rf_convv_split_pg_pack_weight(_p(w.detach()), cout, cin, k, s, stride, _p(out), _stream()), 'rf_convv_split_pg_pack_weight')
+    return out
+
+
+def conv3d_valid_leaky_split_pg(x, w_packed, bias, cout, k, stride, slope):
+    """SplitActs -> SplitActs: valid conv + bias + LeakyReLU, persistent grid form (w_packed from pack_convv_split_pg_weight); bit-identical to
+    conv3d_valid_leaky_split(x, ..., out_split=True)"""
+    if not isinstance(x, SplitActs):
+        raise TypeError('conv3d_valid_leaky_split_pg: the input must be in split form (SplitActs)')
+    xt = x.data
+    _req(xt, 'x')
+    n, cin, s = xt.shape[0], xt.shape[1], xt.shape[2]
+    so = (s - k) // stride + 1
+    out = torch.empty((n, cout, so, so, so), dtype=torch.float32, device=xt.device)
+    _lib.check(_lib.load().rf_conv3d_valid_leaky_split_pg(_p(xt), n, cin, s, _p(w_packed), _p(bias.detach() if bias is not None else None), cout, k, stride, slope,
+                                                          _p(out), _stream()), 'rf_conv3d_valid_leaky_split_pg')
+    return SplitActs(out)
 
 
 USE_CONVV_VALU = True           # False: the first layers of the patch encoders stay on the matrix cores
