@@ -25,10 +25,11 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr float PG_ACT_SCALE = 1.0f / 16, PG_W_SCALE = 16.0f, PG_LO = 2048.0f;
-constexpr int PG_NT = 512, PG_TT = 256, PG_MB = 4, PG_M = 256;  // threads, threads of a team, m-blocks per wave, output voxels per tile (of a team)
+constexpr int PG_NT = 512, PG_TT = 256, PG_MB = 2;               // threads, threads of a team, 32-voxel m-blocks per wave, output voxels per tile (of a team)
 constexpr int PG_SB = 4;                                        // staged items (4 channels of TWO voxels along x: 16 bytes of the h plane, 16 of the l plane) per thread and tile
 constexpr size_t PG_LDS_MAX = 160 * 1024;
 }   // namespace
@@ -42,89 +43,40 @@ struct ConvPGArgs {
     float slope;
     int tz, ty, tx, ntz, nty, ntx;  // output voxels per tile and dim, tiles per dim
     int zi, yi, xi, npos;           // staged input planes / rows per plane / voxels per row, positions per channel group
-    int cg, ksteps, nbt;            // 4-channel groups, k-steps (8 pieces each), n-blocks
+    int cg, ksteps;                 // 4-channel groups, k-steps (16 K values = 4 pieces of (tap, channel group) each)
     int items;                      // cg * npos
-    int rs, ps, cgs, plane;         // LDS image: bytes between rows / planes / channel groups (ps, cgs = 128 mod 256: see convv_pg_pairs), bytes of a plane incl. 64 dump slots
-    signed char sp[96];             // K slot (k-step q, lane group g, half xy) = 8 q + 2 g + xy -> piece tap * cg + group, -1: zero-weight pad
+    int rs, ps, cgs, plane;         // LDS image: bytes between rows / planes / channel groups (ps = 128 mod 256: the two rows of an m-block), bytes of a plane incl. dump slots
     int hdr;                        // ints of the image's table header
     unsigned tiles;                 // n * ntz * nty * ntx
-    int ablate;                     // dev (RF_PG_ABLATE): 1 no epilogue, 2 no staging, 4 no k-loop
+#ifdef RF_PG_DEV
+    int ablate;                     // dev build (tools/convv_pg_bench.py, RF_PG_ABLATE): 1 no epilogue, 2 no staging, 4 no k-loop, 8 stamps, 16 no stores
+#endif
 };
 
 static size_t convv_pg_lds_bytes(const ConvPGArgs& a) {
-    const size_t w = (size_t)a.ksteps * a.nbt * 2 * 64 * 16;
-    const size_t tables = (size_t)a.ksteps * 8 * 4 + 3 * (size_t)PG_M * 4 + 64 * 4;
+    const size_t w = (size_t)a.ksteps * 2 * 64 * 16;
+    const size_t tables = (size_t)a.hdr * 4 + 32 * 4;
     return w + tables + 2 * 2 * (size_t)a.plane;                 // two teams x (h plane, l plane)
 }
 
-// tile choice; depends on the layer only: the tables of the weight image are made for it
-// K order.  A voxel operand is four ds_read_b64 per (m-block, k-step): lane group g reads 16 consecutive voxels (128 bytes) of piece 8 q + 2 g + xy.
-// ds_read_b64 is served in two groups of 32 lanes over 64 x 4-byte banks: lane groups (0, 1) and (2, 3) collide unless their two 128-byte runs
-// start 128 bytes apart mod 256.  In k_convv_split's order (piece = tap * cg + group, dense image) nearly every pair overlaps (measured here: LDS
-// busy 0.83 of a k-step with one team multiplying).  Here the image is padded so that one input plane and one channel group are both 128 mod 256
-// bytes, and the pieces are PAIRED: within a (dy, dx) class, neighbours along the channel group or along dz are 128 apart.  A 3 x 3 (group, dz)
-// grid leaves one piece per class single; singles take a zero-weight pad piece as partner (its offset: the partner's + 128) while pads last (the
-// k-steps have 8 * ksteps - taps * cg of them), the rest pair among themselves (one colliding pair of 44 for 12 -> 24 k3).
-static void convv_pg_pairs(ConvPGArgs& a) {
-    const int k = a.k, C = a.cg, nslot = a.ksteps * 8, npiece = k * k * k * C;
-    int pairs[64][2], np = 0, singles[64], ns = 0;
-    for (int dyx = 0; dyx < k * k; ++dyx) {
-        auto piece = [&](int c, int dz) { return (dz * k * k + dyx) * C + c; };
-        for (int dz = 0; dz < k; ++dz)
-            for (int c = 0; c + 1 < C; c += 2) { pairs[np][0] = piece(c, dz); pairs[np][1] = piece(c + 1, dz); ++np; }
-        if (C & 1) {
-            for (int dz = 0; dz + 1 < k; dz += 2) { pairs[np][0] = piece(C - 1, dz); pairs[np][1] = piece(C - 1, dz + 1); ++np; }
-            if (k & 1) singles[ns++] = piece(C - 1, k - 1);
-        }
-    }
-    int pads = nslot - npiece;
-    for (int i = 0; i < ns;) {
-        if (pads > 0 && (ns - i) <= pads) { pairs[np][0] = singles[i]; pairs[np][1] = -1; ++np; --pads; ++i; }
-        else if (i + 1 < ns) { pairs[np][0] = singles[i]; pairs[np][1] = singles[i + 1]; ++np; i += 2; }
-        else { pairs[np][0] = singles[i]; pairs[np][1] = -1; ++np; --pads; ++i; }
-    }
-    while (np * 2 < nslot) { pairs[np][0] = -1; pairs[np][1] = -1; ++np; }
-    for (int i = 0; i < 96; ++i) a.sp[i] = -1;
-    for (int i = 0; i < np && i * 2 < nslot; ++i) {
-        const int q = i >> 2, xy = (i >> 1) & 1, gh = i & 1;
-        a.sp[q * 8 + 2 * (2 * gh) + xy] = (signed char)pairs[i][0];
-        a.sp[q * 8 + 2 * (2 * gh + 1) + xy] = (signed char)pairs[i][1];
-    }
-}
-
+// the instantiation built: k = 3, 12 input channels, 17..24 couts, tile 4 x 4 x 16 (a wave = one row index y of the tile, an m-block = that row in two
+// adjacent planes); depends on the layer only: the tables of the weight image are made for it
 static bool convv_pg_plan(int cin, int s, int cout, int k, int stride, ConvPGArgs& a) {
     // s even: rows of the input start 16-byte aligned and a tile's row has an even number of voxels in the volume (16-byte requests / stores: two voxels)
-    if (cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || k != 3 || stride != 1 || s < 64 || s > 254 || (s & 1)) return false;
-    const int so = (s - k) / stride + 1;
-    const int cg = cin / 4, k3 = k * k * k;
-    const int ksteps = (k3 * cg + 7) / 8, nbt = rf_round_up(cout, 16) / 16;
-    if (ksteps != 11 || nbt != 2) return false;                 // the instantiation built (PCPatch32 / 48 / 64's 12 -> 24 k3, nf = 12)
-    a.cin = cin; a.s = s; a.cout = cout; a.k = k; a.stride = stride; a.so = so; a.cg = cg; a.ksteps = ksteps; a.nbt = nbt;
-    double best = 0.0;
-    for (int tz = 4; tz <= 4; ++tz)                                 // the instantiation built: a wave = one plane of the tile, an m-block = one row
-        for (int ty = 4; ty <= 4; ++ty)
-            for (int tx = 16; tx <= 16; ++tx) {                     // an m-block = 16 consecutive voxels of a row (convv_pg_pairs)
-                const int V = tz * ty * tx;
-                if (V > PG_M || V < PG_M * 3 / 4) continue;
-                ConvPGArgs t = a;
-                t.tz = tz; t.ty = ty; t.tx = tx;
-                t.zi = (tz - 1) * stride + k; t.yi = (ty - 1) * stride + k; t.xi = (tx - 1) * stride + k;
-                t.npos = t.zi * t.yi * t.xi; t.items = cg * t.npos;
-                t.rs = t.xi * 8;
-                t.ps = t.yi * t.rs; t.ps += (128 - t.ps % 256 + 256) % 256;
-                t.cgs = t.zi * t.ps; t.cgs += (128 - t.cgs % 256 + 256) % 256;
-                t.plane = cg * t.cgs + 64 * 8;
-                if (t.items > 2 * PG_SB * PG_TT || (t.xi & 1) || 2 * t.plane > 65535 || convv_pg_lds_bytes(t) > PG_LDS_MAX) continue;
-                t.ntz = (so + tz - 1) / tz; t.nty = (so + ty - 1) / ty; t.ntx = (so + tx - 1) / tx;
-                // useful share of the MFMAs, less a little for what the halo costs (staging runs in the other team's shadow)
-                const double eff = (double)so * so * so / ((double)t.ntz * t.nty * t.ntx * PG_M) - 0.02 * (double)t.npos / V;
-                if (eff > best + 1e-9) { best = eff; a = t; }
-            }
-    if (best <= 0.0) return false;
-    a.hdr = rf_round_up(a.ksteps * 8 + 3 * PG_M, 4);
-    if (k * k * k * cg > 127) return false;
-    convv_pg_pairs(a);
-    return true;
+    if (cin != 12 || cout <= 16 || cout > 24 || (cout & 3) || k != 3 || stride != 1 || s < 64 || s > 254 || (s & 1)) return false;
+    const int so = s - k + 1, cg = cin / 4;
+    a.cin = cin; a.s = s; a.cout = cout; a.k = k; a.stride = stride; a.so = so; a.cg = cg;
+    a.ksteps = (k * k * k * cg + 3) / 4;
+    a.tz = 4; a.ty = 4; a.tx = 16;
+    a.zi = a.tz - 1 + k; a.yi = a.ty - 1 + k; a.xi = a.tx - 1 + k;
+    a.npos = a.zi * a.yi * a.xi; a.items = cg * a.npos;
+    a.rs = a.xi * 8;
+    a.ps = a.yi * a.rs; a.ps += (128 - a.ps % 256 + 256) % 256;
+    a.cgs = a.zi * a.ps;
+    a.plane = cg * a.cgs + 32 * 16;
+    a.ntz = (so + a.tz - 1) / a.tz; a.nty = (so + a.ty - 1) / a.ty; a.ntx = (so + a.tx - 1) / a.tx;
+    a.hdr = rf_round_up(a.ksteps * 4, 4);
+    return a.items <= 2 * PG_SB * PG_TT && convv_pg_lds_bytes(a) <= PG_LDS_MAX;
 }
 
 extern "C" int rf_conv3d_valid_split_pg_supported(int n, int cin, int s, int cout, int k, int stride) {
@@ -135,59 +87,35 @@ extern "C" int rf_conv3d_valid_split_pg_supported(int n, int cin, int s, int cou
 extern "C" size_t rf_convv_split_pg_packed_bytes(int cout, int cin, int k, int s, int stride) {
     ConvPGArgs a;
     if (!convv_pg_plan(cin, s, cout, k, stride, a)) return 0;
-    return (size_t)a.hdr * 4 + (size_t)a.ksteps * a.nbt * 2 * 64 * 16;
+    return (size_t)a.hdr * 4 + (size_t)a.ksteps * 2 * 64 * 16;
 }
 
-// image header (the tables every workgroup copies to LDS):
-//   [ksteps * 8] byte offset of piece p = (tap, channel group) in the h plane of a staged tile (zero-weight pad pieces: 0);
-//   [PG_M]       byte offset of the input corner of tile voxel m in a plane (m >= tile size: 0 -- computed, never stored);
-//   [PG_M]       offset of tile voxel m in the output volume relative to the tile's first voxel (m >= tile size: -1);
-//   [PG_M]       (lz << 16) | (ly << 8) | lx of tile voxel m (ragged last tiles)
+// image header: [ksteps * 4] byte offset of K slot 4 q + 2 hk + xy = piece (tap, channel group) = tap * cg + group in the h plane of a staged tile
+// (slots behind the last piece: zero weights, offset 0)
 __global__ void k_convv_pg_header(ConvPGArgs a, int* __restrict__ hdr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int np = a.ksteps * 8;
-    if (i < np) {
-        const int k = a.k;
-        auto piece_off = [&](int pc) {
-            const int tap = pc / a.cg, cg = pc - tap * a.cg;
-            return cg * a.cgs + (tap / (k * k)) * a.ps + ((tap / k) % k) * a.rs + (tap % k) * 8;
-        };
-        int off = 0;
-        if (a.sp[i] >= 0) off = piece_off(a.sp[i]);
-        else if (a.sp[i ^ 2] >= 0) {                                // pad: 128 bytes from its partner (staged data or zeroed padding either way)
-            off = piece_off(a.sp[i ^ 2]);
-            off += off >= 128 ? -128 : 128;
-        }
-        hdr[i] = off;
-    } else if (i < np + 3 * PG_M) {
-        const int which = (i - np) / PG_M, m0 = (i - np) % PG_M;
-        const bool in = m0 < a.tz * a.ty * a.tx;
-        const int m = in ? m0 : 0;
-        const int x = m % a.tx, r = m / a.tx, ly = r % a.ty, lz = r / a.ty;
-        if (which == 0) hdr[i] = lz * a.stride * a.ps + ly * a.stride * a.rs + x * a.stride * 8;
-        else if (which == 1) hdr[i] = in ? (lz * a.so + ly) * a.so + x : -1;
-        else hdr[i] = (lz << 16) | (ly << 8) | x;
-    } else if (i < a.hdr) {
-        hdr[i] = 0;
+    if (i >= a.hdr) return;
+    const int k = a.k;
+    int off = 0;
+    if (i < k * k * k * a.cg) {
+        const int tap = i / a.cg, cg = i - tap * a.cg;
+        off = cg * a.cgs + (tap / (k * k)) * a.ps + ((tap / k) % k) * a.rs + (tap % k) * 8;
     }
+    hdr[i] = off;
 }
 
-// fragments [k-step][n-block][h | l][lane][8 halves]: lane (g, j) = cout n-block * 16 + j, pieces 8 q + 2 g and 8 q + 2 g + 1 (4 channels each) -- the
-// K slot order from convv_pg_pairs
+// weight fragments of v_mfma_f32_32x32x16_f16's 32 x 16 operand, [k-step][h | l][lane][8 halves]: lane = 32 hk + cout, K values = slots 4 q + 2 hk, + 1 (4 channels each)
 __global__ void k_convv_pg_pack(ConvPGArgs a, const float* __restrict__ w, h8* __restrict__ wp, size_t total) {
-    const int cout = a.cout, cin = a.cin, k3 = a.k * a.k * a.k, cg = a.cg, nbt = a.nbt;
-    (void)cg;
+    const int cout = a.cout, cin = a.cin, k3 = a.k * a.k * a.k, cg = a.cg;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
-        const size_t f = i >> 7;
-        const int nb = (int)(f % nbt), q = (int)(f / nbt);
-        const int co = nb * 16 + (lane & 15), g = lane >> 4;
+        const int lane = (int)(i & 63), part = (int)((i >> 6) & 1), q = (int)(i >> 7);
+        const int co = lane & 31, hk = lane >> 5;
         h8 out;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int p = a.sp[8 * q + 2 * g + (j >> 2)];
+            const int p = 4 * q + 2 * hk + (j >> 2);
             double v = 0.0;
-            if (p >= 0 && co < cout) v = (double)w[((size_t)co * cin + (p % cg) * 4 + (j & 3)) * k3 + p / cg];
+            if (p < k3 * cg && co < cout) v = (double)w[((size_t)co * cin + (p % cg) * 4 + (j & 3)) * k3 + p / cg];
             v *= (double)PG_W_SCALE;
             v = v > 65504.0 ? 65504.0 : (v < -65504.0 ? -65504.0 : v);
             const _Float16 h = (_Float16)(float)v;
@@ -202,7 +130,7 @@ extern "C" int rf_convv_split_pg_pack_weight(const float* w_oidhw, int cout, int
     ConvPGArgs a;
     RF_REQUIRE(convv_pg_plan(cin, s, cout, k, stride, a), RF_E_UNSUPPORTED,
                "rf_convv_split_pg_pack_weight: layer not taken by the persistent grid form (ask rf_conv3d_valid_split_pg_supported)");
-    const size_t total = (size_t)a.ksteps * a.nbt * 2 * 64;
+    const size_t total = (size_t)a.ksteps * 2 * 64;
     hipLaunchKernelGGL(k_convv_pg_header, dim3((unsigned)((a.hdr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, reinterpret_cast<int*>(w_packed));
     hipLaunchKernelGGL(k_convv_pg_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, w_oidhw,
                        reinterpret_cast<h8*>(w_packed) + a.hdr / 4, total);
@@ -218,30 +146,35 @@ struct PgTile {             // uniform: origin of a tile
 };
 }   // namespace
 
-// dev: s_memtime at the phase borders of every workgroup's 9th round (RF_PG_ABLATE bit 3), both teams; tools/convv_pg_bench.py --stamps
+// dev build (-DRF_PG_DEV): ablations and s_memtime at the phase borders of every workgroup's 9th round (RF_PG_ABLATE bit 3), both teams; tools/convv_pg_bench.py
+#ifdef RF_PG_DEV
+#define PG_ABL(bit_) (a.ablate & (bit_))
 __device__ unsigned long long g_pg_stamps[1024 * 2 * 8];
 extern "C" int rft_pg_read_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pg_stamps), sizeof(g_pg_stamps)); }
 #define PG_STAMP(k_) do { if ((a.ablate & 8) && i == 8 && tw == 0 && lane == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_pg_stamps[(blockIdx.x * 2 + team) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PG_ABL(bit_) false
+#define PG_STAMP(k_) do { } while (0)
+#endif
 
-template <int NB, int KS, int RS, int PLANE>
+template <int KS, int NRQ, int RS, int PS, int PLANE>
 __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
     constexpr int TT = PG_TT, MB = PG_MB, SB = PG_SB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, ttid = tid & (TT - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = wave >> 2, tw = wave & 3;
-    const int j = lane & 15, g = lane >> 4;
+    const int j = lane & 15, zh = (lane >> 4) & 1, hk = lane >> 5;  // voxel column = lane & 31: x = j of row tw in plane 2 mb + zh; K half of the lane
     const int so = a.so, s = a.s, st = a.stride, items = a.items;
     const size_t ivol = (size_t)s * s * s, ovol = (size_t)so * so * so;
 
-    // LDS: weight fragments | piece offsets | voxel tables (corner, output offset, coordinates) | bias | per team: h plane, l plane (+ 64 dump slots each)
+    // LDS: weight fragments | K slot offsets | bias / 16 | per team: h plane, l plane (dump slots behind each)
     const h8* wl = reinterpret_cast<const h8*>(lds);
-    constexpr int WBYTES = KS * NB * 2 * 64 * 16;
+    constexpr int WBYTES = KS * 2 * 64 * 16;
     int* poff = reinterpret_cast<int*>(lds + WBYTES);
-    int* vtab = poff + KS * 8;
-    float* bzt = reinterpret_cast<float*>(vtab + 3 * PG_M);
+    float* bzt = reinterpret_cast<float*>(poff + ((KS * 4 + 3) & ~3));
     constexpr int plane = PLANE;                                    // (the launcher checks the plan against the instantiation)
-    unsigned char* buf = reinterpret_cast<unsigned char*>(bzt + 64) + (size_t)team * 2 * plane;
+    unsigned char* buf = reinterpret_cast<unsigned char*>(bzt + 32) + (size_t)team * 2 * plane;
 
     // tiles of this workgroup: an XCD (blockIdx & 7) walks a contiguous range of the tile list, its workgroups side by side (shared halos meet in its L2);
     // the workgroup's tiles go to the teams alternately
@@ -338,12 +271,12 @@ __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
     // ---- once: weights and tables to LDS, each team's first tile
     {
         const int* hdr = reinterpret_cast<const int*>(a.wp);
-        for (int i = tid; i < KS * 8 + 3 * PG_M; i += PG_NT) poff[i] = hdr[i];
+        for (int i = tid; i < KS * 4; i += PG_NT) poff[i] = hdr[i];
         const h8* wg = a.wp + a.hdr / 4;
         h8* wd = reinterpret_cast<h8*>(lds);
-        for (int i = tid; i < KS * NB * 2 * 64; i += PG_NT) wd[i] = wg[i];
-        if (tid < 64) bzt[tid] = (a.bias && tid < a.cout) ? a.bias[tid] * PG_ACT_SCALE : 0.f;
-        uint2* zb = reinterpret_cast<uint2*>(bzt + 64);               // the images' padding is read (pad pieces, zero weights): zero, not NaN patterns
+        for (int i = tid; i < KS * 2 * 64; i += PG_NT) wd[i] = wg[i];
+        if (tid < 32) bzt[tid] = (a.bias && tid < a.cout) ? a.bias[tid] * PG_ACT_SCALE : 0.f;
+        uint2* zb = reinterpret_cast<uint2*>(bzt + 32);               // the images' padding is never read, the dump slots are never read: tidy all the same
         for (int i = tid; i < 4 * plane / 8; i += PG_NT) zb[i] = make_uint2(0u, 0u);
         __syncthreads();
     }
@@ -356,73 +289,61 @@ __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
     PgTile nxt = walk_tile();
     request(nxt, ph, pl);
     __syncthreads();
-    // input corner of voxel (m-block 0, j) in the team's h plane; m-block mb is row mb of the wave's plane (tile 4 x 4 x 16): + mb * RS, an immediate --
-    // a k-step costs two address additions, not eight (issue slots: ~4 per MFMA and SIMD, for both waves together)
+    // input corner of this lane's voxel of m-block 0 in the team's h plane; m-block mb: + 2 mb PS, an immediate -- a k-step costs two address additions.
+    // A 32-lane half of a ds_read_b64 reads two rows of 16 voxels (128 bytes each) PS apart: PS = 128 mod 256, no bank is asked twice.
     typedef __attribute__((address_space(3))) h4 lds_h4;
     typedef const volatile lds_h4* lds_vh4p;
-    const unsigned bb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)buf + (unsigned)vtab[(tw * MB) * 16 + j];
-    const int2* pop = reinterpret_cast<const int2*>(poff) + g;      // piece offsets of k-step q for this lane group: pop[4 q]
+    const unsigned bb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)buf + (unsigned)(zh * PS + tw * RS + j * 8);
+    const int2* pop = reinterpret_cast<const int2*>(poff) + hk;      // K slot offsets of k-step q for this lane's half: pop[2 q]
+    const int eo0 = (zh * so + tw) * so + j;                        // this lane's voxel of m-block 0 in the output volume, relative to the tile's first voxel
 
     if (team == 1) __builtin_amdgcn_s_barrier();                    // half a period behind team 0 (every wave passes the same number of barriers)
 
     for (unsigned i = 0; i < n_iter; ++i) {
-        // ================= k-loop: operands of k-step q + 1 requested (two bursts) while k-step q multiplies
+        // ================= k-loop: v_mfma_f32_32x32x16_f16, weights = A (M = 32 couts), voxels = B (N = 32 voxels); operands of k-step q + 1 requested between
+        // the MFMAs of k-step q.  (32 x 32 and not 16 x 16 x 32: a SIMD issues ~4 instructions per 16 cycles for BOTH its waves; half as many MFMAs of twice
+        // the length leave the other team's epilogue the slots it needs.)
         PG_STAMP(0);
-        if (a.ablate & 64) __builtin_amdgcn_s_setprio(0);
-        if (a.ablate & 128) __builtin_amdgcn_s_setprio(3);
-        f32x4 hi[MB][NB], lo[MB][NB];
+        f32x16 hi[MB], lo[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) { hi[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lo[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        h8 bh[2][NB], bl[2][NB], ah[2][MB], al[2][MB];
+            for (int r = 0; r < 16; ++r) { hi[mb][r] = 0.f; lo[mb][r] = 0.f; }
+        if (!PG_ABL(4)) {
+        h8 bh[2], bl[2], ah[2][MB], al[2][MB];
         int2 po[2];
-        auto load_b = [&](int q, int sl) {
+        auto load_ops = [&](int q, int sl) {
+            bh[sl] = wl[(q * 2) * 64 + lane];
+            bl[sl] = wl[(q * 2 + 1) * 64 + lane];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) { bh[sl][nb] = wl[((q * NB + nb) * 2) * 64 + lane]; bl[sl][nb] = wl[((q * NB + nb) * 2 + 1) * 64 + lane]; }
+            for (int mb = 0; mb < MB; ++mb) {
+                const unsigned p0 = bb + (unsigned)po[sl].x + mb * 2 * PS, p1 = bb + (unsigned)po[sl].y + mb * 2 * PS;
+                // (volatile: hipcc would merge two reads off one address register into ds_read2_b64 -- half the LDS rate, v_movs to sort the halves into operands)
+                const h4 a0 = *(lds_vh4p)(size_t)p0, a1 = *(lds_vh4p)(size_t)p1;
+                const h4 c0 = *(lds_vh4p)(size_t)(p0 + plane), c1 = *(lds_vh4p)(size_t)(p1 + plane);
+                ah[sl][mb] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                al[sl][mb] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
         };
-        auto load_a = [&](int sl, int mb, const int2& p) {
-            const unsigned p0 = bb + (unsigned)p.x + mb * RS;
-            const unsigned p1 = bb + (unsigned)p.y + mb * RS;
-            // (volatile: hipcc would merge the reads of two m-blocks off one address register into ds_read2_b64 -- half the LDS rate and 260 v_mov per
-            // tile to sort the halves back into operands)
-            const h4 a0 = *(lds_vh4p)(size_t)p0, a1 = *(lds_vh4p)(size_t)p1;
-            const h4 c0 = *(lds_vh4p)(size_t)(p0 + plane), c1 = *(lds_vh4p)(size_t)(p1 + plane);
-            ah[sl][mb] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            al[sl][mb] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        auto mfmas = [&](int sl, int mb) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) hi[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[sl][nb], ah[sl][mb], hi[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) lo[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[sl][nb], ah[sl][mb], lo[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) lo[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[sl][nb], al[sl][mb], lo[mb][nb], 0, 0, 0);
-        };
-        if (!(a.ablate & 4)) {
         po[0] = pop[0];
-        po[1] = pop[4];
-        load_b(0, 0);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) load_a(0, mb, po[0]);
+        po[1] = pop[2];
+        load_ops(0, 0);
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
             const int sl = q & 1, sn = sl ^ 1;
-            // one scheduling region per k-step: k-step q + 1's operand reads go BETWEEN k-step q's MFMAs, one read behind each MFMA (the four waves of the
-            // team run in step: a burst of 13 reads per wave fills the LDS queue and the MFMA behind it waits for its turn to issue)
-            if (q + 2 < KS) po[sl] = pop[4 * (q + 2)];
-            if (q + 1 < KS) {
-                load_b(q + 1, sn);
+            if (q + 1 < KS) load_ops(q + 1, sn);
+            if (q + 2 < KS) po[sl] = pop[2 * (q + 2)];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) load_a(sn, mb, po[sn]);
-            }
+            for (int mb = 0; mb < MB; ++mb) hi[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[sl], ah[sl][mb], hi[mb], 0, 0, 0);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) mfmas(sl, mb);
-            if (q + 1 < KS) {
+            for (int mb = 0; mb < MB; ++mb) lo[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[sl], ah[sl][mb], lo[mb], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 2 * NB + 4 * MB + (q + 2 < KS ? 1 : 0); ++r) {
+            for (int mb = 0; mb < MB; ++mb) lo[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[sl], al[sl][mb], lo[mb], 0, 0, 0);
+            if (q + 1 < KS) {                                       // one scheduling region per k-step: the 10-11 reads spread behind the 6 MFMAs
+#pragma unroll
+                for (int r = 0; r < 3 * MB; ++r) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -433,23 +354,18 @@ __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
         PG_STAMP(2);
 
         // ================= the team's next tile to LDS (requested a round ago), the one behind it requested, this tile's epilogue from registers
-        // (one wave per SIMD runs this phase: nothing hides an LDS round trip -- the epilogue's table entries are requested first)
-        if (a.ablate & 64) __builtin_amdgcn_s_setprio(3);
-        if (a.ablate & 128) __builtin_amdgcn_s_setprio(0);
-        int eo_[MB], ez_[MB];
-        f32x4 bz_[NB];
+        f32x4 bz_[NRQ];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) { eo_[mb] = vtab[PG_M + (tw * MB + mb) * 16 + j]; ez_[mb] = vtab[2 * PG_M + (tw * MB + mb) * 16 + j]; }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bz_[nb] = *reinterpret_cast<const f32x4*>(bzt + (nb * 4 + g) * 4);       // bias / 16
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(a.ablate & 2)) deposit(ph, pl);
+        for (int rq = 0; rq < NRQ; ++rq) bz_[rq] = *reinterpret_cast<const f32x4*>(bzt + (2 * rq + hk) * 4);    // bias / 16 of this lane's channel groups
+        if (!PG_ABL(2)) deposit(ph, pl);
         walk_step();
         const PgTile nn2 = walk_tile();
-        if (!(a.ablate & 2)) request(nn2, ph, pl);                  // (behind the last tile: the last tile again -- harmless, no branch)
+        if (!PG_ABL(2)) request(nn2, ph, pl);                  // (behind the last tile: the last tile again -- harmless, no branch)
         PG_STAMP(3);
         static_assert(PG_ACT_SCALE * PG_W_SCALE == 1.0f, "epilogue assumes the operand scales cancel");
-        if (!(a.ablate & 1) || hi[0][0][0] == 123.456f) {
+        if (!PG_ABL(1) || hi[0][0] == 123.456f) {
+            // accumulator register r of a lane: cout 8 (r / 4) + 4 hk + (r & 3) of its voxel = channel group 2 (r / 4) + hk: rq < NRQ real groups (the couts padded to
+            // 32 are whole registers here: never touched)
             int zlim = so - cur.z0, ylim = so - cur.y0, xlim = so - cur.x0;
             zlim = zlim < a.tz ? zlim : a.tz;
             ylim = ylim < a.ty ? ylim : a.ty;
@@ -459,20 +375,21 @@ __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.nn * obytes, 0, (int)obytes, 0x00020000);
             const unsigned org = (unsigned)((cur.z0 * so + cur.y0) * so + cur.x0) * 8u;
             const unsigned lsoff = (unsigned)ovol * 8u;
+            const bool odd = (j & 1) != 0;
+            const bool yx_in = tw < ylim && j < xlim;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const int eo = eo_[mb], ez = ez_[mb];
-                const bool vin = eo >= 0 && (ez >> 16) < zlim && ((ez >> 8) & 255) < ylim && (ez & 255) < xlim;
+                const bool vin = yx_in && 2 * mb + zh < zlim;
+                const unsigned vox = org + (unsigned)(eo0 + mb * 2 * so * so) * 8u + (odd ? lsoff - 8u : 0u);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int grp = nb * 4 + g;
-                    const f32x4 bz = bz_[nb];
-                    // hi + lo / 2^11 + bias, LeakyReLU, the consumer's 1 / 16, clamp, split -- on register PAIRS (v_pk_*_f32: the other team's MFMAs want the
-                    // issue slots; the 1 / 16 is applied first: exact, every later step scales with it)
+                for (int rq = 0; rq < NRQ; ++rq) {
+                    const int grp = 2 * rq + hk;
+                    // hi + lo / 2^11 + bias, LeakyReLU, the consumer's 1 / 16, clamp, split -- on register PAIRS (v_pk_*_f32); the 1 / 16 is applied first: exact,
+                    // every later step scales with it
                     h4 hh, ll;
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        const f32x2 h2 = {hi[mb][nb][r], hi[mb][nb][r + 1]}, l2 = {lo[mb][nb][r], lo[mb][nb][r + 1]}, b2 = {bz[r], bz[r + 1]};
+                        const f32x2 h2 = {hi[mb][4 * rq + r], hi[mb][4 * rq + r + 1]}, l2 = {lo[mb][4 * rq + r], lo[mb][4 * rq + r + 1]}, b2 = {bz_[rq][r], bz_[rq][r + 1]};
                         const f32x2 t0 = __builtin_elementwise_fma(l2, (f32x2){PG_ACT_SCALE / PG_LO, PG_ACT_SCALE / PG_LO}, h2 * (f32x2){PG_ACT_SCALE, PG_ACT_SCALE}) + b2;
                         const f32x2 ts = t0 * (f32x2){a.slope, a.slope};
                         f32x2 t;
@@ -486,15 +403,14 @@ __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
                     }
                     // 16-byte stores (the store path is issue-bound: half as many, twice as wide): lane pairs (j, j ^ 1) trade halves -- the even lane writes the
                     // h slots of voxels j, j + 1, the odd lane the l slots of voxels j - 1, j (an even number of a row's voxels lies in the volume: so even)
-                    const bool odd = (j & 1) != 0;
                     const u32x2 hw = __builtin_bit_cast(u32x2, hh), lw = __builtin_bit_cast(u32x2, ll);
                     const u32x2 give = odd ? hw : lw;
                     u32x2 recv;
                     recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);        // quad_perm [1, 0, 3, 2]
                     recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
                     const u32x4 ow = odd ? (u32x4){recv.x, recv.y, lw.x, lw.y} : (u32x4){hw.x, hw.y, recv.x, recv.y};
-                    unsigned vo = (vin && grp * 4 < a.cout) ? (unsigned)grp * 2u * (unsigned)ovol * 8u + org + (unsigned)eo * 8u + (odd ? lsoff - 8u : 0u) : 0xfffffff0u;
-                    if (a.ablate & 16) vo = hh[0] == (_Float16)123.0f ? vo : 0xfffffff0u;                       // dev: no stores
+                    unsigned vo = (vin && grp * 4 < a.cout) ? (unsigned)grp * 2u * lsoff + vox : 0xfffffff0u;
+                    if (PG_ABL(16)) vo = hh[0] == (_Float16)123.0f ? vo : 0xfffffff0u;
                     __builtin_amdgcn_raw_buffer_store_b128(ow, ro, (int)vo, 0, 0);
                 }
             }
@@ -519,7 +435,9 @@ extern "C" int rf_conv3d_valid_leaky_split_pg(const void* x, int n, int cin, int
                "rf_conv3d_valid_leaky_split_pg: layer not taken by the persistent grid form (ask rf_conv3d_valid_split_pg_supported)");
     a.n = n; a.x = reinterpret_cast<const unsigned char*>(x); a.wp = reinterpret_cast<const h8*>(w_packed); a.bias = bias; a.out = reinterpret_cast<unsigned char*>(out);
     a.slope = slope;
+#ifdef RF_PG_DEV
     { const char* e = getenv("RF_PG_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+#endif
     const size_t tiles64 = (size_t)a.ntz * a.nty * a.ntx * n;
     RF_REQUIRE(tiles64 < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_split_pg: too many tiles (%zu)", tiles64);
     RF_REQUIRE((size_t)cin / 4 * 2 * s * s * s * 8 < (1ull << 31) && (size_t)cout / 4 * 2 * a.so * a.so * a.so * 8 < (1ull << 31), RF_E_INVALID,
@@ -530,9 +448,10 @@ extern "C" int rf_conv3d_valid_leaky_split_pg(const void* x, int n, int cin, int
     while ((size_t)grid * 2 > tiles64 && grid > 8) grid -= 8;
     const size_t lds = convv_pg_lds_bytes(a);
     static RfLdsOptIn opt_in;
-    RF_REQUIRE(a.tz == 4 && a.ty == 4 && a.tx == 16 && a.rs == 144 && a.plane == 17024, RF_E_UNSUPPORTED, "rf_conv3d_valid_leaky_split_pg: plan differs from the instantiation built");
-    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split_pg<2, 11, 144, 17024>), (int)PG_LDS_MAX, "rf_conv3d_valid_leaky_split_pg")) return rc;
-    hipLaunchKernelGGL((k_convv_split_pg<2, 11, 144, 17024>), dim3(grid), dim3(PG_NT), lds, (hipStream_t)stream, a);
+    RF_REQUIRE(a.ksteps == 21 && a.rs == 144 && a.ps == 896 && a.plane == 16640 && a.cout > 16 && a.cout <= 24, RF_E_UNSUPPORTED,
+               "rf_conv3d_valid_leaky_split_pg: plan differs from the instantiation built");
+    if (int rc = opt_in.ensure(reinterpret_cast<const void*>(k_convv_split_pg<21, 3, 144, 896, 16640>), (int)PG_LDS_MAX, "rf_conv3d_valid_leaky_split_pg")) return rc;
+    hipLaunchKernelGGL((k_convv_split_pg<21, 3, 144, 896, 16640>), dim3(grid), dim3(PG_NT), lds, (hipStream_t)stream, a);
     RF_CHECK_LAUNCH("rf_conv3d_valid_leaky_split_pg");
     return RF_OK;
 }

@@ -1093,6 +1093,88 @@ def test_split_form_between_the_encoder_layers_changes_no_bit(ops, enc):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
 
 
+def _to_split(ops, x):
+    """fp32 [n, c, s, s, s] -> ops.SplitActs as include/rfuse.h defines it: [n][c/4][h | l][voxel][4 halves], h = f16(x/16), l = f16((x/16 - h) * 2^11)"""
+    n, c, s = x.shape[0], x.shape[1], x.shape[2]
+    t = (x * (1.0 / 16)).clamp(-65504.0, 65504.0)
+    h = t.half()
+    l = ((t - h.float()) * 2048.0).half()
+    hl = torch.stack([h, l], 0).view(2, n, c // 4, 4, s * s * s).permute(1, 2, 0, 4, 3).contiguous()
+    return ops.SplitActs(hl.view(torch.float32).view(n, c, s, s, s))
+
+
+def _from_split(xs):
+    n, c, s = xs.shape[0], xs.shape[1], xs.shape[2]
+    hl = xs.data.view(torch.float16).view(n, c // 4, 2, s * s * s, 4).float()
+    return ((hl[:, :, 0] + hl[:, :, 1] * (1.0 / 2048.0)) * 16.0).permute(0, 1, 3, 2).reshape(n, c, s, s, s)
+
+
+@pytest.mark.parametrize('spec', [(2, 70, 24), (1, 92, 24), (1, 140, 24), (3, 64, 20), (1, 66, 24)])
+def test_conv3d_valid_leaky_split_pg(ops, spec):
+    """the persistent two-team form of PCPatch48's 12 -> 24 k3 layer on a whole padded chunk (model/retrieval.py:222 of the reference evaluated fully
+    convolutionally; csrc/conv_valid_split_pg.hip), split form in and out: vs float64 torch on the values the split input stands for, and beside the
+    tile-per-workgroup kernel (same operands, v_mfma 32x32x16 instead of 16x16x32: equal to within the last bits of an fp32 sum).  Edges that leave ragged
+    tiles in every dimension (68 = 4 * 16 + 4 = 17 * 4; 62 ...), several samples (tiles of two samples in one workgroup's walk), cout = 20 (a padded group)."""
+    n, s, cout = spec
+    cin, k = 12, 3
+    gen = torch.Generator().manual_seed(sum(spec) + 6)
+    x, w, b = rnd(gen, n, cin, s, s, s), rnd(gen, cout, cin, k, k, k, scale=1 / np.sqrt(cin * k ** 3)), rnd(gen, cout)
+    xs = _to_split(ops, x.to(DEV))
+    assert ops.conv_valid_split_pg_supported((n, cin, s), cout, k, 1)
+    got = ops.conv3d_valid_leaky_split_pg(xs, ops.pack_convv_split_pg_weight(w.to(DEV), s, 1), b.to(DEV), cout, k, 1, 0.2)
+    assert isinstance(got, ops.SplitActs) and tuple(got.shape) == (n, cout, s - 2, s - 2, s - 2)
+    ref = F.leaky_relu(F.conv3d(_from_split(xs).double().cpu(), w.double(), b.double()), 0.2)
+    err = (_from_split(got).double().cpu() - ref).abs()
+    print(f'valid split pg {spec}: rms {err.pow(2).mean().sqrt():.3e} max {err.max():.3e}')
+    assert err.max() <= 1e-5
+    if cout % 4 == 0 and ops.conv_valid_split_supported(x.to(DEV), cout, k, 1):
+        v1 = ops.conv3d_valid_leaky_split(xs, ops.pack_convv_split_weight(w.to(DEV), s, 1), b.to(DEV), cout, k, 1, 0.2, out_split=True)
+        e1 = (_from_split(v1).double().cpu() - ref).abs()
+        assert err.pow(2).mean().sqrt() <= 1.05 * e1.pow(2).mean().sqrt() and err.max() <= 1.25 * e1.max()
+        assert (_from_split(v1) - _from_split(got)).abs().max() <= 4e-6
+
+
+def test_conv3d_valid_leaky_split_pg_refuses_what_it_was_not_built_for(ops):
+    """only the instantiation built: 12 -> 17..24 couts in fours, k = 3, stride 1, even edges 64..254; a LeakyReLU slope outside [0, 1] is an error (max form)"""
+    for shape, cout, k, stride in [((1, 12, 141), 24, 3, 1), ((1, 12, 60), 24, 3, 1), ((1, 24, 138), 48, 3, 2), ((1, 12, 140), 16, 3, 1), ((1, 12, 140), 24, 5, 1),
+                                   ((1, 8, 140), 24, 3, 1)]:
+        assert not ops.conv_valid_split_pg_supported(shape, cout, k, stride), (shape, cout, k, stride)
+    gen = torch.Generator().manual_seed(3)
+    w, b = rnd(gen, 24, 12, 3, 3, 3).to(DEV), rnd(gen, 24).to(DEV)
+    with pytest.raises(ValueError):
+        ops.pack_convv_split_pg_weight(w, 141, 1)
+    xs = _to_split(ops, rnd(gen, 1, 12, 64, 64, 64).to(DEV))
+    wp = ops.pack_convv_split_pg_weight(w, 64, 1)
+    with pytest.raises(RuntimeError, match='slope'):
+        ops.conv3d_valid_leaky_split_pg(xs, wp, b, 24, 3, 1, 1.5)
+    with pytest.raises(TypeError):
+        ops.conv3d_valid_leaky_split_pg(rnd(gen, 1, 12, 64, 64, 64).to(DEV), wp, b, 24, 3, 1, 0.2)
+
+
+def test_patch_encoder_grid_layer_takes_the_persistent_form(ops):
+    """PCPatch48 on a padded 128^3 chunk (C5): layer 2 of the fully-convolutional evaluation runs through rf_conv3d_valid_leaky_split_pg, and the embeddings
+    are those of the route without it to within the encoder's own tolerance (2e-6 on unit-norm-scale outputs)"""
+    from model.retrieval import PCPatch48
+    torch.manual_seed(5)
+    m = PCPatch48(12, 64).to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    grid = rnd(gen, 1, 1, 144, 144, 144).to(DEV)
+    calls = []
+    orig = ops.conv3d_valid_leaky_split_pg
+    ops.conv3d_valid_leaky_split_pg = lambda *a, **kw: (calls.append(a[0].shape), orig(*a, **kw))[1]
+    try:
+        with torch.no_grad():
+            on = m.forward_grid(grid, 48, 32)
+            ops.USE_CONVV_PG = False
+            off = m.forward_grid(grid, 48, 32)
+    finally:
+        ops.USE_CONVV_PG = True
+        ops.conv3d_valid_leaky_split_pg = orig
+    assert calls == [torch.Size([1, 12, 140, 140, 140])]
+    assert tuple(on.shape) == (64, 64, 1, 1, 1)
+    assert (on - off).abs().max() <= 2e-6 * max(1.0, float(off.abs().max()))
+
+
 def test_split_form_tensor_layout(ops):
     """the split form is what include/rfuse.h says: [n][c/4][h | l][voxel][4 halves] with h = f16(x/16), l = f16((x/16 - h) * 2^11) -- read back from the
     VALU first layer and the split layer, against the fp32 outputs of the same calls"""

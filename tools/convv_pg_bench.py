@@ -1,6 +1,8 @@
 """Dev tool (GPU box): the persistent grid form of the split-operand valid conv (rf_conv3d_valid_leaky_split_pg) beside the tile-per-workgroup kernel
 (rf_conv3d_valid_leaky_split_ex, split form in and out) on PCPatch48's 12 -> 24 k3 layer: bit equality of the split-form outputs, then HIP-event times.
-usage: python tools/convv_pg_bench.py [n s] ...   (default: 2 70, 1 91, 16 140)"""
+usage: python tools/convv_pg_bench.py [n s] ...   (default: 2 70, 1 92, 16 140)
+Ablations / phase stamps need the dev build: python tools/build_variant.py pgdev conv_valid_split_pg.hip -DRF_PG_DEV, then
+RFUSE_LIB=tools/_haz/libpgdev.so RF_PG_ABLATE=<bits> python tools/convv_pg_bench.py 16 140   |   ... RF_PG_ABLATE=8 ... --stamps"""
 import sys
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'retrieval-fuse_amd'))
@@ -40,7 +42,7 @@ def from_split(xs):
 
 def main():
     a = [int(v) for v in sys.argv[1:]]
-    specs = [tuple(a[i:i + 2]) for i in range(0, len(a), 2)] or [(2, 70), (1, 91), (16, 140)]
+    specs = [tuple(a[i:i + 2]) for i in range(0, len(a), 2)] or [(2, 70), (1, 92), (16, 140)]
     cin, cout, k = 12, 24, 3
     for n, s in specs:
         g = torch.Generator().manual_seed(s)
@@ -84,7 +86,7 @@ def stamps():
     for _ in range(3):
         ops.conv3d_valid_leaky_split_pg(xs, wp, b, cout, k, 1, 0.2)
     torch.cuda.synchronize()
-    lib = ctypes.CDLL(_lib.LIB_PATH if hasattr(_lib, 'LIB_PATH') else os.path.join(os.path.dirname(_lib.__file__), 'librfuse_hip.so'))
+    lib = ctypes.CDLL(os.environ.get('RFUSE_LIB') or os.path.join(os.path.dirname(_lib.__file__), 'librfuse_hip.so'))
     buf = (ctypes.c_ulonglong * (1024 * 2 * 8))()
     assert lib.rft_pg_read_stamps(buf) == 0
     st = np.array(buf, dtype=np.uint64).reshape(1024, 2, 8).astype(np.int64)[:256]
