@@ -1075,7 +1075,9 @@ def test_patch_encoder_on_the_grid_equals_the_encoder_on_the_windows(ops, enc):
 @pytest.mark.parametrize('enc', [('PCPatch48', 12, 48, 32), ('Patch32', 8, 32, 16), ('Patch24V2', 8, 24, 16), ('Patch16', 8, 16, 16), ('PCPatch32', 12, 32, 32)])
 def test_split_form_between_the_encoder_layers_changes_no_bit(ops, enc):
     """activations kept in split form between valid-conv layers (the producer scales / clamps / splits once, the consumer's staging is a copy):
-    the same embeddings bit for bit as with fp32 tensors between the layers -- on the windows and on the grid"""
+    the same embeddings bit for bit as with fp32 tensors between the layers -- on the windows and on the grid.  (The persistent grid form of a layer is another
+    kernel with another MFMA shape -- equal to tolerance, test_patch_encoder_grid_layer_takes_the_persistent_form -- and is switched off here: this test is
+    about the hand-over format.)"""
     import model as rf_model
     name, nf, window, step = enc
     torch.manual_seed(6)
@@ -1085,11 +1087,15 @@ def test_split_form_between_the_encoder_layers_changes_no_bit(ops, enc):
     grid = rnd(gen, 2, 1, g, g, g).to(DEV)
     win = rnd(gen, 70, 1, window, window, window).to(DEV)
     res = {}
-    with torch.no_grad():
-        for flag in (False, True):
-            ops.USE_SPLIT_CHAIN = flag
-            res[flag] = (m(win), m.forward_grid(grid, window, step))
-    ops.USE_SPLIT_CHAIN = True
+    ops.USE_CONVV_PG = False
+    try:
+        with torch.no_grad():
+            for flag in (False, True):
+                ops.USE_SPLIT_CHAIN = flag
+                res[flag] = (m(win), m.forward_grid(grid, window, step))
+    finally:
+        ops.USE_SPLIT_CHAIN = True
+        ops.USE_CONVV_PG = True
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
 
 
