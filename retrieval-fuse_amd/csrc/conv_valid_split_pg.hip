@@ -18,7 +18,6 @@
 //       whose voxel lies outside the volume (ragged last tiles) or whose channel group is padding gets an out-of-range offset -- no branch.
 // Split form in and out only (rf_conv3d_valid_leaky_split_ex's in_split = out_split = 1: the layer sits between two layers that read / write it).
 #include "common.h"
-#include <stdlib.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -49,7 +48,7 @@ struct ConvPGArgs {
     int hdr;                        // ints of the image's table header
     unsigned tiles;                 // n * ntz * nty * ntx
 #ifdef RF_PG_DEV
-    int ablate;                     // dev build (tools/convv_pg_bench.py, RF_PG_ABLATE): 1 no epilogue, 2 no staging, 4 no k-loop, 8 stamps, 16 no stores
+    int ablate;                     // dev build (tools/convv_pg_bench.py, rft_pg_set_ablate): 1 no epilogue, 2 no staging, 4 no k-loop, 8 stamps, 16 no stores
 #endif
 };
 
@@ -146,10 +145,12 @@ struct PgTile {             // uniform: origin of a tile
 };
 }   // namespace
 
-// dev build (-DRF_PG_DEV): ablations and s_memtime at the phase borders of every workgroup's 9th round (RF_PG_ABLATE bit 3), both teams; tools/convv_pg_bench.py
+// dev build (-DRF_PG_DEV): ablations and s_memtime at the phase borders of every workgroup's 9th round (rft_pg_set_ablate bit 3), both teams; tools/convv_pg_bench.py
 #ifdef RF_PG_DEV
 #define PG_ABL(bit_) (a.ablate & (bit_))
 __device__ unsigned long long g_pg_stamps[1024 * 2 * 8];
+static int g_pg_ablate = 0;
+extern "C" void rft_pg_set_ablate(int bits) { g_pg_ablate = bits; }
 extern "C" int rft_pg_read_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pg_stamps), sizeof(g_pg_stamps)); }
 #define PG_STAMP(k_) do { if ((a.ablate & 8) && i == 8 && tw == 0 && lane == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_pg_stamps[(blockIdx.x * 2 + team) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
@@ -436,7 +437,7 @@ extern "C" int rf_conv3d_valid_leaky_split_pg(const void* x, int n, int cin, int
     a.n = n; a.x = reinterpret_cast<const unsigned char*>(x); a.wp = reinterpret_cast<const h8*>(w_packed); a.bias = bias; a.out = reinterpret_cast<unsigned char*>(out);
     a.slope = slope;
 #ifdef RF_PG_DEV
-    { const char* e = getenv("RF_PG_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    a.ablate = g_pg_ablate;
 #endif
     const size_t tiles64 = (size_t)a.ntz * a.nty * a.ntx * n;
     RF_REQUIRE(tiles64 < (1ull << 31), RF_E_INVALID, "rf_conv3d_valid_leaky_split_pg: too many tiles (%zu)", tiles64);

@@ -2,7 +2,7 @@
 (rf_conv3d_valid_leaky_split_ex, split form in and out) on PCPatch48's 12 -> 24 k3 layer: bit equality of the split-form outputs, then HIP-event times.
 usage: python tools/convv_pg_bench.py [n s] ...   (default: 2 70, 1 92, 16 140)
 Ablations / phase stamps need the dev build: python tools/build_variant.py pgdev conv_valid_split_pg.hip -DRF_PG_DEV, then
-RFUSE_LIB=tools/_haz/libpgdev.so RF_PG_ABLATE=<bits> python tools/convv_pg_bench.py 16 140   |   ... RF_PG_ABLATE=8 ... --stamps"""
+RFUSE_LIB=tools/_haz/libpgdev.so python tools/convv_pg_bench.py --ablate <bits> 16 140   |   ... --ablate 8 --stamps"""
 import sys
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'retrieval-fuse_amd'))
@@ -73,7 +73,7 @@ def main():
 
 
 def stamps():
-    """RF_PG_ABLATE=8 python tools/convv_pg_bench.py --stamps: phase borders of every workgroup's 9th round"""
+    """--ablate 8 --stamps (dev build): phase borders of every workgroup's 9th round"""
     import ctypes
     import numpy as np
     from rfuse import _lib
@@ -98,6 +98,11 @@ def stamps():
 
 
 if __name__ == '__main__':
+    if '--ablate' in sys.argv:
+        import ctypes
+        i = sys.argv.index('--ablate')
+        ctypes.CDLL(os.environ['RFUSE_LIB']).rft_pg_set_ablate(int(sys.argv[i + 1]))
+        del sys.argv[i:i + 2]
     if '--stamps' in sys.argv:
         stamps()
         sys.exit(0)
