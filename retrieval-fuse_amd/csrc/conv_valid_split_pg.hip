@@ -18,6 +18,7 @@
 //       whose voxel lies outside the volume (ragged last tiles) or whose channel group is padding gets an out-of-range offset -- no branch.
 // Split form in and out only (rf_conv3d_valid_leaky_split_ex's in_split = out_split = 1: the layer sits between two layers that read / write it).
 #include "common.h"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -376,45 +377,45 @@ __global__ __launch_bounds__(PG_NT, 1) void k_convv_split_pg(ConvPGArgs a) {
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.nn * obytes, 0, (int)obytes, 0x00020000);
             const unsigned org = (unsigned)((cur.z0 * so + cur.y0) * so + cur.x0) * 8u;
             const unsigned lsoff = (unsigned)ovol * 8u;
-            const bool odd = (j & 1) != 0;
-            const bool yx_in = tw < ylim && j < xlim;
+            // 8-byte stores, no lane exchange: a 16-byte form (lane pairs trading halves over DPP) was measured -- its 8 extra VALU instructions per store cost more
+            // issue slots beside the other team's MFMAs than the halved store count returned.  INTERIOR tiles (four of five; uniform) skip the per-lane bounds.
+            auto epilogue = [&](auto interior_tag) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
+                const bool yx_in = INTERIOR || (tw < ylim && j < xlim);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const bool vin = yx_in && 2 * mb + zh < zlim;
-                const unsigned vox = org + (unsigned)(eo0 + mb * 2 * so * so) * 8u + (odd ? lsoff - 8u : 0u);
+                for (int mb = 0; mb < MB; ++mb) {
+                    const bool vin = INTERIOR || (yx_in && 2 * mb + zh < zlim);
+                    const unsigned vox = org + (unsigned)(eo0 + mb * 2 * so * so) * 8u;
 #pragma unroll
-                for (int rq = 0; rq < NRQ; ++rq) {
-                    const int grp = 2 * rq + hk;
-                    // hi + lo / 2^11 + bias, LeakyReLU, the consumer's 1 / 16, clamp, split -- on register PAIRS (v_pk_*_f32); the 1 / 16 is applied first: exact,
-                    // every later step scales with it
-                    h4 hh, ll;
+                    for (int rq = 0; rq < NRQ; ++rq) {
+                        const int grp = 2 * rq + hk;
+                        // hi + lo / 2^11 + bias, LeakyReLU, the consumer's 1 / 16, clamp, split -- on register PAIRS (v_pk_*_f32); the 1 / 16 is applied first:
+                        // exact, every later step scales with it
+                        h4 hh, ll;
 #pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const f32x2 h2 = {hi[mb][4 * rq + r], hi[mb][4 * rq + r + 1]}, l2 = {lo[mb][4 * rq + r], lo[mb][4 * rq + r + 1]}, b2 = {bz_[rq][r], bz_[rq][r + 1]};
-                        const f32x2 t0 = __builtin_elementwise_fma(l2, (f32x2){PG_ACT_SCALE / PG_LO, PG_ACT_SCALE / PG_LO}, h2 * (f32x2){PG_ACT_SCALE, PG_ACT_SCALE}) + b2;
-                        const f32x2 ts = t0 * (f32x2){a.slope, a.slope};
-                        f32x2 t;
-                        t.x = __builtin_amdgcn_fmed3f(fmaxf(t0.x, ts.x), -65504.f, 65504.f);
-                        t.y = __builtin_amdgcn_fmed3f(fmaxf(t0.y, ts.y), -65504.f, 65504.f);
-                        const f32x2 tl = t * (f32x2){PG_LO, PG_LO};
-                        const _Float16 ha = (_Float16)t.x, hb = (_Float16)t.y;
-                        hh[r] = ha; hh[r + 1] = hb;
-                        ll[r] = (_Float16)fmaf(-PG_LO, (float)ha, tl.x);
-                        ll[r + 1] = (_Float16)fmaf(-PG_LO, (float)hb, tl.y);
+                        for (int r = 0; r < 4; r += 2) {
+                            const f32x2 h2 = {hi[mb][4 * rq + r], hi[mb][4 * rq + r + 1]}, l2 = {lo[mb][4 * rq + r], lo[mb][4 * rq + r + 1]}, b2 = {bz_[rq][r], bz_[rq][r + 1]};
+                            const f32x2 t0 = __builtin_elementwise_fma(l2, (f32x2){PG_ACT_SCALE / PG_LO, PG_ACT_SCALE / PG_LO}, h2 * (f32x2){PG_ACT_SCALE, PG_ACT_SCALE}) + b2;
+                            const f32x2 ts = t0 * (f32x2){a.slope, a.slope};
+                            f32x2 t;
+                            t.x = __builtin_amdgcn_fmed3f(fmaxf(t0.x, ts.x), -65504.f, 65504.f);
+                            t.y = __builtin_amdgcn_fmed3f(fmaxf(t0.y, ts.y), -65504.f, 65504.f);
+                            const f32x2 tl = t * (f32x2){PG_LO, PG_LO};
+                            const _Float16 ha = (_Float16)t.x, hb = (_Float16)t.y;
+                            hh[r] = ha; hh[r + 1] = hb;
+                            ll[r] = (_Float16)fmaf(-PG_LO, (float)ha, tl.x);
+                            ll[r + 1] = (_Float16)fmaf(-PG_LO, (float)hb, tl.y);
+                        }
+                        unsigned vo = (unsigned)grp * 2u * lsoff + vox;
+                        if (!INTERIOR) vo = (vin && grp * 4 < a.cout) ? vo : 0xfffffff0u;
+                        if (PG_ABL(16)) vo = hh[0] == (_Float16)123.0f ? vo : 0xfffffff0u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), ro, (int)vo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), ro, (int)vo, (int)lsoff, 0);
                     }
-                    // 16-byte stores (the store path is issue-bound: half as many, twice as wide): lane pairs (j, j ^ 1) trade halves -- the even lane writes the
-                    // h slots of voxels j, j + 1, the odd lane the l slots of voxels j - 1, j (an even number of a row's voxels lies in the volume: so even)
-                    const u32x2 hw = __builtin_bit_cast(u32x2, hh), lw = __builtin_bit_cast(u32x2, ll);
-                    const u32x2 give = odd ? hw : lw;
-                    u32x2 recv;
-                    recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);        // quad_perm [1, 0, 3, 2]
-                    recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
-                    const u32x4 ow = odd ? (u32x4){recv.x, recv.y, lw.x, lw.y} : (u32x4){hw.x, hw.y, recv.x, recv.y};
-                    unsigned vo = (vin && grp * 4 < a.cout) ? (unsigned)grp * 2u * lsoff + vox : 0xfffffff0u;
-                    if (PG_ABL(16)) vo = hh[0] == (_Float16)123.0f ? vo : 0xfffffff0u;
-                    __builtin_amdgcn_raw_buffer_store_b128(ow, ro, (int)vo, 0, 0);
                 }
-            }
+            };
+            if (cur.valid && zlim == a.tz && ylim == a.ty && xlim == a.tx && (a.cout >> 2) >= 2 * NRQ) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
         }
         PG_STAMP(4);
         cur = nxt;
