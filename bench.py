@@ -259,7 +259,8 @@ def parity_of_bench_batch(cfg, eng, state, db_host, raws, raw_dev, chunks=(0, 17
 
 
 # entry points that are another one's launch with a different hand-over layout: same argument list, same work
-ENTRY_ALIAS = {'rf_conv3d_up_split_presplit_pm': 'rf_conv3d_up_split_presplit', 'rf_conv3d_split_pre_pm_k3_relu': 'rf_conv3d_split_pre_k3_relu'}
+ENTRY_ALIAS = {'rf_conv3d_up_split_presplit_pm': 'rf_conv3d_up_split_presplit', 'rf_conv3d_split_pre_pm_k3_relu': 'rf_conv3d_split_pre_k3_relu',
+               'rf_conv3d_valid_leaky_split_pg': 'rf_conv3d_valid_leaky_split'}       # (n, cin, s, cout, k, stride): the persistent grid form of the same layer
 
 
 def kernel_bytes(name, a, nulls=()):
@@ -738,6 +739,11 @@ def main():
             # HBM traffic of the dominant kernel: OFFLINE PMC (separate rocprofv3 --pmc passes of this same command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
             # summary committed under profiles/), scaled per sample to this launch; None when the committed summary is of another kernel
             traffic, pmc_name = None, None
+            other = REPO / 'profiles' / ('r06_dominant_kernel_%s.json' % args.config)      # a dominant launch that is not a padded 3^3 conv (C5): matched by entry + arguments
+            if shape is None and other.exists():
+                pmc = json.loads(other.read_text())
+                if pmc.get('entry') == entry and pmc.get('args') == list(ints)[:len(pmc.get('args', []))]:
+                    traffic, pmc_name = pmc['traffic_bytes_per_launch'], other.name
             for pmc_file in (REPO / 'profiles' / 'r06_dominant_kernel.json', REPO / 'profiles' / 'r05_dominant_kernel.json', REPO / 'profiles' / 'r04_dominant_kernel.json'):
                 if not pmc_file.exists() or shape is None:
                     continue
