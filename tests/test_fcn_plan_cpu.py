@@ -42,3 +42,21 @@ def test_grid_plan(name, nf, window, step):
 def test_known_plans():
     assert rf_model.PCPatch48(12, 64).grid_plan(48, 32, 4) == (4, 9, 8)       # 144 -> 140 -> 138 -> 68 -> 33, windows of 9^3 every 8
     assert rf_model.Patch32(8, 64).grid_plan(32, 16, 4) == (4, 10, 8)         # 80 -> 76 -> 74 -> 36 -> 34, windows of 10^3 every 8
+
+
+def test_persistent_grid_form_plan_on_the_host():
+    """CPU: which layers rf_conv3d_valid_leaky_split_pg takes and how big its weight image is are host-side decisions of the C-ABI library (no GPU call):
+    the 12 -> 17..24 couts (in fours) k = 3 stride-1 layer on even edges 64..254 -- PCPatch32 / 48 / 64's second layer on a padded chunk (csrc/conv_valid_split_pg.hip)"""
+    from rfuse import _lib
+    lib = _lib.load()
+    ok = lib.rf_conv3d_valid_split_pg_supported
+    assert ok(16, 12, 140, 24, 3, 1) and ok(1, 12, 64, 20, 3, 1) and ok(3, 12, 254, 24, 3, 1)
+    for n, cin, s, cout, k, stride in [(16, 12, 141, 24, 3, 1), (16, 12, 62, 24, 3, 1), (16, 12, 256, 24, 3, 1), (16, 8, 140, 24, 3, 1), (16, 12, 140, 16, 3, 1),
+                                       (16, 12, 140, 28, 3, 1), (16, 12, 140, 22, 3, 1), (16, 12, 140, 24, 5, 1), (16, 12, 140, 24, 3, 2), (0, 12, 140, 24, 3, 1)]:
+        assert not ok(n, cin, s, cout, k, stride), (n, cin, s, cout, k, stride)
+    # image = table of the 21 k-steps' 84 K slot offsets (ints) + 21 k-steps x (h, l) x 64 lanes x 16 bytes of 32 x 16 weight fragments; 0 when the form does not take the layer
+    assert lib.rf_convv_split_pg_packed_bytes(24, 12, 3, 140, 1) == 84 * 4 + 21 * 2 * 64 * 16
+    assert lib.rf_convv_split_pg_packed_bytes(24, 12, 3, 141, 1) == 0
+    # the encoder's own plan sends exactly that layer of PCPatch48 on C5's 144^3 padded chunk there: layer 2 of the 4 on the grid reads a 140^3 volume of 12 channels
+    enc = rf_model.PCPatch48(12, 64)
+    assert enc.grid_plan(48, 32, 4)[0] == 4 and (enc.SPEC[1][0] * 12, enc.SPEC[1][1] * 12, enc.SPEC[1][2], enc.SPEC[1][3]) == (12, 24, 3, 1)
