@@ -487,6 +487,12 @@ int rf_gather_patches(const float* db_volumes, int64_t n_scenes, const int32_t* 
 int rf_gather_patches_f16(const void* db_volumes_f16, int64_t n_scenes, const int32_t* meta, int chunks, int K,
                           float trunc_fill, float trunc_ratio, float mean, float stddev, int layout,
                           float* out, void* stream);
+/* create_retrieval_from_mapping for an OVERLAPPING patch grid of one scene (util/retrieval.py:145-164 with dataset.no_overlap False; :156: a patch overwrites its box of
+ * retrieval k only while the mean of the distances stored there is above its own).  mapping [P][K][8] float32 rows (scene index, X0, X1, Y0, Y1, Z0, Z1, distance) of the
+ * P patches patch_from_scene_lookup holds, in its order; boxes [P][6] int32 their unpadded target boxes (xx0, xx1, yy0, yy1, zz0, zz1) in the scene; db_volumes
+ * [n_scenes][64^3] float32 (half = 0) or float16 (half = 1); out, dist_ws [K][sx][sy][sz] float32 (dist_ws: workspace).  Sequential over the patches by construction. */
+int rf_compose_overlap(const void* db_volumes, int half, int64_t n_scenes, const float* mapping, const int32_t* boxes, int P, int K, int sx, int sy, int sz,
+                       float trunc_fill, float trunc_ratio, float* out, float* dist_ws, void* stream);
 
 /* out[m][width] = src[idx[m]][width] (width % 4 == 0): row gather used to fetch cached, query-independent retrieval
  * backbone features of database patches (an optional serving mode; the reference recomputes them,

@@ -383,6 +383,60 @@ def gen_retrieval_fixture(seed=5):
     print('retrieval fixture', map_train.shape, composed['train'].shape)
 
 
+def gen_compose_overlap_fixture(seed=11):
+    """create_retrieval_from_mapping on an OVERLAPPING patch grid (stride 8 < patch 16: 7^3 patches per 64^3 scene; dataset.no_overlap False, the branch at
+    util/retrieval.py:156 decides by the mean of the stored distances): random database boxes and distances, a few sentinel hits, some patches visited with equal
+    distances.  The margin between every box mean and the distance it is compared with is asserted (the reference means in float32, the restatement and the
+    device in float64)."""
+    ref_ret = import_reference_util_retrieval()
+    from dataset.scene import SceneHandler
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    K = cfg['K']
+    db = synthetic.make_database(seed, cfg, 64 * 6)
+    scene_names = ['scene%03d' % i for i in range(db['n_scenes'])]
+    rng = np.random.default_rng(seed)
+    ext = SceneHandler.get_extents_for_size([64, 64, 64], 16, 8, 8)            # padded extents, context 8
+    P = ext.shape[0]
+    q_scene = 2
+    names = [SceneHandler.get_name_from_extent(scene_names[q_scene], ext[i]) for i in range(P)]
+    mapping = np.zeros((P, K, 8), dtype=np.float32)
+    pick = rng.integers(0, db['meta'].shape[0] - 1, size=(P, K))
+    mapping[:, :, :7] = db['meta'][pick].astype(np.float32)
+    # distances up to 60: a box's last octant is never covered by an earlier patch of this grid (its stored distances are the initial 100), so means stay >= 12.5 --
+    # both outcomes of the comparison at :156 occur only with distances on that scale
+    mapping[:, :, 7] = rng.uniform(0.05, 60.0, size=(P, K)).astype(np.float32)
+    mapping[rng.integers(0, P, 12), rng.integers(0, K, 12), 0] = -1.0           # sentinel hits (:157-158)
+    mapping[40:60, :, 7] = np.float32(20.0)                                     # a run of equal distances
+    ds_train = _FakeDataset(db['volumes'], scene_names, trunc_t, {})
+    ds = _FakeDataset(db['volumes'], scene_names, trunc_t, {scene_names[q_scene]: names})
+    ds.no_overlap = False
+    with tempfile.TemporaryDirectory() as td:
+        tree = Path(td)
+        (tree / 'index.json').write_text(json.dumps(scene_names))
+        got = ref_ret.create_retrieval_from_mapping(scene_names[q_scene], {n: mapping[i] for i, n in enumerate(names)}, K, ds_train, ds, tree).numpy()
+    boxes = np.stack([np.asarray(ds_train.unpad(*ext[i].tolist()), dtype=np.int32) for i in range(P)])
+    # margin of every decision, replayed in float64
+    dist = np.full((K, 64, 64, 64), 100.0, dtype=np.float32)
+    margin, taken = np.inf, 0
+    for k in range(K):
+        for p in range(P):
+            b = boxes[p]
+            m = dist[k, b[0]:b[1], b[2]:b[3], b[4]:b[5]].astype(np.float64).mean()
+            if m != float(mapping[p, k, 7]):
+                margin = min(margin, abs(m - float(mapping[p, k, 7])) / max(m, 1e-9))
+            if m > float(mapping[p, k, 7]):
+                dist[k, b[0]:b[1], b[2]:b[3], b[4]:b[5]] = mapping[p, k, 7]
+                taken += 1
+    assert margin > 1e-5, margin
+    from oracle import refpath
+    want = refpath.compose_retrieval_overlap(mapping, boxes, db['volumes'], K, trunc_t)
+    assert np.array_equal(want, got), 'oracle restatement differs from the reference'
+    save_fixture('compose_overlap', seed=seed, q_scene=q_scene, n_db_patches=64 * 6, mapping=mapping, boxes=boxes, extents=ext, taken=taken, visited=P * K,
+                 min_relative_margin=margin, db_sha=sha(db['meta'], db['emb'], db['volumes']), composed_sha=sha(got), composed_sub=got[:, ::4, ::4, ::4])
+    print('compose-overlap fixture', got.shape, 'copies', taken, 'of', P * K, 'margin %.2e' % margin)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
@@ -397,6 +451,7 @@ def main():
     for c in ('C1', 'C5'):
         gen_dbrow_fixture(ref_model, c)
     gen_retrieval_fixture()
+    gen_compose_overlap_fixture()
     gen_combine_fixture()
     gen_loss_fixture()
 

@@ -341,6 +341,31 @@ def compose_retrieval(mapping, db_volumes, K, target_trunc, trunc_ratio=1.0, pat
     return out
 
 
+def compose_retrieval_overlap(mapping, boxes, db_volumes, K, target_trunc, trunc_ratio=1.0, size=(64, 64, 64), no_overlap=False):
+    """create_retrieval_from_mapping (util/retrieval.py:145-164) for ANY patch grid of one scene, the OVERLAPPING one included (patch stride < patch size,
+    ``dataset.no_overlap`` False): the patches are visited in the order of ``patch_from_scene_lookup``, and patch p overwrites its box of retrieval k only while the
+    MEAN of the distances stored in that box is above its own distance (:156) -- an order-dependent sequential reduction.
+    mapping [P,K,8] (scene index, X0, X1, Y0, Y1, Z0, Z1, distance) of the P patches the lookup holds, in its order; boxes [P,6] their unpadded target boxes
+    (xx0, xx1, yy0, yy1, zz0, zz1) in the scene (:155).  Returns [K, *size] float32.  The mean is taken in float64 here (torch takes it in float32 with its own
+    summation tree: the two agree unless a mean lies within rounding of the patch's distance; oracle/gen_golden.py asserts a margin for the fixture)."""
+    out = np.ones((K,) + tuple(size), dtype=np.float32) * np.float32(target_trunc)
+    dist = np.ones((K,) + tuple(size), dtype=np.float32) * np.float32(100)
+    for k in range(K):
+        for p in range(mapping.shape[0]):
+            x0, x1, y0, y1, z0, z1 = mapping[p, k, 1:7].astype(np.int32).tolist()
+            cur = mapping[p, k, 7]
+            xx0, xx1, yy0, yy1, zz0, zz1 = [int(v) for v in boxes[p]]
+            if no_overlap or dist[k, xx0:xx1, yy0:yy1, zz0:zz1].astype(np.float64).mean() > float(cur):
+                sidx = int(mapping[p, k, 0])
+                if sidx >= 0:
+                    src = db_volumes[sidx][x0:x1, y0:y1, z0:z1]
+                else:
+                    src = np.ones(tuple(size), dtype=np.float64)[x0:x1, y0:y1, z0:z1] * target_trunc
+                out[k, xx0:xx1, yy0:yy1, zz0:zz1] = (torch.from_numpy(np.ascontiguousarray(src)) * float(trunc_ratio)).numpy()
+                dist[k, xx0:xx1, yy0:yy1, zz0:zz1] = float(cur)
+    return out
+
+
 def knn_cdist_f32(queries, db_emb, n_neighbors):
     """fp32 multi-threaded exact kNN (torch.cdist + topk) -- the CPU-baseline kNN named in BASELINE.md section 3.
     Used ONLY for timing the CPU baseline in bench.py; parity checks use knn_exact (float64)."""

@@ -1247,6 +1247,74 @@ extern "C" int rf_gather_patches_f16(const void* db_volumes_f16, int64_t n_scene
                                     stream, "rf_gather_patches_f16");
 }
 
+// create_retrieval_from_mapping for patch grids WITH overlap (reference util/retrieval.py:145-164 with dataset.no_overlap False: patch stride < patch size).  The patches
+// of a scene are visited in the order of patch_from_scene_lookup; patch p overwrites its box of retrieval k only while the MEAN of the distances stored in that box is
+// above its own distance (:156) -- an order-dependent sequential reduction, so one workgroup per retrieval k walks the patches in order (an offline step of the
+// reference: retrievals_to_disk('compose'); the hot path's chunks have non-overlapping patches and use k_gather_patches).  The box mean is accumulated in float64
+// in a fixed order (thread-strided partial sums, then a tree over the 256 partials).  dist: [K][sx][sy][sz] workspace.
+template <typename T>
+__global__ __launch_bounds__(256) void k_compose_overlap(const T* __restrict__ vols, long long n_scenes, const float* __restrict__ mapping, const int* __restrict__ boxes,
+                                                         int P, int K, int sx, int sy, int sz, float trunc_fill, float ratio, float* __restrict__ out,
+                                                         float* dist) {
+    __shared__ double part[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const size_t vol = (size_t)sx * sy * sz;
+    float* o = out + (size_t)k * vol;
+    volatile float* d = dist + (size_t)k * vol;                     // written and re-read by different threads of the workgroup: not through the L1
+    for (size_t i = tid; i < vol; i += 256) { o[i] = trunc_fill; d[i] = 100.f; }
+    __threadfence();
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {
+        const int* b = boxes + (size_t)p * 6;
+        const float* m = mapping + ((size_t)p * K + k) * 8;
+        const int x0 = b[0], ex = b[1] - b[0], y0 = b[2], ey = b[3] - b[2], z0 = b[4], ez = b[5] - b[4];
+        const int n = ex * ey * ez;
+        const float cur = m[7];
+        double sum = 0.0;
+        for (int i = tid; i < n; i += 256) {
+            const int dz = i % ez, dy = (i / ez) % ey, dx = i / (ez * ey);
+            sum += (double)d[((size_t)(x0 + dx) * sy + (y0 + dy)) * sz + (z0 + dz)];
+        }
+        part[tid] = sum;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) part[tid] += part[tid + s];
+            __syncthreads();
+        }
+        const bool take = n > 0 && part[0] / (double)n > (double)cur;      // uniform
+        __syncthreads();                                                    // everyone has read part[0]
+        if (take) {
+            const int scene = (int)m[0], X0 = (int)m[1], Y0 = (int)m[3], Z0 = (int)m[5];
+            const bool have = scene >= 0 && scene < n_scenes;
+            const T* src = vols + (size_t)(have ? scene : 0) * 64 * 64 * 64;
+            for (int i = tid; i < n; i += 256) {
+                const int dz = i % ez, dy = (i / ez) % ey, dx = i / (ez * ey);
+                float v = trunc_fill;
+                if (have) v = (float)src[((size_t)(X0 + dx) * 64 + (Y0 + dy)) * 64 + (Z0 + dz)];
+                const size_t at = ((size_t)(x0 + dx) * sy + (y0 + dy)) * sz + (z0 + dz);
+                o[at] = __fmul_rn(v, ratio);
+                d[at] = cur;
+            }
+            __threadfence();
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int rf_compose_overlap(const void* db_volumes, int half, int64_t n_scenes, const float* mapping, const int32_t* boxes, int P, int K, int sx, int sy, int sz,
+                                  float trunc_fill, float trunc_ratio, float* out, float* dist_ws, void* stream) {
+    RF_REQUIRE(db_volumes && mapping && boxes && out && dist_ws && n_scenes > 0 && P >= 0 && K > 0 && sx > 0 && sy > 0 && sz > 0, RF_E_INVALID,
+               "rf_compose_overlap: bad arguments");
+    if (half)
+        hipLaunchKernelGGL(k_compose_overlap<_Float16>, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(db_volumes),
+                           (long long)n_scenes, mapping, boxes, P, K, sx, sy, sz, trunc_fill, trunc_ratio, out, dist_ws);
+    else
+        hipLaunchKernelGGL(k_compose_overlap<float>, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(db_volumes),
+                           (long long)n_scenes, mapping, boxes, P, K, sx, sy, sz, trunc_fill, trunc_ratio, out, dist_ws);
+    RF_CHECK_LAUNCH("rf_compose_overlap");
+    return RF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------- row gather
 // out[m][:] = src[idx[m]][:] for rows of `width` floats (width % 4 == 0): fetches cached per-database-patch retrieval
 // features (query independent, see rfuse/database.py:build_feature_cache).  One workgroup per output row.

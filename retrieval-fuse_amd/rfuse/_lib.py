@@ -156,6 +156,7 @@ SIGNATURES = {
     'rf_mc_emit': (c_i, [c_fp, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_fp, c_p, c_p]),
     'rf_gather_patches': (c_i, [c_fp, c_i64, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_fp, c_p]),
     'rf_gather_patches_f16': (c_i, [c_p, c_i64, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_fp, c_p]),
+    'rf_compose_overlap': (c_i, [c_p, c_i, c_i64, c_fp, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp, c_p]),
     'rf_paste_chunks': (c_i, [c_fp, c_i, c_p, c_p, c_i, c_i64, c_i64, c_i, c_p, c_p]),
 }
 

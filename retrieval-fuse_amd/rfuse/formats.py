@@ -141,12 +141,43 @@ def retrieval_mapping(database, q, scene_names, K, index=None, ignore_patches_fr
     return mapping_to_dict([names[i] for i in kept], meta_h[kept], dist_h[kept])
 
 
-def compose_scene(database, mapping, scene, K, trunc_fill, trunc_ratio=1.0, patch_size=16, context=8, no_overlap=True):
+def scene_patch_extents(size, patch_size=16, context=8, stride=16):
+    """Padded target extents [P, 6] of a scene's patches in the reference's enumeration order (dataset/scene.py:152-160 get_extents_for_size)."""
+    axes = [np.linspace(0, s - patch_size, (s - patch_size) // stride + 1).astype(np.int32) for s in size]
+    x, y, z = np.meshgrid(*axes, indexing='ij')
+    w = patch_size + 2 * context
+    return np.stack([x.ravel(), x.ravel() + w, y.ravel(), y.ravel() + w, z.ravel(), z.ravel() + w], axis=1).astype(np.int32)
+
+
+def compose_scene(database, mapping, scene, K, trunc_fill, trunc_ratio=1.0, patch_size=16, context=8, no_overlap=True, stride=None, size=(64, 64, 64),
+                  patch_names=None):
     """``create_retrieval_from_mapping`` (util/retrieval.py:145-164) for one 64^3 scene chunk on the device: the K retrieval volumes [K,64,64,64] float32
     (numpy), raw values (times ``trunc_ratio`` = query trunc / database trunc, :159).  Patches absent from ``mapping`` (occupancy filter) and sentinel hits
-    (scene_idx < 0, :157-158) keep the truncation fill (:148)."""
+    (scene_idx < 0, :157-158) keep the truncation fill (:148).
+
+    ``no_overlap=False`` (a patch grid with ``stride`` < ``patch_size``, ``dataset.no_overlap`` False): the branch at :156 -- the scene's patches are visited in
+    the order of ``patch_names`` (default: the reference's enumeration of the grid, restricted to the names ``mapping`` holds) and a patch overwrites its box of
+    retrieval k only while the mean distance stored in that box is above its own (``rfuse.ops.compose_overlap``)."""
     import torch
     from . import ops
+    if not no_overlap:
+        stride = patch_size if stride is None else stride
+        if patch_names is None:
+            patch_names = [patch_name(scene, tuple(int(v) for v in e)) for e in scene_patch_extents(size, patch_size, context, stride)]
+        names = [n for n in patch_names if n in mapping and mapping[n] is not None]
+        if not names:
+            return np.full((K,) + tuple(size), np.float32(trunc_fill), dtype=np.float32)
+        rows = np.stack([np.asarray(mapping[n], dtype=np.float32)[:K, :8] for n in names])
+        ext = np.array([[int(v) for v in n.split('--')[1].split('_')] for n in names], dtype=np.int32)
+        boxes = ext.copy()
+        boxes[:, 1::2] -= 2 * context                              # unpad (dataset/patched_scene_dataset.py:103-107): the padded extent's target box in the scene
+        if (boxes[:, None, 1::2] - boxes[:, None, 0::2] != (rows[:, :, 2:7:2] - rows[:, :, 1:6:2]).astype(np.int32)).any():
+            raise ValueError('compose_scene: a patch box and its database box differ in size')
+        if (boxes[:, 0::2] < 0).any() or (boxes[:, 1::2] > np.asarray(size)[None, :]).any():
+            raise ValueError('compose_scene: a patch box leaves the scene')
+        out = ops.compose_overlap(database.volumes, torch.from_numpy(rows).to(database.device), torch.from_numpy(boxes).to(database.device), K, size, trunc_fill,
+                                  trunc_ratio)
+        return out.cpu().numpy()
     names = chunk_patch_names(scene, patch_size, context)
     rows = np.zeros((64, K, 7), dtype=np.int32)
     rows[:, :, 0] = -1
@@ -167,7 +198,7 @@ def compose_scene(database, mapping, scene, K, trunc_fill, trunc_ratio=1.0, patc
 
 
 def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=32, use_target_for_feats=False, fenc_target=None, target_chunks=None,
-                       truncations_by_split=None):
+                       truncations_by_split=None, no_overlap=True, patch_stride=None):
     """The reference's ``retrievals_to_disk`` (util/retrieval.py:210-248) driven by the device path.
 
     ``splits``: {'train': (scene_names, input_chunks[, patch_mask]), 'val': (...)} -- ``input_chunks`` [n,S,S,S] raw low-resolution chunks (one per scene
@@ -182,6 +213,9 @@ def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=3
       mode 'compose'  reads the two map files back and writes ``compose/<scene>.npz`` for every scene of both splits (:239-248).  Fill value and scale follow the
                       reference (:148,159): a split's volumes are filled with THAT split's target truncation and database patches are scaled by split
                       truncation / train truncation -- ``truncations_by_split`` {'train': t, 'val': t} when the two datasets differ (default: the config's)
+
+    ``no_overlap`` / ``patch_stride``: the dataset's ``no_overlap`` flag (dataset/patched_scene_dataset.py:113-115) and target patch stride for mode 'compose' -- with
+    overlapping patches the branch at util/retrieval.py:156 decides patch by patch, in order (``compose_scene(no_overlap=False)``).
 
     -> the list of files written."""
     import torch
@@ -222,7 +256,8 @@ def retrievals_to_disk(mode, engine, retrievals_dir, splits, index=None, batch=3
             trunc_split = float(tby.get(split, trunc_t))
             mapping = load_mapping(retrievals_dir / ('map_%s.npy' % split))
             for scene in splits[split][0]:
-                save_compose(retrievals_dir, scene, compose_scene(engine.database, mapping, scene, K, trunc_split, trunc_split / trunc_train, ps, ctx))
+                save_compose(retrievals_dir, scene, compose_scene(engine.database, mapping, scene, K, trunc_split, trunc_split / trunc_train, ps, ctx, no_overlap=no_overlap,
+                                                                   stride=patch_stride))
                 written.append(retrievals_dir / 'compose' / ('%s.npz' % scene))
     else:
         raise ValueError("mode must be 'map' or 'compose' (the reference's 'evaluate' computes IoU / Chamfer metrics: out of scope)")

@@ -1294,10 +1294,11 @@ def gather_rows(src, idx):
 
 def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, std, layout, no_overlap=True):
     """create_retrieval_from_mapping's copy loop (reference util/retrieval.py:145-164) for patch grids WITHOUT overlap (stride == patch size: every shipped
-    config, dataset/patched_scene_dataset.py:113-115), where the branch at :156 always copies.  The overlapping branch (a later patch overwrites a voxel only
-    if its distance is below the mean stored distance of its box: an order-dependent reduction) is not built and is refused, not assumed."""
+    config, dataset/patched_scene_dataset.py:113-115), where the branch at :156 always copies.  The overlapping branch (a later patch overwrites its box only
+    while the mean stored distance of that box is above its own: an order-dependent reduction) is compose_overlap below, scene by scene."""
     if not no_overlap:
-        raise NotImplementedError('gather_patches: only the no_overlap branch of create_retrieval_from_mapping (util/retrieval.py:156) is built')
+        raise NotImplementedError('gather_patches: the per-chunk gather is the no_overlap branch of create_retrieval_from_mapping (util/retrieval.py:156); an '
+                                  'overlapping patch grid is composed scene by scene, in patch order: ops.compose_overlap / formats.compose_scene(no_overlap=False)')
     half = db_volumes.dtype == torch.float16                    # the voxel store in the reference's own precision (PatchDatabase(half_store=True))
     _req(db_volumes, 'db_volumes', torch.float16 if half else torch.float32), _req(meta, 'meta', torch.int32)
     dev = db_volumes.device
@@ -1308,6 +1309,24 @@ def gather_patches(db_volumes, meta, chunks, K, trunc_fill, trunc_ratio, mean, s
     lib = _lib.load()
     fn, name = (lib.rf_gather_patches_f16, 'rf_gather_patches_f16') if half else (lib.rf_gather_patches, 'rf_gather_patches')
     _lib.check(fn(_p(db_volumes), db_volumes.shape[0], _p(meta), chunks, K, trunc_fill, trunc_ratio, mean, std, layout, _p(out), _stream()), name)
+    return out
+
+
+def compose_overlap(db_volumes, mapping, boxes, K, size, trunc_fill, trunc_ratio=1.0):
+    """create_retrieval_from_mapping (reference util/retrieval.py:145-164) for ONE scene whose patch grid overlaps (``dataset.no_overlap`` False): ``mapping``
+    [P, K, 8] float32 rows (scene index, X0, X1, Y0, Y1, Z0, Z1, distance) of the patches ``patch_from_scene_lookup`` holds, in its order, ``boxes`` [P, 6] int32
+    their unpadded target boxes in the scene -> [K, *size] float32.  A patch overwrites its box of retrieval k only while the mean of the distances stored
+    there is above its own (:156); the patches are walked in order by one workgroup per k."""
+    half = db_volumes.dtype == torch.float16
+    _req(db_volumes, 'db_volumes', torch.float16 if half else torch.float32), _req(mapping, 'mapping', torch.float32), _req(boxes, 'boxes', torch.int32)
+    P = mapping.shape[0]
+    if tuple(mapping.shape) != (P, K, 8) or tuple(boxes.shape) != (P, 6):
+        raise ValueError('compose_overlap: mapping must be [P, %d, 8] and boxes [P, 6] (got %s, %s)' % (K, tuple(mapping.shape), tuple(boxes.shape)))
+    sx, sy, sz = (int(v) for v in size)
+    out = torch.empty((K, sx, sy, sz), dtype=torch.float32, device=db_volumes.device)
+    ws = torch.empty((K, sx, sy, sz), dtype=torch.float32, device=db_volumes.device)
+    _lib.check(_lib.load().rf_compose_overlap(_p(db_volumes), int(half), db_volumes.shape[0], _p(mapping), _p(boxes), P, K, sx, sy, sz, trunc_fill, trunc_ratio,
+                                              _p(out), _p(ws), _stream()), 'rf_compose_overlap')
     return out
 
 

@@ -201,8 +201,44 @@ def test_device_written_map_and_compose_files_match_reference_golden(gpu, tmp_pa
     assert list(masked) == [n for n, f in zip(names, keep) if f]
     masked_s = {n: val_s[n] for n in masked}
     assert helpers.sha(formats.compose_scene(pdb, masked_s, scene, K, trunc_t)) == str(fix['compose_masked_sha'])
-    with pytest.raises(NotImplementedError, match='no_overlap'):
-        formats.compose_scene(pdb, val_s, scene, K, trunc_t, no_overlap=False)
+    # the same non-overlapping grid through the ordered, distance-gated branch (:156): every box mean is the initial 100 > any distance -- the same volumes
+    assert helpers.sha(formats.compose_scene(pdb, val_s, scene, K, trunc_t, no_overlap=False)) == str(fix['compose_val_sha'])
+    assert helpers.sha(formats.compose_scene(pdb, masked_s, scene, K, trunc_t, no_overlap=False)) == str(fix['compose_masked_sha'])
+    with pytest.raises(NotImplementedError, match='compose_overlap'):
+        from rfuse import ops
+        ops.gather_patches(pdb.volumes, torch.zeros((64, K, 7), dtype=torch.int32, device=gpu), 1, K, trunc_t, 1.0, 0.0, 1.0, 0, no_overlap=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('half_store', [True, False])
+def test_device_compose_of_an_overlapping_patch_grid_matches_reference_golden(gpu, half_store):
+    """create_retrieval_from_mapping with dataset.no_overlap False (util/retrieval.py:156: a patch overwrites its box only while the mean stored distance of the
+    box is above its own; patch stride 8 < patch size 16, 343 patches in order) -- `formats.compose_scene(no_overlap=False)` / `ops.compose_overlap` against the
+    reference's own output on tests/golden/compose_overlap.npz (937 of 1372 visits copy; sentinel hits; a run of equal distances)."""
+    from rfuse.database import PatchDatabase
+    fix = helpers.load_fixture('compose_overlap')
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    K, q_scene = cfg['K'], int(fix['q_scene'])
+    db = synthetic.make_database(int(fix['seed']), cfg, int(fix['n_db_patches']))
+    assert helpers.sha(db['meta'], db['emb'], db['volumes']) == str(fix['db_sha'])
+    pdb = PatchDatabase(db['emb'], db['meta'], db['volumes'], gpu, half_store=half_store)
+    scene = 'scene%03d' % q_scene
+    ext = formats.scene_patch_extents((64, 64, 64), 16, 8, 8)
+    np.testing.assert_array_equal(ext, fix['extents'])                                  # the reference's get_extents_for_size (dataset/scene.py:152-160)
+    names = [formats.patch_name(scene, e) for e in ext]
+    mapping = {n: fix['mapping'][i] for i, n in enumerate(names)}
+    got = formats.compose_scene(pdb, mapping, scene, K, trunc_t, no_overlap=False, stride=8)
+    assert got.shape == (K, 64, 64, 64) and got.dtype == np.float32
+    np.testing.assert_array_equal(got[:, ::4, ::4, ::4], fix['composed_sub'])
+    assert helpers.sha(got) == str(fix['composed_sha'])
+    assert 0 < int(fix['taken']) < int(fix['visited'])                                  # both outcomes of the comparison occur
+    # patches the lookup does not hold are never visited: dropping the LAST patches leaves their boxes to the earlier ones
+    fewer = {n: mapping[n] for n in names[:200]}
+    part = formats.compose_scene(pdb, fewer, scene, K, trunc_t, no_overlap=False, stride=8)
+    from oracle import refpath
+    want = refpath.compose_retrieval_overlap(fix['mapping'][:200], fix['boxes'][:200], db['volumes'], K, trunc_t)
+    np.testing.assert_array_equal(part, want)
 
 
 @pytest.mark.gpu

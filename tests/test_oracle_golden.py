@@ -149,6 +149,26 @@ def test_oracle_knn_demotion_compose_match_reference():
     np.testing.assert_array_equal(ext[:, [1, 3, 5]] - 16, boxes[:, [1, 3, 5]])
 
 
+def test_oracle_overlapping_compose_matches_reference():
+    """create_retrieval_from_mapping with dataset.no_overlap False (util/retrieval.py:156), an order-dependent reduction: the restatement against the reference's
+    output on a 7^3 grid of 16^3 patches at stride 8 (tests/golden/compose_overlap.npz, generated by oracle/gen_golden.py from the reference itself)"""
+    fix = helpers.load_fixture('compose_overlap')
+    cfg = rf_configs.get_config('C1')
+    _, trunc_t = rf_configs.truncations(cfg)
+    db = synthetic.make_database(int(fix['seed']), cfg, int(fix['n_db_patches']))
+    assert helpers.sha(db['meta'], db['emb'], db['volumes']) == str(fix['db_sha'])
+    got = refpath.compose_retrieval_overlap(fix['mapping'], fix['boxes'], db['volumes'], cfg['K'], trunc_t)
+    assert helpers.sha(got) == str(fix['composed_sha'])
+    np.testing.assert_array_equal(got[:, ::4, ::4, ::4], fix['composed_sub'])
+    assert float(fix['min_relative_margin']) > 1e-5 and 0 < int(fix['taken']) < int(fix['visited'])
+    # with no_overlap the gate is open for every patch: later patches always win
+    always = refpath.compose_retrieval_overlap(fix['mapping'], fix['boxes'], db['volumes'], cfg['K'], trunc_t, no_overlap=True)
+    assert (always != got).any()
+    # boxes = the padded extents without their context (dataset/patched_scene_dataset.py:103-107)
+    np.testing.assert_array_equal(fix['boxes'][:, 0::2], fix['extents'][:, 0::2])
+    np.testing.assert_array_equal(fix['boxes'][:, 1::2], fix['extents'][:, 1::2] - 16)
+
+
 def test_knn_ties_go_to_lower_index():
     db = np.zeros((5, 64), dtype=np.float32)
     db[3, 0] = 1.0
