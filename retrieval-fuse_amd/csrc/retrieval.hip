@@ -23,20 +23,46 @@ typedef unsigned long long u64;
 __device__ __forceinline__ u64 make_key(float dist, unsigned row) { return ((u64)__float_as_uint(dist) << 32) | row; }
 
 // ---------------------------------------------------------------------------------------------- query windows
+// One workgroup per (window, w0) plane, a wave per output ROW (w consecutive elements along the last axis; the element-per-thread form of rounds 1-5
+// spent six 64-bit divisions per element -- 0.25 ms for the 191 MB of C5's sixteen 144^3 query grids, 0.19 of the HBM roofline; now the row decode is
+// amortised over w elements and a lane costs a compare, a load and the IEEE subtract / divide of the normalisation: same bits)
 __global__ __launch_bounds__(256) void k_query_windows(const float* __restrict__ raw, int b, int s, int ps, int ctx, float pad_value,
                                                        float mean, float stddev, float* __restrict__ out) {
-    const int np = s / ps, w = ps + 2 * ctx;
-    const size_t w3 = (size_t)w * w * w, total = (size_t)b * np * np * np * w3;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w2 = (int)(i % w), w1 = (int)((i / w) % w), w0 = (int)((i / ((size_t)w * w)) % w);
-        const size_t win = i / w3;
-        const int p2 = (int)(win % np), p1 = (int)((win / np) % np), p0 = (int)((win / ((size_t)np * np)) % np);
-        const size_t bb = win / ((size_t)np * np * np);
-        const int d0 = p0 * ps + w0 - ctx, d1 = p1 * ps + w1 - ctx, d2 = p2 * ps + w2 - ctx;
-        float v = pad_value;
-        if ((unsigned)d0 < (unsigned)s && (unsigned)d1 < (unsigned)s && (unsigned)d2 < (unsigned)s)
-            v = raw[((bb * s + d0) * s + d1) * s + d2];
-        out[i] = __fdiv_rn(__fsub_rn(v, mean), stddev);
+    const int np = s / ps, w = ps + 2 * ctx, lane = threadIdx.x & 63;
+    // quads of one row never straddle the chunk border when everything is in fours (and raw / out are 16-byte aligned: torch allocations)
+    const bool vec4 = ((w | ps | ctx | s) & 3) == 0 && (((size_t)raw | (size_t)out) & 15) == 0;
+    // a workgroup = one (window, w0) plane of w rows (decoded once, uniform); its four waves take the rows w1 = wave, wave + 4, ...
+    const unsigned plane = blockIdx.x;
+    const int w0 = (int)(plane % (unsigned)w);
+    const unsigned win = plane / (unsigned)w;
+    const int p2 = (int)(win % np), p1 = (int)((win / np) % np), p0 = (int)((win / (np * np)) % np);
+    const size_t bb = win / ((unsigned)np * np * np);
+    for (int w1 = threadIdx.x >> 6; w1 < w; w1 += 4) {
+        const size_t r = (size_t)plane * w + w1;
+        const int d0 = p0 * ps + w0 - ctx, d1 = p1 * ps + w1 - ctx, d2b = p2 * ps - ctx;
+        const bool row_in = (unsigned)d0 < (unsigned)s && (unsigned)d1 < (unsigned)s;
+        const float* src = raw + ((bb * s + (row_in ? d0 : 0)) * s + (row_in ? d1 : 0)) * s;
+        float* dst = out + r * w;
+        if (vec4) {
+            // four consecutive elements per lane (the memory pipes are issue-bound: a quarter of the requests and stores, 16 bytes each); the quad lies in
+            // one row, and inside or outside the chunk as a whole
+            for (int w2 = 4 * lane; w2 < w; w2 += 256) {
+                const int d2 = d2b + w2;
+                float4 v = make_float4(pad_value, pad_value, pad_value, pad_value);
+                if (row_in && (unsigned)d2 < (unsigned)s) v = *reinterpret_cast<const float4*>(src + d2);
+                float4 o;
+                o.x = __fdiv_rn(__fsub_rn(v.x, mean), stddev); o.y = __fdiv_rn(__fsub_rn(v.y, mean), stddev);
+                o.z = __fdiv_rn(__fsub_rn(v.z, mean), stddev); o.w = __fdiv_rn(__fsub_rn(v.w, mean), stddev);
+                *reinterpret_cast<float4*>(dst + w2) = o;
+            }
+        } else {
+            for (int w2 = lane; w2 < w; w2 += 64) {
+                const int d2 = d2b + w2;
+                float v = pad_value;
+                if (row_in && (unsigned)d2 < (unsigned)s) v = src[d2];
+                dst[w2] = __fdiv_rn(__fsub_rn(v, mean), stddev);
+            }
+        }
     }
 }
 
@@ -44,10 +70,9 @@ extern "C" int rf_query_windows(const float* raw, int b, int s, int ps, int ctx,
                                 float* out, void* stream) {
     RF_REQUIRE(raw && out && b > 0 && s > 0 && ps > 0 && ctx >= 0 && s % ps == 0, RF_E_INVALID, "rf_query_windows: bad arguments");
     const int np = s / ps, w = ps + 2 * ctx;
-    const size_t total = (size_t)b * np * np * np * w * w * w;
-    const size_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_query_windows, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, raw, b, s, ps, ctx,
-                       pad_value, mean, stddev, out);
+    const size_t planes = (size_t)b * np * np * np * w;
+    RF_REQUIRE(planes < (1ull << 31), RF_E_INVALID, "rf_query_windows: too many window planes (%zu)", planes);
+    hipLaunchKernelGGL(k_query_windows, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, raw, b, s, ps, ctx, pad_value, mean, stddev, out);
     RF_CHECK_LAUNCH("rf_query_windows");
     return RF_OK;
 }
@@ -55,27 +80,39 @@ extern "C" int rf_query_windows(const float* raw, int b, int s, int ps, int ctx,
 // ---------------------------------------------------------------------------------------- windows of a feature grid
 // The patch encoders evaluated fully convolutionally (model/retrieval.py forward_grid): the first layers run once on the padded chunk, then
 // the (np)^3 windows of edge w at stride `step` are cut out of the feature grid [n][c][g^3] -> [(n np^3)][c][w^3] for the remaining layers.
+// One workgroup per (window, channel), a wave per w0 plane of w x w elements (a lane's (w1, w2) by one float reciprocal): the element-per-thread form of rounds 3-5
+// decoded every element with 64-bit divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void k_gather_windows(const T* __restrict__ grid, int n, int c, int g, int w, int step, int np,
                                                         T* __restrict__ out) {
-    const size_t w3 = (size_t)w * w * w, g3 = (size_t)g * g * g, total = (size_t)n * np * np * np * c * w3;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w2 = (int)(i % w), w1 = (int)((i / w) % w), w0 = (int)((i / ((size_t)w * w)) % w);
-        const size_t cw = i / w3;
-        const int ch = (int)(cw % c);
-        const size_t win = cw / c;
-        const int p2 = (int)(win % np), p1 = (int)((win / np) % np), p0 = (int)((win / ((size_t)np * np)) % np);
-        const size_t bb = win / ((size_t)np * np * np);
-        out[i] = grid[(bb * c + ch) * g3 + ((size_t)(p0 * step + w0) * g + (p1 * step + w1)) * g + (p2 * step + w2)];
+    const int lane = threadIdx.x & 63, w2n = w * w;
+    const float inv_w = 1.0f / (float)w;
+    const size_t g3 = (size_t)g * g * g;
+    // a workgroup = one (window, channel) (decoded once, uniform); its four waves take the planes w0 = wave, wave + 4, ...
+    const unsigned cw = blockIdx.x;
+    const int ch = (int)(cw % (unsigned)c);
+    const unsigned win = cw / (unsigned)c;
+    const int p2 = (int)(win % np), p1 = (int)((win / np) % np), p0 = (int)((win / (np * np)) % np);
+    const size_t bb = win / ((unsigned)np * np * np);
+    const T* src0 = grid + (bb * c + ch) * g3 + ((size_t)(p0 * step) * g + p1 * step) * g + p2 * step;
+    T* dst0 = out + (size_t)cw * w * w2n;
+    for (int w0 = threadIdx.x >> 6; w0 < w; w0 += 4) {
+        const T* src = src0 + (size_t)w0 * g * g;
+        T* dst = dst0 + (size_t)w0 * w2n;
+        for (int e = lane; e < w2n; e += 64) {
+            const int w1 = (int)(((float)e + 0.5f) * inv_w), w2 = e - w1 * w;      // e < 2^16: (e + 0.5) / w truncates to e / w
+            dst[e] = src[(size_t)w1 * g + w2];
+        }
     }
 }
 
 extern "C" int rf_gather_windows(const float* grid, int n, int c, int g, int w, int step, int np, float* out, void* stream) {
     RF_REQUIRE(grid && out && n > 0 && c > 0 && g > 0 && w > 0 && step > 0 && np > 0 && (np - 1) * step + w <= g, RF_E_INVALID,
                "rf_gather_windows: bad arguments (the last window must end inside the grid)");
-    const size_t total = (size_t)n * np * np * np * c * w * w * w;
-    const size_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_gather_windows<float>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, grid, n, c, g, w, step, np, out);
+    RF_REQUIRE(w <= 255, RF_E_INVALID, "rf_gather_windows: window edge %d", w);
+    const size_t blocks = (size_t)n * np * np * np * c;
+    RF_REQUIRE(blocks < (1ull << 31), RF_E_INVALID, "rf_gather_windows: too many (window, channel) pairs (%zu)", blocks);
+    hipLaunchKernelGGL(k_gather_windows<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grid, n, c, g, w, step, np, out);
     RF_CHECK_LAUNCH("rf_gather_windows");
     return RF_OK;
 }
@@ -84,9 +121,10 @@ extern "C" int rf_gather_windows(const float* grid, int n, int c, int g, int w, 
 extern "C" int rf_gather_windows_split(const void* grid, int n, int c, int g, int w, int step, int np, void* out, void* stream) {
     RF_REQUIRE(grid && out && n > 0 && c > 0 && (c & 3) == 0 && g > 0 && w > 0 && step > 0 && np > 0 && (np - 1) * step + w <= g, RF_E_INVALID,
                "rf_gather_windows_split: bad arguments (channels in fours; the last window must end inside the grid)");
-    const size_t total = (size_t)n * np * np * np * (c / 2) * w * w * w;
-    const size_t want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_gather_windows<double>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream,
+    RF_REQUIRE(w <= 255, RF_E_INVALID, "rf_gather_windows_split: window edge %d", w);
+    const size_t blocks = (size_t)n * np * np * np * (c / 2);
+    RF_REQUIRE(blocks < (1ull << 31), RF_E_INVALID, "rf_gather_windows_split: too many (window, channel pair) units (%zu)", blocks);
+    hipLaunchKernelGGL(k_gather_windows<double>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const double*>(grid), n, c / 2, g, w, step, np, reinterpret_cast<double*>(out));
     RF_CHECK_LAUNCH("rf_gather_windows_split");
     return RF_OK;
