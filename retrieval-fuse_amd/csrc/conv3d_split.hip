@@ -701,7 +701,14 @@ extern "C" int rf_conv3d_split_supported(int c0, int c1, int n, int edge, int co
     const int cout16 = rf_round_up(cout, 16);
     // >= 256 boxes (rf_conv_use_big asks for 1024 workgroups: a chip-filling launch): the chunk-level U-Net's 32 -> 32 @16^3 conv at B = 32 is 256 boxes and took
     // 0.25 ms of a 1024-workgroup fp32-MFMA launch beside the retrieval path; the box kernel does it in a fraction of that on the F16 cores
-    return cout16 <= 32 && (rf_conv_use_big(n, edge, cout16) || (long long)n * (edge / 8) * (edge / 8) * (edge / 8) >= 256);
+    const long long boxes = (long long)n * (edge / 8) * (edge / 8) * (edge / 8);
+    if (cout16 <= 32) return rf_conv_use_big(n, edge, cout16) || boxes >= 256;
+    // more couts (round 6; the deep levels of the chunk-level U-Nets: 24 -> 48 @32^3, 48 -> 96 and 96 -> 96 @16^3 at 16 chunks): cout blocks of 16 / 32 on grid.y, every block
+    // staging the box again -- still a third of the fp32-MFMA form's time (C5: 0.33 / 0.18 / 0.34 ms) as long as the launch has a couple of workgroups per CU
+#ifdef RF_SPLIT_NARROW_ONLY                                          // dev A/B (tools/build_variant.py): rounds 2-5's rule
+    return 0;
+#endif
+    return cout16 <= 192 && boxes * (cout16 / 16) >= 512;
 }
 
 template <int NB, int WPS, bool ONE, bool PADC = false, bool PRE = false>
@@ -751,7 +758,7 @@ static int split_run(const ConvArgs& a, void* stream) {
 extern "C" int rf_conv3d_split_k3_gn_relu(const float* src, int cin, int n, int edge, const float* gn_affine, const void* w_packed, int cout,
                                            float* out, double* stats, float* pool_out, double* pool_stats, void* stream) {
     RF_REQUIRE(rf_conv3d_split_supported(cin, 0, n, edge, cout), RF_E_UNSUPPORTED,
-               "rf_conv3d_split_k3_gn_relu: takes cin >= 6 (at least 3/4 of the next multiple of 8), up to 32 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
+               "rf_conv3d_split_k3_gn_relu: takes cin >= 6 (at least 3/4 of the next multiple of 8), up to 192 couts, edge >= 8 and enough 8^3 boxes (got cin=%d n=%d edge=%d cout=%d)",
                cin, n, edge, cout);
     RF_REQUIRE(src && gn_affine && w_packed && (out || pool_out), RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: null pointer");
     RF_REQUIRE(out || !stats, RF_E_INVALID, "rf_conv3d_split_k3_gn_relu: statistics of an output that is not written");

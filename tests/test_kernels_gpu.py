@@ -198,6 +198,11 @@ SPLIT_BOX_CASES = [
     (1030, 24, 4, 48, 6),      # nf = 12 (C5): 48 couts in one workgroup (NB 3)
     (1026, 48, 4, 96, 6),      # ... 96 couts: two workgroups of 48
     (1025, 16, 4, 44, 4),      # padded couts in the NB 3 instance
+    (16, 24, 32, 48, 6),       # more than 32 couts (round 6; the deep levels of C5's U-Net at 16 chunks): three 16-cout blocks on grid.y, fused max-pool + statistics
+    (16, 48, 16, 96, 6),       # ... 128 boxes x three 32-cout blocks
+    (16, 96, 16, 96, 6),       # ... twelve chunks
+    (32, 32, 16, 64, 8),       # ... the nf = 16 U-Nets' 32 -> 64 @16^3 at B = 32
+    (9, 16, 32, 40, 4),        # ... a padded last block (40 -> 48)
 ]
 
 
