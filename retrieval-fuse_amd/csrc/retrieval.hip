@@ -1252,6 +1252,30 @@ __global__ __launch_bounds__(256) void k_gather_patches(const T* __restrict__ vo
         dst = out + ((size_t)chunk * K + k) * 262144 + ((size_t)xx * 64 + yy) * 64 + zz;
         dsx = 4096; dsy = 64;
     }
+    if ((z0 & 3) == 0 && (((size_t)vols | (size_t)out) & 15) == 0) {
+        // four voxels of a row per thread (the patch rows are 16 voxels: 8- / 16-byte requests, 16-byte stores -- a quarter of the memory instructions; the usual case:
+        // database patches lie on the 16-voxel grid of their scenes)
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            const int dz = (i & 3) * 4, dy = (i >> 2) & 15, dx = i >> 6;
+            float v[4] = {trunc_fill, trunc_fill, trunc_fill, trunc_fill};
+            if (have) {
+                const T* p = src + ((size_t)(x0 + dx) * 64 + (y0 + dy)) * 64 + (z0 + dz);
+                if constexpr (sizeof(T) == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+                    typedef _Float16 gp_h4 __attribute__((ext_vector_type(4)));
+                    const gp_h4 q = *reinterpret_cast<const gp_h4*>(p);
+                    v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+                }
+            }
+            float4 o;
+            o.x = __fdiv_rn(__fsub_rn(__fmul_rn(v[0], ratio), mean), stddev); o.y = __fdiv_rn(__fsub_rn(__fmul_rn(v[1], ratio), mean), stddev);
+            o.z = __fdiv_rn(__fsub_rn(__fmul_rn(v[2], ratio), mean), stddev); o.w = __fdiv_rn(__fsub_rn(__fmul_rn(v[3], ratio), mean), stddev);
+            *reinterpret_cast<float4*>(dst + dx * dsx + dy * dsy + dz) = o;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const int dz = i & 15, dy = (i >> 4) & 15, dx = i >> 8;
         float v = trunc_fill;

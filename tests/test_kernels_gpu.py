@@ -913,6 +913,22 @@ def test_demote_and_gather_match_oracle(ops):
         ref = ((ref - np.float32(dd['target_mean'])) / np.float32(dd['target_std'])).astype(np.float32)    # patched_scene_dataset.py:133
         assert np.array_equal(composed[c], ref)
     assert torch.equal(rows16, refpath.unfold3d(torch.from_numpy(composed).reshape(2 * K, 1, 64, 64, 64), 16))
+    # database boxes OFF the 16-voxel grid (any extent is legal in a mapping row, util/retrieval.py:152): origins with z0 % 4 != 0 take the element-wise route, the others the
+    # 16-byte route -- both against the restatement, with the fp32 and the float16 voxel store
+    m2 = m.clone()
+    rng2 = np.random.default_rng(9)
+    o = rng2.integers(0, 49, size=(m2.shape[0], m2.shape[1], 3))
+    o[::3, :, 2] = (o[::3, :, 2] // 4) * 4                                                 # a third of them 16-byte aligned in z
+    m2[:, :, 1] = torch.from_numpy(o[..., 0]).int(); m2[:, :, 2] = m2[:, :, 1] + 16
+    m2[:, :, 3] = torch.from_numpy(o[..., 1]).int(); m2[:, :, 4] = m2[:, :, 3] + 16
+    m2[:, :, 5] = torch.from_numpy(o[..., 2]).int(); m2[:, :, 6] = m2[:, :, 5] + 16
+    ref_map2 = ref_map.copy()
+    ref_map2[..., :7] = m2.cpu().numpy()
+    for store in (vols, vols.half()):
+        got2 = ops.gather_patches(store, m2, 2, K, trunc_t, 1.0, dd['target_mean'], dd['target_std'], layout=0).cpu().numpy()
+        for c in range(2):
+            ref = refpath.compose_retrieval(ref_map2[c * 64:(c + 1) * 64], db['volumes'], K, trunc_t)
+            assert np.array_equal(got2[c], ((ref - np.float32(dd['target_mean'])) / np.float32(dd['target_std'])).astype(np.float32))
 
 
 @pytest.mark.parametrize('spec', [(3, 1, 8, 16, 3, 1), (2, 4, 12, 8, 3, 2), (2, 3, 6, 5, 2, 1), (1, 1, 20, 6, 5, 1), (2, 8, 4, 8, 4, 1)])
