@@ -149,6 +149,16 @@ def victims(ops):
         wv2s = ops.pack_convv_split_weight(wv2, 22, 2)
         v['split valid conv (24->24 k3 s2 @22^3 x 64)'] = lambda: ops.conv3d_valid_leaky_split(xv2, wv2s, bv, 24, 3, 2, 0.2)
 
+    # the persistent two-team grid form (packed-fp32 epilogue of one team beside the other team's -- and the load's -- F16 MFMAs)
+    if ops.conv_valid_split_pg_supported((2, 12, 64), 24, 3, 1):
+        x_pg = rnd(g, 2, 12, 64, 64, 64).to(DEV)
+        t_pg = (x_pg * (1.0 / 16)).clamp(-65504.0, 65504.0)
+        h_pg = t_pg.half()
+        l_pg = ((t_pg - h_pg.float()) * 2048.0).half()
+        xs_pg = ops.SplitActs(torch.stack([h_pg, l_pg], 0).view(2, 2, 3, 4, 64 ** 3).permute(1, 2, 0, 4, 3).contiguous().view(torch.float32).view(2, 12, 64, 64, 64))
+        wpg = ops.pack_convv_split_pg_weight(wv, 64, 1)
+        v['persistent grid valid conv (12->24 k3 @64^3 x 2, split form)'] = lambda: ops.conv3d_valid_leaky_split_pg(xs_pg, wpg, bv, 24, 3, 1, 0.2).data
+
     # linear layers and the attention kernels
     xr = rnd(g, 4096, 128).to(DEV)
     wlin, blin = rnd(g, 128, 128, scale=0.1).to(DEV), rnd(g, 128).to(DEV)
