@@ -1,6 +1,6 @@
 """CPU: the planner of the fully-convolutional patch-encoder evaluation (model/retrieval.py grid_plan) -- which leading layers run on the
 whole padded chunk.  The rule: the window origins must stay on the layers' sampling lattice, and the grid must have fewer output voxels
-than the windows together.  (The arithmetic itself is GPU-tested: tests/test_kernels_gpu.py.)"""
+than the windows together (ties go to the grid).  (The arithmetic itself is GPU-tested: tests/test_kernels_gpu.py.)"""
 import sys
 from pathlib import Path
 
@@ -18,7 +18,7 @@ def brute_force_plan(spec, window, step, npatch):
             break
         sw2, sg2 = (sw - k) // st + 1, (sg - k) // st + 1
         origins = [a * (lat // st) for a in range(npatch)]
-        if origins[-1] + sw2 > sg2 or sg2 ** 3 >= npatch ** 3 * sw2 ** 3:
+        if origins[-1] + sw2 > sg2 or sg2 ** 3 > npatch ** 3 * sw2 ** 3:
             break
         sw, sg, lat, n = sw2, sg2, lat // st, n + 1
     return n, sw, lat
@@ -40,8 +40,8 @@ def test_grid_plan(name, nf, window, step):
 
 
 def test_known_plans():
-    assert rf_model.PCPatch48(12, 64).grid_plan(48, 32, 4) == (4, 9, 8)       # 144 -> 140 -> 138 -> 68 -> 33, windows of 9^3 every 8
-    assert rf_model.Patch32(8, 64).grid_plan(32, 16, 4) == (4, 10, 8)         # 80 -> 76 -> 74 -> 36 -> 34, windows of 10^3 every 8
+    assert rf_model.PCPatch48(12, 64).grid_plan(48, 32, 4) == (5, 4, 4)       # 144 -> 140 -> 138 -> 68 -> 33 -> 16, windows of 4^3 every 4 (the last step is a tie: 16^3 = 64 x 4^3)
+    assert rf_model.Patch32(8, 64).grid_plan(32, 16, 4) == (5, 4, 4)          # 80 -> 76 -> 74 -> 36 -> 34 -> 16, windows of 4^3 every 4
 
 
 def test_persistent_grid_form_plan_on_the_host():
@@ -59,4 +59,4 @@ def test_persistent_grid_form_plan_on_the_host():
     assert lib.rf_convv_split_pg_packed_bytes(24, 12, 3, 141, 1) == 0
     # the encoder's own plan sends exactly that layer of PCPatch48 on C5's 144^3 padded chunk there: layer 2 of the 4 on the grid reads a 140^3 volume of 12 channels
     enc = rf_model.PCPatch48(12, 64)
-    assert enc.grid_plan(48, 32, 4)[0] == 4 and (enc.SPEC[1][0] * 12, enc.SPEC[1][1] * 12, enc.SPEC[1][2], enc.SPEC[1][3]) == (12, 24, 3, 1)
+    assert enc.grid_plan(48, 32, 4)[0] == 5 and (enc.SPEC[1][0] * 12, enc.SPEC[1][1] * 12, enc.SPEC[1][2], enc.SPEC[1][3]) == (12, 24, 3, 1)
