@@ -165,6 +165,13 @@ class SingleConv(nn.Module):
         elif ops.conv_up_split_supported(x, upsampled, cout):
             c0 = x.shape[1] if x is not None else 0
             out = ops.conv3d_up_split_gn_relu(x, upsampled, aff, self.conv.packed_up_split(c0), cout)
+        elif upsampled is not None and edge >= 8 and ops.conv_split_supported_shape(upsampled.shape[0], (x.shape[1] if x is not None else 0) + upsampled.shape[1], edge, cout):
+            # a decoder stage outside the decoder forms of the F16 cores (C5's 96 + 192 -> 96 @16^3 at 16 chunks: 192 upsampled channels, 128 boxes): the
+            # concatenation written out once (as for the 2^3 stage above; 75 MB there) and the layer run by the split-operand box kernel with its cout blocks
+            # on grid.y -- 0.53 ms as the fp32-MFMA decoder form.  The affine table is per channel of the concatenation either way.
+            up = upsampled.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+            xc = torch.cat((x, up), dim=1) if x is not None else up
+            out = ops.conv3d_split_gn_relu(xc, aff, self.conv.packed_split(), cout)
         elif ops.conv_up_supported(x, upsampled, cout):
             c0 = x.shape[1] if x is not None else 0
             out = ops.conv3d_up_gn_relu(x, upsampled, aff, self.conv.packed_up(c0), cout)

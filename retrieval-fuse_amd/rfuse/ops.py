@@ -579,6 +579,11 @@ class PreSplit:
         return self.data.device
 
 
+def conv_split_supported_shape(n, cin, edge, cout):
+    """conv_split_supported for a tensor that does not exist yet (a concatenation about to be written): [n, cin, edge^3] -> cout"""
+    return CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_split_supported(int(cin), 0, int(n), int(edge), int(cout)))
+
+
 def conv_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups):
     return USE_PREPOOL and USE_PRESPLIT and CONV_ARITH == 'split' and bool(_lib.load().rf_conv3d_split_pre_pool_presplit_supported(cin, n, edge, cout, next_groups))
 
