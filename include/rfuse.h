@@ -139,7 +139,8 @@ int rf_convv_split_pack_weight(const float* w_oidhw, int cout, int cin, int k, i
 size_t rf_convv_split_packed_bytes(int cout, int cin, int k, int s, int stride);
 /* ... and as a PERSISTENT kernel for the layers the encoders evaluate once on the whole padded chunk instead of per window (PCPatch48's 12 -> 24 k3 @140^3,
  * model/retrieval.py:222): weights and tables LDS-resident, 512-voxel tiles double buffered, split form in and out (x and out as rf_conv3d_valid_leaky_split_ex
- * with in_split = out_split = 1), the epilogue from registers.  Bit-identical to rf_conv3d_valid_leaky_split_ex; its own weight image. */
+ * with in_split = out_split = 1), the epilogue from registers.  Same operands and K order as rf_conv3d_valid_leaky_split_ex on another MFMA shape: equal to it within the last
+ * bits of an fp32 sum; its own weight image.  The instantiation built: 12 input channels, 17..24 couts in fours, k = 3, stride 1, even edges 64..254. */
 int rf_conv3d_valid_split_pg_supported(int n, int cin, int s, int cout, int k, int stride);
 int rf_conv3d_valid_leaky_split_pg(const void* x, int n, int cin, int s, const void* w_packed, const float* bias, int cout, int k, int stride,
                                    float slope, void* out, void* stream);

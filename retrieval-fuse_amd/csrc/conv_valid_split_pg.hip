@@ -1,7 +1,9 @@
 // rf_conv3d_valid_leaky_split_pg: the split-operand valid conv of conv_valid_split.hip for the layers the patch encoders evaluate ON THE GRID
 // (fully convolutional, model/retrieval.py forward_grid of this package; reference model/retrieval.py:217-243 PCPatch48, layer 12 -> 24 k3 @140^3 of
-// config/surface_reconstruction/ShapeNetV2/refinement_128_064.yaml) as a PERSISTENT kernel.  Same arithmetic, same K order, same weight fragments as
-// k_convv_split (bit-identical outputs); what changes is where the operands come from and what runs beside what:
+// config/surface_reconstruction/ShapeNetV2/refinement_128_064.yaml) as a PERSISTENT kernel.  Same operands (x = h + l / 2^11, three MFMAs per product), same K
+// order of (tap, 4-channel group) pieces as k_convv_split, on v_mfma_f32_32x32x16_f16 instead of 16x16x32: equal to it within the last bits of an fp32 sum (tests:
+// <= 4e-6 on O(1) outputs, both 2e-6 from float64).  What changes is where the operands come from and what runs beside what (every step measured:
+// profiles/r06_convv_pg_variants.md):
 //
 //   k_convv_split, one 256-voxel tile per workgroup: every wave streams the whole weight image (45 KB for 12 -> 24) global -> VGPR per tile -- 29.5 GB per
 //       launch through the L2 for a layer whose tensors are 6.1 GB --, per-tile tables and staging latencies, an epilogue through an LDS tile; three
@@ -10,9 +12,10 @@
 //       while team A runs a tile's k-loop (MFMAs + LDS operand reads), team B runs the previous tile's epilogue and stages its next tile (VALU, global
 //       loads / stores, LDS writes), then they swap -- two barriers per tile pair.  The matrix pipe always has a wave in its k-loop; what a first
 //       single-team build spent behind it (ablations on the 16 x 140^3 launch: k-loop 1.95 ms, epilogue 0.88, staging 0.38; 3.25 ms in all) runs in
-//       its shadow.  A team's input tile needs no double buffer: it is re-filled in the team's own VALU phase.
-//   The weight image and the tables are copied to LDS once per workgroup; a k-step's operands are requested one k-step ahead (two bursts of <= 12
-//       ds_reads: lgkmcnt counts to 15).
+//       its shadow -- the memory part of it: on this part VALU work beside another wave's MFMAs takes issue slots out of that wave's stream, what the teams
+//       hide is request / store / LDS-write time.  A team's input tile needs no double buffer: it is re-filled in the team's own non-MFMA phase.
+//   The weight image and the tables are copied to LDS once per workgroup; a k-step's operands are requested one k-step ahead, the reads placed BETWEEN
+//       the MFMAs (sched_group_barrier: a burst per k-step fills the LDS queue and the MFMA behind it waits for its turn to issue).
 //   MFMA roles swapped (weights = A / M = couts, voxels = B / N): an accumulator lane holds 4 consecutive couts of ONE voxel = one 8-byte slot of the
 //       split-form output; bias, LeakyReLU, the h / l split and the stores leave from registers (no LDS tile).  Stores are BUFFER stores: a lane
 //       whose voxel lies outside the volume (ragged last tiles) or whose channel group is padding gets an out-of-range offset -- no branch.

@@ -907,8 +907,8 @@ def pack_convv_split_pg_weight(w, s, stride):
 
 
 def conv3d_valid_leaky_split_pg(x, w_packed, bias, cout, k, stride, slope):
-    """SplitActs -> SplitActs: valid conv + bias + LeakyReLU, persistent grid form (w_packed from pack_convv_split_pg_weight); bit-identical to
-    conv3d_valid_leaky_split(x, ..., out_split=True)"""
+    """SplitActs -> SplitActs: valid conv + bias + LeakyReLU, persistent grid form (w_packed from pack_convv_split_pg_weight); equal to
+    conv3d_valid_leaky_split(x, ..., out_split=True) within the last bits of an fp32 sum (another MFMA shape)"""
     if not isinstance(x, SplitActs):
         raise TypeError('conv3d_valid_leaky_split_pg: the input must be in split form (SplitActs)')
     xt = x.data
